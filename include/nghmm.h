@@ -1,0 +1,169 @@
+/*
+ * nghmm.h -- C ABI of the MI355X-native ngsF-HMM EM hot path.
+ *
+ * The reference (fgvieira/ngsF-HMM v1.1.0) has no plugin/FFI interface: its EM
+ * engine (EM.cpp) calls its numerical routines (shared/HMM.hpp:8-15,
+ * shared/gen_func.hpp:94-103, shared/bfgs.h:54-57) directly through pthread-pool
+ * tasks (EM.cpp:385-445).  This header is the seam a maintainer would bind
+ * instead: each entry point names the reference call sites it replaces.  All
+ * per-site-per-individual arithmetic runs in HIP kernels on one GPU per handle;
+ * large state stays device-resident between calls.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `double` is IEEE binary64;
+ *   - sites are 0-based here: site s is the reference's site s+1; the
+ *     reference's virtual site 0 is implicit;
+ *   - every function returns 0 (NGHMM_OK) or a negative code; the codes -1..-5
+ *     correspond to the reference's fatal error() messages, which a host maps
+ *     back to the same text (nghmm_strerror); nghmm_last_error() gives detail;
+ *   - host buffers are owned by the caller, device buffers by the handle;
+ *   - a handle is bound to one HIP device and one stream; calls on different
+ *     handles may be made from different threads.
+ */
+#ifndef NGHMM_H
+#define NGHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nghmm_handle nghmm_t;
+
+enum {
+  NGHMM_OK = 0,
+  NGHMM_ERR_INVALID_LKL = -1, /* "invalid Lkl found!"          shared/HMM.cpp:18-21,45-48 */
+  NGHMM_ERR_FW_BW = -2,       /* "Fw and Bw lkl do not match!" EM.cpp:166-170 */
+  NGHMM_ERR_INVALID_MAF = -3, /* "invalid MAF!"                shared/HMM.cpp:145-146 */
+  NGHMM_ERR_NAN = -4,         /* "value is NaN!"               shared/gen_func.cpp:56-57 */
+  NGHMM_ERR_FREQ_EST2 = -5,   /* "invalid allele frequencies": --freq_est 2 aborts in the
+                                 reference at the first site (EM.cpp:235-238,
+                                 shared/gen_func.cpp:1030-1031) */
+  NGHMM_ERR_ARG = -10,        /* bad argument / call order */
+  NGHMM_ERR_HIP = -11,        /* HIP runtime error */
+  NGHMM_ERR_NOMEM = -12
+};
+
+/* Arithmetic mode of a handle. */
+enum {
+  /* Log-space recursions in the reference's operation order, exp/log from
+   * csrc/detmath.h: results are bit-identical to the oracle's `det` build. */
+  NGHMM_MODE_EXACT = 0,
+  /* Linear-space, chunk-parallel scan over sites with rescaling (the
+   * throughput path); per-call results within 1e-9 relative of exact mode. */
+  NGHMM_MODE_FAST = 1
+};
+
+/* Statistics of one indF/alpha M-step (shared/bfgs.cpp rounds). */
+typedef struct {
+  uint32_t rounds;          /* lock-step objective rounds (GPU launches)            */
+  uint64_t points;          /* objective evaluations sent to the GPU                */
+  uint64_t ref_forward_calls; /* forward passes the reference would have spent      */
+} nghmm_mstep_stats;
+
+const char* nghmm_last_error(void);
+const char* nghmm_strerror(int code);
+/* 1 if the library was built with its HIP kernels (always, for the shipped .so). */
+int nghmm_has_hip(void);
+
+/* Create the state for n_ind individuals x n_sites sites on HIP device `device`
+ * (replaces the allocations of read_geno/init_output, shared/read_data.cpp:21,
+ * parse_args.cpp:245-412, and iter_EM's per-iteration Fw/Bw, EM.cpp:140-143). */
+int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, int mode);
+int nghmm_destroy(nghmm_t* h);
+
+/* Upload genotype likelihoods: natural-log, normalised, site-major [S][I][3]
+ * (= the reference's binary --geno file order, shared/read_data.cpp:28-31, after
+ * its normalisation) and per-site distances in Mb, +inf at chromosome starts
+ * (ngsF-HMM.cpp:75-86).  Host pointers. */
+int nghmm_load_gl(nghmm_t* h, const double* gl_site_major, const double* pos_dist_mb);
+/* Same, from buffers already resident on the handle's device. */
+int nghmm_load_gl_device(nghmm_t* h, const double* d_gl_site_major, const double* d_pos_dist_mb);
+
+/* indF[I], alpha[I], freq[S]; NULL leaves a vector unchanged (parse_args.cpp:245-363). */
+int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const double* freq);
+int nghmm_get_params(nghmm_t* h, double* indF, double* alpha, double* freq);
+
+/* Emission probabilities of every cell from the current freq
+ * (calc_emission, shared/HMM.cpp:144-154, as called at parse_args.cpp:381-386). */
+int nghmm_emission(nghmm_t* h);
+
+/* E-step: forward, backward, Fw/Bw consistency check, posteriors
+ * (EM.cpp:147-185; shared/HMM.cpp:6-60).  ind_lkl[I] (host, may be NULL). */
+int nghmm_estep(nghmm_t* h, double* ind_lkl);
+
+/* Objective of the indF/alpha M-step for a batch of probe points: lkl[p] =
+ * forward log-likelihood of individual ind[p] with q = (1-F[p], F[p]) and
+ * transition rate alpha[p], under the current emissions (EM.cpp:449-464 returns
+ * its negative).  Host pointers. */
+int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
+                    const double* alpha, double* lkl);
+
+/* indF/alpha M-step for all individuals: one bound-constrained L-BFGS-B problem
+ * per individual (EM.cpp:198-201,423-440; shared/bfgs.cpp:83-138), advanced in
+ * lock-step rounds with nghmm_lkl_batch as the objective.  stats may be NULL. */
+int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats);
+
+/* The same lock-step batched L-BFGS-B machinery with a caller-supplied objective
+ * (host only, no GPU involved): fn returns the forward log-likelihood of
+ * individual `ind` at (F, alpha).  indF/alpha are updated in place.  Lets a host
+ * plug another objective in, and lets the CPU test-suite exercise the state
+ * machines without a device. */
+typedef double (*nghmm_objective_fn)(uint32_t ind, double F, double alpha, void* user);
+int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
+                          int alpha_fixed, nghmm_objective_fn fn, void* user,
+                          nghmm_mstep_stats* stats);
+
+/* Allele-frequency M-step + emission refresh (EM.cpp:210-272; est_maf,
+ * shared/gen_func.cpp:974-1009).  freq_est 0 = keep, 1 = per-site EM,
+ * 2 = NGHMM_ERR_FREQ_EST2 (the reference aborts). */
+int nghmm_mstep_freq(nghmm_t* h, int freq_est);
+
+/* One whole EM iteration = iter_EM (EM.cpp:139-289). */
+int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, double* ind_lkl,
+                  nghmm_mstep_stats* stats);
+
+/* Viterbi decoding with the current parameters (EM.cpp:105-116;
+ * shared/HMM.cpp:98-125).  path[I][S] bytes 0/1 (host). */
+int nghmm_viterbi(nghmm_t* h, uint8_t* path);
+
+/* Posterior of the IBD state from the last E-step, marg_prob[i][s][1], as
+ * [I][S] doubles (host) -- what EM.cpp:347-353 prints. */
+int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd);
+/* Current emissions [I][S][2] (host); test/debug aid. */
+int nghmm_get_emissions(nghmm_t* h, double* e_prob);
+
+/* ---- multi-GPU (individuals sharded over ranks) ----
+ * The allele-frequency step needs every individual of a site.  A rank owns the
+ * individuals [ind_begin, ind_begin + n_ind) of n_ind_total for all sites, and
+ * the sites [site_begin, site_begin + n_sites_own) for the frequency step.
+ * The host moves posteriors between ranks with an all-to-all and frequencies with
+ * an all-gather (RCCL through torch.distributed or rccl.h); these calls take raw
+ * DEVICE pointers to the exchange buffers. */
+int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uint64_t site_begin,
+                       uint64_t n_sites_own);
+/* static site-shard copy of the GLs of ALL individuals: [n_sites_own][n_ind_total][3] (host) */
+int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard);
+/* pack posteriors of the own individuals for destination rank r's site range:
+ * d_out[(s - site_lo) * n_ind + i], s in [site_lo, site_hi) */
+int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, double* d_out);
+/* d_marg_sites: [n_sites_own][n_ind_total] posteriors of the own site range (device);
+ * runs est_maf on them, writes d_freq_out[n_sites_own] (device) */
+int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_sites, double* d_freq_out);
+/* install the gathered freq[S] (device pointer) and refresh the own emissions */
+int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all);
+
+/* Device pointer + stream access for host-side plumbing (torch tensors, events). */
+void* nghmm_stream(nghmm_t* h);
+int nghmm_synchronize(nghmm_t* h);
+/* HIP-event timing of the last call of each kernel family, in milliseconds:
+ * 0 emission, 1 forward(store), 2 backward+posterior, 3 lkl_batch (sum over rounds of
+ * the last mstep_indf or the last lkl_batch call), 4 est_maf+emission, 5 viterbi.
+ * Also the launch count behind slot 3. */
+int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGHMM_H */

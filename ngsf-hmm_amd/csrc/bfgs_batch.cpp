@@ -1,0 +1,188 @@
+// bfgs_batch.cpp -- see bfgs_batch.hpp.  Compile with -ffp-contract=off.
+#include "bfgs_batch.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace nghmm {
+
+namespace {
+constexpr double kINF = 1e15;  // shared/gen_func.hpp:15
+inline bool same_bits(const double* a, const double* b) { return std::memcmp(a, b, 16) == 0; }
+inline bool nonfinite(double v) { return std::isnan(v) || std::isinf(v); }
+}  // namespace
+
+void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, bool F_fixed,
+                      bool alpha_fixed) {
+  probs_.clear();
+  probs_.resize(n_ind);
+  rounds_ = 0;
+  points_ = 0;
+  ref_calls_ = 0;
+  n_active_ = n_ind;
+  for (uint64_t i = 0; i < n_ind; ++i) {
+    Problem& p = probs_[i];
+    p.solver.reset(2, 10);  // MVAL, shared/bfgs.h:23
+    p.x[0] = indF[i];
+    p.x[1] = alpha[i];
+    // EM.cpp:424-436
+    p.lb[0] = 1 / kINF;
+    p.lb[1] = 1 / kINF;
+    p.ub[0] = 1 - p.lb[0];
+    p.ub[1] = 10;
+    if (F_fixed) p.lb[0] = p.ub[0] = indF[i];
+    if (alpha_fixed) p.lb[1] = p.ub[1] = alpha[i];
+    p.like = 0;
+    p.grad[0] = p.grad[1] = 0;
+    p.have_eval = false;
+    p.started = false;
+    p.active = true;
+  }
+}
+
+// The points one objective + gradient evaluation needs (bfgs.cpp:22-43,54).
+void BfgsBatch::plan(Problem& p) {
+  for (int k = 0; k < 5; ++k) p.slot_used[k] = false;
+  p.pt[0][0] = p.x[0];
+  p.pt[0][1] = p.x[1];
+  p.slot_used[0] = true;
+  for (int i = 0; i < 2; ++i) {
+    const int sa = 1 + 2 * i, sb = 2 + 2 * i;
+    if (p.lb[i] == p.ub[i]) {
+      // Fixed parameter: the reference still spends one probe on it, but the
+      // bound check (bfgs.cpp:58-63) then forces the component to zero.
+      p.probe_kind[i] = 3;
+      continue;
+    }
+    const double eh = std::pow(1.e-8 * (std::fabs(p.x[i]) + 1), 0.67);
+    p.eh[i] = eh;
+    double x0 = p.x[i], x1 = p.x[i];
+    x0 -= eh;
+    x1 += eh;
+    for (int k = sa; k <= sb; ++k) {
+      p.pt[k][0] = p.x[0];
+      p.pt[k][1] = p.x[1];
+    }
+    if (x0 < p.lb[i]) {
+      x1 += eh;
+      p.probe_kind[i] = 1;
+      p.pt[sa][i] = x1;
+      p.slot_used[sa] = true;
+    } else if (x1 > p.ub[i]) {
+      x0 -= eh;
+      p.probe_kind[i] = 2;
+      p.pt[sa][i] = x0;
+      p.slot_used[sa] = true;
+    } else {
+      p.probe_kind[i] = 0;
+      p.pt[sa][i] = x1;
+      p.pt[sb][i] = x0;
+      p.slot_used[sa] = p.slot_used[sb] = true;
+    }
+  }
+  for (int k = 0; k < 5; ++k)
+    p.slot_nonfinite[k] = p.slot_used[k] && (nonfinite(p.pt[k][0]) || nonfinite(p.pt[k][1]));
+}
+
+size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
+                         std::vector<double>& alpha) {
+  ind.clear();
+  F.clear();
+  alpha.clear();
+  if (n_active_ == 0) return 0;
+  for (auto& p : probs_)
+    if (p.active) plan(p);
+  for (int k = 0; k < 5; ++k) {
+    for (size_t i = 0; i < probs_.size(); ++i) {
+      Problem& p = probs_[i];
+      if (!p.active || !p.slot_used[k] || p.slot_nonfinite[k]) continue;
+      p.slot_pos[k] = (uint32_t)ind.size();
+      ind.push_back((uint32_t)i);
+      F.push_back(p.pt[k][0]);
+      alpha.push_back(p.pt[k][1]);
+    }
+  }
+  ++rounds_;
+  points_ += ind.size();
+  return ind.size();
+}
+
+void BfgsBatch::consume(Problem& p, const double* lkl) {
+  // objective = -forward log-likelihood; non-finite parameters give -INF... i.e.
+  // lkl = INF and the function returns -lkl (EM.cpp:454-463)
+  double fv[5] = {0, 0, 0, 0, 0};
+  for (int k = 0; k < 5; ++k) {
+    if (!p.slot_used[k]) continue;
+    fv[k] = p.slot_nonfinite[k] ? -kINF : -lkl[p.slot_pos[k]];
+  }
+  const double f0 = fv[0];
+  p.like = fv[0];
+  uint64_t calls = 2;  // fun(x) in findmax_bfgs + fun(x) again inside getgradient
+  for (int i = 0; i < 2; ++i) {
+    const int sa = 1 + 2 * i, sb = 2 + 2 * i;
+    double g;
+    switch (p.probe_kind[i]) {
+      case 0:
+        g = (fv[sa] - fv[sb]) / (p.eh[i] * 2.0);
+        calls += 2;
+        break;
+      case 1:
+        g = (fv[sa] - f0) / (p.eh[i] * 2.0);
+        calls += 1;
+        break;
+      case 2:
+        g = (f0 - fv[sa]) / (p.eh[i] * 2.0);
+        calls += 1;
+        break;
+      default:
+        g = 0.0;
+        calls += 1;
+        break;
+    }
+    if (p.x[i] <= p.lb[i] && g > 0.0) g = 0.0;  // bfgs.cpp:58-63
+    if (p.x[i] >= p.ub[i] && g < 0.0) g = 0.0;
+    p.grad[i] = g;
+  }
+  ref_calls_ += calls;
+  p.eval_x[0] = p.x[0];
+  p.eval_x[1] = p.x[1];
+  p.have_eval = true;
+
+  if (!p.started) {
+    const int nbd[2] = {2, 2};
+    p.solver.start(p.x, p.lb, p.ub, nbd, 1.0e6, 1.0e-3);  // FACTR, PGTOL: bfgs.h:24-25
+    p.started = true;
+  }
+  for (;;) {
+    const Lbfgsb::Task task = p.solver.advance(&p.like, p.grad);
+    p.x[0] = p.solver.x()[0];
+    p.x[1] = p.solver.x()[1];
+    if (task == Lbfgsb::Task::EvalFG) {
+      if (p.have_eval && same_bits(p.x, p.eval_x)) {
+        // the START call asks for f and g at the point just evaluated
+        // (bfgs.cpp:901,114-121): same x, same values.
+        ref_calls_ += calls;
+        continue;
+      }
+      return;  // wants a new round
+    }
+    if (task == Lbfgsb::Task::NewX) continue;
+    p.active = false;
+    --n_active_;
+    return;
+  }
+}
+
+void BfgsBatch::scatter(const double* lkl) {
+  for (auto& p : probs_)
+    if (p.active) consume(p, lkl);
+}
+
+void BfgsBatch::result(double* indF, double* alpha) const {
+  for (size_t i = 0; i < probs_.size(); ++i) {
+    indF[i] = probs_[i].x[0];
+    alpha[i] = probs_[i].x[1];
+  }
+}
+
+}  // namespace nghmm

@@ -1,0 +1,68 @@
+// bfgs_batch.hpp -- the reference's per-individual indF/alpha optimisation
+// (thread_slave type 4, EM.cpp:423-440; findmax_bfgs + getgradient/Yanggradient,
+// shared/bfgs.cpp:22-138) for ALL individuals at once.
+//
+// The reference runs one blocking findmax_bfgs per pool task; every objective
+// call is a full forward pass on the CPU.  Here each individual is a resumable
+// Lbfgsb state machine; a "round" collects the (F, alpha) points all still-active
+// machines need next (f(x) plus the finite-difference probes: at most five
+// distinct points per individual), the caller evaluates them in one GPU launch,
+// and the values are scattered back.  Per individual the sequence of points and
+// every arithmetic step is the reference's, so the final (indF, alpha) are
+// bit-identical to running findmax_bfgs on the same objective values.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "lbfgsb.hpp"
+
+namespace nghmm {
+
+class BfgsBatch {
+ public:
+  // Bounds as in EM.cpp:424-436.
+  void begin(uint64_t n_ind, const double* indF, const double* alpha, bool F_fixed,
+             bool alpha_fixed);
+
+  // Points wanted this round, ordered probe-slot-major so that lanes of a wave
+  // read consecutive individuals.  Returns the count (0 when all are done).
+  size_t gather(std::vector<uint32_t>& ind, std::vector<double>& F, std::vector<double>& alpha);
+
+  // lkl[p] = forward log-likelihood of point p of the last gather().
+  void scatter(const double* lkl);
+
+  bool done() const { return n_active_ == 0; }
+  void result(double* indF, double* alpha) const;
+
+  uint32_t rounds() const { return rounds_; }
+  uint64_t points() const { return points_; }
+  uint64_t ref_forward_calls() const { return ref_calls_; }
+
+ private:
+  struct Problem {
+    Lbfgsb solver;
+    double x[2], lb[2], ub[2];
+    double like, grad[2];
+    double eval_x[2];   // where (like, grad) were last evaluated
+    bool have_eval = false;
+    bool started = false;
+    bool active = true;
+    // plan of the current round
+    int probe_kind[2];  // 0 central, 1 forward (x + 2eh), 2 backward (x - 2eh), 3 fixed (skipped)
+    double eh[2];
+    double pt[5][2];    // slot 0 = x; slots 1,2 = param 0 probes; 3,4 = param 1 probes
+    bool slot_used[5];
+    bool slot_nonfinite[5];
+    uint32_t slot_pos[5];
+  };
+  std::vector<Problem> probs_;
+  uint64_t n_active_ = 0;
+  uint32_t rounds_ = 0;
+  uint64_t points_ = 0, ref_calls_ = 0;
+
+  void plan(Problem& p);
+  void consume(Problem& p, const double* lkl);
+};
+
+}  // namespace nghmm

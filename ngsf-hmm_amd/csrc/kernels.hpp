@@ -1,0 +1,52 @@
+// kernels.hpp -- launch interface of the HIP kernels (gfx950) behind the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace nghmm {
+
+// Error flags raised by kernels (device int[NFLAGS]); the C ABI maps them to the
+// reference's fatal messages.
+enum Flag { FLAG_INVALID_LKL = 0, FLAG_FW_BW = 1, FLAG_INVALID_MAF = 2, FLAG_NAN = 3, NFLAGS = 8 };
+
+// ---------------- exact mode (kernels_exact.hip) ----------------
+// All arrays site-major: gl [S][I][3], eprob [S][I][2], fw [S+1][I][2], marg [S][I].
+
+// e_prob[s][i][k] = calc_emission(gl[s][i], freq[s], k)   (shared/HMM.cpp:144-154)
+void launch_emission_exact(hipStream_t st, const double* gl, const double* freq, double* eprob,
+                           uint64_t S, uint64_t I, int* flags);
+
+// forward recursion (shared/HMM.cpp:6-28) for n_pts (individual, F, alpha) points;
+// ind == nullptr means point p is individual p.  fw (nullable) receives Fw.
+void launch_forward_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                          uint64_t I, uint32_t n_pts, const uint32_t* ind, const double* F,
+                          const double* alpha, double* lkl_out, double* fw, int* flags);
+
+// backward recursion + posteriors + Fw/Bw check (shared/HMM.cpp:33-60, EM.cpp:166-185)
+void launch_backward_exact(hipStream_t st, const double* eprob, const double* pos, const double* fw,
+                           uint64_t S, uint64_t I, const double* indF, const double* alpha,
+                           const double* ind_lkl, double* marg, int* flags);
+
+// est_maf per site (shared/gen_func.cpp:974-1009): gl_sites [S_own][I_tot][3],
+// marg_sites [S_own][I_tot] -> freq_out[S_own]; passes_out (nullable) counts passes.
+void launch_estmaf_exact(hipStream_t st, const double* gl_sites, const double* marg_sites,
+                         uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out);
+
+// Viterbi (shared/HMM.cpp:98-125): bp [S][I] scratch bytes, path_sites [S][I] bytes
+void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                          uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
+                          uint8_t* path_sites);
+
+// ---------------- layout helpers (kernels_util.hip) ----------------
+// out[c][r] = in[r][c]
+void launch_transpose_f64(hipStream_t st, const double* in, double* out, uint64_t rows, uint64_t cols);
+void launch_transpose_u8(hipStream_t st, const uint8_t* in, uint8_t* out, uint64_t rows, uint64_t cols);
+// eprob [S][I][2] -> out [I][S][2]
+void launch_transpose_pairs_f64(hipStream_t st, const double* in, double* out, uint64_t rows,
+                                uint64_t cols);
+// out[(s - lo) * I + i] = marg[s][i] for s in [lo, hi): a contiguous slice copy in site-major
+void launch_copy_f64(hipStream_t st, const double* in, double* out, uint64_t n);
+
+}  // namespace nghmm

@@ -1,0 +1,481 @@
+// kernels_exact.hip -- exact-mode HIP kernels for gfx950.
+//
+// "Exact" = the reference's log-space formulation in the reference's operation
+// order (shared/HMM.cpp, shared/gen_func.cpp:856-1009), with exp/log taken from
+// detmath.h.  IEEE add/sub/mul/div are correctly rounded on CDNA4 and this file
+// is compiled with -ffp-contract=off, so every value equals, bit for bit, what
+// the oracle's `det` build computes on the host.  That turns "GPU == CPU" into a
+// testable statement despite the chaotic finite-difference M-step (SURVEY.md
+// finding 4).  These kernels are the correctness anchor; kernels_fast.hip holds
+// the throughput path.
+//
+// Parallel decomposition: the recursions are sequential in the site index, so a
+// lane owns one (individual, parameter point) chain and walks the sites; lanes of
+// a wave own consecutive individuals, which makes every site-major load a
+// contiguous 1 KiB (e_prob) or 512 B (marg) segment.  Loads are software-
+// prefetched one group of sites ahead because a chain has no other work to hide
+// HBM latency behind.  est_maf gives a wave to a site and strides lanes over the
+// individuals, then accumulates the per-individual terms in individual order so
+// the sums round exactly like the reference's serial loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "detmath.h"
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace nghmm {
+
+namespace {
+
+constexpr double kINF = 1e15;      // shared/gen_func.hpp:15
+constexpr double kEPS = 1e-5;      // shared/gen_func.hpp:16
+#define NEG_INFINITY (-__builtin_huge_val())
+
+// shared/gen_func.cpp:135-151, n = 2.  max() there is the macro (a >= b ? a : b).
+__device__ __forceinline__ double logsum2(double a0, double a1) {
+  double M = a0;
+  M = (a1 >= M) ? a1 : M;
+  if (M == NEG_INFINITY) return NEG_INFINITY;
+  double sum = 0;
+  sum += det_exp(a0 - M);
+  sum += det_exp(a1 - M);
+  return det_log(sum) + M;
+}
+
+// shared/gen_func.cpp:135-151, n = 3
+__device__ __forceinline__ double logsum3(double a0, double a1, double a2) {
+  double M = a0;
+  M = (a1 >= M) ? a1 : M;
+  M = (a2 >= M) ? a2 : M;
+  if (M == NEG_INFINITY) return NEG_INFINITY;
+  double sum = 0;
+  sum += det_exp(a0 - M);
+  sum += det_exp(a1 - M);
+  sum += det_exp(a2 - M);
+  return det_log(sum) + M;
+}
+
+// conv_space(.., log) for one value (shared/gen_func.cpp:123-130)
+__device__ __forceinline__ double log_or_minf(double v) {
+  double r = det_log(v);
+  return (r == NEG_INFINITY) ? -kINF : r;
+}
+
+// calc_HWE, log scale (shared/gen_func.cpp:938-957)
+__device__ __forceinline__ void hwe_log(double maf, double F, double& h0, double& h1, double& h2) {
+  h0 = (1 - maf) * (1 - maf) + (1 - maf) * maf * F;
+  h1 = 2 * (1 - maf) * maf - 2 * (1 - maf) * maf * F;
+  h2 = maf * maf + (1 - maf) * maf * F;
+  h0 = log_or_minf(h0);
+  h1 = log_or_minf(h1);
+  h2 = log_or_minf(h2);
+  if (F == 1) h1 = -kINF;
+}
+
+// calc_emission (shared/HMM.cpp:144-154)
+__device__ __forceinline__ double emission_log(double g0, double g1, double g2, double maf, int k) {
+  double h0, h1, h2;
+  hwe_log(maf, (double)k, h0, h1, h2);
+  return logsum3(g0 + h0, g1 + h1, g2 + h2);
+}
+
+// the four log transition probabilities of one site (shared/HMM.cpp:130-139)
+struct Trans {
+  double t00, t10, t01, t11;  // t[k][l]
+};
+__device__ __forceinline__ Trans calc_trans_all(double q0, double q1, double alpha, double d) {
+  Trans t;
+  double c = det_exp(-alpha * d);
+  double b0 = (1 - c) * q0;
+  double b1 = (1 - c) * q1;
+  t.t10 = det_log(b0);      // k=1 -> l=0
+  t.t00 = det_log(b0 + c);  // k=0 -> l=0
+  t.t01 = det_log(b1);      // k=0 -> l=1
+  t.t11 = det_log(b1 + c);  // k=1 -> l=1
+  return t;
+}
+
+constexpr int U = 4;  // sites per prefetch group
+
+// ------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_emission_exact(const double* __restrict__ gl, const double* __restrict__ freq,
+                 double* __restrict__ eprob, uint64_t S, uint64_t I, int* __restrict__ flags) {
+  const uint64_t n = S * I;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = c / I;
+    const double maf = freq[s];
+    const double g0 = gl[c * 3], g1 = gl[c * 3 + 1], g2 = gl[c * 3 + 2];
+    double e0, e1;
+    if (maf < 0 || maf > 1) {
+      flags[FLAG_INVALID_MAF] = 1;
+      e0 = e1 = __builtin_nan("");
+    } else {
+      e0 = emission_log(g0, g1, g2, maf, 0);
+      e1 = emission_log(g0, g1, g2, maf, 1);
+    }
+    eprob[c * 2] = e0;
+    eprob[c * 2 + 1] = e1;
+  }
+}
+
+// ------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_forward_exact(const double* __restrict__ eprob, const double* __restrict__ pos, uint64_t S,
+                uint64_t I, uint32_t n_pts, const uint32_t* __restrict__ ind,
+                const double* __restrict__ Fv, const double* __restrict__ Av,
+                double* __restrict__ lkl_out, double* __restrict__ fw, int* __restrict__ flags) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  const uint64_t i = ind ? ind[p] : p;
+  const double f = Fv[p], a = Av[p];
+  const double q0 = 1 - f, q1 = f;  // EM.cpp:415
+  double prev0 = det_log(q0), prev1 = det_log(q1);
+  if (fw) {
+    fw[i * 2] = prev0;
+    fw[i * 2 + 1] = prev1;
+  }
+  bool bad = false;
+  const double2* e2 = reinterpret_cast<const double2*>(eprob);
+
+  double2 ecur[U], enxt[U];
+  double dcur[U], dnxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t s = u;
+    const bool v = s < S;
+    ecur[u] = v ? e2[s * I + i] : double2{0, 0};
+    dcur[u] = v ? pos[s] : 0.0;
+  }
+  for (uint64_t s0 = 0; s0 < S; s0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t s = s0 + U + u;
+      const bool v = s < S;
+      enxt[u] = v ? e2[s * I + i] : double2{0, 0};
+      dnxt[u] = v ? pos[s] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t s = s0 + u;
+      if (s < S) {
+        const Trans t = calc_trans_all(q0, q1, a, dcur[u]);
+        double tmp0 = prev0 + t.t00, tmp1 = prev1 + t.t10;
+        bad |= (tmp0 != tmp0) | (tmp1 != tmp1);
+        const double cur0 = logsum2(tmp0, tmp1) + ecur[u].x;
+        tmp0 = prev0 + t.t01;
+        tmp1 = prev1 + t.t11;
+        bad |= (tmp0 != tmp0) | (tmp1 != tmp1);
+        const double cur1 = logsum2(tmp0, tmp1) + ecur[u].y;
+        prev0 = cur0;
+        prev1 = cur1;
+        if (fw) {
+          fw[((s + 1) * I + i) * 2] = cur0;
+          fw[((s + 1) * I + i) * 2 + 1] = cur1;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ecur[u] = enxt[u];
+      dcur[u] = dnxt[u];
+    }
+  }
+  lkl_out[p] = logsum2(prev0, prev1);
+  if (bad) flags[FLAG_INVALID_LKL] = 1;
+}
+
+// ------------------------------------------------------------------
+// shared/gen_func.cpp:55-70
+__device__ __forceinline__ double check_interv(double v, bool& isnan_flag) {
+  if (v != v) {
+    isnan_flag = true;
+    return v;
+  }
+  if (v < kEPS)
+    v = 0;
+  else if (v > 1 - kEPS)
+    v = 1;
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+k_backward_exact(const double* __restrict__ eprob, const double* __restrict__ pos,
+                 const double* __restrict__ fw, uint64_t S, uint64_t I,
+                 const double* __restrict__ indF, const double* __restrict__ alpha,
+                 const double* __restrict__ ind_lkl, double* __restrict__ marg,
+                 int* __restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  const double f = indF[i], a = alpha[i];
+  const double q0 = 1 - f, q1 = f;
+  const double lkl = ind_lkl[i];
+  double b0 = det_log(1.0), b1 = det_log(1.0);  // HMM.cpp:37
+  bool bad = false, nanflag = false;
+  const double2* e2 = reinterpret_cast<const double2*>(eprob);
+  const double2* f2 = reinterpret_cast<const double2*>(fw);
+
+  // walk s = S .. 1 (reference numbering); site index here is s-1
+  double2 ecur[U], enxt[U], fcur[U], fnxt[U];
+  double dcur[U], dnxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool v = (uint64_t)u < S;
+    const uint64_t s = S - (v ? u : 0);  // reference site number
+    ecur[u] = v ? e2[(s - 1) * I + i] : double2{0, 0};
+    fcur[u] = v ? f2[s * I + i] : double2{0, 0};
+    dcur[u] = v ? pos[s - 1] : 0.0;
+  }
+  for (uint64_t r0 = 0; r0 < S; r0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t r = r0 + U + u;
+      const bool v = r < S;
+      const uint64_t s = S - (v ? r : 0);
+      enxt[u] = v ? e2[(s - 1) * I + i] : double2{0, 0};
+      fnxt[u] = v ? f2[s * I + i] : double2{0, 0};
+      dnxt[u] = v ? pos[s - 1] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t r = r0 + u;
+      if (r < S) {
+        const uint64_t s = S - r;
+        // posterior of site s (EM.cpp:184); k = 0 is computed for its NaN check only
+        const double m0 = check_interv(det_exp(b0 + fcur[u].x - lkl), nanflag);
+        const double m1 = check_interv(det_exp(b1 + fcur[u].y - lkl), nanflag);
+        (void)m0;
+        marg[(s - 1) * I + i] = m1;
+        // Bw[s-1] (HMM.cpp:40-52)
+        const Trans t = calc_trans_all(q0, q1, a, dcur[u]);
+        double tmp0 = t.t00 + ecur[u].x + b0;
+        double tmp1 = t.t01 + ecur[u].y + b1;
+        bad |= (tmp0 != tmp0) | (tmp1 != tmp1);
+        const double nb0 = logsum2(tmp0, tmp1);
+        tmp0 = t.t10 + ecur[u].x + b0;
+        tmp1 = t.t11 + ecur[u].y + b1;
+        bad |= (tmp0 != tmp0) | (tmp1 != tmp1);
+        const double nb1 = logsum2(tmp0, tmp1);
+        b0 = nb0;
+        b1 = nb1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ecur[u] = enxt[u];
+      fcur[u] = fnxt[u];
+      dcur[u] = dnxt[u];
+    }
+  }
+  b0 += det_log(q0);  // HMM.cpp:55-56
+  b1 += det_log(q1);
+  const double bl = logsum2(b0, b1);
+  const double2 fS = f2[S * I + i];
+  const double fl = logsum2(fS.x, fS.y);
+  const double diff = fl - bl;
+  const double adiff = (diff >= 0) ? diff : -diff;  // the reference's abs macro
+  if (adiff > 0.001) flags[FLAG_FW_BW] = 1;         // EM.cpp:167
+  if (bad) flags[FLAG_INVALID_LKL] = 1;
+  if (nanflag) flags[FLAG_NAN] = 1;
+}
+
+// ------------------------------------------------------------------
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  const uint64_t bits = ngh_bits(v);
+  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)(bits & 0xffffffffu), lane);
+  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), lane);
+  return ngh_from_bits(((uint64_t)hi << 32) | lo);
+}
+
+// One wave per site.  Per pass every lane evaluates the posterior genotype terms
+// of its individuals, then the 64 terms of a chunk are added to (num, den) in
+// individual order by all lanes redundantly, so the running sums are wave-uniform
+// and round exactly as the reference's `for i` loop (gen_func.cpp:984-1003).
+__global__ void __launch_bounds__(256)
+k_estmaf_exact(const double* __restrict__ gl, const double* __restrict__ marg, uint64_t S_own,
+               uint64_t I, double* __restrict__ freq_out, uint32_t* __restrict__ passes_out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (site >= S_own) return;
+  const double* gls = gl + site * I * 3;
+  const double* ms = marg + site * I;
+
+  int iters = 0;
+  uint32_t passes = 0;
+  double num = 0, den = 0;
+  double prev_freq, freq = 0.01;
+  bool again;
+  do {
+    prev_freq = freq;
+    ++passes;
+    for (uint64_t base = 0; base < I; base += 64) {
+      const uint64_t i = base + lane;
+      double tn = 0, td = 0;
+      if (i < I) {
+        const double F = ms[i];
+        const double g0 = gls[i * 3], g1 = gls[i * 3 + 1], g2 = gls[i * 3 + 2];
+        double h0, h1, h2;
+        hwe_log(freq, F, h0, h1, h2);
+        double p0 = g0 + h0, p1 = g1 + h1, p2 = g2 + h2;  // post_prob, gen_func.cpp:920-932
+        const double norm = logsum3(p0, p1, p2);
+        p0 -= norm;
+        p1 -= norm;
+        p2 -= norm;
+        p0 = det_exp(p0);
+        p1 = det_exp(p1);
+        p2 = det_exp(p2);
+        tn = p1 + p2 * (2 - F);
+        td = 2 * p1 + (p0 + p2) * (2 - F);
+      }
+      const int cnt = (I - base) < 64 ? (int)(I - base) : 64;
+      for (int j = 0; j < cnt; ++j) {
+        num += bcast_lane(tn, j);
+        den += bcast_lane(td, j);
+      }
+    }
+    freq = num / den;
+    const double dlt = prev_freq - freq;
+    const double adl = (dlt >= 0) ? dlt : -dlt;
+    again = (adl > kEPS) && (iters++ < 100);
+  } while (again);
+  if (lane == 0) {
+    freq_out[site] = freq;
+    if (passes_out) passes_out[site] = passes;
+  }
+}
+
+// ------------------------------------------------------------------
+// Viterbi forward sweep: back-pointers for both states of every site.
+__global__ void __launch_bounds__(64)
+k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__ pos, uint64_t S,
+                    uint64_t I, const double* __restrict__ indF, const double* __restrict__ alpha,
+                    uint8_t* __restrict__ bp, uint8_t* __restrict__ last_state) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  const double f = indF[i], a = alpha[i];
+  const double q0 = 1 - f, q1 = f;
+  double v0 = det_log(q0), v1 = det_log(q1);
+  const double2* e2 = reinterpret_cast<const double2*>(eprob);
+
+  double2 ecur[U], enxt[U];
+  double dcur[U], dnxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t s = u;
+    const bool v = s < S;
+    ecur[u] = v ? e2[s * I + i] : double2{0, 0};
+    dcur[u] = v ? pos[s] : 0.0;
+  }
+  for (uint64_t s0 = 0; s0 < S; s0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t s = s0 + U + u;
+      const bool v = s < S;
+      enxt[u] = v ? e2[s * I + i] : double2{0, 0};
+      dnxt[u] = v ? pos[s] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t s = s0 + u;
+      if (s < S) {
+        const Trans t = calc_trans_all(q0, q1, a, dcur[u]);
+        // l = 0 (HMM.cpp:105-116)
+        double vmax = -kINF;
+        int k0 = 0;
+        double pval = v0 + t.t00;
+        if (vmax < pval) { vmax = pval; k0 = 0; }
+        pval = v1 + t.t10;
+        if (vmax < pval) { vmax = pval; k0 = 1; }
+        v0 = vmax + ecur[u].x;  // in place: l = 1 below reads the NEW v0 (reference behaviour)
+        // l = 1
+        vmax = -kINF;
+        int k1 = 0;
+        pval = v0 + t.t01;
+        if (vmax < pval) { vmax = pval; k1 = 0; }
+        pval = v1 + t.t11;
+        if (vmax < pval) { vmax = pval; k1 = 1; }
+        v1 = vmax + ecur[u].y;
+        bp[s * I + i] = (uint8_t)(k0 | (k1 << 1));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ecur[u] = enxt[u];
+      dcur[u] = dnxt[u];
+    }
+  }
+  // array_max_pos (gen_func.cpp:73-84): strict >, starting from -inf
+  int res = 0;
+  double mx = NEG_INFINITY;
+  if (v0 > mx) { res = 0; mx = v0; }
+  if (v1 > mx) { res = 1; mx = v1; }
+  last_state[i] = (uint8_t)res;
+}
+
+// Trace back (HMM.cpp:119-122): path of reference site s (1-based) = state at s.
+__global__ void __launch_bounds__(64)
+k_viterbi_back(const uint8_t* __restrict__ bp, const uint8_t* __restrict__ last_state, uint64_t S,
+               uint64_t I, uint8_t* __restrict__ path_sites) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I || S == 0) return;
+  int st = last_state[i];
+  for (uint64_t s = S; s >= 1; --s) {
+    path_sites[(s - 1) * I + i] = (uint8_t)st;  // path[s]
+    const int b = bp[(s - 1) * I + i];          // Vi[s][.]
+    st = (b >> st) & 1;                         // path[s-1] = Vi[s][path[s]]
+  }
+}
+
+}  // namespace
+
+void launch_emission_exact(hipStream_t st, const double* gl, const double* freq, double* eprob,
+                           uint64_t S, uint64_t I, int* flags) {
+  const uint64_t n = S * I;
+  if (n == 0) return;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(k_emission_exact, dim3((unsigned)blocks), dim3(256), 0, st, gl, freq, eprob, S,
+                     I, flags);
+}
+
+void launch_forward_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                          uint64_t I, uint32_t n_pts, const uint32_t* ind, const double* F,
+                          const double* alpha, double* lkl_out, double* fw, int* flags) {
+  if (n_pts == 0) return;
+  hipLaunchKernelGGL(k_forward_exact, dim3((n_pts + 63) / 64), dim3(64), 0, st, eprob, pos, S, I,
+                     n_pts, ind, F, alpha, lkl_out, fw, flags);
+}
+
+void launch_backward_exact(hipStream_t st, const double* eprob, const double* pos, const double* fw,
+                           uint64_t S, uint64_t I, const double* indF, const double* alpha,
+                           const double* ind_lkl, double* marg, int* flags) {
+  if (I == 0) return;
+  hipLaunchKernelGGL(k_backward_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob, pos,
+                     fw, S, I, indF, alpha, ind_lkl, marg, flags);
+}
+
+void launch_estmaf_exact(hipStream_t st, const double* gl_sites, const double* marg_sites,
+                         uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out) {
+  if (S_own == 0) return;
+  hipLaunchKernelGGL(k_estmaf_exact, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
+                     marg_sites, S_own, I_tot, freq_out, passes_out);
+}
+
+void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                          uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
+                          uint8_t* path_sites) {
+  if (I == 0 || S == 0) return;
+  // the last-state bytes live behind the back-pointers (bp holds S*I + I bytes)
+  uint8_t* last_state = bp + S * I;
+  hipLaunchKernelGGL(k_viterbi_fwd_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob,
+                     pos, S, I, indF, alpha, bp, last_state);
+  hipLaunchKernelGGL(k_viterbi_back, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, bp,
+                     last_state, S, I, path_sites);
+}
+
+}  // namespace nghmm

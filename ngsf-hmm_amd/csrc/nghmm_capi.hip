@@ -1,0 +1,680 @@
+// nghmm_capi.hip -- implementation of include/nghmm.h on one MI355X.
+//
+// Device-resident state, site-major:
+//   gl     [S][I][3]  log GL, as uploaded            24 B / site-individual
+//   eprob  [S][I][2]  log emissions                  16 B
+//   fw     [S+1][I][2] forward variable (E-step)     16 B
+//   marg   [S][I]     posterior of the IBD state      8 B
+//   pos[S], freq[S], indF[I], alpha[I], ind_lkl[I]
+// Nothing of size S*I crosses PCIe inside an EM iteration: per round of the
+// indF/alpha M-step only the probe points (20 B each) go down and their
+// log-likelihoods (8 B each) come back.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nghmm.h"
+#include "bfgs_batch.hpp"
+#include "kernels.hpp"
+#include "kernels_fast.hpp"
+
+using namespace nghmm;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess) {                                                       \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,  \
+                __LINE__);                                                         \
+      return NGHMM_ERR_HIP;                                                        \
+    }                                                                              \
+  } while (0)
+
+enum Slot { SLOT_EMISSION = 0, SLOT_FORWARD = 1, SLOT_BACKWARD = 2, SLOT_LKL = 3, SLOT_ESTMAF = 4,
+            SLOT_VITERBI = 5, NSLOTS = 6 };
+
+}  // namespace
+
+struct nghmm_handle {
+  uint64_t I = 0, S = 0;
+  int device = 0, mode = NGHMM_MODE_EXACT;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool loaded = false;
+
+  double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
+         *d_marg = nullptr, *d_indF = nullptr, *d_alpha = nullptr, *d_ind_lkl = nullptr;
+  int* d_flags = nullptr;
+
+  uint32_t* d_pt_ind = nullptr;
+  double *d_pt_F = nullptr, *d_pt_A = nullptr, *d_pt_lkl = nullptr;
+  size_t pt_cap = 0;
+
+  uint8_t *d_bp = nullptr, *d_path_sites = nullptr, *d_path = nullptr;
+  double* d_tmp = nullptr;  // S*I*2 doubles, transposes for host read-back
+  uint32_t* d_passes = nullptr;
+
+  // multi-GPU shard
+  uint64_t I_tot = 0, ind_begin = 0, site_begin = 0, S_own = 0;
+  double* d_gl_shard = nullptr;
+
+  FastState fast;  // fast-mode layouts (kernels_fast.hip)
+
+  std::vector<double> h_indF, h_alpha;
+  double ms[NSLOTS] = {0, 0, 0, 0, 0, 0};
+  uint32_t launches[NSLOTS] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int use_device(nghmm_t* h) {
+  HIP_TRY(hipSetDevice(h->device));
+  return NGHMM_OK;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t n) {
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) {
+    set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return NGHMM_ERR_NOMEM;
+  }
+  return NGHMM_OK;
+}
+
+void tic(nghmm_t* h) { (void)hipEventRecord(h->ev0, h->stream); }
+
+// stops the timer, synchronises the stream and stores/accumulates the time
+int toc(nghmm_t* h, int slot, bool accumulate) {
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  if (accumulate) {
+    h->ms[slot] += ms;
+    h->launches[slot] += 1;
+  } else {
+    h->ms[slot] = ms;
+    h->launches[slot] = 1;
+  }
+  return NGHMM_OK;
+}
+
+int clear_flags(nghmm_t* h) {
+  HIP_TRY(hipMemsetAsync(h->d_flags, 0, NFLAGS * sizeof(int), h->stream));
+  return NGHMM_OK;
+}
+
+// Reads the kernel error flags and maps them to the reference's fatal errors.
+int check_flags(nghmm_t* h) {
+  int f[NFLAGS];
+  HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (f[FLAG_INVALID_LKL]) {
+    set_error("invalid Lkl found!");
+    return NGHMM_ERR_INVALID_LKL;
+  }
+  if (f[FLAG_FW_BW]) {
+    set_error("Fw and Bw lkl do not match!");
+    return NGHMM_ERR_FW_BW;
+  }
+  if (f[FLAG_INVALID_MAF]) {
+    set_error("invalid MAF!");
+    return NGHMM_ERR_INVALID_MAF;
+  }
+  if (f[FLAG_NAN]) {
+    set_error("value is NaN!");
+    return NGHMM_ERR_NAN;
+  }
+  return NGHMM_OK;
+}
+
+int ensure_points(nghmm_t* h, size_t n) {
+  if (n <= h->pt_cap) return NGHMM_OK;
+  size_t cap = n + n / 4 + 1024;
+  if (h->d_pt_ind) (void)hipFree(h->d_pt_ind);
+  if (h->d_pt_F) (void)hipFree(h->d_pt_F);
+  if (h->d_pt_A) (void)hipFree(h->d_pt_A);
+  if (h->d_pt_lkl) (void)hipFree(h->d_pt_lkl);
+  h->d_pt_ind = nullptr;
+  h->d_pt_F = h->d_pt_A = h->d_pt_lkl = nullptr;
+  h->pt_cap = 0;
+  int rc;
+  if ((rc = dev_alloc(&h->d_pt_ind, cap))) return rc;
+  if ((rc = dev_alloc(&h->d_pt_F, cap))) return rc;
+  if ((rc = dev_alloc(&h->d_pt_A, cap))) return rc;
+  if ((rc = dev_alloc(&h->d_pt_lkl, cap))) return rc;
+  h->pt_cap = cap;
+  return NGHMM_OK;
+}
+
+int ensure_tmp(nghmm_t* h) {
+  if (h->d_tmp) return NGHMM_OK;
+  return dev_alloc(&h->d_tmp, h->S * h->I * 2);
+}
+
+// objective launch for points already on the device
+int launch_lkl_points(nghmm_t* h, uint32_t n_pts) {
+  if (h->mode == NGHMM_MODE_FAST)
+    return fast_lkl_batch(h->fast, h->stream, n_pts, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
+                          h->d_pt_lkl, h->d_flags)
+               ? NGHMM_OK
+               : NGHMM_ERR_HIP;
+  launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind, h->d_pt_F,
+                       h->d_pt_A, h->d_pt_lkl, nullptr, h->d_flags);
+  return NGHMM_OK;
+}
+
+int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
+                   const double* alpha, double* lkl, bool accumulate) {
+  if (n_pts == 0) return NGHMM_OK;
+  for (uint32_t p = 0; p < n_pts; ++p)
+    if (ind[p] >= h->I) {
+      set_error("nghmm_lkl_batch: individual index %u out of range", ind[p]);
+      return NGHMM_ERR_ARG;
+    }
+  int rc;
+  if ((rc = ensure_points(h, n_pts))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_pt_ind, ind, n_pts * sizeof(uint32_t), hipMemcpyHostToDevice,
+                         h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_pt_F, F, n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_pt_A, alpha, n_pts * sizeof(double), hipMemcpyHostToDevice,
+                         h->stream));
+  if ((rc = clear_flags(h))) return rc;
+  tic(h);
+  if ((rc = launch_lkl_points(h, n_pts))) return rc;
+  if ((rc = toc(h, SLOT_LKL, accumulate))) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(lkl, h->d_pt_lkl, n_pts * sizeof(double), hipMemcpyDeviceToHost,
+                         h->stream));
+  return check_flags(h);
+}
+
+int emission_impl(nghmm_t* h) {
+  int rc;
+  if ((rc = clear_flags(h))) return rc;
+  tic(h);
+  if (h->mode == NGHMM_MODE_FAST) {
+    if (!fast_refresh_site_tables(h->fast, h->stream, h->d_freq, h->d_flags)) return NGHMM_ERR_HIP;
+  } else {
+    launch_emission_exact(h->stream, h->d_gl, h->d_freq, h->d_eprob, h->S, h->I, h->d_flags);
+  }
+  if ((rc = toc(h, SLOT_EMISSION, false))) return rc;
+  HIP_TRY(hipGetLastError());
+  return check_flags(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nghmm_last_error(void) { return g_last_error.c_str(); }
+
+const char* nghmm_strerror(int code) {
+  switch (code) {
+    case NGHMM_OK: return "ok";
+    case NGHMM_ERR_INVALID_LKL: return "invalid Lkl found!";
+    case NGHMM_ERR_FW_BW: return "Fw and Bw lkl do not match!";
+    case NGHMM_ERR_INVALID_MAF: return "invalid MAF!";
+    case NGHMM_ERR_NAN: return "value is NaN!\n";
+    case NGHMM_ERR_FREQ_EST2: return "invalid allele frequencies";
+    case NGHMM_ERR_ARG: return "invalid argument";
+    case NGHMM_ERR_HIP: return "HIP runtime error";
+    case NGHMM_ERR_NOMEM: return "out of device memory";
+    default: return "unknown error";
+  }
+}
+
+int nghmm_has_hip(void) { return 1; }
+
+int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, int mode) {
+  if (!out || n_ind == 0 || n_sites == 0 || n_ind > 0xffffffffull ||
+      (mode != NGHMM_MODE_EXACT && mode != NGHMM_MODE_FAST)) {
+    set_error("nghmm_create: bad argument");
+    return NGHMM_ERR_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available (%s): the hot path has no CPU fallback",
+              hipGetErrorString(e));
+    return NGHMM_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("nghmm_create: device %d out of range (%d devices)", device, ndev);
+    return NGHMM_ERR_ARG;
+  }
+  nghmm_t* h = new (std::nothrow) nghmm_handle;
+  if (!h) return NGHMM_ERR_NOMEM;
+  h->I = n_ind;
+  h->S = n_sites;
+  h->device = device;
+  h->mode = mode;
+  h->I_tot = n_ind;
+  h->S_own = n_sites;
+  int rc = NGHMM_OK;
+  do {
+    if (hipSetDevice(device) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    const size_t cells = (size_t)n_ind * n_sites;
+    if ((rc = dev_alloc(&h->d_gl, cells * 3))) break;
+    if ((rc = dev_alloc(&h->d_pos, n_sites))) break;
+    if ((rc = dev_alloc(&h->d_freq, n_sites))) break;
+    if ((rc = dev_alloc(&h->d_marg, cells))) break;
+    if ((rc = dev_alloc(&h->d_indF, n_ind))) break;
+    if ((rc = dev_alloc(&h->d_alpha, n_ind))) break;
+    if ((rc = dev_alloc(&h->d_ind_lkl, n_ind))) break;
+    if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
+    if (mode == NGHMM_MODE_EXACT) {
+      if ((rc = dev_alloc(&h->d_eprob, cells * 2))) break;
+      if ((rc = dev_alloc(&h->d_fw, (cells + n_ind) * 2))) break;
+    }
+    if (hipMemset(h->d_marg, 0, cells * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    if (hipMemset(h->d_freq, 0, n_sites * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    h->h_indF.assign(n_ind, 0.0);
+    h->h_alpha.assign(n_ind, 0.0);
+    if (mode == NGHMM_MODE_FAST && !fast_create(h->fast, n_ind, n_sites)) { rc = NGHMM_ERR_NOMEM; break; }
+  } while (0);
+  if (rc != NGHMM_OK) {
+    if (g_last_error.empty()) set_error("nghmm_create failed (%d)", rc);
+    nghmm_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return NGHMM_OK;
+}
+
+int nghmm_destroy(nghmm_t* h) {
+  if (!h) return NGHMM_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->d_gl, h->d_pos, h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
+                  h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
+                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes,
+                  h->d_gl_shard};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  fast_destroy(h->fast);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return NGHMM_OK;
+}
+
+static int after_gl_load(nghmm_t* h) {
+  h->loaded = true;
+  if (h->mode == NGHMM_MODE_FAST) {
+    if (!fast_load(h->fast, h->stream, h->d_gl, h->d_pos)) return NGHMM_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return NGHMM_OK;
+}
+
+int nghmm_load_gl(nghmm_t* h, const double* gl, const double* pos) {
+  if (!h || !gl || !pos) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t cells = (size_t)h->I * h->S;
+  HIP_TRY(hipMemcpyAsync(h->d_gl, gl, cells * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return after_gl_load(h);
+}
+
+int nghmm_load_gl_device(nghmm_t* h, const double* d_gl, const double* d_pos) {
+  if (!h || !d_gl || !d_pos) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t cells = (size_t)h->I * h->S;
+  HIP_TRY(hipMemcpyAsync(h->d_gl, d_gl, cells * 3 * sizeof(double), hipMemcpyDeviceToDevice,
+                         h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_pos, d_pos, h->S * sizeof(double), hipMemcpyDeviceToDevice,
+                         h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return after_gl_load(h);
+}
+
+int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const double* freq) {
+  if (!h) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (indF) {
+    std::memcpy(h->h_indF.data(), indF, h->I * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(h->d_indF, indF, h->I * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  if (alpha) {
+    std::memcpy(h->h_alpha.data(), alpha, h->I * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(h->d_alpha, alpha, h->I * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+  }
+  if (freq)
+    HIP_TRY(hipMemcpyAsync(h->d_freq, freq, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_get_params(nghmm_t* h, double* indF, double* alpha, double* freq) {
+  if (!h) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (indF) std::memcpy(indF, h->h_indF.data(), h->I * sizeof(double));
+  if (alpha) std::memcpy(alpha, h->h_alpha.data(), h->I * sizeof(double));
+  if (freq) {
+    HIP_TRY(hipMemcpyAsync(freq, h->d_freq, h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return NGHMM_OK;
+}
+
+int nghmm_emission(nghmm_t* h) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  return emission_impl(h);
+}
+
+int nghmm_estep(nghmm_t* h, double* ind_lkl) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if ((rc = clear_flags(h))) return rc;
+  if (h->mode == NGHMM_MODE_FAST) {
+    tic(h);
+    if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_marg, h->d_flags))
+      return NGHMM_ERR_HIP;
+    if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
+    h->ms[SLOT_BACKWARD] = 0;
+    h->launches[SLOT_BACKWARD] = 0;
+  } else {
+    tic(h);
+    launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr,
+                         h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_fw, h->d_flags);
+    if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
+    tic(h);
+    launch_backward_exact(h->stream, h->d_eprob, h->d_pos, h->d_fw, h->S, h->I, h->d_indF,
+                          h->d_alpha, h->d_ind_lkl, h->d_marg, h->d_flags);
+    if ((rc = toc(h, SLOT_BACKWARD, false))) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  if (ind_lkl)
+    HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+  return check_flags(h);
+}
+
+int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
+                    const double* alpha, double* lkl) {
+  if (!h || !h->loaded || (n_pts && (!ind || !F || !alpha || !lkl))) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  return lkl_batch_impl(h, n_pts, ind, F, alpha, lkl, false);
+}
+
+int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  h->ms[SLOT_LKL] = 0;
+  h->launches[SLOT_LKL] = 0;
+  if (indF_fixed && alpha_fixed) return NGHMM_OK;  // EM.cpp:191-193
+
+  BfgsBatch batch;
+  batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
+  std::vector<uint32_t> ind;
+  std::vector<double> F, A, lkl;
+  while (!batch.done()) {
+    const size_t n = batch.gather(ind, F, A);
+    lkl.resize(n);
+    if (n) {
+      if ((rc = lkl_batch_impl(h, (uint32_t)n, ind.data(), F.data(), A.data(), lkl.data(), true)))
+        return rc;
+    }
+    batch.scatter(lkl.data());
+  }
+  batch.result(h->h_indF.data(), h->h_alpha.data());
+  HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
+                         h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_alpha, h->h_alpha.data(), h->I * sizeof(double),
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (stats) {
+    stats->rounds = batch.rounds();
+    stats->points = batch.points();
+    stats->ref_forward_calls = batch.ref_forward_calls();
+  }
+  return NGHMM_OK;
+}
+
+int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
+                          int alpha_fixed, nghmm_objective_fn fn, void* user,
+                          nghmm_mstep_stats* stats) {
+  if (!indF || !alpha || !fn) return NGHMM_ERR_ARG;
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  if (indF_fixed && alpha_fixed) return NGHMM_OK;
+  BfgsBatch batch;
+  batch.begin(n_ind, indF, alpha, indF_fixed != 0, alpha_fixed != 0);
+  std::vector<uint32_t> ind;
+  std::vector<double> F, A, lkl;
+  while (!batch.done()) {
+    const size_t n = batch.gather(ind, F, A);
+    lkl.resize(n);
+    for (size_t p = 0; p < n; ++p) lkl[p] = fn(ind[p], F[p], A[p], user);
+    batch.scatter(lkl.data());
+  }
+  batch.result(indF, alpha);
+  if (stats) {
+    stats->rounds = batch.rounds();
+    stats->points = batch.points();
+    stats->ref_forward_calls = batch.ref_forward_calls();
+  }
+  return NGHMM_OK;
+}
+
+static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double* d_marg_blocks,
+                              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* d_freq_out) {
+  int rc;
+  tic(h);
+  if (h->mode == NGHMM_MODE_FAST) {
+    if (!fast_estmaf(h->fast, h->stream, d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out))
+      return NGHMM_ERR_HIP;
+  } else {
+    if (I_blk != I_tot) {
+      set_error("exact-mode est_maf expects one posterior block");
+      return NGHMM_ERR_ARG;
+    }
+    launch_estmaf_exact(h->stream, d_gl_sites, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr);
+  }
+  if ((rc = toc(h, SLOT_ESTMAF, false))) return rc;
+  HIP_TRY(hipGetLastError());
+  return NGHMM_OK;
+}
+
+int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (freq_est == 0) return NGHMM_OK;  // EM.cpp:212-214
+  if (freq_est == 2) {
+    set_error("invalid allele frequencies");
+    return NGHMM_ERR_FREQ_EST2;
+  }
+  if (freq_est != 1) {
+    set_error("wrong MAF estimation method!");
+    return NGHMM_ERR_ARG;
+  }
+  if (h->I_tot != h->I) {
+    set_error("sharded handle: use nghmm_mstep_freq_sites_dev");
+    return NGHMM_ERR_ARG;
+  }
+  if ((rc = estmaf_and_refresh(h, h->d_gl, h->d_marg, h->S, h->I, h->I, h->d_freq))) return rc;
+  return emission_impl(h);
+}
+
+int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, double* ind_lkl,
+                  nghmm_mstep_stats* stats) {
+  int rc;
+  if ((rc = nghmm_estep(h, ind_lkl))) return rc;
+  if ((rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats))) return rc;
+  return nghmm_mstep_freq(h, freq_est);
+}
+
+int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
+  if (!h || !h->loaded || !path) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t cells = (size_t)h->I * h->S;
+  if (!h->d_bp && (rc = dev_alloc(&h->d_bp, cells + h->I))) return rc;
+  if (!h->d_path_sites && (rc = dev_alloc(&h->d_path_sites, cells))) return rc;
+  if (!h->d_path && (rc = dev_alloc(&h->d_path, cells))) return rc;
+  tic(h);
+  if (h->mode == NGHMM_MODE_FAST) {
+    if (!fast_viterbi(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_bp, h->d_path_sites))
+      return NGHMM_ERR_HIP;
+  } else {
+    launch_viterbi_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, h->d_indF, h->d_alpha,
+                         h->d_bp, h->d_path_sites);
+  }
+  launch_transpose_u8(h->stream, h->d_path_sites, h->d_path, h->S, h->I);
+  if ((rc = toc(h, SLOT_VITERBI, false))) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(path, h->d_path, cells, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
+  if (!h || !marg_ibd) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if ((rc = ensure_tmp(h))) return rc;
+  launch_transpose_f64(h->stream, h->d_marg, h->d_tmp, h->S, h->I);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(marg_ibd, h->d_tmp, (size_t)h->I * h->S * sizeof(double),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
+  if (!h || !e_prob) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if ((rc = ensure_tmp(h))) return rc;
+  if (h->mode == NGHMM_MODE_FAST) {
+    if (!fast_export_emissions(h->fast, h->stream, h->d_tmp)) return NGHMM_ERR_HIP;
+  } else {
+    launch_transpose_pairs_f64(h->stream, h->d_eprob, h->d_tmp, h->S, h->I);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(e_prob, h->d_tmp, (size_t)h->I * h->S * 2 * sizeof(double),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+// ---------------- multi-GPU ----------------
+
+int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uint64_t site_begin,
+                       uint64_t n_sites_own) {
+  if (!h || n_ind_total < h->I || ind_begin + h->I > n_ind_total ||
+      site_begin + n_sites_own > h->S || n_ind_total % h->I != 0) {
+    set_error("nghmm_shard_config: inconsistent shard (equal individuals per rank required)");
+    return NGHMM_ERR_ARG;
+  }
+  h->I_tot = n_ind_total;
+  h->ind_begin = ind_begin;
+  h->site_begin = site_begin;
+  h->S_own = n_sites_own;
+  return NGHMM_OK;
+}
+
+int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
+  if (!h || !gl_site_shard) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t n = (size_t)h->S_own * h->I_tot * 3;
+  if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
+  h->d_gl_shard = nullptr;
+  if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_gl_shard, gl_site_shard, n * sizeof(double), hipMemcpyHostToDevice,
+                         h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, double* d_out) {
+  if (!h || !d_out || site_lo > site_hi || site_hi > h->S) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  // marg is site-major [S][I]: the slice of a destination rank is contiguous
+  launch_copy_f64(h->stream, h->d_marg + site_lo * h->I, d_out, (site_hi - site_lo) * h->I);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_blocks, double* d_freq_out) {
+  if (!h || !d_marg_blocks || !d_freq_out || !h->d_gl_shard) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (h->mode != NGHMM_MODE_FAST && h->I_tot != h->I) {
+    // exact mode wants [S_own][I_tot]: re-block [rank][S_own][I] through the scratch buffer
+    set_error("exact-mode sharded est_maf is not available; use NGHMM_MODE_FAST");
+    return NGHMM_ERR_ARG;
+  }
+  if ((rc = estmaf_and_refresh(h, h->d_gl_shard, d_marg_blocks, h->S_own, h->I_tot, h->I,
+                               d_freq_out)))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all) {
+  if (!h || !d_freq_all) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_freq, d_freq_all, h->S * sizeof(double), hipMemcpyDeviceToDevice,
+                         h->stream));
+  return emission_impl(h);
+}
+
+void* nghmm_stream(nghmm_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int nghmm_synchronize(nghmm_t* h) {
+  if (!h) return NGHMM_ERR_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches) {
+  if (!h || slot < 0 || slot >= NSLOTS) return NGHMM_ERR_ARG;
+  if (ms) *ms = h->ms[slot];
+  if (launches) *launches = h->launches[slot];
+  return NGHMM_OK;
+}
+
+}  // extern "C"

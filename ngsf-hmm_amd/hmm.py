@@ -1,0 +1,325 @@
+"""Host-side mirror of the reference's EM interface over the C ABI (include/nghmm.h).
+
+Names follow the reference: ``EM`` (EM.cpp:27-135), ``iter_EM`` (EM.cpp:139-289),
+``viterbi`` (shared/HMM.cpp:98-125), ``lkl`` (EM.cpp:449-464), the ``params`` fields
+``indF / alpha / freq / marg_prob / ind_lkl / e_prob / path / tot_lkl``
+(ngsF-HMM.hpp:13-52).  Errors the reference reports through ``error()`` +
+``exit(-1)`` are raised as :class:`NgsFHMMError` carrying the same message.
+
+All arithmetic happens in ``libnghmm.so`` (HIP kernels).  This module never
+computes a result itself and has no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+MODE_EXACT = 0
+MODE_FAST = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class NgsFHMMError(RuntimeError):
+    """A fatal condition of the reference (its message) or a runtime failure."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class MstepStats(C.Structure):
+    _fields_ = [("rounds", C.c_uint32), ("points", C.c_uint64), ("ref_forward_calls", C.c_uint64)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libnghmm.so")
+
+
+def build_library(verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=True, stdout=out)
+    return library_path()
+
+
+def load_library():
+    """dlopen libnghmm.so and declare every entry point of include/nghmm.h."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise NgsFHMMError(-11, f"{path} is missing: build it with "
+                                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the hot path has no CPU fallback)")
+    L = C.CDLL(path)
+    vp, u64, u32, i32, d = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    dp = c_double_p
+    sig = {
+        "nghmm_last_error": (C.c_char_p, []),
+        "nghmm_strerror": (C.c_char_p, [i32]),
+        "nghmm_has_hip": (i32, []),
+        "nghmm_create": (i32, [C.POINTER(vp), u64, u64, i32, i32]),
+        "nghmm_destroy": (i32, [vp]),
+        "nghmm_load_gl": (i32, [vp, dp, dp]),
+        "nghmm_load_gl_device": (i32, [vp, vp, vp]),
+        "nghmm_set_params": (i32, [vp, dp, dp, dp]),
+        "nghmm_get_params": (i32, [vp, dp, dp, dp]),
+        "nghmm_emission": (i32, [vp]),
+        "nghmm_estep": (i32, [vp, dp]),
+        "nghmm_lkl_batch": (i32, [vp, u32, C.POINTER(u32), dp, dp, dp]),
+        "nghmm_mstep_indf": (i32, [vp, i32, i32, C.POINTER(MstepStats)]),
+        "nghmm_bfgs_batch_host": (i32, [u64, dp, dp, i32, i32, vp, vp, C.POINTER(MstepStats)]),
+        "nghmm_mstep_freq": (i32, [vp, i32]),
+        "nghmm_iter_em": (i32, [vp, i32, i32, i32, dp, C.POINTER(MstepStats)]),
+        "nghmm_viterbi": (i32, [vp, C.POINTER(C.c_uint8)]),
+        "nghmm_get_posteriors": (i32, [vp, dp]),
+        "nghmm_get_emissions": (i32, [vp, dp]),
+        "nghmm_shard_config": (i32, [vp, u64, u64, u64, u64]),
+        "nghmm_load_gl_site_shard": (i32, [vp, dp]),
+        "nghmm_pack_posteriors_dev": (i32, [vp, u64, u64, vp]),
+        "nghmm_mstep_freq_sites_dev": (i32, [vp, vp, vp]),
+        "nghmm_set_freq_dev": (i32, [vp, vp]),
+        "nghmm_stream": (vp, [vp]),
+        "nghmm_synchronize": (i32, [vp]),
+        "nghmm_kernel_ms": (i32, [vp, i32, dp, C.POINTER(u32)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+EXPORTED_SYMBOLS = [
+    "nghmm_last_error", "nghmm_strerror", "nghmm_has_hip", "nghmm_create", "nghmm_destroy",
+    "nghmm_load_gl", "nghmm_load_gl_device", "nghmm_set_params", "nghmm_get_params",
+    "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
+    "nghmm_bfgs_batch_host", "nghmm_mstep_freq",
+    "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
+    "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_pack_posteriors_dev",
+    "nghmm_mstep_freq_sites_dev", "nghmm_set_freq_dev", "nghmm_stream", "nghmm_synchronize",
+    "nghmm_kernel_ms",
+]
+
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_void_p)
+
+
+def bfgs_batch_host(indF, alpha, objective, indF_fixed=False, alpha_fixed=False):
+    """Lock-step batched L-BFGS-B (the indF/alpha M-step's host half) with a Python
+    objective ``objective(ind, F, alpha) -> forward log-likelihood``.  Returns
+    (indF, alpha, stats)."""
+    L = load_library()
+    F = np.array(indF, dtype=np.float64)
+    A = np.array(alpha, dtype=np.float64)
+    st = MstepStats()
+    cb = OBJECTIVE_FN(lambda i, f, a, _u: float(objective(i, f, a)))
+    rc = L.nghmm_bfgs_batch_host(len(F), _dp(F), _dp(A), int(indF_fixed), int(alpha_fixed),
+                                 C.cast(cb, C.c_void_p), None, C.byref(st))
+    if rc != 0:
+        raise NgsFHMMError(rc, L.nghmm_strerror(rc).decode())
+    return F, A, st
+
+
+KERNEL_SLOTS = {"emission": 0, "forward": 1, "backward": 2, "lkl_batch": 3, "est_maf": 4,
+                "viterbi": 5}
+
+
+class NgsFHMM:
+    """Device-resident EM state of one GPU (the reference's ``params`` + ``EM``)."""
+
+    def __init__(self, n_ind, n_sites, device=0, mode=MODE_EXACT):
+        self.lib = load_library()
+        self.n_ind, self.n_sites = int(n_ind), int(n_sites)
+        self.mode = mode
+        self._h = C.c_void_p()
+        self._check(self.lib.nghmm_create(C.byref(self._h), self.n_ind, self.n_sites, device, mode))
+        self.tot_lkl = 0.0        # parse_args.cpp:31-32
+        self.prev_tot_lkl = 0.0
+        self.ind_lkl = np.full(self.n_ind, -math.inf)  # parse_args.cpp:412
+        self.last_stats = None
+        self.iterations = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.nghmm_last_error().decode() or self.lib.nghmm_strerror(rc).decode()
+            raise NgsFHMMError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.nghmm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- data --------------------------------------------------------------
+    def load(self, gl, pos_dist):
+        """gl: [S][I][3] normalised natural-log GLs (binary --geno order);
+        pos_dist: [S] distances in Mb, inf at chromosome starts."""
+        gl = np.ascontiguousarray(gl, dtype=np.float64)
+        pos_dist = np.ascontiguousarray(pos_dist, dtype=np.float64)
+        if gl.shape != (self.n_sites, self.n_ind, 3) or pos_dist.shape != (self.n_sites,):
+            raise NgsFHMMError(-10, f"load: shapes {gl.shape} {pos_dist.shape} do not match "
+                                    f"({self.n_sites}, {self.n_ind}, 3)")
+        self._check(self.lib.nghmm_load_gl(self._h, _dp(gl), _dp(pos_dist)))
+
+    def load_device(self, gl_ptr, pos_ptr):
+        """Same as load() from raw device pointers (e.g. torch tensors' data_ptr())."""
+        self._check(self.lib.nghmm_load_gl_device(self._h, C.c_void_p(gl_ptr), C.c_void_p(pos_ptr)))
+
+    def set_params(self, indF=None, alpha=None, freq=None):
+        def prep(a, n):
+            if a is None:
+                return None
+            return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (n,)))
+        a, b, c = prep(indF, self.n_ind), prep(alpha, self.n_ind), prep(freq, self.n_sites)
+        self._check(self.lib.nghmm_set_params(self._h, _dp(a) if a is not None else None,
+                                              _dp(b) if b is not None else None,
+                                              _dp(c) if c is not None else None))
+
+    def _get(self, which):
+        out = np.empty(self.n_sites if which == 2 else self.n_ind)
+        args = [None, None, None]
+        args[which] = _dp(out)
+        self._check(self.lib.nghmm_get_params(self._h, *args))
+        return out
+
+    @property
+    def indF(self):
+        return self._get(0)
+
+    @property
+    def alpha(self):
+        return self._get(1)
+
+    @property
+    def freq(self):
+        return self._get(2)
+
+    @property
+    def marg_prob(self):
+        """[I][S] posterior of the IBD state (marg_prob[i][s][1]) of the last E-step."""
+        out = np.empty((self.n_ind, self.n_sites))
+        self._check(self.lib.nghmm_get_posteriors(self._h, _dp(out)))
+        return out
+
+    @property
+    def e_prob(self):
+        """[I][S][2] log emission probabilities."""
+        out = np.empty((self.n_ind, self.n_sites, 2))
+        self._check(self.lib.nghmm_get_emissions(self._h, _dp(out)))
+        return out
+
+    # -- the hot path ------------------------------------------------------
+    def init_emission(self):
+        """parse_args.cpp:372-387."""
+        self._check(self.lib.nghmm_emission(self._h))
+
+    def estep(self):
+        """EM.cpp:147-185; returns ind_lkl."""
+        self._check(self.lib.nghmm_estep(self._h, _dp(self.ind_lkl)))
+        return self.ind_lkl
+
+    def lkl(self, ind, F, alpha):
+        """Forward log-likelihood of (individual, F, alpha) points (EM.cpp:449-464 negated)."""
+        ind = np.ascontiguousarray(ind, dtype=np.uint32)
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        out = np.empty(len(ind))
+        self._check(self.lib.nghmm_lkl_batch(self._h, len(ind),
+                                             ind.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(F),
+                                             _dp(alpha), _dp(out)))
+        return out
+
+    def mstep_indf(self, indF_fixed=False, alpha_fixed=False):
+        st = MstepStats()
+        self._check(self.lib.nghmm_mstep_indf(self._h, int(indF_fixed), int(alpha_fixed),
+                                              C.byref(st)))
+        self.last_stats = st
+        return st
+
+    def mstep_freq(self, freq_est=1):
+        self._check(self.lib.nghmm_mstep_freq(self._h, int(freq_est)))
+
+    def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        """One EM iteration (EM.cpp:139-289)."""
+        st = MstepStats()
+        self._check(self.lib.nghmm_iter_em(self._h, int(freq_est), int(indF_fixed),
+                                           int(alpha_fixed), _dp(self.ind_lkl), C.byref(st)))
+        self.last_stats = st
+        return st
+
+    def EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False, min_iters=10, max_iters=100,
+           min_epsilon=1e-5, callback=None):
+        """The iteration loop and convergence test of EM.cpp:27-103 (host control only).
+        Returns the number of iterations run."""
+        it = 0
+        max_lkl_epsilon = -math.inf
+        prev_ind_lkl = np.full(self.n_ind, -math.inf)
+        while ((self.prev_tot_lkl - self.tot_lkl > min_epsilon or max_lkl_epsilon > min_epsilon
+                or it < min_iters) and it < max_iters):
+            it += 1
+            self.iter_EM(freq_est, indF_fixed, alpha_fixed)
+            self.prev_tot_lkl = self.tot_lkl
+            tot = 0.0
+            for v in self.ind_lkl:          # EM.cpp:77-79: summation in individual order
+                tot += float(v)
+            self.tot_lkl = tot
+            with np.errstate(invalid="ignore", divide="ignore"):
+                eps = (self.ind_lkl - prev_ind_lkl) / np.abs(prev_ind_lkl)
+            # array_max_pos (gen_func.cpp:73-84): strict '>' from -inf, NaN never wins
+            best, mx = 0, -math.inf
+            for i, v in enumerate(eps):
+                if v > mx:
+                    best, mx = i, v
+            max_lkl_epsilon = float(eps[best])
+            prev_ind_lkl = self.ind_lkl.copy()
+            if callback:
+                callback(it, self)
+        self.iterations = it
+        return it
+
+    def viterbi(self):
+        """[I][S] most probable IBD path (EM.cpp:105-116)."""
+        path = np.empty((self.n_ind, self.n_sites), dtype=np.uint8)
+        self._check(self.lib.nghmm_viterbi(self._h, path.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return path
+
+    # -- measurement -------------------------------------------------------
+    def kernel_ms(self, name):
+        ms = C.c_double(0)
+        n = C.c_uint32(0)
+        self._check(self.lib.nghmm_kernel_ms(self._h, KERNEL_SLOTS[name], C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        self._check(self.lib.nghmm_synchronize(self._h))
