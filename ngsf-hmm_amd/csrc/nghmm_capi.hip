@@ -173,18 +173,6 @@ int ensure_tmp(nghmm_t* h) {
   return dev_alloc(&h->d_tmp, h->S * h->I * 2);
 }
 
-// objective launch for points already on the device
-int launch_lkl_points(nghmm_t* h, uint32_t n_pts) {
-  if (h->mode == NGHMM_MODE_FAST)
-    return fast_lkl_batch(h->fast, h->stream, n_pts, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
-                          h->d_pt_lkl, h->d_flags)
-               ? NGHMM_OK
-               : NGHMM_ERR_HIP;
-  launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind, h->d_pt_F,
-                       h->d_pt_A, h->d_pt_lkl, nullptr, h->d_flags);
-  return NGHMM_OK;
-}
-
 int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
                    const double* alpha, double* lkl, bool accumulate) {
   if (n_pts == 0) return NGHMM_OK;
@@ -195,14 +183,25 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     }
   int rc;
   if ((rc = ensure_points(h, n_pts))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_pt_ind, ind, n_pts * sizeof(uint32_t), hipMemcpyHostToDevice,
-                         h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_pt_F, F, n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_pt_A, alpha, n_pts * sizeof(double), hipMemcpyHostToDevice,
-                         h->stream));
   if ((rc = clear_flags(h))) return rc;
-  tic(h);
-  if ((rc = launch_lkl_points(h, n_pts))) return rc;
+  if (h->mode == NGHMM_MODE_FAST) {
+    // the fast path groups the points by individual on the host and uploads
+    // compact group descriptors itself
+    tic(h);
+    if (!fast_lkl_batch(h->fast, h->stream, n_pts, ind, F, alpha, h->d_pt_lkl, h->d_flags)) {
+      set_error("fast_lkl_batch launch failed: %s", hipGetErrorString(hipGetLastError()));
+      return NGHMM_ERR_HIP;
+    }
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->d_pt_ind, ind, n_pts * sizeof(uint32_t), hipMemcpyHostToDevice,
+                           h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_pt_F, F, n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_pt_A, alpha, n_pts * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+    tic(h);
+    launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind,
+                         h->d_pt_F, h->d_pt_A, h->d_pt_lkl, nullptr, h->d_flags);
+  }
   if ((rc = toc(h, SLOT_LKL, accumulate))) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(lkl, h->d_pt_lkl, n_pts * sizeof(double), hipMemcpyDeviceToHost,
@@ -551,7 +550,9 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   if (!h->d_path && (rc = dev_alloc(&h->d_path, cells))) return rc;
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
-    if (!fast_viterbi(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_bp, h->d_path_sites))
+    if ((rc = clear_flags(h))) return rc;
+    if (!fast_viterbi(h->fast, h->stream, h->d_freq, h->d_indF, h->d_alpha, h->d_bp,
+                      h->d_path_sites, h->d_flags))
       return NGHMM_ERR_HIP;
   } else {
     launch_viterbi_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, h->d_indF, h->d_alpha,

@@ -1,0 +1,180 @@
+"""GPU parity of FAST mode (linear-space, chunk-parallel kernels) against the oracle.
+
+Fast mode re-associates the recursions (products of 2x2 operators) and works in
+linear space, so it cannot be bitwise; the bar is BASELINE.json's: per-call
+log-likelihoods, posteriors and frequencies within 1e-9 relative of the reference
+arithmetic (oracle, libm build), Viterbi paths identical for identical parameters.
+End-to-end indF/alpha after several EM iterations are compared at the spread the
+reference shows against itself under a different libm/FMA build (SURVEY.md
+finding 4: ~1e-5 absolute), because the finite-difference L-BFGS-B amplifies
+last-bit noise."""
+import numpy as np
+import pytest
+
+import orclib
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+RTOL = 1e-9
+
+
+def _pair(pkg, orc, gl, pos, indF=0.1, alpha=0.2, freq=0.1):
+    S, I = gl.shape[0], gl.shape[1]
+    em = orclib.OracleEM(orc, gl, pos)
+    em.set_params(indF, alpha, freq)
+    hmm = pkg.NgsFHMM(I, S, device=0, mode=pkg.MODE_FAST)
+    hmm.load(gl, pos)
+    hmm.set_params(indF, alpha, freq)
+    return hmm, em
+
+
+@pytest.fixture(scope="module")
+def mid_sim(pkg):
+    d = pkg.simulate.simulate(37, 5000, seed=99, n_chrom=3, missing_rate=0.03, indF="r",
+                              alpha=0.3, freq="r")
+    return d, pkg.simulate.normalise_log_gl(d.gl)
+
+
+def test_fast_emission(pkg, orc_libm, mid_sim):
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb, freq=np.linspace(0.0, 1.0, d.n_sites))
+    em.init_emission(); hmm.init_emission()
+    np.testing.assert_allclose(np.exp(hmm.e_prob), np.exp(em.e_prob), rtol=RTOL, atol=1e-300)
+    hmm.close()
+
+
+def test_fast_estep(pkg, orc_libm, mid_sim):
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb, indF=np.linspace(0.01, 0.95, d.n_ind),
+                    alpha=np.linspace(0.01, 8, d.n_ind))
+    em.init_emission(); hmm.init_emission()
+    assert em.estep() == 0
+    lk = hmm.estep()
+    np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-12)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+    hmm.close()
+
+
+def test_fast_lkl_batch(pkg, orc_libm, mid_sim):
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission(); hmm.init_emission()
+    rng = np.random.default_rng(3)
+    n = 500
+    ind = rng.integers(0, d.n_ind, n)          # unsorted, > 5 points for some individuals
+    F = rng.uniform(1e-15, 1 - 1e-15, n)
+    A = rng.uniform(1e-15, 10, n)
+    F[:4] = [1e-15, 1 - 1e-15, 0.5, 1e-6]; A[:4] = [1e-15, 10.0, 1e-15, 10.0]
+    got = hmm.lkl(ind, F, A)
+    e = em.e_prob
+    want = np.array([-orc_libm.lkl([F[p], A[p]], e[ind[p]], d.pos_dist_mb) for p in range(n)])
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    # the finite-difference pattern: 5 points per individual, three sharing alpha
+    ind5 = np.repeat(np.arange(d.n_ind), 5)
+    eh = 4e-6
+    F5 = np.tile([0.3, 0.3 + eh, 0.3 - eh, 0.3, 0.3], d.n_ind)
+    A5 = np.tile([0.7, 0.7, 0.7, 0.7 + eh, 0.7 - eh], d.n_ind)
+    got5 = hmm.lkl(ind5, F5, A5)
+    want5 = np.array([-orc_libm.lkl([F5[p], A5[p]], e[ind5[p]], d.pos_dist_mb)
+                      for p in range(len(ind5))])
+    np.testing.assert_allclose(got5, want5, rtol=1e-12)
+    # finite differences themselves (what the optimizer consumes) to 1e-5 relative
+    g_got = (got5[1::5] - got5[2::5]) / (2 * eh)
+    g_want = (want5[1::5] - want5[2::5]) / (2 * eh)
+    np.testing.assert_allclose(g_got, g_want, rtol=1e-4, atol=1e-3)
+    hmm.close()
+
+
+def test_fast_mstep_freq(pkg, orc_libm, mid_sim):
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission(); hmm.init_emission()
+    em.estep(); hmm.estep()
+    assert em.mstep_freq(1) == 0
+    hmm.mstep_freq(1)
+    np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
+    np.testing.assert_allclose(np.exp(hmm.e_prob), np.exp(em.e_prob), rtol=RTOL, atol=1e-300)
+    hmm.close()
+
+
+def test_fast_whole_em_vs_oracle(pkg, orc_libm, mid_sim):
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission(); hmm.init_emission()
+    for it in range(4):
+        assert em.iterate() == 0
+        hmm.iter_EM()
+        np.testing.assert_allclose(hmm.ind_lkl, em.ind_lkl, rtol=1e-9)
+    np.testing.assert_allclose(hmm.indF, em.indF, atol=2e-4)
+    np.testing.assert_allclose(hmm.alpha, em.alpha, rtol=2e-2, atol=2e-4)
+    np.testing.assert_allclose(hmm.freq, em.freq, atol=1e-5)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, atol=1e-3)
+    vp, op = hmm.viterbi(), em.viterbi()
+    assert (vp != op).mean() < 1e-3
+    hmm.close()
+
+
+def test_fast_viterbi_identical_for_identical_parameters(pkg, orc_det, mid_sim):
+    """Decoding uses the exact-mode kernel: with the same parameters the path is the
+    reference's path bit for bit, whatever mode the EM ran in."""
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_det, gl, d.pos_dist_mb, indF=0.4, alpha=0.05, freq=0.2)
+    em.init_emission(); hmm.init_emission()
+    assert np.array_equal(hmm.viterbi(), em.viterbi())
+    hmm.close()
+
+
+def test_fast_teacher_forced_iterations(pkg, orc_libm, mid_sim):
+    """Feed the oracle's state of iteration t, compare the outputs of iteration t+1
+    before the optimizer can amplify anything: E-step and frequency step at 1e-9."""
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission()
+    for it in range(3):
+        hmm.set_params(em.indF, em.alpha, em.freq)
+        hmm.init_emission()
+        assert em.estep() == 0
+        lk = hmm.estep()
+        np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-12)
+        np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+        assert em.mstep_indf() == 0
+        assert em.mstep_freq(1) == 0
+        hmm.mstep_freq(1)
+        np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
+    hmm.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 70), (3, 17), (65, 1030), (130, 2049)])
+def test_fast_ragged_shapes(pkg, orc_libm, shape):
+    I, S = shape
+    d = pkg.simulate.simulate(I, S, seed=I * 1000 + S, missing_rate=0.1, n_chrom=2 if S > 10 else 1)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission(); hmm.init_emission()
+    assert em.estep() == 0
+    lk = hmm.estep()
+    np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-11)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+    em.mstep_freq(1); hmm.mstep_freq(1)
+    np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
+    st = hmm.mstep_indf()
+    assert st.rounds >= 1
+    hmm.close()
+
+
+def test_fast_called_genotypes(pkg, orc_libm):
+    """One-hot GLs (-1e15 elsewhere): impossible emissions are exact zeros in linear space."""
+    d = pkg.simulate.simulate(12, 900, seed=77, n_chrom=4)
+    geno = d.geno.copy()
+    geno[::17, ::3] = -1
+    gl = pkg.simulate.called_genotype_gl(geno)
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb, indF=0.5, alpha=0.01, freq=0.2)
+    em.init_emission(); hmm.init_emission()
+    assert em.estep() == 0
+    lk = hmm.estep()
+    np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-11)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+    em.mstep_freq(1); hmm.mstep_freq(1)
+    np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
+    hmm.close()
