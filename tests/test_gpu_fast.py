@@ -105,7 +105,10 @@ def test_fast_whole_em_vs_oracle(pkg, orc_libm, mid_sim):
     for it in range(4):
         assert em.iterate() == 0
         hmm.iter_EM()
-        np.testing.assert_allclose(hmm.ind_lkl, em.ind_lkl, rtol=1e-9)
+        # from iteration 2 on the likelihoods are evaluated at optimizer outputs that
+        # already differ at the 1e-5 level, so this is a trajectory check, not a
+        # per-call one (those are above, at 1e-12)
+        np.testing.assert_allclose(hmm.ind_lkl, em.ind_lkl, rtol=1e-12 if it == 0 else 1e-6)
     np.testing.assert_allclose(hmm.indF, em.indF, atol=2e-4)
     np.testing.assert_allclose(hmm.alpha, em.alpha, rtol=2e-2, atol=2e-4)
     np.testing.assert_allclose(hmm.freq, em.freq, atol=1e-5)
