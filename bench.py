@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the EM hot path on MI355X.
+
+A "step" is one EM iteration (iter_EM, EM.cpp:139-289) over one synthetic data set:
+E-step, per-individual L-BFGS-B M-step for (indF, alpha), per-site allele-frequency
+EM + emission refresh.  Default workload = BASELINE.json configs[2]: 1000 individuals
+x 1,000,000 sites, --freq_est 1 (the reference aborts on --freq_est 2), starting
+values of examples/test.sh "normal" (--freq 0.1 --indF 0.1,0.2), inputs resident in
+HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|tiny] [--mode fast|exact]
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns
+its own 1000 individuals for all sites (weak scaling) and the frequency step is
+site-sharded: posteriors move by an RCCL all-to-all, frequencies by an all-gather.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c3": dict(n_ind=1000, n_sites=1_000_000,
+               name="1000 ind x 1M sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
+                    "--freq 0.1 --indF 0.1,0.2"),
+    "c2": dict(n_ind=100, n_sites=100_000,
+               name="100 ind x 100k sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
+                    "--freq 0.1 --indF 0.1,0.2"),
+    "tiny": dict(n_ind=64, n_sites=20_000, name="64 ind x 20k sites (smoke)"),
+}
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def cpu_baseline(pkg, seconds_budget=20.0):
+    """The oracle (libm build = the reference's arithmetic; its L-BFGS-B core is pinned
+    bit for bit to the reference object) timed on this box's host cores on a bounded
+    sample of the same workload: per-individual phases threaded like the reference's
+    pool, the frequency loop serial as in the reference (EM.cpp:224)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    cores = os.cpu_count() or 1
+    n_ind, n_sites = 100, 4000
+    d = pkg.simulate.simulate(n_ind, n_sites, seed=777)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    orc = orclib.Oracle("libm")
+    em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
+    em.set_params(0.1, 0.2, 0.1)
+    em.init_emission()
+    t0 = time.time()
+    iters = 0
+    while iters < 3 and (time.time() - t0) < seconds_budget:
+        rc = em.iterate(n_threads=min(cores, n_ind))
+        assert rc == 0
+        iters += 1
+    dt = time.time() - t0
+    return {
+        "value": n_ind * n_sites * iters / dt,
+        "unit": "site-ind updates/s",
+        "cores": min(cores, n_ind),
+        "kind": "port",
+        "sample": f"{n_ind} ind x {n_sites} sites, {iters} EM iterations in {dt:.1f} s, oracle libm "
+                  f"build, per-individual phases on {min(cores, n_ind)} threads, allele-frequency "
+                  f"loop serial as in the reference (EM.cpp:224)",
+        "forward_passes_per_ind_iter": em.lkl_calls / (n_ind * iters),
+        "est_maf_passes_per_site": em.maf_passes / (n_sites * iters),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--n_ind", type=int, default=None)
+    ap.add_argument("--n_sites", type=int, default=None)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    pkg = importlib.import_module("ngsf-hmm_amd")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.n_ind:
+        wl["n_ind"] = args.n_ind
+    if args.n_sites:
+        wl["n_sites"] = args.n_sites
+    I, S = wl["n_ind"], wl["n_sites"]
+    mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
+
+    # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
+    gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank)
+    torch.cuda.synchronize()
+
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world)
+    em.load_device(gl, pos)
+    del gl
+    torch.cuda.empty_cache()
+    em.set_params(0.1, 0.2, 0.1)
+    em.init_emission()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        em.iter_EM()
+    fam = {k: 0.0 for k in ("emission", "forward", "backward", "lkl_batch", "est_maf")}
+    launches = dict.fromkeys(fam, 0)
+    rounds = points = ind_rounds = ref_calls = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = em.iter_EM()
+        rounds += st.rounds
+        points += st.points
+        ind_rounds += st.ind_rounds
+        ref_calls += st.ref_forward_calls
+        for k in fam:
+            ms, n = em.hmm.kernel_ms(k)
+            fam[k] += ms
+            launches[k] += n
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        K = max(args.steps, 1)
+        units = float(I) * S * world * K
+        # dominant kernel family by measured time, and its algorithmic traffic per launch
+        # (DESIGN.md section 5): objective = 16 B emission pair per site per individual
+        # still being optimised; est_maf = 24 B GL + 8 B posterior per site-individual;
+        # E-step (fast mode, 4 sweeps + de-interleave) = 88 B per site-individual
+        algo = {
+            "lkl_batch": 16.0 * S * ind_rounds / max(launches["lkl_batch"], 1),
+            "est_maf": 32.0 * S * I * world,
+            "forward": (88.0 if args.mode == "fast" else 40.0) * S * I,
+            "backward": 48.0 * S * I,
+            "emission": (40.0) * S * I,
+        }
+        dom = max(fam, key=lambda k: fam[k])
+        avg_ms = fam[dom] / max(launches[dom], 1)
+        achieved = algo[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "site-ind updates/sec (EM iterations x individuals x sites / s), 1M sites x 1k ind",
+            "value": units / dt,
+            "unit": "site-ind updates/s",
+            "em_iters_per_sec": K / dt,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "n_ind_per_gpu": I, "n_sites": S,
+                       "mode": args.mode, "freq_est": 1,
+                       "sharding": "individuals per GPU; site-sharded allele-frequency step"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": launches[dom]},
+            "per_step_kernel_ms": {k: fam[k] / K for k in fam},
+            "bfgs": {"rounds_per_iter": rounds / K, "points_per_iter": points / K,
+                     "ind_rounds_per_iter": ind_rounds / K,
+                     "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg)
+        print(json.dumps(out))
+    em.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,8 @@ typedef struct {
   uint32_t rounds;          /* lock-step objective rounds (GPU launches)            */
   uint64_t points;          /* objective evaluations sent to the GPU                */
   uint64_t ref_forward_calls; /* forward passes the reference would have spent      */
+  uint64_t ind_rounds;      /* sum over rounds of the individuals still being optimised:
+                               each costs one pass over that individual's emissions */
 } nghmm_mstep_stats;
 
 const char* nghmm_last_error(void);
@@ -145,6 +147,8 @@ int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uin
                        uint64_t n_sites_own);
 /* static site-shard copy of the GLs of ALL individuals: [n_sites_own][n_ind_total][3] (host) */
 int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard);
+/* same, from a device buffer */
+int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard);
 /* pack posteriors of the own individuals for destination rank r's site range:
  * d_out[(s - site_lo) * n_ind + i], s in [site_lo, site_hi) */
 int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, double* d_out);

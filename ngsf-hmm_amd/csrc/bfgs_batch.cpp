@@ -19,6 +19,7 @@ void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, b
   rounds_ = 0;
   points_ = 0;
   ref_calls_ = 0;
+  ind_rounds_ = 0;
   n_active_ = n_ind;
   for (uint64_t i = 0; i < n_ind; ++i) {
     Problem& p = probs_[i];
@@ -104,6 +105,7 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
   }
   ++rounds_;
   points_ += ind.size();
+  ind_rounds_ += n_active_;
   return ind.size();
 }
 

@@ -38,6 +38,7 @@ class BfgsBatch {
   uint32_t rounds() const { return rounds_; }
   uint64_t points() const { return points_; }
   uint64_t ref_forward_calls() const { return ref_calls_; }
+  uint64_t ind_rounds() const { return ind_rounds_; }
 
  private:
   struct Problem {
@@ -59,7 +60,7 @@ class BfgsBatch {
   std::vector<Problem> probs_;
   uint64_t n_active_ = 0;
   uint32_t rounds_ = 0;
-  uint64_t points_ = 0, ref_calls_ = 0;
+  uint64_t points_ = 0, ref_calls_ = 0, ind_rounds_ = 0;
 
   void plan(Problem& p);
   void consume(Problem& p, const double* lkl);

@@ -790,8 +790,9 @@ bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_fre
   return hipGetLastError() == hipSuccess;
 }
 
-bool fast_lkl_batch(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
-                    const double* h_F, const double* h_A, double* d_lkl, int* d_flags) {
+bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
+                      const double* h_F, const double* h_A) {
+  fs.n_groups = 0;
   if (n_pts == 0) return true;
   // group the points by individual (<= MAXP per group)
   std::vector<uint32_t> order(n_pts);
@@ -841,6 +842,13 @@ bool fast_lkl_batch(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_
   if (hipMemcpyAsync(fs.grp_dev, fs.grp_host.data(), gbytes, hipMemcpyHostToDevice, st) !=
       hipSuccess)
     return false;
+  fs.n_groups = ng;
+  return true;
+}
+
+bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags) {
+  const uint32_t ng = fs.n_groups;
+  if (ng == 0) return true;
   const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(fs.grp_dev);
   hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP>), dim3(ng * fs.C), dim3(64), 0, st,
                      reinterpret_cast<const double2*>(fs.e_il), fs.pos_il, fs.T, fs.C, dg,

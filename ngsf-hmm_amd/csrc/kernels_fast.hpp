@@ -29,6 +29,7 @@ struct FastState {
   void* grp_dev = nullptr;        // packed group descriptors
   size_t grp_cap = 0;
   std::vector<unsigned char> grp_host;
+  uint32_t n_groups = 0;
 };
 
 bool fast_create(FastState& fs, uint64_t I, uint64_t S);
@@ -37,9 +38,12 @@ void fast_destroy(FastState& fs);
 bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* d_pos);
 // linear-space emissions of every cell from freq, into the interleaved layout
 bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags);
-// objective for host-side points; d_lkl (device) receives the values in point order
-bool fast_lkl_batch(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
-                    const double* h_F, const double* h_A, double* d_lkl, int* d_flags);
+// objective for host-side points: prepare() groups them by individual and uploads
+// the descriptors, launch() runs the two kernels; d_lkl (device) receives the values
+// in point order
+bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
+                      const double* h_F, const double* h_A);
+bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags);
 // forward + backward + posteriors; marg out is site-major [S][I]
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
                 double* d_ind_lkl, double* d_marg, int* d_flags);

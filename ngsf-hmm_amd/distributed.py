@@ -1,0 +1,151 @@
+"""Multi-GPU EM: individuals sharded over ranks, one process per GPU.
+
+Everything per individual (E-step, L-BFGS-B M-step, Viterbi) needs no communication.
+The allele-frequency step (est_maf, shared/gen_func.cpp:974-1009) needs, for a site,
+the posteriors of EVERY individual, summed in individual order.  Each rank therefore
+also owns a contiguous range of sites for that step and a static copy of all
+individuals' genotype likelihoods for that range.  Per EM iteration:
+
+  1. local E-step + indF/alpha M-step                        (no communication)
+  2. all-to-all of the posteriors: rank r sends every other rank q the slice of its
+     site-major posterior matrix that covers q's site range (contiguous, so no
+     packing kernel is needed beyond one copy)                (RCCL all_to_all_single)
+  3. est_maf on the own site range over all individuals, in global individual order
+     (rank-major), i.e. exactly the single-GPU summation order
+  4. all-gather of the per-range frequencies                  (RCCL all_gather)
+  5. local emission refresh
+
+This is the bit-faithful alternative to 101 all-reduce rounds (SURVEY.md section 8e,
+design 2): two collectives per iteration, both using every xGMI link.
+
+The compute backend is anything with the small interface of :class:`GpuBackend`
+(tests/ uses a CPU stand-in with the gloo backend to exercise the exchange logic).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+
+def site_ranges(n_sites: int, world: int):
+    """Contiguous, equal site ranges (the all-to-all uses equal splits)."""
+    if n_sites % world != 0:
+        raise ValueError(f"n_sites ({n_sites}) must be divisible by the number of ranks ({world})")
+    step = n_sites // world
+    return [(r * step, (r + 1) * step) for r in range(world)]
+
+
+class GpuBackend:
+    """The C-ABI handle plus torch tensors used as exchange buffers."""
+
+    def __init__(self, pkg, n_ind, n_sites, device_index, mode):
+        import torch
+        self.torch = torch
+        self.pkg = pkg
+        self.hmm = pkg.NgsFHMM(n_ind, n_sites, device=device_index, mode=mode)
+        self.device = torch.device("cuda", device_index)
+        self.n_ind, self.n_sites = n_ind, n_sites
+
+    def empty(self, *shape):
+        return self.torch.empty(shape, device=self.device, dtype=self.torch.float64)
+
+    def estep(self):
+        return self.hmm.estep()
+
+    def mstep_indf(self, indF_fixed, alpha_fixed):
+        return self.hmm.mstep_indf(indF_fixed, alpha_fixed)
+
+    def pack_posteriors(self, lo, hi, out):
+        self.hmm._check(self.hmm.lib.nghmm_pack_posteriors_dev(self.hmm.handle, lo, hi,
+                                                               C.c_void_p(out.data_ptr())))
+
+    def mstep_freq_sites(self, marg_blocks, freq_out):
+        self.hmm._check(self.hmm.lib.nghmm_mstep_freq_sites_dev(
+            self.hmm.handle, C.c_void_p(marg_blocks.data_ptr()), C.c_void_p(freq_out.data_ptr())))
+
+    def set_freq(self, freq_all):
+        self.hmm._check(self.hmm.lib.nghmm_set_freq_dev(self.hmm.handle,
+                                                        C.c_void_p(freq_all.data_ptr())))
+
+    def shard_config(self, n_ind_total, ind_begin, site_begin, n_sites_own):
+        self.hmm._check(self.hmm.lib.nghmm_shard_config(self.hmm.handle, n_ind_total, ind_begin,
+                                                        site_begin, n_sites_own))
+
+    def load_site_shard_device(self, gl_shard):
+        """gl_shard: device tensor [S_own][I_tot][3]."""
+        self.hmm._check(self.hmm.lib.nghmm_load_gl_site_shard_dev(
+            self.hmm.handle, C.c_void_p(gl_shard.data_ptr())))
+
+
+class ShardedEM:
+    """iter_EM across `world` ranks (world == 1: plain single-GPU path)."""
+
+    def __init__(self, pkg, n_ind, n_sites, device_index=0, mode=None, rank=0, world=1,
+                 backend=None):
+        self.rank, self.world = rank, world
+        self.n_ind, self.n_sites = n_ind, n_sites
+        self.backend = backend or GpuBackend(pkg, n_ind, n_sites, device_index,
+                                             pkg.MODE_FAST if mode is None else mode)
+        self.hmm = getattr(self.backend, "hmm", None)
+        self.ind_lkl = None
+        if world > 1:
+            self.ranges = site_ranges(n_sites, world)
+            lo, hi = self.ranges[rank]
+            self.S_own = hi - lo
+            self.backend.shard_config(n_ind * world, rank * n_ind, lo, self.S_own)
+            self._send = self.backend.empty(world, self.S_own, n_ind)
+            self._recv = self.backend.empty(world, self.S_own, n_ind)
+            self._freq_own = self.backend.empty(self.S_own)
+            self._freq_all = self.backend.empty(n_sites)
+
+    # -- data ---------------------------------------------------------------
+    def load_device(self, gl, pos):
+        """gl: device tensor [S][I_local][3]; pos: device tensor [S]."""
+        self.hmm.load_device(gl.data_ptr(), pos.data_ptr())
+        if self.world > 1:
+            self._exchange_site_shard(gl)
+
+    def _exchange_site_shard(self, gl):
+        """One-off: build [S_own][I_tot][3] from every rank's [S][I_loc][3]."""
+        import torch.distributed as dist
+        world, I = self.world, self.n_ind
+        send = gl.reshape(world, self.S_own, I, 3).contiguous()   # slices by destination
+        recv = self.backend.empty(world, self.S_own, I, 3)
+        dist.all_to_all_single(recv.view(-1), send.view(-1))
+        shard = recv.permute(1, 0, 2, 3).contiguous().view(self.S_own, world * I, 3)
+        self.backend.load_site_shard_device(shard)
+        del send, recv, shard
+
+    def set_params(self, indF, alpha, freq):
+        self.hmm.set_params(indF, alpha, freq)
+
+    def init_emission(self):
+        self.hmm.init_emission()
+
+    # -- one EM iteration ------------------------------------------------------
+    def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        if self.world == 1:
+            st = self.hmm.iter_EM(freq_est, indF_fixed, alpha_fixed)
+            self.ind_lkl = self.hmm.ind_lkl
+            return st
+        self.ind_lkl = self.backend.estep()
+        st = self.backend.mstep_indf(indF_fixed, alpha_fixed)
+        if freq_est:
+            self.exchange_and_update_freq()
+        return st
+
+    def exchange_and_update_freq(self):
+        import torch.distributed as dist
+        for q, (lo, hi) in enumerate(self.ranges):
+            self.backend.pack_posteriors(lo, hi, self._send[q])
+        dist.all_to_all_single(self._recv.view(-1), self._send.view(-1))
+        # _recv is [source rank][S_own][I_loc]: the rank-blocked layout est_maf reads
+        self.backend.mstep_freq_sites(self._recv, self._freq_own)
+        dist.all_gather_into_tensor(self._freq_all, self._freq_own)
+        self.backend.set_freq(self._freq_all)
+
+    def close(self):
+        if self.hmm is not None:
+            self.hmm.close()

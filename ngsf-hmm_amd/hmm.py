@@ -37,7 +37,8 @@ class NgsFHMMError(RuntimeError):
 
 
 class MstepStats(C.Structure):
-    _fields_ = [("rounds", C.c_uint32), ("points", C.c_uint64), ("ref_forward_calls", C.c_uint64)]
+    _fields_ = [("rounds", C.c_uint32), ("points", C.c_uint64),
+                ("ref_forward_calls", C.c_uint64), ("ind_rounds", C.c_uint64)]
 
 
 def library_path():
@@ -86,6 +87,7 @@ def load_library():
         "nghmm_get_emissions": (i32, [vp, dp]),
         "nghmm_shard_config": (i32, [vp, u64, u64, u64, u64]),
         "nghmm_load_gl_site_shard": (i32, [vp, dp]),
+        "nghmm_load_gl_site_shard_dev": (i32, [vp, vp]),
         "nghmm_pack_posteriors_dev": (i32, [vp, u64, u64, vp]),
         "nghmm_mstep_freq_sites_dev": (i32, [vp, vp, vp]),
         "nghmm_set_freq_dev": (i32, [vp, vp]),
@@ -111,7 +113,8 @@ EXPORTED_SYMBOLS = [
     "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
     "nghmm_bfgs_batch_host", "nghmm_mstep_freq",
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
-    "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_pack_posteriors_dev",
+    "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_load_gl_site_shard_dev",
+    "nghmm_pack_posteriors_dev",
     "nghmm_mstep_freq_sites_dev", "nghmm_set_freq_dev", "nghmm_stream", "nghmm_synchronize",
     "nghmm_kernel_ms",
 ]
