@@ -625,34 +625,98 @@ __device__ double2 estmaf_term_logspace(const double* g, double freq, double F) 
   return double2{pp[1] + pp[2] * (2 - F), 2 * pp[1] + (pp[0] + pp[2]) * (2 - F)};
 }
 
-// One wave per site, NI individuals per lane held in registers (linear GL + F).
-// The <= 101 passes of the reference's do-while (gen_func.cpp:981-1006) never
-// touch memory again.
+// ---- wave-wide sum that ends in a wave-uniform value -----------------------
+// DPP moves stay inside the SIMD (no LDS round trip as with ds_bpermute), which
+// matters here: est_maf has one dependent reduction per pass and ~100 passes.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const uint64_t b = ngh_bits(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, false);
+  return ngh_from_bits(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const uint64_t b = ngh_bits(v);
+  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+  return ngh_from_bits(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double wave_sum_uniform(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror: every lane now holds its 16-lane row total
+  return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
+}
+
+// 1/x to ~46 bits: v_rcp_f64 (about 23 bits) + one Newton step; x in (0, 3]
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
+// One wave per site, NI individuals per lane held in registers.  With
+//   A = (1-f)^2, b = (1-f) f, C = f^2
+// the weights w_g = p_g * HWE_g(f, F) of calc_HWE/post_prob (gen_func.cpp:920-957) are
+// linear in (A, b, C):  w0 = p0 (A + bF), w1 = b c1 with c1 = 2 p1 (1-F), w2 = p2 (C + bF),
+// and the reference's per-individual terms (gen_func.cpp:999-1000) become
+//   num-term = (w1 + (2-F) w2) / sum
+//   den-term = (2 w1 + (2-F)(w0 + w2)) / sum = (2-F) + F w1 / sum
+// so a pass needs six per-individual constants, one reciprocal and ~12 FMAs, and the
+// (2-F) part of the denominator is a per-site constant.  The <= 101 passes of the
+// reference's do-while (gen_func.cpp:981-1006) never touch memory again.  A site with a
+// cell whose weights all vanish (a called heterozygote at posterior IBD = 1, ...) is
+// flagged and redone by k_fast_estmaf_stream, which takes the reference-order
+// log-space route for such cells.
+//
+// Two waves share a site (workgroup = 128 threads): 6*NI constants plus the
+// temporaries of NI = 16 do not fit in 256 VGPRs, and a single wave per SIMD cannot
+// hide the serial tail of a pass (reduction, division, loop test).  The two partial
+// sums meet in LDS once per pass (double-buffered, one barrier).
 template <int NI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(128)
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
-              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out) {
+              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
+              uint8_t* __restrict__ redo) {
+  __shared__ double xch[2][2][4];  // [buffer][wave][num, den, bad, -]
   const int lane = threadIdx.x & 63;
-  const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (site >= S_own) return;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t site = blockIdx.x;
   const double* gls = gl + site * I_tot * 3;
 
-  double p0[NI], p1[NI], p2[NI], Fv[NI];
+  double sA[NI], sC[NI], c1[NI], Fv[NI], nC[NI];
+  double tF_lane = 0;
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    const uint64_t i = (uint64_t)lane + 64ull * k;
+    const uint64_t i = (uint64_t)threadIdx.x + 128ull * k;
     if (i < I_tot) {
-      p0[k] = exp(gls[i * 3]);
-      p1[k] = exp(gls[i * 3 + 1]);
-      p2[k] = exp(gls[i * 3 + 2]);
-      Fv[k] = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
-    } else {
-      p0[k] = p1[k] = p2[k] = 0;
-      Fv[k] = -1;  // marks an empty slot
+      const double p0 = exp(gls[i * 3]), p1 = exp(gls[i * 3 + 1]), p2 = exp(gls[i * 3 + 2]);
+      const double F = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
+      const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
+      sA[k] = p0;
+      sC[k] = p2;
+      c1[k] = cc;
+      Fv[k] = F;
+      nC[k] = (2 - F) * p2;
+      tF_lane += 2 - F;
+    } else {  // empty slot: sum = A + C >= 1/2, numerators 0: contributes nothing
+      sA[k] = 1; sC[k] = 1;
+      c1[k] = Fv[k] = nC[k] = 0;
     }
   }
+  {
+    const double t = wave_sum_uniform(tF_lane);
+    if (lane == 0) xch[1][wv][0] = t;
+  }
+  __syncthreads();
+  const double tF_sum = xch[1][0][0] + xch[1][1][0];
+  __syncthreads();
 
   int iters = 0;
+  int buf = 0;
   double num = 0, den = 0, freq = 0.01, prev;
   bool again;
   do {
@@ -661,44 +725,86 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     const double b = om * freq;
     const double A = om * om, Cq = freq * freq;
     double pn = 0, pd = 0;
+    bool bad = false;
+    if constexpr (NI >= 4) {
+      // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step
+      // and 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const double F = Fv[k];
-      if (F >= 0) {
-        const double bF = b * F;
-        const double h0 = A + bF, h2 = Cq + bF;
-        const double h1 = (F == 1) ? 0.0 : (2 * b - 2 * bF);
-        const double w0 = p0[k] * h0, w1 = p1[k] * h1, w2 = p2[k] * h2;
-        const double sum = w0 + w1 + w2;
-        const double tF = 2 - F;
-        if (sum > 0) {
-          const double inv = 1.0 / sum;
-          pn += fma(w2, tF, w1) * inv;
-          pd += fma(w0 + w2, tF, 2 * w1) * inv;
-        } else {
-          const uint64_t i = (uint64_t)lane + 64ull * k;
-          const double2 tt = estmaf_term_logspace(gls + i * 3, freq, F);
-          pn += tt.x;
-          pd += tt.y;
+      for (int k0 = 0; k0 < NI; k0 += 4) {
+        double w1[4], sm[4], nn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + j;
+          w1[j] = b * c1[k];
+          // sb = F (p0 + p2) + c1 is recomputed: keeping it would push the kernel past
+          // 256 VGPRs (one wave per SIMD and AGPR traffic)
+          const double sbk = fma(Fv[k], sA[k] + sC[k], c1[k]);
+          sm[j] = fma(A, sA[k], fma(b, sbk, Cq * sC[k]));
+          nn[j] = fma(nC[k], fma(b, Fv[k], Cq), w1[j]);
         }
+        const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
+        const double P = p01 * p23;
+        bad |= !(P > 0);   // sums are >= 0: the product is > 0 iff every sum is
+        const double R = rcp_nr(P);
+        const double r01 = R * p23, r23 = R * p01;
+        const double inv0 = r01 * sm[1], inv1 = r01 * sm[0];
+        const double inv2 = r23 * sm[3], inv3 = r23 * sm[2];
+        pn = fma(nn[0], inv0, pn);
+        pd = fma(Fv[k0] * w1[0], inv0, pd);
+        pn = fma(nn[1], inv1, pn);
+        pd = fma(Fv[k0 + 1] * w1[1], inv1, pd);
+        pn = fma(nn[2], inv2, pn);
+        pd = fma(Fv[k0 + 2] * w1[2], inv2, pd);
+        pn = fma(nn[3], inv3, pn);
+        pd = fma(Fv[k0 + 3] * w1[3], inv3, pd);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const double w1 = b * c1[k];
+        const double sbk = fma(Fv[k], sA[k] + sC[k], c1[k]);
+        const double sum = fma(A, sA[k], fma(b, sbk, Cq * sC[k]));
+        const double nn = fma(nC[k], fma(b, Fv[k], Cq), w1);
+        bad |= !(sum > 0);
+        const double inv = rcp_nr(sum);
+        pn = fma(nn, inv, pn);
+        pd = fma(Fv[k] * w1, inv, pd);
       }
     }
-    num += wave_sum(pn);
-    den += wave_sum(pd);
+    {
+      const double wn = wave_sum_uniform(pn), wd = wave_sum_uniform(pd);
+      if (lane == 0) {
+        xch[buf][wv][0] = wn;
+        xch[buf][wv][1] = wd;
+        xch[buf][wv][2] = __ballot(bad) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    if (xch[buf][0][2] + xch[buf][1][2] != 0.0) {  // block-uniform: careful kernel takes over
+      if (threadIdx.x == 0) redo[site] = 1;
+      return;
+    }
+    num += xch[buf][0][0] + xch[buf][1][0];
+    den += tF_sum + (xch[buf][0][1] + xch[buf][1][1]);
+    buf ^= 1;
     freq = num / den;
     again = (fabs(prev - freq) > kEPS) && (iters++ < 100);
   } while (again);
-  if (lane == 0) freq_out[site] = freq;
+  if (threadIdx.x == 0) {
+    freq_out[site] = freq;
+    redo[site] = 0;
+  }
 }
 
 // any number of individuals: re-reads the (L2-resident) site row every pass
 __global__ void __launch_bounds__(256)
 k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
                      uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
-                     double* __restrict__ freq_out) {
+                     double* __restrict__ freq_out, const uint8_t* __restrict__ redo) {
   const int lane = threadIdx.x & 63;
   const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (site >= S_own) return;
+  if (redo && !redo[site]) return;
   const double* gls = gl + site * I_tot * 3;
   int iters = 0;
   double num = 0, den = 0, freq = 0.01, prev;
@@ -768,7 +874,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
 
 void fast_destroy(FastState& fs) {
   void* ptrs[] = {fs.e_il, fs.pos_il, fs.r_il, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
-                  fs.grp_dev};
+                  fs.grp_dev, fs.redo};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fs = FastState();
@@ -879,21 +985,28 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
 bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out) {
-  (void)fs;
   if (S_own == 0) return true;
   const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
-  const uint64_t per_lane = (I_tot + 63) / 64;
-#define LAUNCH_NI(N)                                                                           \
-  hipLaunchKernelGGL((k_fast_estmaf<N>), grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own, \
-                     I_tot, I_blk, d_freq_out)
+  const uint64_t per_lane = (I_tot + 127) / 128;  // two waves per site
+  if (S_own > fs.redo_cap) {
+    if (fs.redo) (void)hipFree(fs.redo);
+    fs.redo = nullptr;
+    fs.redo_cap = 0;
+    if (hipMalloc((void**)&fs.redo, S_own) != hipSuccess) return false;
+    fs.redo_cap = S_own;
+  }
+#define LAUNCH_NI(N)                                                                      \
+  hipLaunchKernelGGL((k_fast_estmaf<N>), dim3((unsigned)S_own), dim3(128), 0, st, d_gl_sites, \
+                     d_marg_blocks, S_own, I_tot, I_blk, d_freq_out, fs.redo)
+  const uint8_t* redo = fs.redo;
   if (per_lane <= 1) LAUNCH_NI(1);
   else if (per_lane <= 2) LAUNCH_NI(2);
   else if (per_lane <= 4) LAUNCH_NI(4);
   else if (per_lane <= 8) LAUNCH_NI(8);
   else if (per_lane <= 16) LAUNCH_NI(16);
-  else
-    hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
-                       I_tot, I_blk, d_freq_out);
+  else redo = nullptr;  // too many individuals for registers: stream every site
+  hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
+                     I_tot, I_blk, d_freq_out, redo);
 #undef LAUNCH_NI
   return hipGetLastError() == hipSuccess;
 }

@@ -30,6 +30,8 @@ struct FastState {
   size_t grp_cap = 0;
   std::vector<unsigned char> grp_host;
   uint32_t n_groups = 0;
+  uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
+  size_t redo_cap = 0;
 };
 
 bool fast_create(FastState& fs, uint64_t I, uint64_t S);
