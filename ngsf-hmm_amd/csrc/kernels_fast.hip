@@ -34,10 +34,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "detmath.h"
+#include "fastmath.h"
 #include "kernels.hpp"
 #include "kernels_fast.hpp"
 
@@ -51,7 +53,9 @@ constexpr double kINF = 1e15;
 constexpr double kEPS = 1e-5;
 constexpr int MAXP = 5;   // probe points per group (f(x) + 4 finite-difference probes)
 constexpr int RENORM = 8; // sites between rescalings
-constexpr int UF = 4;     // prefetch depth (sites)
+constexpr int UF = 4;     // prefetch depth (sites) of the E-step sweeps
+constexpr int NB = 4;     // objective kernel: load buffers in flight ...
+constexpr int UG = 2;     // ... of this many sites each (NB * UG == RENORM)
 
 struct GroupDesc {
   uint32_t ind;
@@ -115,19 +119,24 @@ __device__ __forceinline__ Op op_shfl_down(const Op& m, int off) {
 }
 
 // one site applied to both rows of an operator:  row' = (c row + a (row.1) q) * e
-__device__ __forceinline__ void op_step(Op& m, double c, double aq0, double aq1, double e0,
-                                        double e1) {
+// with the products ce_k = c e_k and g_k = a e_k q_k formed by the caller
+__device__ __forceinline__ void op_step(Op& m, double ce0, double ce1, double g0, double g1) {
   const double s0 = m.a00 + m.a01;
   const double s1 = m.a10 + m.a11;
-  m.a00 = fma(aq0, s0, c * m.a00) * e0;
-  m.a01 = fma(aq1, s0, c * m.a01) * e1;
-  m.a10 = fma(aq0, s1, c * m.a10) * e0;
-  m.a11 = fma(aq1, s1, c * m.a11) * e1;
+  m.a00 = fma(g0, s0, ce0 * m.a00);
+  m.a01 = fma(g1, s0, ce1 * m.a01);
+  m.a10 = fma(g0, s1, ce0 * m.a10);
+  m.a11 = fma(g1, s1, ce1 * m.a11);
+}
+
+// exp(x) for |x| <= 1e-3 to < 1e-17 relative (x^6/720 is the first dropped term)
+__device__ __forceinline__ double exp_small(double x) {
+  return fma(x, fma(x, fma(x, fma(x, fma(x, 1.0 / 120, 1.0 / 24), 1.0 / 6), 0.5), 1.0), 1.0);
 }
 
 __device__ __forceinline__ double coanc(double alpha, double d) {
   // exp(-alpha d): 0 at chromosome starts (d = +inf), 1 on padding sites (d = 0)
-  return exp(-alpha * d);
+  return exp_nonpos(-alpha * d);
 }
 
 // ---- objective: chunk operators of <= 5 points per individual ------------
@@ -157,56 +166,72 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
   const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
 
-  double2 ecur[UF], enxt[UF];
-  double dcur[UF], dnxt[UF];
+  // Software pipeline: NB buffers of UG sites.  A buffer is refilled right after it
+  // has been consumed, i.e. (NB-1) groups = 6 sites before it is needed again, which
+  // covers HBM latency at two waves per SIMD (a one-group-ahead scheme stalled on
+  // every group: 2.4 TB/s instead of ~4).
+  double2 eb[NB][UG];
+  double db[NB][UG];
 #pragma unroll
-  for (int u = 0; u < UF; ++u) {
-    const bool v = (uint64_t)u < T;
-    ecur[u] = v ? ep[(uint64_t)u * 64] : double2{1, 1};
-    dcur[u] = v ? dp[(uint64_t)u * 64] : 0.0;
-  }
-  for (uint64_t t0 = 0; t0 < T; t0 += UF) {
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const uint64_t t = t0 + UF + u;
+    for (int u = 0; u < UG; ++u) {
+      const uint64_t t = (uint64_t)b * UG + u;
       const bool v = t < T;
-      enxt[u] = v ? ep[t * 64] : double2{1, 1};
-      dnxt[u] = v ? dp[t * 64] : 0.0;
+      eb[b][u] = v ? ep[t * 64] : double2{1, 1};
+      db[b][u] = v ? dp[t * 64] : 0.0;
     }
+  }
+  for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
 #pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      // sites past T are identity operators (e = 1, d = 0), so no bound check
-      const double e0 = ecur[u].x, e1 = ecur[u].y, d = dcur[u];
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        // sites past T are identity operators (e = 1, d = 0), so no bound check
+        const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
       if (NP_MAX >= 5 && shared3) {
-        const double c0 = coanc(al[0], d), c3 = coanc(al[3], d), c4 = coanc(al[4], d);
-        const double a0 = 1 - c0;
-        op_step(R[0], c0, a0 * q0[0], a0 * q1[0], e0, e1);
-        op_step(R[1], c0, a0 * q0[1], a0 * q1[1], e0, e1);
-        op_step(R[2], c0, a0 * q0[2], a0 * q1[2], e0, e1);
-        const double a3 = 1 - c3, a4 = 1 - c4;
-        op_step(R[3], c3, a3 * q0[3], a3 * q1[3], e0, e1);
-        op_step(R[4], c4, a4 * q0[4], a4 * q1[4], e0, e1);
-      } else {
-#pragma unroll
-        for (int p = 0; p < NP_MAX; ++p) {
-          if (p < (int)np) {
-            const double cc = coanc(al[p], d);
-            const double a = 1 - cc;
-            op_step(R[p], cc, a * q0[p], a * q1[p], e0, e1);
+          // the finite-difference pattern: points 0..2 share alpha; points 3 and 4 sit at
+          // alpha +- eh, so their c is c0 * exp(-+ eh d) with a tiny argument
+          const double c0 = coanc(al[0], d);
+          const double x3 = (al[0] - al[3]) * d, x4 = (al[0] - al[4]) * d;
+          double c3, c4;
+          if (fabs(x3) <= 1e-3 && fabs(x4) <= 1e-3) {
+            c3 = c0 * exp_small(x3);
+            c4 = c0 * exp_small(x4);
+          } else {  // chromosome starts (d = inf) and very long gaps
+            c3 = coanc(al[3], d);
+            c4 = coanc(al[4], d);
+          }
+          const double a0 = 1 - c0;
+          const double ce0 = c0 * e0, ce1 = c0 * e1, ae0 = a0 * e0, ae1 = a0 * e1;
+          op_step(R[0], ce0, ce1, ae0 * q0[0], ae1 * q1[0]);
+          op_step(R[1], ce0, ce1, ae0 * q0[1], ae1 * q1[1]);
+          op_step(R[2], ce0, ce1, ae0 * q0[2], ae1 * q1[2]);
+          const double a3 = 1 - c3, a4 = 1 - c4;
+          op_step(R[3], c3 * e0, c3 * e1, a3 * e0 * q0[3], a3 * e1 * q1[3]);
+          op_step(R[4], c4 * e0, c4 * e1, a4 * e0 * q0[4], a4 * e1 * q1[4]);
+        } else {
+  #pragma unroll
+          for (int p = 0; p < NP_MAX; ++p) {
+            if (p < (int)np) {
+              const double cc = coanc(al[p], d);
+              const double a = 1 - cc;
+              op_step(R[p], cc * e0, cc * e1, a * e0 * q0[p], a * e1 * q1[p]);
+            }
           }
         }
       }
-    }
-    if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) {
 #pragma unroll
-      for (int p = 0; p < NP_MAX; ++p)
-        if (p < (int)np) renorm(R[p]);
+      for (int u = 0; u < UG; ++u) {
+        const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
+        const bool v = t < T;
+        eb[b][u] = v ? ep[t * 64] : double2{1, 1};
+        db[b][u] = v ? dp[t * 64] : 0.0;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      ecur[u] = enxt[u];
-      dcur[u] = dnxt[u];
-    }
+    for (int p = 0; p < NP_MAX; ++p)
+      if (p < (int)np) renorm(R[p]);
   }
   // ordered product over the 64 lanes
 #pragma unroll
@@ -290,7 +315,7 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
     for (int u = 0; u < UF; ++u) {
       const double cc = coanc(al, dcur[u]);
       const double a = 1 - cc;
-      op_step(R, cc, a * q0, a * q1, ecur[u].x, ecur[u].y);
+      op_step(R, cc * ecur[u].x, cc * ecur[u].y, a * ecur[u].x * q0, a * ecur[u].y * q1);
     }
     if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) renorm(R);
 #pragma unroll
@@ -651,6 +676,14 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {
   return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
 }
 
+// 1/x to full precision (two Newton steps); x finite and > 0
+__device__ __forceinline__ double rcp_nr2(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
 // 1/x to ~46 bits: v_rcp_f64 (about 23 bits) + one Newton step; x in (0, 3]
 __device__ __forceinline__ double rcp_nr(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -687,7 +720,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   const uint64_t site = blockIdx.x;
   const double* gls = gl + site * I_tot * 3;
 
-  double sA[NI], sC[NI], c1[NI], Fv[NI], nC[NI];
+  double sA[NI], sb[NI], sC[NI], c1[NI], Fv[NI], nC[NI], fc[NI];
   double tF_lane = 0;
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
@@ -700,11 +733,13 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       sC[k] = p2;
       c1[k] = cc;
       Fv[k] = F;
+      sb[k] = fma(F, p0 + p2, cc);
       nC[k] = (2 - F) * p2;
+      fc[k] = F * cc;
       tF_lane += 2 - F;
-    } else {  // empty slot: sum = A + C >= 1/2, numerators 0: contributes nothing
+    } else {  // empty slot: sum' = 1 + r^2 > 0, numerators 0: contributes nothing
       sA[k] = 1; sC[k] = 1;
-      c1[k] = Fv[k] = nC[k] = 0;
+      sb[k] = c1[k] = Fv[k] = nC[k] = fc[k] = 0;
     }
   }
   {
@@ -721,26 +756,24 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   bool again;
   do {
     prev = freq;
+    // Divide every weight by (1-f)^2: with the odds r = f/(1-f),
+    //   sum' = sA + r sb + r^2 sC,  num-term = r (nC (F + r) + c1) / sum',
+    //   den-term = (2-F) + r F c1 / sum'      (ratios are scale-free)
     const double om = 1 - freq;
-    const double b = om * freq;
-    const double A = om * om, Cq = freq * freq;
+    const double r = freq * rcp_nr2(om);
     double pn = 0, pd = 0;
-    bool bad = false;
+    bool bad = !(om > 0);
     if constexpr (NI >= 4) {
       // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step
       // and 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
 #pragma unroll
       for (int k0 = 0; k0 < NI; k0 += 4) {
-        double w1[4], sm[4], nn[4];
+        double sm[4], un[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int k = k0 + j;
-          w1[j] = b * c1[k];
-          // sb = F (p0 + p2) + c1 is recomputed: keeping it would push the kernel past
-          // 256 VGPRs (one wave per SIMD and AGPR traffic)
-          const double sbk = fma(Fv[k], sA[k] + sC[k], c1[k]);
-          sm[j] = fma(A, sA[k], fma(b, sbk, Cq * sC[k]));
-          nn[j] = fma(nC[k], fma(b, Fv[k], Cq), w1[j]);
+          sm[j] = fma(r, fma(r, sC[k], sb[k]), sA[k]);
+          un[j] = fma(nC[k], Fv[k] + r, c1[k]);
         }
         const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
         const double P = p01 * p23;
@@ -749,28 +782,28 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
         const double r01 = R * p23, r23 = R * p01;
         const double inv0 = r01 * sm[1], inv1 = r01 * sm[0];
         const double inv2 = r23 * sm[3], inv3 = r23 * sm[2];
-        pn = fma(nn[0], inv0, pn);
-        pd = fma(Fv[k0] * w1[0], inv0, pd);
-        pn = fma(nn[1], inv1, pn);
-        pd = fma(Fv[k0 + 1] * w1[1], inv1, pd);
-        pn = fma(nn[2], inv2, pn);
-        pd = fma(Fv[k0 + 2] * w1[2], inv2, pd);
-        pn = fma(nn[3], inv3, pn);
-        pd = fma(Fv[k0 + 3] * w1[3], inv3, pd);
+        pn = fma(un[0], inv0, pn);
+        pd = fma(fc[k0], inv0, pd);
+        pn = fma(un[1], inv1, pn);
+        pd = fma(fc[k0 + 1], inv1, pd);
+        pn = fma(un[2], inv2, pn);
+        pd = fma(fc[k0 + 2], inv2, pd);
+        pn = fma(un[3], inv3, pn);
+        pd = fma(fc[k0 + 3], inv3, pd);
       }
     } else {
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
-        const double w1 = b * c1[k];
-        const double sbk = fma(Fv[k], sA[k] + sC[k], c1[k]);
-        const double sum = fma(A, sA[k], fma(b, sbk, Cq * sC[k]));
-        const double nn = fma(nC[k], fma(b, Fv[k], Cq), w1);
+        const double sum = fma(r, fma(r, sC[k], sb[k]), sA[k]);
+        const double un = fma(nC[k], Fv[k] + r, c1[k]);
         bad |= !(sum > 0);
         const double inv = rcp_nr(sum);
-        pn = fma(nn, inv, pn);
-        pd = fma(Fv[k] * w1, inv, pd);
+        pn = fma(un, inv, pn);
+        pd = fma(fc[k], inv, pd);
       }
     }
+    pn *= r;
+    pd *= r;
     {
       const double wn = wave_sum_uniform(pn), wd = wave_sum_uniform(pd);
       if (lane == 0) {
@@ -787,7 +820,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     num += xch[buf][0][0] + xch[buf][1][0];
     den += tF_sum + (xch[buf][0][1] + xch[buf][1][1]);
     buf ^= 1;
-    freq = num / den;
+    freq = num * rcp_nr2(den);
     again = (fabs(prev - freq) > kEPS) && (iters++ < 100);
   } while (again);
   if (threadIdx.x == 0) {
@@ -856,6 +889,10 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   fs.S = S;
   // enough waves to fill 256 CUs several times over, but at least 16 sites per lane
   uint64_t C = (8192 + I - 1) / I;
+  if (const char* env = std::getenv("NGHMM_FAST_C")) {  // tuning knob: waves per individual
+    const long v = std::atol(env);
+    if (v >= 1) C = (uint64_t)v;
+  }
   if (C > 64) C = 64;
   while (C > 1 && (S + 64 * C - 1) / (64 * C) < 16) --C;
   if (C < 1) C = 1;
