@@ -194,11 +194,11 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
           // alpha +- eh, so their c is c0 * exp(-+ eh d) with a tiny argument
           const double c0 = coanc(al[0], d);
           const double x3 = (al[0] - al[3]) * d, x4 = (al[0] - al[4]) * d;
-          double c3, c4;
-          if (fabs(x3) <= 1e-3 && fabs(x4) <= 1e-3) {
-            c3 = c0 * exp_small(x3);
-            c4 = c0 * exp_small(x4);
-          } else {  // chromosome starts (d = inf) and very long gaps
+          double c3 = c0 * exp_small(x3);
+          double c4 = c0 * exp_small(x4);
+          // chromosome starts (d = inf) and very long gaps: a wave-uniform branch, so
+          // the two full exps are not if-converted into the common path
+          if (__ballot(!(fabs(x3) <= 1e-3 && fabs(x4) <= 1e-3))) {
             c3 = coanc(al[3], d);
             c4 = coanc(al[4], d);
           }
@@ -668,6 +668,27 @@ __device__ __forceinline__ double lane_value(double v, int lane) {
   return ngh_from_bits(((uint64_t)hi << 32) | lo);
 }
 
+// total in the lanes of the last row (48..63); other lanes hold partial sums
+__device__ __forceinline__ double wave_sum_lastrow(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror: every lane holds its row total
+  {  // row_bcast15 into rows 1 and 3, then row_bcast31 into rows 2 and 3
+    const uint64_t b = ngh_bits(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x142, 0xa, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x142, 0xa, 0xf, false);
+    v += ngh_from_bits(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+  }
+  {
+    const uint64_t b = ngh_bits(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x143, 0xc, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x143, 0xc, 0xf, false);
+    v += ngh_from_bits(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+  }
+  return v;
+}
+
 __device__ __forceinline__ double wave_sum_uniform(double v) {
   v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -805,11 +826,12 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     pn *= r;
     pd *= r;
     {
-      const double wn = wave_sum_uniform(pn), wd = wave_sum_uniform(pd);
-      if (lane == 0) {
+      const double wn = wave_sum_lastrow(pn), wd = wave_sum_lastrow(pd);
+      const bool anybad = __ballot(bad) != 0;
+      if (lane == 63) {
         xch[buf][wv][0] = wn;
         xch[buf][wv][1] = wd;
-        xch[buf][wv][2] = __ballot(bad) ? 1.0 : 0.0;
+        xch[buf][wv][2] = anybad ? 1.0 : 0.0;
       }
     }
     __syncthreads();
