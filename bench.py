@@ -39,6 +39,38 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
+LIMITER_NOTES = {
+    "est_maf": "FP64-VALU-issue bound, not HBM bound: the reference's est_maf makes ~100 passes "
+               "per site over in-register data (SQ_ACTIVE_INST_VALU ~35% per wave x 3 waves/SIMD, "
+               "profiles/r01_pmc_summary.json); HBM traffic is one read of GL + posteriors",
+    "lkl_batch": "objective of the L-BFGS-B M-step: one 16 B emission pair per site and individual "
+                 "per round; FP64-VALU issue is saturated at two waves per SIMD",
+    "forward": "E-step: operators, boundary vectors, forward odds, backward posteriors, "
+               "de-interleave (five launches, timed together)",
+}
+
+_KERNEL_OF = {"lkl_batch": "k_fast_lkl_chunks", "est_maf": "k_fast_estmaf<8>",
+              "emission": "k_fast_emission"}
+
+
+def pmc_traffic(family, args, I, S, ind_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction).
+    Only valid for the workload it was collected on (c3, fast mode); else None."""
+    if args.workload != "c3" or args.mode != "fast" or family not in _KERNEL_OF:
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path)).get(_KERNEL_OF[family])
+    if not d or "hbm_bytes_per_launch" not in d:
+        return None
+    t = d["hbm_bytes_per_launch"]
+    if family == "lkl_batch" and d.get("avg_individuals_per_launch"):
+        t *= ind_per_launch / d["avg_individuals_per_launch"]   # launches differ in width
+    return t
+
+
 def cpu_baseline(pkg, seconds_budget=20.0):
     """The oracle (libm build = the reference's arithmetic; its L-BFGS-B core is pinned
     bit for bit to the reference object) timed on this box's host cores on a bounded
@@ -169,6 +201,14 @@ def main():
         dom = max(fam, key=lambda k: fam[k])
         avg_ms = fam[dom] / max(launches[dom], 1)
         achieved = algo[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = pmc_traffic(dom, args, I, S, ind_rounds / max(launches["lkl_batch"], 1))
+        # every kernel family against the HBM roof (the dominant one is repeated above)
+        fam_roof = {}
+        for k in fam:
+            if launches[k] and fam[k] > 0:
+                gbs = algo[k] / (fam[k] / launches[k] * 1e-3) / 1e9
+                fam_roof[k] = {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                               "avg_launch_ms": fam[k] / launches[k], "launches": launches[k]}
         out = {
             "metric": "site-ind updates/sec (EM iterations x individuals x sites / s), 1M sites x 1k ind",
             "value": units / dt,
@@ -187,8 +227,11 @@ def main():
                        "mode": args.mode, "freq_est": 1,
                        "sharding": "individuals per GPU; site-sharded allele-frequency step"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": avg_ms, "launches": launches[dom]},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": launches[dom],
+                         "algorithmic_bytes_per_launch": algo[dom],
+                         "note": LIMITER_NOTES.get(dom, "")},
+            "roofline_all_kernels": fam_roof,
             "per_step_kernel_ms": {k: fam[k] / K for k in fam},
             "bfgs": {"rounds_per_iter": rounds / K, "points_per_iter": points / K,
                      "ind_rounds_per_iter": ind_rounds / K,

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (one directory per pass, CSV output) into a small JSON
+that bench.py reads for the `roofline.traffic` field.
+
+HBM bytes per launch follow MI355X_MICROARCH.md section HBM / cdna_hip_programming.md
+section 7: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the
+bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled for kernels whose
+dominant loads are 16 B per lane (the interleaved emission stream); WRITE_SIZE is exact.
+Collected in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+
+usage: summarize_pmc.py <sq.csv> <fetch.csv> <write.csv> <out.json> [C]
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def short(name):
+    n = name.split("::")[-1].split("(")[0]
+    if "GroupDesc const*, double" in name or "k_fast_lkl_chunks" in name:
+        return "k_fast_lkl_chunks"
+    if "k_fast_lkl_finish" in name or "GroupDesc const*, unsign" in name:
+        return "k_fast_lkl_finish"
+    return n.strip()
+
+
+def per_kernel(path, counter=None):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    grid = collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        if "nghmm" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in n[k]:
+            n[k].add(r["Dispatch_Id"])
+            grid[k] += float(r["Grid_Size"])
+    return acc, {k: len(v) for k, v in n.items()}, grid
+
+
+def main():
+    sq, fetch, write, out = sys.argv[1:5]
+    C = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+    a_sq, n_sq, _ = per_kernel(sq)
+    a_f, n_f, grid_f = per_kernel(fetch)
+    a_w, n_w, _ = per_kernel(write)
+    res = {}
+    for k in sorted(set(a_sq) | set(a_f)):
+        d = {}
+        if k in a_f:
+            raw = a_f[k]["FETCH_SIZE"] * 1024.0 / n_f[k]
+            d["fetch_bytes_raw_per_launch"] = raw
+            d["fetch_bytes_corrected_per_launch"] = 2.0 * raw
+            d["launches_fetch_pass"] = n_f[k]
+            d["avg_grid_threads"] = grid_f[k] / n_f[k]
+        if k in a_w:
+            d["write_bytes_per_launch"] = a_w[k]["WRITE_SIZE"] * 1024.0 / n_w[k]
+        if k in a_sq:
+            c = a_sq[k]
+            wc = c["SQ_WAVE_CYCLES"] or 1.0
+            d.update({
+                "valu_active_frac_per_wave": c["SQ_ACTIVE_INST_VALU"] / wc,
+                "wait_inst_frac": c["SQ_WAIT_INST_ANY"] / wc,
+                "wait_any_frac": c["SQ_WAIT_ANY"] / wc,
+                "insts_valu_per_launch": c["SQ_INSTS_VALU"] / n_sq[k],
+                "grbm_gui_active_per_launch": c["GRBM_GUI_ACTIVE"] / n_sq[k],
+            })
+        if "fetch_bytes_corrected_per_launch" in d:
+            d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected_per_launch"] + d.get(
+                "write_bytes_per_launch", 0.0)
+        if k == "k_fast_lkl_chunks" and "avg_grid_threads" in d:
+            d["avg_individuals_per_launch"] = d["avg_grid_threads"] / 64.0 / C
+        res[k] = d
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for k, d in res.items():
+        print(k, {kk: (f"{vv:.4g}" if isinstance(vv, float) else vv) for kk, vv in d.items()})
+
+
+if __name__ == "__main__":
+    main()
