@@ -1,0 +1,618 @@
+// ngsF-HMM (MI355X) -- C++ host of the GPU EM hot path.
+//
+// Keeps the reference's command line (parse_args.cpp:43-68: same long options, also
+// with a single dash), its input conventions (shared/read_data.cpp) and its output
+// files (.indF / .ibd / .geno, EM.cpp:293-380) byte-compatible, and runs the EM loop
+// of EM.cpp:27-135 with every per-site-per-individual computation behind the C ABI of
+// include/nghmm.h (HIP kernels).  Host-side work is what the reference also does once,
+// outside its hot loop: argument parsing, file I/O, GL normalisation, initial values.
+//
+// Extra options: --mode exact|fast (default fast), --device N.
+#include <getopt.h>
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../../include/nghmm.h"
+
+namespace {
+
+const char* kVersion = "1.1.0-mi355x";
+constexpr double kINF = 1e15;        // shared/gen_func.hpp:15
+constexpr double kEPSILON = 1e-5;    // shared/gen_func.hpp:16
+constexpr size_t kBuffLen = 500000;  // shared/gen_func.hpp:17
+
+struct Params {  // ngsF-HMM.hpp:13-52
+  const char* in_geno = nullptr;
+  const char* in_pos = nullptr;
+  bool in_bin = false, in_lkl = false, in_loglkl = false;
+  uint64_t n_ind = 0, n_sites = 0;
+  bool call_geno = false;
+  std::string in_freq, in_indF;
+  int freq_est = 1, e_prob_calc = 1;
+  bool indF_fixed = false, alpha_fixed = false;
+  const char* out_prefix = nullptr;
+  unsigned log = 0;
+  bool log_bin = false;
+  unsigned min_iters = 10, max_iters = 100;
+  double min_epsilon = 1e-5;
+  unsigned n_threads = 1, verbose = 1, seed = 0;
+  int mode = NGHMM_MODE_FAST, device = 0;
+
+  std::vector<double> gl;        // [S][I][3] log, normalised
+  std::vector<double> pos_dist;  // [S] Mb
+  std::vector<double> freq, indF, alpha, ind_lkl, marg;
+  std::vector<uint8_t> path;
+  double tot_lkl = 0, prev_tot_lkl = 0;
+};
+
+[[noreturn]] void fatal(const char* func, const char* msg) {  // gen_func.cpp:12-18
+  fflush(stdout);
+  fprintf(stderr, "\n=====\nERROR: [%s] %s\n=====\n\n", func, msg);
+  fflush(stderr);
+  exit(-1);
+}
+
+void warn(const char* func, const char* msg) {
+  fflush(stdout);
+  fprintf(stderr, "\n=======\nWARNING: [%s] %s\n=======\n\n", func, msg);
+  fflush(stderr);
+}
+
+void check(int rc, const char* where) {
+  if (rc == NGHMM_OK) return;
+  const char* detail = nghmm_last_error();
+  fatal(where, (detail && *detail) ? detail : nghmm_strerror(rc));
+}
+
+// --- the reference's logsum / post_prob / call_geno on the host (input preparation) ---
+double logsum3(const double* a) {  // gen_func.cpp:135-151
+  double M = a[0];
+  for (int i = 1; i < 3; i++) M = (a[i] >= M) ? a[i] : M;
+  if (M == -INFINITY) return -INFINITY;
+  double sum = 0;
+  for (int i = 0; i < 3; i++) sum += exp(a[i] - M);
+  return log(sum) + M;
+}
+
+void post_prob_self(double* g) {  // gen_func.cpp:920-932 with prior == NULL
+  const double norm = logsum3(g);
+  for (int k = 0; k < 3; k++) g[k] -= norm;
+}
+
+void call_geno(double* g) {  // gen_func.cpp:886-914, defaults (log scale, thresholds 0, miss 0)
+  int max_pos = 0, min_pos = 0;
+  double mx = -INFINITY, mn = INFINITY;
+  for (int k = 0; k < 3; k++) {
+    if (g[k] > mx) { mx = g[k]; max_pos = k; }
+    if (g[k] < mn) { mn = g[k]; min_pos = k; }
+  }
+  double max_pp = exp(g[max_pos]);
+  if (g[min_pos] == g[max_pos]) max_pp = -1;
+  if (max_pp < 0)
+    for (int k = 0; k < 3; k++) g[k] = log((double)1 / 3);
+  if (max_pp >= 0) {
+    for (int k = 0; k < 3; k++) g[k] = -kINF;
+    g[max_pos] = log(1);
+  }
+}
+
+// --- text parsing: tokens on the separators, non-numeric tokens dropped (gen_func.cpp:390-417) ---
+size_t split_doubles(char* line, const char* sep, std::vector<double>& out) {
+  out.clear();
+  char* p = line;
+  while (*p) {
+    p += strspn(p, sep);
+    if (!*p) break;
+    size_t len = strcspn(p, sep);
+    char saved = p[len];
+    p[len] = '\0';
+    char* end = nullptr;
+    double v = strtod(p, &end);
+    if (end != p && *end == '\0') out.push_back(v);
+    p[len] = saved;
+    p += len;
+  }
+  return out.size();
+}
+
+void chomp(char* s) {
+  size_t n = strlen(s);
+  while (n && (s[n - 1] == '\n' || s[n - 1] == '\r')) s[--n] = '\0';
+}
+
+// shared/read_data.cpp:165-218 + ngsF-HMM.cpp:75-86
+void read_dist(Params& P) {
+  gzFile fh = gzopen(P.in_pos, "r");
+  if (!fh) fatal(__FUNCTION__, "cannot open POS file!");
+  std::vector<char> buf(kBuffLen);
+  P.pos_dist.assign(P.n_sites, INFINITY);
+  std::string prev_chr;
+  uint64_t prev_pos = 0, s = 0;
+  while (gzgets(fh, buf.data(), (int)kBuffLen) != nullptr) {
+    chomp(buf.data());
+    if (buf[0] == '\0' || buf[0] == '#') continue;
+    char* tab = strpbrk(buf.data(), "\t");
+    if (!tab) fatal(__FUNCTION__, "wrong POS file format!");
+    std::string chr(buf.data(), tab - buf.data());
+    const char* pos_s = tab + 1;
+    if (strtod(pos_s, nullptr) == 0) {  // header
+      fprintf(stderr, "> Header found! Skipping line...\n");
+      continue;
+    }
+    if (s >= P.n_sites) fatal(__FUNCTION__, "wrong number of lines in POS file!");
+    if (prev_chr.empty()) prev_chr = chr;
+    if (chr == prev_chr) {
+      P.pos_dist[s] = strtod(pos_s, nullptr) - (double)prev_pos;
+      if (P.pos_dist[s] < 1) fatal(__FUNCTION__, "invalid distance between adjacent sites!");
+    } else {
+      P.pos_dist[s] = INFINITY;
+      prev_chr = chr;
+    }
+    prev_pos = strtoul(pos_s, nullptr, 0);
+    s++;
+  }
+  gzclose(fh);
+  if (s != P.n_sites) fatal(__FUNCTION__, "wrong number of lines in POS file!");
+  for (auto& d : P.pos_dist) d /= 1e6;
+}
+
+// shared/read_data.cpp:13-116
+void read_geno(Params& P) {
+  const uint64_t I = P.n_ind, S = P.n_sites;
+  const uint64_t n_geno = P.in_lkl ? 3 : 1;
+  P.gl.assign((size_t)S * I * 3, -kINF);
+  gzFile fh = gzopen(P.in_geno, P.in_bin ? "rb" : "r");
+  if (!fh) fatal(__FUNCTION__, "cannot open GENO file!");
+  gzbuffer(fh, 1 << 20);
+  if (P.in_bin) {
+    for (uint64_t s = 0; s < S; s++) {
+      double* row = &P.gl[s * I * 3];
+      const int want = (int)(I * 3 * sizeof(double));
+      if (gzread(fh, row, want) != want)
+        fatal(__FUNCTION__, gzeof(fh)
+                                ? "GENO file at premature EOF. Check GENO file and number of sites!"
+                                : "cannot read binary GENO file. Check GENO file and number of sites!");
+      for (uint64_t i = 0; i < I; i++) {
+        double* g = row + i * 3;
+        if (!P.in_loglkl)
+          for (int k = 0; k < 3; k++) {
+            g[k] = log(g[k]);
+            if (g[k] == -INFINITY) g[k] = -kINF;
+          }
+        post_prob_self(g);
+        if (std::isnan(g[0]) || std::isnan(g[1]) || std::isnan(g[2]))
+          fatal(__FUNCTION__, "NaN found! Is the file format correct?");
+      }
+    }
+  } else {
+    std::vector<char> buf(kBuffLen);
+    std::vector<double> t;
+    for (uint64_t s = 0; s < S; s++) {
+      if (gzgets(fh, buf.data(), (int)kBuffLen) == nullptr)
+        fatal(__FUNCTION__, gzeof(fh)
+                                ? "GENO file at premature EOF. Check GENO file and number of sites!"
+                                : "cannot read GZip GENO file. Check GENO file and number of sites!");
+      chomp(buf.data());
+      if (buf[0] == '\0') continue;  // (sic) an empty line still consumes a site, as in the reference
+      const size_t n_fields = split_doubles(buf.data(), " \t", t);
+      if (!n_fields || (s == 0 && n_fields < I * n_geno)) {
+        fprintf(stderr, "> Header found! Skipping line...\n");
+        if (s != 0) warn(__FUNCTION__, " header found but not on first line. Is this an error?");
+        s--;
+        continue;
+      }
+      if (n_fields < I * n_geno)
+        fatal(__FUNCTION__, "wrong GENO file format. Less fields than expected!");
+      const double* ptr = t.data() + (n_fields - I * n_geno);  // last I*n_geno columns
+      for (uint64_t i = 0; i < I; i++) {
+        double* g = &P.gl[(s * I + i) * 3];
+        if (P.in_lkl) {
+          for (int k = 0; k < 3; k++) g[k] = P.in_loglkl ? ptr[i * 3 + k] : log(ptr[i * 3 + k]);
+        } else {
+          const int gg = (int)ptr[i];
+          if (gg >= 0) {
+            if (gg > 2)
+              fatal(__FUNCTION__,
+                    "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+            g[gg] = log(1);
+          } else {
+            g[0] = g[1] = g[2] = log((double)1 / 3);
+          }
+        }
+        post_prob_self(g);
+      }
+    }
+  }
+  char c;
+  gzread(fh, &c, 1);
+  if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
+  gzclose(fh);
+  // ngsF-HMM.cpp:101-117: optional genotype calling, then a second normalisation
+  for (uint64_t c2 = 0; c2 < (uint64_t)S * I; c2++) {
+    double* g = &P.gl[c2 * 3];
+    if (P.call_geno) call_geno(g);
+    post_prob_self(g);
+  }
+}
+
+// GSL's gsl_rng_taus (Tausworthe, L'Ecuyer 1996), the only GSL generator the reference
+// uses (parse_args.cpp:232-233); restated from the published recurrence.
+struct Taus {
+  uint32_t s1, s2, s3;
+  static uint32_t lcg(uint32_t n) { return 69069u * n; }
+  uint32_t next() {
+    s1 = ((s1 & 4294967294u) << 12) ^ (((s1 << 13) ^ s1) >> 19);
+    s2 = ((s2 & 4294967288u) << 4) ^ (((s2 << 2) ^ s2) >> 25);
+    s3 = ((s3 & 4294967280u) << 17) ^ (((s3 << 3) ^ s3) >> 11);
+    return s1 ^ s2 ^ s3;
+  }
+  explicit Taus(uint32_t s) {
+    if (s == 0) s = 1;
+    s1 = lcg(s);
+    s2 = lcg(s1);
+    s3 = lcg(s2);
+    for (int i = 0; i < 6; i++) next();
+  }
+  double uniform() { return next() / 4294967296.0; }
+};
+
+double clampd(double v, double lo, double hi) {
+  const double a = (v >= lo) ? v : lo;  // the reference's max/min macros
+  return (a <= hi) ? a : hi;
+}
+
+// parse_args.cpp:229-363 (initial indF/alpha and freq); --freq e is done on the GPU
+bool init_values(Params& P, nghmm_t* h) {
+  const uint64_t I = P.n_ind, S = P.n_sites;
+  Taus rng(P.seed);
+  const double f_min = 0.000001, f_max = 1 - f_min;
+  P.indF.assign(I, 0);
+  P.alpha.assign(I, 0);
+  std::vector<double> t;
+  std::vector<char> buf(kBuffLen);
+  gzFile fh;
+  if (P.in_indF == "r") {
+    if (P.verbose >= 1) printf("==> Using random initial inbreeding values.\n");
+    for (uint64_t i = 0; i < I; i++) {
+      P.indF[i] = f_min + rng.uniform() * (f_max - f_min);
+      P.alpha[i] = f_min + rng.uniform() * (f_max - f_min);
+    }
+  } else if ((fh = gzopen(P.in_indF.c_str(), "r")) != nullptr) {
+    if (P.verbose >= 1)
+      printf("==> Reading initial inbreeding values from file \"%s\".\n", P.in_indF.c_str());
+    uint64_t i = 0;
+    while (gzgets(fh, buf.data(), (int)kBuffLen) != nullptr) {
+      chomp(buf.data());
+      if (buf[0] == '\0') continue;
+      if (i >= I || split_doubles(buf.data(), " ,-\t", t) != 2)
+        fatal(__FUNCTION__, "wrong INDF file format!");
+      P.indF[i] = clampd(t[0], f_min, f_max);
+      P.alpha[i] = clampd(t[1], f_min, f_max);
+      i++;
+    }
+    gzclose(fh);
+  } else {
+    if (P.verbose >= 1)
+      printf("==> Setting initial inbreeding values to: %s\n", P.in_indF.c_str());
+    std::string tmp = P.in_indF;
+    if (split_doubles(&tmp[0], ",-", t) != 2) fatal(__FUNCTION__, "wrong INDF parameters format!");
+    for (uint64_t i = 0; i < I; i++) {
+      P.indF[i] = clampd(t[0], f_min, f_max);
+      P.alpha[i] = clampd(t[1], f_min, f_max);
+    }
+  }
+
+  const double q_min = 0.01, q_max = 0.5 - q_min;
+  P.freq.assign(S, q_min);
+  bool estimate = false;
+  if (P.in_freq == "r") {
+    if (P.verbose >= 1) printf("==> Using random initial frequency values.\n");
+    for (uint64_t s = 0; s < S; s++) P.freq[s] = q_min + rng.uniform() * (q_max - q_min);
+  } else if (P.in_freq == "e") {
+    if (P.verbose >= 1) printf("==> Estimating initial frequency values assuming HWE.\n");
+    estimate = true;
+  } else if ((fh = gzopen(P.in_freq.c_str(), "r")) != nullptr) {
+    if (P.verbose >= 1)
+      printf("==> Reading initial frequency values from file \"%s\".\n", P.in_freq.c_str());
+    uint64_t s = 0;
+    while (gzgets(fh, buf.data(), (int)kBuffLen) != nullptr) {
+      chomp(buf.data());
+      if (buf[0] == '\0') continue;
+      const size_t n = split_doubles(buf.data(), " ,-\t", t);
+      if (!n) {
+        printf("> Header found! Skipping line...\n");
+        continue;
+      }
+      if (s >= S || n != 1) fatal(__FUNCTION__, "wrong FREQ file format!");
+      P.freq[s++] = clampd(t[0], q_min, q_max);
+    }
+    gzclose(fh);
+  } else {
+    if (P.verbose >= 1) printf("==> Setting initial frequency values to: %s\n", P.in_freq.c_str());
+    for (uint64_t s = 0; s < S; s++) P.freq[s] = clampd(atof(P.in_freq.c_str()), q_min, q_max);
+  }
+  check(nghmm_set_params(h, P.indF.data(), P.alpha.data(), P.freq.data()), "init_output");
+  return estimate;
+}
+
+// gen_func.cpp:938-957 + 920-932 on the host, for the .geno posteriors (EM.cpp:367-376)
+void geno_posterior(const double* gl, double maf, double F, double* pp) {
+  double h[3];
+  h[0] = (1 - maf) * (1 - maf) + (1 - maf) * maf * F;
+  h[1] = 2 * (1 - maf) * maf - 2 * (1 - maf) * maf * F;
+  h[2] = maf * maf + (1 - maf) * maf * F;
+  for (int k = 0; k < 3; k++) {
+    h[k] = log(h[k]);
+    if (h[k] == -INFINITY) h[k] = -kINF;
+  }
+  if (F == 1) h[1] = -kINF;
+  for (int k = 0; k < 3; k++) pp[k] = gl[k] + h[k];
+  const double norm = logsum3(pp);
+  for (int k = 0; k < 3; k++) pp[k] = exp(pp[k] - norm);
+}
+
+// EM.cpp:293-380
+void print_iter(const Params& P) {
+  const uint64_t I = P.n_ind, S = P.n_sites;
+  std::string name = std::string(P.out_prefix) + ".indF";
+  FILE* fh = fopen(name.c_str(), "w");
+  if (!fh) fatal(__FUNCTION__, "cannot open INDF output file!");
+  fprintf(fh, "%.10f\n", P.tot_lkl);
+  for (uint16_t i = 0; i < I; i++) {  // (sic) uint16_t as in the reference
+    if (P.indF[i] < kEPSILON)
+      fprintf(fh, "%.5f\tNA\n", (double)0);
+    else if (P.indF[i] > 1 - kEPSILON)
+      fprintf(fh, "%.5f\tNA\n", (double)1);
+    else
+      fprintf(fh, "%.5f\t%f\n", P.indF[i], P.alpha[i]);
+  }
+  for (uint64_t s = 0; s < S; s++) fprintf(fh, "%f\n", P.freq[s]);
+  fclose(fh);
+
+  name = std::string(P.out_prefix) + ".ibd";
+  fh = fopen(name.c_str(), "w");
+  if (!fh) fatal(__FUNCTION__, "cannot open IBD output file!");
+  setvbuf(fh, nullptr, _IOFBF, 1 << 22);
+  fputs("//", fh);
+  for (uint64_t i = 0; i < I; i++) fprintf(fh, "\t%.10f", P.ind_lkl[i]);
+  fputc('\n', fh);
+  std::vector<char> line(S + 1);
+  for (uint64_t i = 0; i < I; i++) {
+    for (uint64_t s = 0; s < S; s++) line[s] = (char)(P.path[i * S + s] + 48);
+    line[S] = '\n';
+    fwrite(line.data(), 1, S + 1, fh);
+  }
+  for (uint64_t i = 0; i < I; i++) {
+    fprintf(fh, "%f", P.marg[i * S]);
+    for (uint64_t s = 1; s < S; s++) fprintf(fh, "\t%f", P.marg[i * S + s]);
+    fputc('\n', fh);
+  }
+  fclose(fh);
+
+  name = std::string(P.out_prefix) + ".geno";
+  fh = fopen(name.c_str(), "wb");
+  if (!fh) fatal(__FUNCTION__, "cannot open GENO output file!");
+  setvbuf(fh, nullptr, _IOFBF, 1 << 22);
+  double pp[3];
+  for (uint64_t s = 0; s < S; s++)
+    for (uint64_t i = 0; i < I; i++) {
+      geno_posterior(&P.gl[(s * I + i) * 3], P.freq[s], (double)P.path[i * S + s], pp);
+      fwrite(pp, sizeof(double), 3, fh);
+    }
+  fclose(fh);
+}
+
+void sync_outputs(Params& P, nghmm_t* h, bool with_viterbi) {
+  check(nghmm_get_params(h, P.indF.data(), P.alpha.data(), P.freq.data()), "print_iter");
+  P.marg.resize((size_t)P.n_ind * P.n_sites);
+  check(nghmm_get_posteriors(h, P.marg.data()), "print_iter");
+  P.path.resize((size_t)P.n_ind * P.n_sites, 0);
+  if (with_viterbi) check(nghmm_viterbi(h, P.path.data()), "viterbi");
+}
+
+void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-225
+  static struct option long_options[] = {
+      {"geno", required_argument, nullptr, 'g'},      {"pos", required_argument, nullptr, 'Z'},
+      {"lkl", no_argument, nullptr, 'l'},             {"loglkl", no_argument, nullptr, 'L'},
+      {"n_ind", required_argument, nullptr, 'n'},     {"n_sites", required_argument, nullptr, 's'},
+      {"call_geno", no_argument, nullptr, 'G'},       {"freq", required_argument, nullptr, 'f'},
+      {"freq_est", required_argument, nullptr, 'F'},  {"e_prob", required_argument, nullptr, 'e'},
+      {"indF", required_argument, nullptr, 'i'},      {"indF_fixed", no_argument, nullptr, 'I'},
+      {"alpha_fixed", no_argument, nullptr, 'A'},     {"out", required_argument, nullptr, 'o'},
+      {"log", required_argument, nullptr, 'X'},       {"log_bin", required_argument, nullptr, 'b'},
+      {"min_iters", required_argument, nullptr, 'm'}, {"max_iters", required_argument, nullptr, 'M'},
+      {"min_epsilon", required_argument, nullptr, 'E'},
+      {"n_threads", required_argument, nullptr, 'x'}, {"verbose", required_argument, nullptr, 'V'},
+      {"seed", required_argument, nullptr, 'S'},      {"mode", required_argument, nullptr, 1000},
+      {"device", required_argument, nullptr, 1001},   {0, 0, 0, 0}};
+  P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
+  int c;
+  while ((c = getopt_long_only(argc, argv, "g:Z:lLn:s:Gf:F:e:i:IAo:X:b:m:M:E:x:V:S:", long_options,
+                               nullptr)) != -1)
+    switch (c) {
+      case 'g': P.in_geno = optarg; break;
+      case 'Z': P.in_pos = optarg; break;
+      case 'l': P.in_lkl = true; break;
+      case 'L': P.in_lkl = true; P.in_loglkl = true; break;
+      case 'n': P.n_ind = atoi(optarg); break;
+      case 's': P.n_sites = atoi(optarg); break;
+      case 'G': P.call_geno = true; break;
+      case 'f': P.in_freq = optarg; break;
+      case 'F': P.freq_est = atoi(optarg); break;
+      case 'e': P.e_prob_calc = atoi(optarg); break;
+      case 'i': P.in_indF = optarg; break;
+      case 'I': P.indF_fixed = true; break;
+      case 'A': P.alpha_fixed = true; break;
+      case 'o': P.out_prefix = optarg; break;
+      case 'X': P.log = atoi(optarg); break;
+      case 'b': P.log = atoi(optarg); P.log_bin = true; break;
+      case 'm': P.min_iters = atoi(optarg); break;
+      case 'M': P.max_iters = atoi(optarg); break;
+      case 'E': P.min_epsilon = atof(optarg); break;
+      case 'x': P.n_threads = atoi(optarg); break;
+      case 'V': P.verbose = atoi(optarg); break;
+      case 'S': P.seed = atoi(optarg); break;
+      case 1000:
+        if (!strcmp(optarg, "exact")) P.mode = NGHMM_MODE_EXACT;
+        else if (!strcmp(optarg, "fast")) P.mode = NGHMM_MODE_FAST;
+        else fatal(__FUNCTION__, "invalid --mode (exact|fast)!");
+        break;
+      case 1001: P.device = atoi(optarg); break;
+      default: exit(-1);
+    }
+  if (P.in_freq.empty()) P.in_freq = "r";
+  if (P.in_indF.empty()) P.in_indF = "0.01-0.001";
+  if (P.verbose >= 1) {
+    printf("==> Input Arguments:\n");
+    printf("\tgeno: %s\n\tpos: %s\n\tlkl: %s\n\tloglkl: %s\n\tn_ind: %lu\n\tn_sites: %lu\n\tcall_geno: "
+           "%s\n\tfreq: %s\n\tfreq_est: %d\n\te_prob: %d\n\tindF: %s\n\tindF_fixed: %s\n\talpha_fixed: "
+           "%s\n\tout: %s\n\tlog: %u\n\tlog_bin: %s\n\tmin_iters: %d\n\tmax_iters: %d\n\tmin_epsilon: "
+           "%.10f\n\tn_threads: %d\n\tverbose: %d\n\tseed: %d\n\tversion: %s (%s @ %s)\n\n",
+           P.in_geno, P.in_pos, P.in_lkl ? "true" : "false", P.in_loglkl ? "true" : "false",
+           (unsigned long)P.n_ind, (unsigned long)P.n_sites, P.call_geno ? "true" : "false",
+           P.in_freq.c_str(), P.freq_est, P.e_prob_calc, P.in_indF.c_str(),
+           P.indF_fixed ? "true" : "false", P.alpha_fixed ? "true" : "false", P.out_prefix, P.log,
+           P.log_bin ? "true" : "false", P.min_iters, P.max_iters, P.min_epsilon, P.n_threads,
+           P.verbose, P.seed, kVersion, __DATE__, __TIME__);
+  }
+  if (!P.in_geno) fatal(__FUNCTION__, "genotype input file (--geno) missing!");
+  if (!P.in_pos) fatal(__FUNCTION__, "positions input file (--pos) missing!");
+  if (P.n_ind == 0) fatal(__FUNCTION__, "number of individuals (--n_ind) missing!");
+  if (P.n_sites == 0) fatal(__FUNCTION__, "number of sites (--n_sites) missing!");
+  if (P.call_geno && !P.in_lkl) fatal(__FUNCTION__, "can only call genotypes from likelihoods!");
+  if (P.freq_est < 0 || P.freq_est > 2) fatal(__FUNCTION__, "invalid MAF estimation method!");
+  if (P.e_prob_calc < 0 || P.e_prob_calc > 2)
+    fatal(__FUNCTION__, "invalid emission probability calculation method!");
+  if (P.e_prob_calc > 1)
+    warn(__FUNCTION__,
+         "calculation of emission probabilities accounting for LD is still under development!");
+  if (!P.out_prefix) fatal(__FUNCTION__, "output prefix (--out) missing!");
+  if (P.min_iters < 1 || P.max_iters < 1 || P.min_iters >= P.max_iters)
+    fatal(__FUNCTION__, "invalid number of iterations!");
+  if (P.n_threads < 1) fatal(__FUNCTION__, "invalid number of threads!");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Params P;
+  parse_cmd_args(P, argc, argv);
+  if (P.n_threads > P.n_ind) {  // ngsF-HMM.cpp:36-39
+    warn(__FUNCTION__, "adjusting threads (--n_threads) to match number of individuals!");
+    P.n_threads = (unsigned)P.n_ind;
+  }
+  struct stat st;  // ngsF-HMM.cpp:47-63
+  if (stat(P.in_geno, &st) != 0) fatal(__FUNCTION__, "cannot check GENO file size!");
+  const char* dot = strrchr(P.in_geno, '.');
+  if (dot && strcmp(dot, ".gz") == 0) {
+    if (P.verbose >= 1) printf("==> GZIP input file (not BINARY)\n");
+    P.in_bin = false;
+  } else {
+    if (P.verbose >= 1) printf("==> BINARY input file (always lkl)\n");
+    P.in_bin = true;
+    P.in_lkl = true;
+    if (P.n_sites != (uint64_t)st.st_size / sizeof(double) / P.n_ind / 3)
+      fatal(__FUNCTION__, "invalid/corrupt genotype input file!");
+  }
+  if (P.verbose >= 1) {
+    printf("==> Reading data\n");
+    printf("> Sites coordinates\n");
+  }
+  read_dist(P);
+  if (P.verbose >= 1) printf("> GENO data\n");
+  read_geno(P);
+
+  // The reference dies inside iter_EM for these (EM.cpp:235-238 -> gen_func.cpp:1030-1031);
+  // same message, same exit code, before any GPU work.
+  if (P.freq_est == 2 || P.e_prob_calc == 2) fatal("haplo_freq", "invalid allele frequencies");
+
+  nghmm_t* h = nullptr;
+  check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode), "nghmm_create");
+  check(nghmm_load_gl(h, P.gl.data(), P.pos_dist.data()), "nghmm_load_gl");
+  const bool estimate_freq = init_values(P, h);
+  if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
+    check(nghmm_mstep_freq(h, 1), "init_output");
+  if (P.verbose >= 1) printf("==> Calculating initial emission probabilities\n");
+  check(nghmm_emission(h), "calc_emission");
+
+  // ---- EM.cpp:27-103 ----
+  const uint64_t I = P.n_ind;
+  P.ind_lkl.assign(I, -INFINITY);
+  std::vector<double> prev_ind_lkl(I, -INFINITY), eps(I, -INFINITY);
+  double max_lkl_epsilon = -INFINITY;
+  uint64_t iter = 0;
+  while ((P.prev_tot_lkl - P.tot_lkl > P.min_epsilon || max_lkl_epsilon > P.min_epsilon ||
+          iter < P.min_iters) &&
+         iter < P.max_iters) {
+    if (P.log && (iter == 1 || iter % P.log == 0)) {
+      if (P.verbose >= 1) printf("==> Printing current iteration parameters\n");
+      sync_outputs(P, h, false);
+      print_iter(P);
+    }
+    const time_t iter_start = time(nullptr);
+    iter++;
+    if (P.verbose >= 1) printf("\nIteration %lu:\n", (unsigned long)iter);
+    if (P.verbose >= 1)
+      printf("==> Forward Recursion\n==> Backward Recursion\n==> Marginal probabilities\n");
+    nghmm_mstep_stats stats;
+    check(nghmm_estep(h, P.ind_lkl.data()), "iter_EM");
+    if (P.indF_fixed && P.alpha_fixed) {
+      if (P.verbose >= 1) printf("==> Inbreeding and transition parameter not estimated!\n");
+    } else {
+      if (P.verbose >= 1) printf("==> Update inbreeding and transition parameter\n");
+      check(nghmm_mstep_indf(h, P.indF_fixed, P.alpha_fixed, &stats), "iter_EM");
+    }
+    if (P.freq_est == 0) {
+      if (P.verbose >= 1) printf("==> Alelle frequencies not estimated!\n");
+    } else {
+      if (P.verbose >= 1)
+        printf("==> Estimating allele frequencies and calculating emission probabilities\n");
+      check(nghmm_mstep_freq(h, P.freq_est), "iter_EM");
+    }
+    P.prev_tot_lkl = P.tot_lkl;
+    P.tot_lkl = 0;
+    for (uint64_t i = 0; i < I; i++) {
+      P.tot_lkl += P.ind_lkl[i];
+      eps[i] = (P.ind_lkl[i] - prev_ind_lkl[i]) / fabs(prev_ind_lkl[i]);
+    }
+    uint64_t best = 0;  // array_max_pos, gen_func.cpp:73-84
+    double mx = -INFINITY;
+    for (uint64_t i = 0; i < I; i++)
+      if (eps[i] > mx) { best = i; mx = eps[i]; }
+    max_lkl_epsilon = eps[best];
+    prev_ind_lkl = P.ind_lkl;
+    const time_t iter_end = time(nullptr);
+    if (P.verbose >= 1)
+      printf("\tLogLkl: %.15f\t max lkl epsilon: %.15f\ttime: %.0f (s)\n", P.tot_lkl,
+             max_lkl_epsilon, difftime(iter_end, iter_start));
+    if (P.verbose >= 3)
+      for (uint64_t i = 0; i < I; i++)
+        printf("\tInd %lu: %.15f\t lkl epsilon: %.15f%s\n", (unsigned long)(i + 1), P.ind_lkl[i],
+               eps[i], i == best ? " (max)" : "");
+    fflush(stdout);
+  }
+  if (iter >= P.max_iters)
+    printf("WARN: Maximum number of iterations reached! Check if analysis converged... \n");
+
+  // ---- EM.cpp:105-127 ----
+  if (P.verbose >= 1) printf("\n==> Decoding most probable path (Viterbi)\n");
+  sync_outputs(P, h, true);
+  if (P.verbose >= 1) {
+    printf("Final logLkl: %f\n", P.tot_lkl);
+    printf("Printing final results\n");
+  }
+  print_iter(P);
+  if (P.verbose >= 1) printf("Freeing memory...\n");
+  nghmm_destroy(h);
+  if (P.verbose >= 1) printf("Done!\n");
+  return 0;
+}

@@ -1,0 +1,81 @@
+"""Helpers for the command-line tests: write reference-format input files, and build
+the expected .indF / .ibd / .geno bytes (EM.cpp:293-380) from oracle results."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BINARY = os.path.join(ROOT, "ngsf-hmm_amd", "ngsF-HMM")
+
+
+def write_inputs(tmp, d, gl_raw):
+    """gl_raw: [S][I][3] log GLs as the simulator emits them (not yet normalised)."""
+    S, I = gl_raw.shape[:2]
+    paths = {}
+    paths["glf_gz"] = os.path.join(tmp, "sim.glf.gz")
+    with gzip.open(paths["glf_gz"], "wt") as fh:
+        for s in range(S):
+            fh.write("\t".join(repr(float(v)) for v in gl_raw[s].reshape(-1)) + "\n")
+    paths["glf_bin"] = os.path.join(tmp, "sim.glf")
+    gl_raw.astype("<f8").tofile(paths["glf_bin"])
+    paths["geno_gz"] = os.path.join(tmp, "sim.geno.gz")
+    with gzip.open(paths["geno_gz"], "wt") as fh:
+        for s in range(S):
+            fh.write("\t".join(str(int(v)) for v in d.geno[s]) + "\n")
+    paths["pos_gz"] = os.path.join(tmp, "sim.pos.gz")
+    with gzip.open(paths["pos_gz"], "wt") as fh:
+        for s in range(S):
+            fh.write(f"chr{int(d.chrom[s])}\t{int(d.pos[s])}\t0.2\n")
+    return paths
+
+
+def host_normalise(orc_libm, gl, call_geno=False):
+    """What the host does to log GLs (shared/read_data.cpp:40,98 then ngsF-HMM.cpp:101-117):
+    post_prob, optional call_geno, post_prob again -- with libm, cell by cell."""
+    import ctypes as C
+    out = np.ascontiguousarray(gl, dtype=np.float64).copy()
+    flat = out.reshape(-1, 3)
+    dp = C.POINTER(C.c_double)
+    for r in flat:
+        p = r.ctypes.data_as(dp)
+        orc_libm.lib.orc_post_prob(p, p, None)
+        if call_geno:
+            if r.min() == r.max():
+                r[:] = np.log(1.0 / 3.0)
+            else:
+                k = int(np.argmax(r))
+                r[:] = -1e15
+                r[k] = 0.0
+        orc_libm.lib.orc_post_prob(p, p, None)
+    return out
+
+
+def expected_files(tot_lkl, indF, alpha, freq, ind_lkl, path, marg, geno_post):
+    """Bytes of PREFIX.indF / .ibd / .geno as EM.cpp:293-380 prints them."""
+    I, S = path.shape
+    lines = ["%.10f\n" % tot_lkl]
+    for i in range(I):
+        if indF[i] < 1e-5:
+            lines.append("%.5f\tNA\n" % 0.0)
+        elif indF[i] > 1 - 1e-5:
+            lines.append("%.5f\tNA\n" % 1.0)
+        else:
+            lines.append("%.5f\t%f\n" % (indF[i], alpha[i]))
+    lines += ["%f\n" % f for f in freq]
+    f_indF = "".join(lines).encode()
+    out = ["//\t" + "\t".join("%.10f" % v for v in ind_lkl) + "\n"]
+    for i in range(I):
+        out.append("".join(chr(48 + int(v)) for v in path[i]) + "\n")
+    for i in range(I):
+        out.append("\t".join("%f" % v for v in marg[i]) + "\n")
+    f_ibd = "".join(out).encode()
+    f_geno = np.ascontiguousarray(geno_post, dtype="<f8").tobytes()
+    return f_indF, f_ibd, f_geno
+
+
+def run_cli(args, check=True):
+    return subprocess.run([BINARY] + [str(a) for a in args], capture_output=True, text=True,
+                          check=check)
