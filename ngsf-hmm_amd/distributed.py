@@ -51,6 +51,25 @@ class GpuBackend:
     def empty(self, *shape):
         return self.torch.empty(shape, device=self.device, dtype=self.torch.float64)
 
+    def sync(self):
+        """The library runs on its own HIP stream and the collectives on torch's: make the
+        collective's result visible before the library reads it (and vice versa; library
+        calls already synchronise their stream before returning)."""
+        self.torch.cuda.synchronize(self.device)
+
+    def load_device(self, gl, pos):
+        self.hmm.load_device(gl.data_ptr(), pos.data_ptr())
+
+    def set_params(self, indF, alpha, freq):
+        self.hmm.set_params(indF, alpha, freq)
+
+    def init_emission(self):
+        self.hmm.init_emission()
+
+    def iter_em_local(self, freq_est, indF_fixed, alpha_fixed):
+        st = self.hmm.iter_EM(freq_est, indF_fixed, alpha_fixed)
+        return st, self.hmm.ind_lkl
+
     def estep(self):
         return self.hmm.estep()
 
@@ -102,8 +121,8 @@ class ShardedEM:
 
     # -- data ---------------------------------------------------------------
     def load_device(self, gl, pos):
-        """gl: device tensor [S][I_local][3]; pos: device tensor [S]."""
-        self.hmm.load_device(gl.data_ptr(), pos.data_ptr())
+        """gl: tensor [S][I_local][3]; pos: tensor [S] (on the backend's device)."""
+        self.backend.load_device(gl, pos)
         if self.world > 1:
             self._exchange_site_shard(gl)
 
@@ -115,20 +134,20 @@ class ShardedEM:
         recv = self.backend.empty(world, self.S_own, I, 3)
         dist.all_to_all_single(recv.view(-1), send.view(-1))
         shard = recv.permute(1, 0, 2, 3).contiguous().view(self.S_own, world * I, 3)
+        self._sync()
         self.backend.load_site_shard_device(shard)
         del send, recv, shard
 
     def set_params(self, indF, alpha, freq):
-        self.hmm.set_params(indF, alpha, freq)
+        self.backend.set_params(indF, alpha, freq)
 
     def init_emission(self):
-        self.hmm.init_emission()
+        self.backend.init_emission()
 
     # -- one EM iteration ------------------------------------------------------
     def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
         if self.world == 1:
-            st = self.hmm.iter_EM(freq_est, indF_fixed, alpha_fixed)
-            self.ind_lkl = self.hmm.ind_lkl
+            st, self.ind_lkl = self.backend.iter_em_local(freq_est, indF_fixed, alpha_fixed)
             return st
         self.ind_lkl = self.backend.estep()
         st = self.backend.mstep_indf(indF_fixed, alpha_fixed)
@@ -141,11 +160,19 @@ class ShardedEM:
         for q, (lo, hi) in enumerate(self.ranges):
             self.backend.pack_posteriors(lo, hi, self._send[q])
         dist.all_to_all_single(self._recv.view(-1), self._send.view(-1))
+        self._sync()
         # _recv is [source rank][S_own][I_loc]: the rank-blocked layout est_maf reads
         self.backend.mstep_freq_sites(self._recv, self._freq_own)
         dist.all_gather_into_tensor(self._freq_all, self._freq_own)
+        self._sync()
         self.backend.set_freq(self._freq_all)
+
+    def _sync(self):
+        if hasattr(self.backend, "sync"):
+            self.backend.sync()
 
     def close(self):
         if self.hmm is not None:
             self.hmm.close()
+        elif hasattr(self.backend, "close"):
+            self.backend.close()

@@ -1,0 +1,116 @@
+"""The multi-rank EM orchestration (ngsf-hmm_amd/distributed.py) on CPU: two processes,
+gloo backend, a CPU stand-in for the GPU backend built on the oracle.  Individuals are
+sharded over the ranks; posteriors travel by all-to-all into site-sharded blocks,
+frequencies by all-gather.  The result must equal a single-process run over all
+individuals BIT FOR BIT (est_maf sums individuals in global order: rank-major)."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orclib
+pkg = importlib.import_module("ngsf-hmm_amd")
+dd = importlib.import_module("ngsf-hmm_amd.distributed")
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+I_loc, S = 5, 240
+d = pkg.simulate.simulate(I_loc * world, S, seed=31, n_chrom=2, missing_rate=0.05)
+gl_all = pkg.simulate.normalise_log_gl(d.gl)
+gl_loc = np.ascontiguousarray(gl_all[:, rank * I_loc:(rank + 1) * I_loc, :])
+orc = orclib.Oracle("libm")
+
+
+class OracleBackend:
+    """Same interface as distributed.GpuBackend, computing with the CPU oracle."""
+    def __init__(self):
+        self.em = None
+    def empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float64)
+    def load_device(self, gl, pos):
+        self.em = orclib.OracleEM(orc, gl.numpy(), pos.numpy())
+        self.pos = pos.numpy()
+    def set_params(self, indF, alpha, freq):
+        self.em.set_params(indF, alpha, freq)
+    def init_emission(self):
+        assert self.em.init_emission() == 0
+    def estep(self):
+        assert self.em.estep() == 0
+        return self.em.ind_lkl
+    def mstep_indf(self, a, b):
+        assert self.em.mstep_indf(a, b) == 0
+        return None
+    def shard_config(self, I_tot, ind_begin, site_begin, S_own):
+        self.I_tot, self.site_begin, self.S_own = I_tot, site_begin, S_own
+    def load_site_shard_device(self, shard):
+        self.gl_shard = shard.numpy().copy()                     # [S_own][I_tot][3]
+    def pack_posteriors(self, lo, hi, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(self.em.marg.T[lo:hi])))   # [sites][I_loc]
+    def mstep_freq_sites(self, blocks, freq_out):
+        b = blocks.numpy()                                       # [rank][S_own][I_loc]
+        for s in range(self.S_own):
+            F = np.concatenate([b[q, s] for q in range(b.shape[0])])   # global individual order
+            freq_out[s] = orc.est_maf(self.gl_shard[s], F)[0]
+    def set_freq(self, freq_all):
+        self.em.set_params(None, None, freq_all.numpy())
+        assert self.em.init_emission() == 0                      # emission refresh from freq
+
+
+be = OracleBackend()
+em = dd.ShardedEM(pkg, I_loc, S, rank=rank, world=world, backend=be)
+em.load_device(torch.from_numpy(gl_loc), torch.from_numpy(d.pos_dist_mb.copy()))
+em.set_params(0.1, 0.2, 0.1)
+em.init_emission()
+for _ in range(3):
+    em.iter_EM()
+np.savez(os.path.join(OUT, f"rank{rank}.npz"), indF=be.em.indF, alpha=be.em.alpha,
+         freq=be.em.freq, marg=be.em.marg, ind_lkl=be.em.ind_lkl)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharded_em_equals_single_process(tmp_path, pkg, orc_libm):
+    import orclib
+    world = 2
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\nOUT = {str(tmp_path)!r}\n" + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)))
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+
+    I_loc, S = 5, 240
+    d = pkg.simulate.simulate(I_loc * world, S, seed=31, n_chrom=2, missing_rate=0.05)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    ref = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
+    ref.set_params(0.1, 0.2, 0.1)
+    ref.init_emission()
+    for _ in range(3):
+        assert ref.iterate() == 0
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        sl = slice(r * I_loc, (r + 1) * I_loc)
+        assert np.array_equal(got["indF"], ref.indF[sl])
+        assert np.array_equal(got["alpha"], ref.alpha[sl])
+        assert np.array_equal(got["freq"], ref.freq)
+        assert np.array_equal(got["marg"], ref.marg[sl])
+        assert np.array_equal(got["ind_lkl"], ref.ind_lkl[sl])
+
+
+def test_site_ranges(pkg):
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    assert dd.site_ranges(12, 4) == [(0, 3), (3, 6), (6, 9), (9, 12)]
+    with pytest.raises(ValueError):
+        dd.site_ranges(10, 4)
