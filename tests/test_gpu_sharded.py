@@ -1,0 +1,70 @@
+"""The multi-GPU entry points of the C ABI on ONE GPU: two handles play two ranks
+(individuals split in halves), the test moves the buffers between them exactly as the
+all-to-all / all-gather of ngsf-hmm_amd/distributed.py would, and the result must equal
+a single handle that owns every individual."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def test_two_shards_equal_one_handle(pkg):
+    import torch
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    world, I_loc, S = 2, 33, 1200
+    d = pkg.simulate.simulate(I_loc * world, S, seed=8, n_chrom=2, missing_rate=0.05, indF="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    dev = torch.device("cuda", 0)
+
+    whole = pkg.NgsFHMM(I_loc * world, S, mode=pkg.MODE_FAST)
+    whole.load(gl, d.pos_dist_mb)
+    whole.set_params(0.1, 0.2, 0.1)
+    whole.init_emission()
+
+    ranges = dd.site_ranges(S, world)
+    S_own = S // world
+    ranks = []
+    for r in range(world):
+        be = dd.GpuBackend(pkg, I_loc, S, 0, pkg.MODE_FAST)
+        be.hmm.load(np.ascontiguousarray(gl[:, r * I_loc:(r + 1) * I_loc]), d.pos_dist_mb)
+        be.hmm.set_params(0.1, 0.2, 0.1)
+        be.hmm.init_emission()
+        be.shard_config(I_loc * world, r * I_loc, ranges[r][0], S_own)
+        shard = torch.from_numpy(np.ascontiguousarray(gl[ranges[r][0]:ranges[r][1]])).to(dev)
+        be.load_site_shard_device(shard)
+        ranks.append(be)
+
+    for it in range(2):
+        whole.estep(); whole.mstep_indf(); whole.mstep_freq(1)
+        send = []
+        for be in ranks:
+            be.estep(); be.mstep_indf(False, False)
+            buf = be.empty(world, S_own, I_loc)
+            for q, (lo, hi) in enumerate(ranges):
+                be.pack_posteriors(lo, hi, buf[q])
+            send.append(buf)
+        torch.cuda.synchronize()
+        freq_all = torch.empty(S, device=dev, dtype=torch.float64)
+        for r, be in enumerate(ranks):
+            recv = torch.stack([send[q][r] for q in range(world)]).contiguous()   # the all-to-all
+            own = be.empty(S_own)
+            torch.cuda.synchronize()
+            be.mstep_freq_sites(recv, own)
+            freq_all[ranges[r][0]:ranges[r][1]] = own                             # the all-gather
+        torch.cuda.synchronize()
+        for be in ranks:
+            be.set_freq(freq_all)
+        got_freq = ranks[0].hmm.freq
+        np.testing.assert_allclose(got_freq, whole.freq, rtol=1e-12)
+        for r, be in enumerate(ranks):
+            sl = slice(r * I_loc, (r + 1) * I_loc)
+            np.testing.assert_allclose(be.hmm.ind_lkl, whole.ind_lkl[sl], rtol=1e-12)
+            np.testing.assert_allclose(be.hmm.indF, whole.indF[sl], atol=1e-6)
+    for be in ranks:
+        be.hmm.close()
+    whole.close()
