@@ -127,8 +127,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # NGHMM_BENCH_BACKEND=gloo + NGHMM_BENCH_ONE_GPU=1: functional test of the
+        # multi-rank path on a single-GPU box (all ranks share cuda:0, collectives staged
+        # through the host); the measured configuration is always nccl = RCCL.
+        backend = os.environ.get("NGHMM_BENCH_BACKEND", "nccl")
+        if os.environ.get("NGHMM_BENCH_ONE_GPU"):
+            local_rank = 0
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)
@@ -180,7 +189,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

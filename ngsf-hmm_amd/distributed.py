@@ -29,6 +29,34 @@ import math
 import numpy as np
 
 
+def _staged(t):
+    """gloo has no all-to-all / all-gather for device tensors: stage through the host.
+    Only used when the process group is gloo (functional tests on one GPU); with the
+    nccl (= RCCL) backend tensors stay on the device."""
+    import torch.distributed as dist
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
+def all_to_all(recv, send):
+    import torch.distributed as dist
+    if _staged(send):
+        r = recv.cpu()
+        dist.all_to_all_single(r.view(-1), send.cpu().view(-1))
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv.view(-1), send.view(-1))
+
+
+def all_gather(out, inp):
+    import torch.distributed as dist
+    if _staged(inp):
+        o = out.cpu()
+        dist.all_gather_into_tensor(o, inp.cpu())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
 def site_ranges(n_sites: int, world: int):
     """Contiguous, equal site ranges (the all-to-all uses equal splits)."""
     if n_sites % world != 0:
@@ -132,7 +160,7 @@ class ShardedEM:
         world, I = self.world, self.n_ind
         send = gl.reshape(world, self.S_own, I, 3).contiguous()   # slices by destination
         recv = self.backend.empty(world, self.S_own, I, 3)
-        dist.all_to_all_single(recv.view(-1), send.view(-1))
+        all_to_all(recv, send)
         shard = recv.permute(1, 0, 2, 3).contiguous().view(self.S_own, world * I, 3)
         self._sync()
         self.backend.load_site_shard_device(shard)
@@ -159,11 +187,11 @@ class ShardedEM:
         import torch.distributed as dist
         for q, (lo, hi) in enumerate(self.ranges):
             self.backend.pack_posteriors(lo, hi, self._send[q])
-        dist.all_to_all_single(self._recv.view(-1), self._send.view(-1))
+        all_to_all(self._recv, self._send)
         self._sync()
         # _recv is [source rank][S_own][I_loc]: the rank-blocked layout est_maf reads
         self.backend.mstep_freq_sites(self._recv, self._freq_own)
-        dist.all_gather_into_tensor(self._freq_all, self._freq_own)
+        all_gather(self._freq_all, self._freq_own)
         self._sync()
         self.backend.set_freq(self._freq_all)
 

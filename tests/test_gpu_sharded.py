@@ -68,3 +68,48 @@ def test_two_shards_equal_one_handle(pkg):
     for be in ranks:
         be.hmm.close()
     whole.close()
+
+
+def test_bench_multi_rank_path_on_one_gpu(pkg):
+    """bench.py --gpus 2 end to end (torch.distributed.run, 2 ranks, ShardedEM with the
+    all-to-all / all-gather exchange), both ranks on cuda:0 with the gloo backend staging
+    collectives through the host.  Functional check only; the measured multi-GPU
+    configuration uses nccl (= RCCL) and is run by the driver on an 8-GPU node."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGHMM_BENCH_BACKEND="gloo", NGHMM_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny",
+           "--no_cpu_baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("I", [600, 1100, 2100])
+def test_est_maf_register_and_stream_variants(pkg, I):
+    """est_maf picks a kernel by the number of individuals (registers: 2 waves x NI <= 16
+    per lane; beyond 2048 the streaming kernel): all must agree with the oracle."""
+    import orclib
+    S = 96
+    d = pkg.simulate.simulate(I, S, seed=I, missing_rate=0.05)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    orc = orclib.Oracle("libm")
+    em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
+    em.set_params(0.3, 0.05, 0.1)
+    em.init_emission()
+    assert em.estep() == 0 and em.mstep_freq(1) == 0
+    hmm = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST)
+    hmm.load(gl, d.pos_dist_mb)
+    hmm.set_params(0.3, 0.05, 0.1)
+    hmm.init_emission()
+    hmm.estep()
+    hmm.mstep_freq(1)
+    np.testing.assert_allclose(hmm.freq, em.freq, rtol=1e-9)
+    hmm.close()
