@@ -34,10 +34,16 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
 void launch_estmaf_exact(hipStream_t st, const double* gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out);
 
-// Viterbi (shared/HMM.cpp:98-125): bp [S][I] scratch bytes, path_sites [S][I] bytes
+// Viterbi (shared/HMM.cpp:98-125): bp [viterbi_blocked_bytes + I] scratch bytes, path_sites
+// [viterbi_blocked_bytes] bytes blocked [site/16][I][16] (launch_unblock_path gives [I][S]),
+// scratch [chunk_sites*I*4 + I*2] doubles (chunk_sites from viterbi_chunk_sites)
 void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                           uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                          uint8_t* path_sites);
+                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites);
+uint64_t viterbi_chunk_sites(uint64_t S, uint64_t I);
+uint64_t viterbi_blocked_bytes(uint64_t S, uint64_t I);
+void launch_unblock_path(hipStream_t st, const uint8_t* path16, uint64_t S, uint64_t I,
+                         uint8_t* out);
 
 // ---------------- layout helpers (kernels_util.hip) ----------------
 // out[c][r] = in[r][c]

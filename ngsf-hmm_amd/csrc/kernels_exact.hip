@@ -350,84 +350,166 @@ k_estmaf_exact(const double* __restrict__ gl, const double* __restrict__ marg, u
 }
 
 // ------------------------------------------------------------------
-// Viterbi forward sweep: back-pointers for both states of every site.
+// Viterbi, two kernels per chunk of sites.  The four log transition probabilities of
+// a site (one exp + four logs, shared/HMM.cpp:130-139) do not depend on the recursion
+// state, so they are computed for a whole chunk in parallel first; the sequential
+// sweep is then only the additions and comparisons of HMM.cpp:104-117, in the same
+// order on the same values -- the path stays the reference's bit for bit, and the
+// sweep no longer waits on ~70 dependent transcendental steps per site.
+__global__ void __launch_bounds__(256)
+k_trans_log_exact(const double* __restrict__ pos, const double* __restrict__ indF,
+                  const double* __restrict__ alpha, uint64_t s0, uint64_t n_s, uint64_t I,
+                  double* __restrict__ tl) {
+  const uint64_t n = n_s * I;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = c / I, i = c % I;
+    const double f = indF[i];
+    const Trans t = calc_trans_all(1 - f, f, alpha[i], pos[s0 + s]);
+    double* o = tl + c * 4;
+    o[0] = t.t00;
+    o[1] = t.t10;
+    o[2] = t.t01;
+    o[3] = t.t11;
+  }
+}
+
+// state [I][2] carries (Vi_prob[0], Vi_prob[1]) between chunks
 __global__ void __launch_bounds__(64)
-k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__ pos, uint64_t S,
-                    uint64_t I, const double* __restrict__ indF, const double* __restrict__ alpha,
-                    uint8_t* __restrict__ bp, uint8_t* __restrict__ last_state) {
+k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__ tl, uint64_t s0,
+                    uint64_t n_s, uint64_t S, uint64_t I, const double* __restrict__ indF,
+                    double* __restrict__ state, uint8_t* __restrict__ bp,
+                    uint8_t* __restrict__ last_state) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I) return;
-  const double f = indF[i], a = alpha[i];
-  const double q0 = 1 - f, q1 = f;
-  double v0 = det_log(q0), v1 = det_log(q1);
-  const double2* e2 = reinterpret_cast<const double2*>(eprob);
-
-  double2 ecur[U], enxt[U];
-  double dcur[U], dnxt[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint64_t s = u;
-    const bool v = s < S;
-    ecur[u] = v ? e2[s * I + i] : double2{0, 0};
-    dcur[u] = v ? pos[s] : 0.0;
+  double v0, v1;
+  if (s0 == 0) {
+    const double f = indF[i];
+    v0 = det_log(1 - f);  // HMM.cpp:101-102
+    v1 = det_log(f);
+  } else {
+    v0 = state[i * 2];
+    v1 = state[i * 2 + 1];
   }
-  for (uint64_t s0 = 0; s0 < S; s0 += U) {
+  const double2* e2 = reinterpret_cast<const double2*>(eprob);
+  const double4* t4 = reinterpret_cast<const double4*>(tl);
+
+  // 16 sites per group and two groups in flight: with only I/64 waves on the whole GPU
+  // the sweep is bound by (bytes in flight) / (HBM latency), so it prefetches as deep as
+  // the register file allows (one wave per SIMD is all there is anyway)
+  constexpr int UV = 16;
+  double2 ecur[UV], enxt[UV];
+  double4 tcur[UV], tnxt[UV];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t s = s0 + U + u;
-      const bool v = s < S;
-      enxt[u] = v ? e2[s * I + i] : double2{0, 0};
-      dnxt[u] = v ? pos[s] : 0.0;
+  for (int u = 0; u < UV; ++u) {
+    const bool v = (uint64_t)u < n_s;
+    ecur[u] = v ? e2[(s0 + u) * I + i] : double2{0, 0};
+    tcur[u] = v ? t4[(uint64_t)u * I + i] : double4{0, 0, 0, 0};
+  }
+  uint32_t bpw[4] = {0, 0, 0, 0};
+  for (uint64_t r0 = 0; r0 < n_s; r0 += UV) {
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const uint64_t r = r0 + UV + u;
+      const bool v = r < n_s;
+      enxt[u] = v ? e2[(s0 + r) * I + i] : double2{0, 0};
+      tnxt[u] = v ? t4[r * I + i] : double4{0, 0, 0, 0};
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t s = s0 + u;
-      if (s < S) {
-        const Trans t = calc_trans_all(q0, q1, a, dcur[u]);
+    for (int u = 0; u < UV; ++u) {
+      const uint64_t r = r0 + u;
+      if (r < n_s) {
         // l = 0 (HMM.cpp:105-116)
         double vmax = -kINF;
         int k0 = 0;
-        double pval = v0 + t.t00;
+        double pval = v0 + tcur[u].x;  // k = 0 -> l = 0
         if (vmax < pval) { vmax = pval; k0 = 0; }
-        pval = v1 + t.t10;
+        pval = v1 + tcur[u].y;         // k = 1 -> l = 0
         if (vmax < pval) { vmax = pval; k0 = 1; }
         v0 = vmax + ecur[u].x;  // in place: l = 1 below reads the NEW v0 (reference behaviour)
         // l = 1
         vmax = -kINF;
         int k1 = 0;
-        pval = v0 + t.t01;
+        pval = v0 + tcur[u].z;         // k = 0 -> l = 1
         if (vmax < pval) { vmax = pval; k1 = 0; }
-        pval = v1 + t.t11;
+        pval = v1 + tcur[u].w;         // k = 1 -> l = 1
         if (vmax < pval) { vmax = pval; k1 = 1; }
         v1 = vmax + ecur[u].y;
-        bp[s * I + i] = (uint8_t)(k0 | (k1 << 1));
+        bpw[u >> 2] |= (uint32_t)(k0 | (k1 << 1)) << (8 * (u & 3));
       }
     }
+    // back-pointers of 16 consecutive sites of one individual = one 16-byte store;
+    // layout [site/16][individual][16]  (s0 and r0 are multiples of 16)
+    *reinterpret_cast<uint4*>(bp + (((s0 + r0) >> 4) * I + i) * 16) =
+        uint4{bpw[0], bpw[1], bpw[2], bpw[3]};
+    bpw[0] = bpw[1] = bpw[2] = bpw[3] = 0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UV; ++u) {
       ecur[u] = enxt[u];
-      dcur[u] = dnxt[u];
+      tcur[u] = tnxt[u];
     }
   }
-  // array_max_pos (gen_func.cpp:73-84): strict >, starting from -inf
-  int res = 0;
-  double mx = NEG_INFINITY;
-  if (v0 > mx) { res = 0; mx = v0; }
-  if (v1 > mx) { res = 1; mx = v1; }
-  last_state[i] = (uint8_t)res;
+  state[i * 2] = v0;
+  state[i * 2 + 1] = v1;
+  if (s0 + n_s >= S) {
+    // array_max_pos (gen_func.cpp:73-84): strict >, starting from -inf
+    int res = 0;
+    double mx = NEG_INFINITY;
+    if (v0 > mx) { res = 0; mx = v0; }
+    if (v1 > mx) { res = 1; mx = v1; }
+    last_state[i] = (uint8_t)res;
+  }
 }
 
 // Trace back (HMM.cpp:119-122): path of reference site s (1-based) = state at s.
+// Back-pointers and the path are blocked [site/16][individual][16], so a lane moves 16
+// sites per load/store; only the 1-bit select chain is sequential.
 __global__ void __launch_bounds__(64)
 k_viterbi_back(const uint8_t* __restrict__ bp, const uint8_t* __restrict__ last_state, uint64_t S,
-               uint64_t I, uint8_t* __restrict__ path_sites) {
+               uint64_t I, uint8_t* __restrict__ path16) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I || S == 0) return;
   int st = last_state[i];
-  for (uint64_t s = S; s >= 1; --s) {
-    path_sites[(s - 1) * I + i] = (uint8_t)st;  // path[s]
-    const int b = bp[(s - 1) * I + i];          // Vi[s][.]
-    st = (b >> st) & 1;                         // path[s-1] = Vi[s][path[s]]
+  const uint64_t nblk = (S + 15) / 16;
+  uint4 cur = *reinterpret_cast<const uint4*>(bp + ((nblk - 1) * I + i) * 16);
+  for (uint64_t bb = nblk; bb >= 1; --bb) {
+    const uint64_t blk = bb - 1;
+    uint4 nxt = uint4{0, 0, 0, 0};
+    if (blk >= 1) nxt = *reinterpret_cast<const uint4*>(bp + ((blk - 1) * I + i) * 16);
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 15; u >= 0; --u) {
+      const uint64_t s = blk * 16 + u;  // 0-based site = reference site s+1
+      if (s < S) {
+        o[u >> 2] |= (uint32_t)st << (8 * (u & 3));           // path[s+1]
+        const uint32_t b = (w[u >> 2] >> (8 * (u & 3))) & 0xff;  // Vi[s+1][.]
+        st = (b >> st) & 1;                                     // path[s] = Vi[s+1][path[s+1]]
+      }
+    }
+    *reinterpret_cast<uint4*>(path16 + (blk * I + i) * 16) = uint4{o[0], o[1], o[2], o[3]};
+    cur = nxt;
+  }
+}
+
+// blocked [site/16][individual][16] -> [individual][site]
+__global__ void __launch_bounds__(256)
+k_unblock_path(const uint8_t* __restrict__ path16, uint64_t S, uint64_t I,
+               uint8_t* __restrict__ out) {
+  const uint64_t nblk = (S + 15) / 16;
+  const uint64_t n = nblk * I;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t blk = c / I, i = c % I;
+    const uint4 v = *reinterpret_cast<const uint4*>(path16 + c * 16);
+    const uint64_t s = blk * 16;
+    uint8_t* dst = out + i * S + s;
+    if (s + 16 <= S && (((uintptr_t)dst) & 15) == 0) {
+      *reinterpret_cast<uint4*>(dst) = v;
+    } else {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      for (int u = 0; u < 16 && s + u < S; ++u) dst[u] = (uint8_t)(w[u >> 2] >> (8 * (u & 3)));
+    }
   }
 }
 
@@ -468,14 +550,40 @@ void launch_estmaf_exact(hipStream_t st, const double* gl_sites, const double* m
 
 void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                           uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                          uint8_t* path_sites) {
+                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites) {
   if (I == 0 || S == 0) return;
-  // the last-state bytes live behind the back-pointers (bp holds S*I + I bytes)
-  uint8_t* last_state = bp + S * I;
-  hipLaunchKernelGGL(k_viterbi_fwd_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob,
-                     pos, S, I, indF, alpha, bp, last_state);
+  // bp holds ceil(S/16)*16*I back-pointer bytes (blocked) followed by I last-state
+  // bytes; scratch holds chunk_sites*I*4 transition logs followed by I*2 state doubles
+  uint8_t* last_state = bp + ((S + 15) / 16) * 16 * I;
+  double* tl = scratch;
+  double* state = scratch + chunk_sites * I * 4;
+  for (uint64_t s0 = 0; s0 < S; s0 += chunk_sites) {
+    const uint64_t n_s = (S - s0) < chunk_sites ? (S - s0) : chunk_sites;
+    uint64_t blocks = (n_s * I + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_trans_log_exact, dim3((unsigned)blocks), dim3(256), 0, st, pos, indF,
+                       alpha, s0, n_s, I, tl);
+    hipLaunchKernelGGL(k_viterbi_fwd_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob,
+                       tl, s0, n_s, S, I, indF, state, bp, last_state);
+  }
   hipLaunchKernelGGL(k_viterbi_back, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, bp,
                      last_state, S, I, path_sites);
 }
+
+void launch_unblock_path(hipStream_t st, const uint8_t* path16, uint64_t S, uint64_t I,
+                         uint8_t* out) {
+  hipLaunchKernelGGL(k_unblock_path, dim3(4096), dim3(256), 0, st, path16, S, I, out);
+}
+
+uint64_t viterbi_chunk_sites(uint64_t S, uint64_t I) {
+  // about 2 GiB of transition logs per chunk; a multiple of 16 (blocked back-pointers)
+  uint64_t ch = (2ull << 30) / (I * 32);
+  ch &= ~15ull;
+  if (ch < 64) ch = 64;
+  const uint64_t Sp = (S + 15) & ~15ull;
+  return ch < Sp ? ch : Sp;
+}
+
+uint64_t viterbi_blocked_bytes(uint64_t S, uint64_t I) { return ((S + 15) / 16) * 16 * I; }
 
 }  // namespace nghmm

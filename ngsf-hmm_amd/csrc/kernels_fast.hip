@@ -1076,12 +1076,14 @@ static bool ensure_eprob_log(FastState& fs) {
 }
 
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
-                  const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags) {
+                  const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags,
+                  double* d_scratch, uint64_t chunk_sites) {
   // Decoding runs once per analysis and must give the reference's path, ties and
   // its in-place update included: use the exact-mode kernels on log emissions.
   if (!ensure_eprob_log(fs)) return false;
   launch_emission_exact(st, fs.d_gl, d_freq, fs.eprob_log, fs.S, fs.I, d_flags);
-  launch_viterbi_exact(st, fs.eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites);
+  launch_viterbi_exact(st, fs.eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites,
+                       d_scratch, chunk_sites);
   return hipGetLastError() == hipSuccess;
 }
 

@@ -55,7 +55,8 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out);
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
-                  const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags);
+                  const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags,
+                  double* d_scratch, uint64_t chunk_sites);
 // log of the stored linear emissions as [I][S][2] (device), for host read-back
 bool fast_export_emissions(FastState& fs, hipStream_t st, double* d_out);
 

@@ -70,6 +70,7 @@ struct nghmm_handle {
   size_t pt_cap = 0;
 
   uint8_t *d_bp = nullptr, *d_path_sites = nullptr, *d_path = nullptr;
+  double* d_vit = nullptr;  // Viterbi scratch: transition logs of one site chunk + carry state
   double* d_tmp = nullptr;  // S*I*2 doubles, transposes for host read-back
   uint32_t* d_passes = nullptr;
 
@@ -314,7 +315,7 @@ int nghmm_destroy(nghmm_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_gl, h->d_pos, h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
                   h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
-                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes,
+                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
                   h->d_gl_shard};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -551,20 +552,23 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   int rc;
   if ((rc = use_device(h))) return rc;
   const size_t cells = (size_t)h->I * h->S;
-  if (!h->d_bp && (rc = dev_alloc(&h->d_bp, cells + h->I))) return rc;
-  if (!h->d_path_sites && (rc = dev_alloc(&h->d_path_sites, cells))) return rc;
+  const size_t blocked = viterbi_blocked_bytes(h->S, h->I);
+  if (!h->d_bp && (rc = dev_alloc(&h->d_bp, blocked + h->I))) return rc;
+  if (!h->d_path_sites && (rc = dev_alloc(&h->d_path_sites, blocked))) return rc;
   if (!h->d_path && (rc = dev_alloc(&h->d_path, cells))) return rc;
+  const uint64_t chunk = viterbi_chunk_sites(h->S, h->I);
+  if (!h->d_vit && (rc = dev_alloc(&h->d_vit, (size_t)chunk * h->I * 4 + h->I * 2))) return rc;
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
     if ((rc = clear_flags(h))) return rc;
     if (!fast_viterbi(h->fast, h->stream, h->d_freq, h->d_indF, h->d_alpha, h->d_bp,
-                      h->d_path_sites, h->d_flags))
+                      h->d_path_sites, h->d_flags, h->d_vit, chunk))
       return NGHMM_ERR_HIP;
   } else {
     launch_viterbi_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, h->d_indF, h->d_alpha,
-                         h->d_bp, h->d_path_sites);
+                         h->d_bp, h->d_path_sites, h->d_vit, chunk);
   }
-  launch_transpose_u8(h->stream, h->d_path_sites, h->d_path, h->S, h->I);
+  launch_unblock_path(h->stream, h->d_path_sites, h->S, h->I, h->d_path);
   if ((rc = toc(h, SLOT_VITERBI, false))) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(path, h->d_path, cells, hipMemcpyDeviceToHost, h->stream));
