@@ -172,14 +172,16 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
   // every group: 2.4 TB/s instead of ~4).
   double2 eb[NB][UG];
   double db[NB][UG];
+  // T is a multiple of NB*UG and the arrays carry one group of slack at the end, so
+  // neither the prologue nor the refills need bound checks (values read past T are
+  // never used)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
       const uint64_t t = (uint64_t)b * UG + u;
-      const bool v = t < T;
-      eb[b][u] = v ? ep[t * 64] : double2{1, 1};
-      db[b][u] = v ? dp[t * 64] : 0.0;
+      eb[b][u] = ep[t * 64];
+      db[b][u] = dp[t * 64];
     }
   }
   for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
@@ -194,14 +196,11 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
           // alpha +- eh, so their c is c0 * exp(-+ eh d) with a tiny argument
           const double c0 = coanc(al[0], d);
           const double x3 = (al[0] - al[3]) * d, x4 = (al[0] - al[4]) * d;
-          double c3 = c0 * exp_small(x3);
-          double c4 = c0 * exp_small(x4);
-          // chromosome starts (d = inf) and very long gaps: a wave-uniform branch, so
-          // the two full exps are not if-converted into the common path
-          if (__ballot(!(fabs(x3) <= 1e-3 && fabs(x4) <= 1e-3))) {
-            c3 = coanc(al[3], d);
-            c4 = coanc(al[4], d);
-          }
+          // |x| <= 1e-3 on every finite distance is checked by the host before it marks
+          // a group shared3; chromosome starts are stored as d = 1e30, where c0 = 0 and
+          // exp_small stays finite, so the products are exactly 0 as they must be
+          const double c3 = c0 * exp_small(x3);
+          const double c4 = c0 * exp_small(x4);
           const double a0 = 1 - c0;
           const double ce0 = c0 * e0, ce1 = c0 * e1, ae0 = a0 * e0, ae1 = a0 * e1;
           op_step(R[0], ce0, ce1, ae0 * q0[0], ae1 * q1[0]);
@@ -224,9 +223,8 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
 #pragma unroll
       for (int u = 0; u < UG; ++u) {
         const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
-        const bool v = t < T;
-        eb[b][u] = v ? ep[t * 64] : double2{1, 1};
-        db[b][u] = v ? dp[t * 64] : 0.0;
+        eb[b][u] = ep[t * 64];
+        db[b][u] = dp[t * 64];
       }
     }
 #pragma unroll
@@ -299,17 +297,15 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
   double dcur[UF], dnxt[UF];
 #pragma unroll
   for (int u = 0; u < UF; ++u) {
-    const bool v = (uint64_t)u < T;
-    ecur[u] = v ? ep[(uint64_t)u * 64] : double2{1, 1};
-    dcur[u] = v ? dp[(uint64_t)u * 64] : 0.0;
+    ecur[u] = ep[(uint64_t)u * 64];  // T is a multiple of 8; arrays carry a group of slack
+    dcur[u] = dp[(uint64_t)u * 64];
   }
   for (uint64_t t0 = 0; t0 < T; t0 += UF) {
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       const uint64_t t = t0 + UF + u;
-      const bool v = t < T;
-      enxt[u] = v ? ep[t * 64] : double2{1, 1};
-      dnxt[u] = v ? dp[t * 64] : 0.0;
+      enxt[u] = ep[t * 64];
+      dnxt[u] = dp[t * 64];
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
@@ -401,18 +397,16 @@ k_fast_fwd_odds(const double2* __restrict__ e_il, const double* __restrict__ pos
   double dcur[UF], dnxt[UF];
 #pragma unroll
   for (int u = 0; u < UF; ++u) {
-    const bool v = (uint64_t)u < T;
-    ecur[u] = v ? ep[(uint64_t)u * 64] : double2{1, 1};
-    dcur[u] = v ? dp[(uint64_t)u * 64] : 0.0;
+    ecur[u] = ep[(uint64_t)u * 64];  // T is a multiple of 8; arrays carry a group of slack
+    dcur[u] = dp[(uint64_t)u * 64];
   }
   int exd = 0;
   for (uint64_t t0 = 0; t0 < T; t0 += UF) {
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       const uint64_t t = t0 + UF + u;
-      const bool v = t < T;
-      enxt[u] = v ? ep[t * 64] : double2{1, 1};
-      dnxt[u] = v ? dp[t * 64] : 0.0;
+      enxt[u] = ep[t * 64];
+      dnxt[u] = dp[t * 64];
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
@@ -422,7 +416,7 @@ k_fast_fwd_odds(const double2* __restrict__ e_il, const double* __restrict__ pos
       const double s = v0 + v1;
       v0 = fma(a * q0, s, cc * v0) * ecur[u].x;
       v1 = fma(a * q1, s, cc * v1) * ecur[u].y;
-      if (t < T) rp[t * 64] = v1 / v0;
+      rp[t * 64] = v1 / v0;
     }
     if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) renorm2(v0, v1, exd);
 #pragma unroll
@@ -588,6 +582,21 @@ k_fast_emission(const double* __restrict__ gl, const double* __restrict__ freq, 
   }
 }
 
+// largest finite distance (bit pattern order == value order for non-negative doubles)
+__global__ void __launch_bounds__(256)
+k_fast_max_finite(const double* __restrict__ pos, uint64_t S, unsigned long long* __restrict__ out) {
+  unsigned long long m = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < S;
+       k += (uint64_t)gridDim.x * blockDim.x) {
+    const double d = pos[k];
+    if (d >= 0 && d < 1e30) {
+      const unsigned long long b = ngh_bits(d);
+      m = b > m ? b : m;
+    }
+  }
+  atomicMax(out, m);
+}
+
 __global__ void __launch_bounds__(256)
 k_fast_pos_interleave(const double* __restrict__ pos, uint64_t S, uint64_t T, uint32_t C,
                       double* __restrict__ pos_il) {
@@ -597,7 +606,10 @@ k_fast_pos_interleave(const double* __restrict__ pos, uint64_t S, uint64_t T, ui
     const uint64_t lane = k & 63, ct = k >> 6;
     const uint64_t c = ct / T, t = ct % T;
     const uint64_t s = (c * 64 + lane) * T + t;
-    pos_il[k] = (s < S) ? pos[s] : 0.0;  // padding: d = 0 -> c = 1 -> identity transition
+    // padding: d = 0 -> c = 1 -> identity transition; chromosome starts: +inf is stored
+    // as 1e30 (exp(-alpha 1e30) = 0 for every alpha >= 1e-15, and no inf*0 can arise)
+    const double d = (s < S) ? pos[s] : 0.0;
+    pos_il[k] = (d < 1e30) ? d : 1e30;
   }
 }
 
@@ -921,10 +933,14 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   fs.C = (uint32_t)C;
   fs.J = 64 * C;
   fs.T = (S + fs.J - 1) / fs.J;
+  fs.T = (fs.T + 7) & ~7ull;  // whole prefetch groups: the main loops need no bound checks
   fs.Spad = fs.J * fs.T;
   const size_t cells = (size_t)I * fs.Spad;
-  if (!dalloc(&fs.e_il, cells * 2)) return false;
-  if (!dalloc(&fs.pos_il, (size_t)fs.Spad)) return false;
+  const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
+  if (!dalloc(&fs.e_il, (cells + slack) * 2)) return false;
+  if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
+  if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
+  if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.r_il, cells)) return false;
   if (!dalloc(&fs.lane_ops, (size_t)I * fs.J * 5)) return false;
   if (!dalloc(&fs.bound, (size_t)I * fs.J * 4)) return false;
@@ -944,6 +960,15 @@ bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* 
   fs.d_pos = d_pos;
   hipLaunchKernelGGL(k_fast_pos_interleave, dim3(1024), dim3(256), 0, st, d_pos, fs.S, fs.T, fs.C,
                      fs.pos_il);
+  // the largest finite distance decides when the objective kernel may use its
+  // small-argument exp for the alpha +- eh probes
+  unsigned long long* d_m = reinterpret_cast<unsigned long long*>(fs.bound);
+  if (hipMemsetAsync(d_m, 0, sizeof(unsigned long long), st) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_fast_max_finite, dim3(256), dim3(256), 0, st, d_pos, fs.S, d_m);
+  unsigned long long bits = 0;
+  if (hipMemcpyAsync(&bits, d_m, sizeof bits, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+  if (hipStreamSynchronize(st) != hipSuccess) return false;
+  std::memcpy(&fs.dmax_finite, &bits, sizeof bits);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -979,7 +1004,13 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    G.shared3 = (np == 5 && G.A[0] == G.A[1] && G.A[0] == G.A[2]) ? 1u : 0u;
+    // the finite-difference pattern, with alpha probes close enough for exp_small on
+    // every finite distance of this data set
+    G.shared3 = (np == 5 && G.A[0] == G.A[1] && G.A[0] == G.A[2] &&
+                 std::fabs(G.A[0] - G.A[3]) * fs.dmax_finite <= 1e-3 &&
+                 std::fabs(G.A[0] - G.A[4]) * fs.dmax_finite <= 1e-3)
+                    ? 1u
+                    : 0u;
     groups.push_back(G);
   }
   const uint32_t ng = (uint32_t)groups.size();

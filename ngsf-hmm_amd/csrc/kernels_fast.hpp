@@ -30,6 +30,7 @@ struct FastState {
   size_t grp_cap = 0;
   std::vector<unsigned char> grp_host;
   uint32_t n_groups = 0;
+  double dmax_finite = 0;         // largest finite distance of the loaded data
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;
 };
