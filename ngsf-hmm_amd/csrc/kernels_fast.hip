@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -738,18 +739,23 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // flagged and redone by k_fast_estmaf_stream, which takes the reference-order
 // log-space route for such cells.
 //
-// Two waves share a site (workgroup = 128 threads): 6*NI constants plus the
-// temporaries of NI = 16 do not fit in 256 VGPRs, and a single wave per SIMD cannot
-// hide the serial tail of a pass (reduction, division, loop test).  The two partial
-// sums meet in LDS once per pass (double-buffered, one barrier).
-template <int NI>
-__global__ void __launch_bounds__(128)
+// W = blockDim.x / 64 waves share a site (2 for up to 1024 individuals, up to 16 for
+// 8192 and more, e.g. the site-sharded frequency step of a multi-GPU run): 7*NI
+// constants plus the temporaries of NI = 16 do not fit in 256 VGPRs, and a single wave
+// per SIMD cannot hide the serial tail of a pass (reduction, division, loop test).  The
+// partial sums meet in LDS once per pass (double-buffered, one barrier) and are added in
+// wave order, so the result does not depend on scheduling.
+constexpr int ESTMAF_MAXW = 16;
+template <int NI, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
               uint8_t* __restrict__ redo) {
-  __shared__ double xch[2][2][4];  // [buffer][wave][num, den, bad, -]
+  __shared__ double xch[2][ESTMAF_MAXW][4];  // [buffer][wave][num, den, bad, -]
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
+  constexpr int W = BLOCK / 64;
+  constexpr uint64_t stride = BLOCK;
   const uint64_t site = blockIdx.x;
   const double* gls = gl + site * I_tot * 3;
 
@@ -757,7 +763,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   double tF_lane = 0;
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    const uint64_t i = (uint64_t)threadIdx.x + 128ull * k;
+    const uint64_t i = (uint64_t)threadIdx.x + stride * k;
     if (i < I_tot) {
       const double p0 = exp(gls[i * 3]), p1 = exp(gls[i * 3 + 1]), p2 = exp(gls[i * 3 + 2]);
       const double F = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
@@ -780,7 +786,8 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     if (lane == 0) xch[1][wv][0] = t;
   }
   __syncthreads();
-  const double tF_sum = xch[1][0][0] + xch[1][1][0];
+  double tF_sum = 0;
+  for (int w = 0; w < W; ++w) tF_sum += xch[1][w][0];
   __syncthreads();
 
   int iters = 0;
@@ -847,12 +854,18 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       }
     }
     __syncthreads();
-    if (xch[buf][0][2] + xch[buf][1][2] != 0.0) {  // block-uniform: careful kernel takes over
+    double sn = 0, sd = 0, sbad = 0;
+    for (int w = 0; w < W; ++w) {
+      sn += xch[buf][w][0];
+      sd += xch[buf][w][1];
+      sbad += xch[buf][w][2];
+    }
+    if (sbad != 0.0) {  // block-uniform: the careful kernel takes this site over
       if (threadIdx.x == 0) redo[site] = 1;
       return;
     }
-    num += xch[buf][0][0] + xch[buf][1][0];
-    den += tF_sum + (xch[buf][0][1] + xch[buf][1][1]);
+    num += sn;
+    den += tF_sum + sd;
     buf ^= 1;
     freq = num * rcp_nr2(den);
     again = (fabs(prev - freq) > kEPS) && (iters++ < 100);
@@ -1077,7 +1090,6 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                  double* d_freq_out) {
   if (S_own == 0) return true;
   const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
-  const uint64_t per_lane = (I_tot + 127) / 128;  // two waves per site
   if (S_own > fs.redo_cap) {
     if (fs.redo) (void)hipFree(fs.redo);
     fs.redo = nullptr;
@@ -1085,16 +1097,33 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
     if (hipMalloc((void**)&fs.redo, S_own) != hipSuccess) return false;
     fs.redo_cap = S_own;
   }
-#define LAUNCH_NI(N)                                                                      \
-  hipLaunchKernelGGL((k_fast_estmaf<N>), dim3((unsigned)S_own), dim3(128), 0, st, d_gl_sites, \
+  // waves per site (W) and individuals per lane (NI): registers allow NI = 8 at three
+  // waves per SIMD and NI = 16 at two; a workgroup must fit one CU
+#define LAUNCH_NI(N, B)                                                                      \
+  hipLaunchKernelGGL((k_fast_estmaf<N, B>), dim3((unsigned)S_own), dim3(B), 0, st, d_gl_sites, \
                      d_marg_blocks, S_own, I_tot, I_blk, d_freq_out, fs.redo)
   const uint8_t* redo = fs.redo;
-  if (per_lane <= 1) LAUNCH_NI(1);
-  else if (per_lane <= 2) LAUNCH_NI(2);
-  else if (per_lane <= 4) LAUNCH_NI(4);
-  else if (per_lane <= 8) LAUNCH_NI(8);
-  else if (per_lane <= 16) LAUNCH_NI(16);
-  else redo = nullptr;  // too many individuals for registers: stream every site
+  int cfg_ni = 0, cfg_b = 0;
+  if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
+  if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
+    if (cfg_ni == 16 && cfg_b == 64) LAUNCH_NI(16, 64);
+    else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);
+    else if (cfg_ni == 16 && cfg_b == 256) LAUNCH_NI(16, 256);
+    else if (cfg_ni == 16 && cfg_b == 512) LAUNCH_NI(16, 512);
+    else if (cfg_ni == 8 && cfg_b == 128) LAUNCH_NI(8, 128);
+    else if (cfg_ni == 8 && cfg_b == 256) LAUNCH_NI(8, 256);
+    else if (cfg_ni == 8 && cfg_b == 512) LAUNCH_NI(8, 512);
+    else if (cfg_ni == 4 && cfg_b == 256) LAUNCH_NI(4, 256);
+    else if (cfg_ni == 4 && cfg_b == 512) LAUNCH_NI(4, 512);
+    else return false;
+  } else if (I_tot <= 128) LAUNCH_NI(1, 128);
+  else if (I_tot <= 256) LAUNCH_NI(2, 128);
+  else if (I_tot <= 512) LAUNCH_NI(4, 128);
+  else if (I_tot <= 1024) LAUNCH_NI(8, 128);
+  else if (I_tot <= 2048) LAUNCH_NI(8, 256);
+  else if (I_tot <= 4096) LAUNCH_NI(16, 256);
+  else if (I_tot <= 8192) LAUNCH_NI(16, 512);
+  else redo = nullptr;  // more individuals than registers hold: stream every site
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
                      I_tot, I_blk, d_freq_out, redo);
 #undef LAUNCH_NI

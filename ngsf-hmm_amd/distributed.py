@@ -178,16 +178,27 @@ class ShardedEM:
             st, self.ind_lkl = self.backend.iter_em_local(freq_est, indF_fixed, alpha_fixed)
             return st
         self.ind_lkl = self.backend.estep()
+        # the posteriors are final after the E-step and the indF/alpha M-step neither reads
+        # nor writes them: start their all-to-all now and let it run under the M-step
+        work = self.start_posterior_exchange() if freq_est else None
         st = self.backend.mstep_indf(indF_fixed, alpha_fixed)
         if freq_est:
-            self.exchange_and_update_freq()
+            self.finish_exchange_and_update_freq(work)
         return st
 
-    def exchange_and_update_freq(self):
+    def start_posterior_exchange(self):
         import torch.distributed as dist
         for q, (lo, hi) in enumerate(self.ranges):
             self.backend.pack_posteriors(lo, hi, self._send[q])
-        all_to_all(self._recv, self._send)
+        self._sync()
+        if _staged(self._send):
+            all_to_all(self._recv, self._send)
+            return None
+        return dist.all_to_all_single(self._recv.view(-1), self._send.view(-1), async_op=True)
+
+    def finish_exchange_and_update_freq(self, work):
+        if work is not None:
+            work.wait()
         self._sync()
         # _recv is [source rank][S_own][I_loc]: the rank-blocked layout est_maf reads
         self.backend.mstep_freq_sites(self._recv, self._freq_own)
