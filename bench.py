@@ -49,7 +49,7 @@ LIMITER_NOTES = {
                "de-interleave (five launches, timed together)",
 }
 
-_KERNEL_OF = {"lkl_batch": "k_fast_lkl_chunks", "est_maf": "k_fast_estmaf<8>",
+_KERNEL_OF = {"lkl_batch": "k_fast_lkl_chunks", "est_maf": "k_fast_estmaf<8, 128>",
               "emission": "k_fast_emission"}
 
 
