@@ -7,11 +7,15 @@
 // include/nghmm.h (HIP kernels).  Host-side work is what the reference also does once,
 // outside its hot loop: argument parsing, file I/O, GL normalisation, initial values.
 //
-// Extra options: --mode exact|fast (default fast), --device N.
+// Extra options: --mode exact|fast (default fast), --device N.  --n_threads (the
+// reference's pool size) sets the host threads used for input normalisation and output
+// formatting; results do not depend on it.
 #include <getopt.h>
+#include <omp.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -181,18 +185,20 @@ void read_geno(Params& P) {
         fatal(__FUNCTION__, gzeof(fh)
                                 ? "GENO file at premature EOF. Check GENO file and number of sites!"
                                 : "cannot read binary GENO file. Check GENO file and number of sites!");
-      for (uint64_t i = 0; i < I; i++) {
-        double* g = row + i * 3;
-        if (!P.in_loglkl)
-          for (int k = 0; k < 3; k++) {
-            g[k] = log(g[k]);
-            if (g[k] == -INFINITY) g[k] = -kINF;
-          }
-        post_prob_self(g);
-        if (std::isnan(g[0]) || std::isnan(g[1]) || std::isnan(g[2]))
-          fatal(__FUNCTION__, "NaN found! Is the file format correct?");
-      }
     }
+    bool nan_found = false;
+#pragma omp parallel for schedule(static) reduction(|| : nan_found)
+    for (uint64_t c2 = 0; c2 < (uint64_t)S * I; c2++) {
+      double* g = &P.gl[c2 * 3];
+      if (!P.in_loglkl)
+        for (int k = 0; k < 3; k++) {
+          g[k] = log(g[k]);
+          if (g[k] == -INFINITY) g[k] = -kINF;
+        }
+      post_prob_self(g);
+      if (std::isnan(g[0]) || std::isnan(g[1]) || std::isnan(g[2])) nan_found = true;
+    }
+    if (nan_found) fatal(__FUNCTION__, "NaN found! Is the file format correct?");
   } else {
     std::vector<char> buf(kBuffLen);
     std::vector<double> t;
@@ -237,6 +243,7 @@ void read_geno(Params& P) {
   if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
   gzclose(fh);
   // ngsF-HMM.cpp:101-117: optional genotype calling, then a second normalisation
+#pragma omp parallel for schedule(static)
   for (uint64_t c2 = 0; c2 < (uint64_t)S * I; c2++) {
     double* g = &P.gl[c2 * 3];
     if (P.call_geno) call_geno(g);
@@ -360,12 +367,21 @@ void geno_posterior(const double* gl, double maf, double F, double* pp) {
   for (int k = 0; k < 3; k++) pp[k] = exp(pp[k] - norm);
 }
 
+// printf("%f") / printf("%.10f") through std::to_chars: the same correctly rounded
+// digits (checked against printf on 5M values incl. ties), ~10x faster, thread-safe
+inline char* put_fixed(char* p, double v, int prec) {
+  if (std::isnan(v) || std::isinf(v)) return p + sprintf(p, prec == 6 ? "%f" : "%.10f", v);
+  auto r = std::to_chars(p, p + 400, v, std::chars_format::fixed, prec);
+  return r.ptr;
+}
+
 // EM.cpp:293-380
 void print_iter(const Params& P) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   std::string name = std::string(P.out_prefix) + ".indF";
   FILE* fh = fopen(name.c_str(), "w");
   if (!fh) fatal(__FUNCTION__, "cannot open INDF output file!");
+  setvbuf(fh, nullptr, _IOFBF, 1 << 22);
   fprintf(fh, "%.10f\n", P.tot_lkl);
   for (uint16_t i = 0; i < I; i++) {  // (sic) uint16_t as in the reference
     if (P.indF[i] < kEPSILON)
@@ -375,7 +391,14 @@ void print_iter(const Params& P) {
     else
       fprintf(fh, "%.5f\t%f\n", P.indF[i], P.alpha[i]);
   }
-  for (uint64_t s = 0; s < S; s++) fprintf(fh, "%f\n", P.freq[s]);
+  {
+    char buf[512];
+    for (uint64_t s = 0; s < S; s++) {
+      char* e = put_fixed(buf, P.freq[s], 6);
+      *e++ = '\n';
+      fwrite(buf, 1, e - buf, fh);
+    }
+  }
   fclose(fh);
 
   name = std::string(P.out_prefix) + ".ibd";
@@ -391,10 +414,26 @@ void print_iter(const Params& P) {
     line[S] = '\n';
     fwrite(line.data(), 1, S + 1, fh);
   }
-  for (uint64_t i = 0; i < I; i++) {
-    fprintf(fh, "%f", P.marg[i * S]);
-    for (uint64_t s = 1; s < S; s++) fprintf(fh, "\t%f", P.marg[i * S + s]);
-    fputc('\n', fh);
+  // posterior lines: formatted in parallel, one batch of individuals at a time
+  const int nt = omp_get_max_threads();
+  std::vector<std::vector<char>> bufs(nt);
+  std::vector<size_t> lens(nt);
+  for (uint64_t i0 = 0; i0 < I; i0 += nt) {
+    const int nb = (int)((I - i0) < (uint64_t)nt ? (I - i0) : nt);
+#pragma omp parallel for schedule(static, 1)
+    for (int b2 = 0; b2 < nb; b2++) {
+      std::vector<char>& bf = bufs[b2];
+      bf.resize(S * 12 + 64);
+      char* p = bf.data();
+      const double* m = &P.marg[(i0 + b2) * S];
+      for (uint64_t s = 0; s < S; s++) {
+        if (s) *p++ = '\t';
+        p = put_fixed(p, m[s], 6);
+      }
+      *p++ = '\n';
+      lens[b2] = p - bf.data();
+    }
+    for (int b2 = 0; b2 < nb; b2++) fwrite(bufs[b2].data(), 1, lens[b2], fh);
   }
   fclose(fh);
 
@@ -402,12 +441,17 @@ void print_iter(const Params& P) {
   fh = fopen(name.c_str(), "wb");
   if (!fh) fatal(__FUNCTION__, "cannot open GENO output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
-  double pp[3];
-  for (uint64_t s = 0; s < S; s++)
-    for (uint64_t i = 0; i < I; i++) {
-      geno_posterior(&P.gl[(s * I + i) * 3], P.freq[s], (double)P.path[i * S + s], pp);
-      fwrite(pp, sizeof(double), 3, fh);
+  const uint64_t chunk = 4096;  // sites per block
+  std::vector<double> blk(chunk * I * 3);
+  for (uint64_t s0 = 0; s0 < S; s0 += chunk) {
+    const uint64_t ns = (S - s0) < chunk ? (S - s0) : chunk;
+#pragma omp parallel for schedule(static)
+    for (uint64_t c2 = 0; c2 < ns * I; c2++) {
+      const uint64_t s = s0 + c2 / I, i = c2 % I;
+      geno_posterior(&P.gl[(s * I + i) * 3], P.freq[s], (double)P.path[i * S + s], &blk[c2 * 3]);
     }
+    fwrite(blk.data(), sizeof(double), ns * I * 3, fh);
+  }
   fclose(fh);
 }
 
@@ -510,6 +554,7 @@ int main(int argc, char** argv) {
     warn(__FUNCTION__, "adjusting threads (--n_threads) to match number of individuals!");
     P.n_threads = (unsigned)P.n_ind;
   }
+  omp_set_num_threads((int)P.n_threads);
   struct stat st;  // ngsF-HMM.cpp:47-63
   if (stat(P.in_geno, &st) != 0) fatal(__FUNCTION__, "cannot check GENO file size!");
   const char* dot = strrchr(P.in_geno, '.');

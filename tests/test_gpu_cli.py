@@ -61,7 +61,7 @@ def test_cli_outputs_byte_identical(pkg, orc_det, orc_libm, data, name, flags, k
     r = cli_util.run_cli(["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I,
                           "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
                           "--min_iters", 3, "--max_iters", 5, "--mode", "exact", "--seed", 12345,
-                          "--verbose", 1])
+                          "--n_threads", 4 if name != "TG" else 1, "--verbose", 1])
     n, (f_indF, f_ibd, f_geno) = _oracle_outputs(orc_det, orc_libm, gl, d, 0.1, 0.1, 0.2, 3, 5)
     assert f"Iteration {n}:" in r.stdout and f"Iteration {n + 1}:" not in r.stdout
     assert open(out + ".indF", "rb").read() == f_indF
