@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
               uint8_t* __restrict__ redo) {
-  __shared__ double xch[2][ESTMAF_MAXW][4];  // [buffer][wave][num, den, bad, -]
+  __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   constexpr int W = BLOCK / 64;
@@ -802,7 +802,6 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     const double om = 1 - freq;
     const double r = freq * rcp_nr2(om);
     double pn = 0, pd = 0;
-    bool bad = !(om > 0);
     if constexpr (NI >= 4) {
       // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step
       // and 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
@@ -816,9 +815,9 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
           un[j] = fma(nC[k], Fv[k] + r, c1[k]);
         }
         const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
-        const double P = p01 * p23;
-        bad |= !(P > 0);   // sums are >= 0: the product is > 0 iff every sum is
-        const double R = rcp_nr(P);
+        // a vanishing sum makes R infinite and the site's freq non-finite, which ends the
+        // loop (the comparison below is false for NaN) and flags the site after it
+        const double R = rcp_nr(p01 * p23);
         const double r01 = R * p23, r23 = R * p01;
         const double inv0 = r01 * sm[1], inv1 = r01 * sm[0];
         const double inv2 = r23 * sm[3], inv3 = r23 * sm[2];
@@ -836,7 +835,6 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       for (int k = 0; k < NI; ++k) {
         const double sum = fma(r, fma(r, sC[k], sb[k]), sA[k]);
         const double un = fma(nC[k], Fv[k] + r, c1[k]);
-        bad |= !(sum > 0);
         const double inv = rcp_nr(sum);
         pn = fma(un, inv, pn);
         pd = fma(fc[k], inv, pd);
@@ -846,23 +844,17 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     pd *= r;
     {
       const double wn = wave_sum_lastrow(pn), wd = wave_sum_lastrow(pd);
-      const bool anybad = __ballot(bad) != 0;
       if (lane == 63) {
         xch[buf][wv][0] = wn;
         xch[buf][wv][1] = wd;
-        xch[buf][wv][2] = anybad ? 1.0 : 0.0;
       }
     }
     __syncthreads();
-    double sn = 0, sd = 0, sbad = 0;
+    double sn = 0, sd = 0;
+#pragma unroll
     for (int w = 0; w < W; ++w) {
       sn += xch[buf][w][0];
       sd += xch[buf][w][1];
-      sbad += xch[buf][w][2];
-    }
-    if (sbad != 0.0) {  // block-uniform: the careful kernel takes this site over
-      if (threadIdx.x == 0) redo[site] = 1;
-      return;
     }
     num += sn;
     den += tF_sum + sd;
@@ -871,8 +863,11 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     again = (fabs(prev - freq) > kEPS) && (iters++ < 100);
   } while (again);
   if (threadIdx.x == 0) {
+    // non-finite or out-of-range result: a cell with vanishing weights (or f reaching 1);
+    // the careful kernel redoes the site in the reference's log-space order
+    const bool ok = freq >= 0 && freq < 1;
     freq_out[site] = freq;
-    redo[site] = 0;
+    redo[site] = ok ? 0 : 1;
   }
 }
 
