@@ -668,9 +668,11 @@ __device__ double2 estmaf_term_logspace(const double* g, double freq, double F) 
 // matters here: est_maf has one dependent reduction per pass and ~100 passes.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
+  // full row mask and in-row permutations: every lane is written, so the "old" operand
+  // is irrelevant (mov_dpp leaves it undefined and saves the two zeroing moves)
   const uint64_t b = ngh_bits(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, true);
   return ngh_from_bits(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
