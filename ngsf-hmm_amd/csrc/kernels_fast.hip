@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "detmath.h"
@@ -167,71 +168,81 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
   const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
 
+  // The loop body exists in two versions (finite-difference pattern / general points)
+  // selected ONCE per wave, so that the unrolled body of eight sites is a single basic
+  // block the scheduler can overlap the exp chains of one site with the row updates of
+  // the previous ones in.
+  auto run = [&](auto tag) {
   // Software pipeline: NB buffers of UG sites.  A buffer is refilled right after it
-  // has been consumed, i.e. (NB-1) groups = 6 sites before it is needed again, which
-  // covers HBM latency at two waves per SIMD (a one-group-ahead scheme stalled on
-  // every group: 2.4 TB/s instead of ~4).
-  double2 eb[NB][UG];
-  double db[NB][UG];
-  // T is a multiple of NB*UG and the arrays carry one group of slack at the end, so
-  // neither the prologue nor the refills need bound checks (values read past T are
-  // never used)
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-#pragma unroll
-    for (int u = 0; u < UG; ++u) {
-      const uint64_t t = (uint64_t)b * UG + u;
-      eb[b][u] = ep[t * 64];
-      db[b][u] = dp[t * 64];
-    }
-  }
-  for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int u = 0; u < UG; ++u) {
-        // sites past T are identity operators (e = 1, d = 0), so no bound check
-        const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
-      if (NP_MAX >= 5 && shared3) {
-          // the finite-difference pattern: points 0..2 share alpha; points 3 and 4 sit at
-          // alpha +- eh, so their c is c0 * exp(-+ eh d) with a tiny argument
-          const double c0 = coanc(al[0], d);
-          const double x3 = (al[0] - al[3]) * d, x4 = (al[0] - al[4]) * d;
-          // |x| <= 1e-3 on every finite distance is checked by the host before it marks
-          // a group shared3; chromosome starts are stored as d = 1e30, where c0 = 0 and
-          // exp_small stays finite, so the products are exactly 0 as they must be
-          const double c3 = c0 * exp_small(x3);
-          const double c4 = c0 * exp_small(x4);
-          const double a0 = 1 - c0;
-          const double ce0 = c0 * e0, ce1 = c0 * e1, ae0 = a0 * e0, ae1 = a0 * e1;
-          op_step(R[0], ce0, ce1, ae0 * q0[0], ae1 * q1[0]);
-          op_step(R[1], ce0, ce1, ae0 * q0[1], ae1 * q1[1]);
-          op_step(R[2], ce0, ce1, ae0 * q0[2], ae1 * q1[2]);
-          const double a3 = 1 - c3, a4 = 1 - c4;
-          op_step(R[3], c3 * e0, c3 * e1, a3 * e0 * q0[3], a3 * e1 * q1[3]);
-          op_step(R[4], c4 * e0, c4 * e1, a4 * e0 * q0[4], a4 * e1 * q1[4]);
-        } else {
+    // has been consumed, i.e. (NB-1) groups = 6 sites before it is needed again, which
+    // covers HBM latency at two waves per SIMD (a one-group-ahead scheme stalled on
+    // every group: 2.4 TB/s instead of ~4).
+    double2 eb[NB][UG];
+    double db[NB][UG];
+    // T is a multiple of NB*UG and the arrays carry one group of slack at the end, so
+    // neither the prologue nor the refills need bound checks (values read past T are
+    // never used)
   #pragma unroll
-          for (int p = 0; p < NP_MAX; ++p) {
-            if (p < (int)np) {
-              const double cc = coanc(al[p], d);
-              const double a = 1 - cc;
-              op_step(R[p], cc * e0, cc * e1, a * e0 * q0[p], a * e1 * q1[p]);
-            }
-          }
-        }
-      }
-#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+  #pragma unroll
       for (int u = 0; u < UG; ++u) {
-        const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
+        const uint64_t t = (uint64_t)b * UG + u;
         eb[b][u] = ep[t * 64];
         db[b][u] = dp[t * 64];
       }
     }
-#pragma unroll
-    for (int p = 0; p < NP_MAX; ++p)
-      if (p < (int)np) renorm(R[p]);
-  }
+    for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
+  #pragma unroll
+      for (int b = 0; b < NB; ++b) {
+  #pragma unroll
+        for (int u = 0; u < UG; ++u) {
+          // sites past T are identity operators (e = 1, d = 0), so no bound check
+          const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
+        if constexpr (NP_MAX >= 5 && decltype(tag)::value) {
+            // the finite-difference pattern: points 0..2 share alpha; points 3 and 4 sit at
+            // alpha +- eh, so their c is c0 * exp(-+ eh d) with a tiny argument
+            const double c0 = coanc(al[0], d);
+            const double x3 = (al[0] - al[3]) * d, x4 = (al[0] - al[4]) * d;
+            // |x| <= 1e-3 on every finite distance is checked by the host before it marks
+            // a group shared3; chromosome starts are stored as d = 1e30, where c0 = 0 and
+            // exp_small stays finite, so the products are exactly 0 as they must be
+            const double c3 = c0 * exp_small(x3);
+            const double c4 = c0 * exp_small(x4);
+            const double a0 = 1 - c0;
+            const double ce0 = c0 * e0, ce1 = c0 * e1, ae0 = a0 * e0, ae1 = a0 * e1;
+            op_step(R[0], ce0, ce1, ae0 * q0[0], ae1 * q1[0]);
+            op_step(R[1], ce0, ce1, ae0 * q0[1], ae1 * q1[1]);
+            op_step(R[2], ce0, ce1, ae0 * q0[2], ae1 * q1[2]);
+            const double a3 = 1 - c3, a4 = 1 - c4;
+            op_step(R[3], c3 * e0, c3 * e1, a3 * e0 * q0[3], a3 * e1 * q1[3]);
+            op_step(R[4], c4 * e0, c4 * e1, a4 * e0 * q0[4], a4 * e1 * q1[4]);
+          } else {
+    #pragma unroll
+            for (int p = 0; p < NP_MAX; ++p) {
+              if (p < (int)np) {
+                const double cc = coanc(al[p], d);
+                const double a = 1 - cc;
+                op_step(R[p], cc * e0, cc * e1, a * e0 * q0[p], a * e1 * q1[p]);
+              }
+            }
+          }
+        }
+  #pragma unroll
+        for (int u = 0; u < UG; ++u) {
+          const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
+          eb[b][u] = ep[t * 64];
+          db[b][u] = dp[t * 64];
+        }
+      }
+  #pragma unroll
+      for (int p = 0; p < NP_MAX; ++p)
+        if (p < (int)np) renorm(R[p]);
+    }
+  };
+  if (shared3)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
   // ordered product over the 64 lanes
 #pragma unroll
   for (int p = 0; p < NP_MAX; ++p) {
