@@ -181,3 +181,30 @@ def test_fast_called_genotypes(pkg, orc_libm):
     em.mstep_freq(1); hmm.mstep_freq(1)
     np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
     hmm.close()
+
+
+def test_fast_reference_fatal_errors(pkg):
+    """The reference's fatal conditions surface as the same messages in fast mode."""
+    import math
+    d = pkg.simulate.simulate(9, 300, seed=4)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    hmm = pkg.NgsFHMM(9, 300, mode=pkg.MODE_FAST)
+    hmm.load(gl, d.pos_dist_mb)
+    hmm.set_params(0.1, 0.2, -0.2)
+    with pytest.raises(pkg.NgsFHMMError) as ei:
+        hmm.init_emission()
+    assert ei.value.code == -3 and "invalid MAF!" in ei.value.message
+    hmm.set_params(0.1, 0.2, 0.1)
+    hmm.init_emission()
+    hmm.estep()
+    with pytest.raises(pkg.NgsFHMMError) as ei:
+        hmm.mstep_freq(2)
+    assert ei.value.code == -5
+    bad = gl.copy()
+    bad[7, 3, :] = math.nan
+    hmm.load(bad, d.pos_dist_mb)
+    hmm.init_emission()
+    with pytest.raises(pkg.NgsFHMMError) as ei:
+        hmm.estep()
+    assert ei.value.code in (-1, -4)
+    hmm.close()
