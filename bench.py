@@ -41,10 +41,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s me
 
 LIMITER_NOTES = {
     "est_maf": "FP64-VALU-issue bound, not HBM bound: the reference's est_maf makes ~100 passes "
-               "per site over in-register data (SQ_ACTIVE_INST_VALU ~35% per wave x 3 waves/SIMD, "
+               "per site over in-register data (SQ_ACTIVE_INST_VALU ~38% per wave x 3 waves/SIMD, "
                "profiles/r01_pmc_summary.json); HBM traffic is one read of GL + posteriors",
     "lkl_batch": "objective of the L-BFGS-B M-step: one 16 B emission pair per site and individual "
-                 "per round; FP64-VALU issue is saturated at two waves per SIMD",
+                 "per round; FP64-VALU issue is saturated (~37% per wave x 3 waves per SIMD)",
     "forward": "E-step: operators, boundary vectors, forward odds, backward posteriors, "
                "de-interleave (five launches, timed together)",
 }
