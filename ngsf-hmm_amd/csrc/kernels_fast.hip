@@ -738,41 +738,68 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return r;
 }
 
-// One wave per site, NI individuals per lane held in registers.  With
+// Sums of two per-lane values over the wave in ONE reduction tree: the first step swaps
+// the upper half of pn with the lower half of pd (v_permlane32_swap, gfx950), so lanes
+// 0..31 carry pn partials and lanes 32..63 pd partials; four in-row DPP steps and one
+// row_bcast15 finish both.  Returns the value whose lane 31 holds sum(pn) and lane 63
+// sum(pd).
+__device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
+  const uint64_t bn = ngh_bits(pn), bd = ngh_bits(pd);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)bn, (unsigned)bd, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(bn >> 32), (unsigned)(bd >> 32),
+                                                   false, false);
+  double v = ngh_from_bits(((uint64_t)hi[0] << 32) | lo[0]) +
+             ngh_from_bits(((uint64_t)hi[1] << 32) | lo[1]);
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror: every lane holds its row total
+  {  // row_bcast15 into rows 1 and 3
+    const uint64_t b = ngh_bits(v);
+    const int l = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x142, 0xa, 0xf, false);
+    const int h = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x142, 0xa, 0xf, false);
+    v += ngh_from_bits(((uint64_t)(uint32_t)h << 32) | (uint32_t)l);
+  }
+  return v;
+}
+
+// W = BLOCK/64 waves per site, NI individuals per lane held in registers.  With
 //   A = (1-f)^2, b = (1-f) f, C = f^2
 // the weights w_g = p_g * HWE_g(f, F) of calc_HWE/post_prob (gen_func.cpp:920-957) are
 // linear in (A, b, C):  w0 = p0 (A + bF), w1 = b c1 with c1 = 2 p1 (1-F), w2 = p2 (C + bF),
 // and the reference's per-individual terms (gen_func.cpp:999-1000) become
 //   num-term = (w1 + (2-F) w2) / sum
 //   den-term = (2 w1 + (2-F)(w0 + w2)) / sum = (2-F) + F w1 / sum
-// so a pass needs six per-individual constants, one reciprocal and ~12 FMAs, and the
-// (2-F) part of the denominator is a per-site constant.  The <= 101 passes of the
-// reference's do-while (gen_func.cpp:981-1006) never touch memory again.  A site with a
-// cell whose weights all vanish (a called heterozygote at posterior IBD = 1, ...) is
-// flagged and redone by k_fast_estmaf_stream, which takes the reference-order
-// log-space route for such cells.
+// Dividing every weight by (1-f)^2 leaves, in the odds r = f/(1-f),
+//   sum' = sA + r sb + r^2 sC,  num-term = r (u0 + r nC) / sum',  den-term = (2-F) + r fc / sum'
+// six constants per individual, 8 FP64 instructions per individual and pass with the
+// reciprocals taken four at a time, and the (2-F) part of the denominator a per-site
+// constant.  The <= 101 passes of the reference's do-while
+// (gen_func.cpp:981-1006) never touch memory again.  A site with a cell whose weights all
+// vanish (a called heterozygote at posterior IBD = 1, ...) ends with a non-finite
+// frequency, is flagged and redone by k_fast_estmaf_stream, which takes the
+// reference-order log-space route for such cells.
 //
-// W = blockDim.x / 64 waves share a site (2 for up to 1024 individuals, up to 16 for
-// 8192 and more, e.g. the site-sharded frequency step of a multi-GPU run): 7*NI
-// constants plus the temporaries of NI = 16 do not fit in 256 VGPRs, and a single wave
-// per SIMD cannot hide the serial tail of a pass (reduction, division, loop test).  The
-// partial sums meet in LDS once per pass (double-buffered, one barrier) and are added in
-// wave order, so the result does not depend on scheduling.
+// Up to 1024 individuals one wave holds the whole site (NI <= 16: 192 VGPRs of constants,
+// two waves per SIMD) and a pass is 128 + ~45 instructions; beyond that W waves share a
+// site (e.g. the site-sharded frequency step of a multi-GPU run), their partial sums meet
+// in LDS once per pass (double-buffered, one barrier) and are added in wave order, so the
+// result does not depend on scheduling.
 constexpr int ESTMAF_MAXW = 16;
 template <int NI, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
               uint8_t* __restrict__ redo) {
+  constexpr int W = BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  constexpr int W = BLOCK / 64;
   constexpr uint64_t stride = BLOCK;
   const uint64_t site = blockIdx.x;
   const double* gls = gl + site * I_tot * 3;
 
-  double sA[NI], sb[NI], sC[NI], c1[NI], Fv[NI], nC[NI], fc[NI];
+  double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
   double tF_lane = 0;
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
@@ -781,100 +808,120 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       const double p0 = exp(gls[i * 3]), p1 = exp(gls[i * 3 + 1]), p2 = exp(gls[i * 3 + 2]);
       const double F = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
       const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
+      const double n2 = (2 - F) * p2;
       sA[k] = p0;
-      sC[k] = p2;
-      c1[k] = cc;
-      Fv[k] = F;
       sb[k] = fma(F, p0 + p2, cc);
-      nC[k] = (2 - F) * p2;
+      sC[k] = p2;
+      u0[k] = fma(n2, F, cc);
+      nC[k] = n2;
       fc[k] = F * cc;
       tF_lane += 2 - F;
-    } else {  // empty slot: sum' = 1 + r^2 > 0, numerators 0: contributes nothing
-      sA[k] = 1; sC[k] = 1;
-      sb[k] = c1[k] = Fv[k] = nC[k] = fc[k] = 0;
+    } else {  // empty slot: sum' = 1, numerators 0: contributes nothing
+      sA[k] = 1;
+      sb[k] = sC[k] = u0[k] = nC[k] = fc[k] = 0;
     }
   }
-  {
-    const double t = wave_sum_uniform(tF_lane);
-    if (lane == 0) xch[1][wv][0] = t;
+  double tF_sum = wave_sum_uniform(tF_lane);
+  if constexpr (W > 1) {
+    if (lane == 0) xch[1][wv][0] = tF_sum;
+    __syncthreads();
+    tF_sum = xch[1][0][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) tF_sum += xch[1][w][0];
+    __syncthreads();
   }
-  __syncthreads();
-  double tF_sum = 0;
-  for (int w = 0; w < W; ++w) tF_sum += xch[1][w][0];
-  __syncthreads();
 
   int iters = 0;
   int buf = 0;
-  double num = 0, den = 0, freq = 0.01, prev;
+  // The loop carries num and den only.  The odds of freq = num/den are num/(den - num):
+  // one reciprocal on the serial path instead of two, and the reference's stopping rule
+  // |prev - freq| > EPSILON (gen_func.cpp:1006) is tested cross-multiplied,
+  // |num_prev den - num den_prev| > EPSILON den den_prev, which needs no quotient.
+  double num = 0, den = 0;
+  double pnum = 0.01, pden = 1.0;  // freq = 0.01 (gen_func.cpp:976)
   bool again;
   do {
-    prev = freq;
-    // Divide every weight by (1-f)^2: with the odds r = f/(1-f),
-    //   sum' = sA + r sb + r^2 sC,  num-term = r (nC (F + r) + c1) / sum',
-    //   den-term = (2-F) + r F c1 / sum'      (ratios are scale-free)
-    const double om = 1 - freq;
-    const double r = freq * rcp_nr2(om);
+    const double r = pnum * rcp_nr2(pden - pnum);
     double pn = 0, pd = 0;
-    if constexpr (NI >= 4) {
-      // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step
-      // and 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
+    if constexpr (NI >= 8) {
+      // reciprocals eight at a time (Montgomery's trick): one v_rcp_f64 + Newton step and
+      // 21 multiplies instead of eight reciprocals; v_rcp_f64 is the slow instruction
 #pragma unroll
-      for (int k0 = 0; k0 < NI; k0 += 4) {
-        double sm[4], un[4];
+      for (int k0 = 0; k0 < NI; k0 += 8) {
+        double sm[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = k0 + j;
-          sm[j] = fma(r, fma(r, sC[k], sb[k]), sA[k]);
-          un[j] = fma(nC[k], Fv[k] + r, c1[k]);
-        }
+        for (int j = 0; j < 8; ++j) sm[j] = fma(r, fma(r, sC[k0 + j], sb[k0 + j]), sA[k0 + j]);
         const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
+        const double p45 = sm[4] * sm[5], p67 = sm[6] * sm[7];
+        const double pa = p01 * p23, pb = p45 * p67;
         // a vanishing sum makes R infinite and the site's freq non-finite, which ends the
         // loop (the comparison below is false for NaN) and flags the site after it
+        const double R = rcp_nr(pa * pb);
+        const double Ra = R * pb, Rb = R * pa;
+        const double r01 = Ra * p23, r23 = Ra * p01, r45 = Rb * p67, r67 = Rb * p45;
+        double inv[8];
+        inv[0] = r01 * sm[1]; inv[1] = r01 * sm[0];
+        inv[2] = r23 * sm[3]; inv[3] = r23 * sm[2];
+        inv[4] = r45 * sm[5]; inv[5] = r45 * sm[4];
+        inv[6] = r67 * sm[7]; inv[7] = r67 * sm[6];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pn = fma(fma(nC[k0 + j], r, u0[k0 + j]), inv[j], pn);
+          pd = fma(fc[k0 + j], inv[j], pd);
+        }
+      }
+    } else if constexpr (NI >= 4) {
+#pragma unroll
+      for (int k0 = 0; k0 < NI; k0 += 4) {
+        double sm[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[j] = fma(r, fma(r, sC[k0 + j], sb[k0 + j]), sA[k0 + j]);
+        const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
         const double R = rcp_nr(p01 * p23);
         const double r01 = R * p23, r23 = R * p01;
         const double inv0 = r01 * sm[1], inv1 = r01 * sm[0];
         const double inv2 = r23 * sm[3], inv3 = r23 * sm[2];
-        pn = fma(un[0], inv0, pn);
+        pn = fma(fma(nC[k0], r, u0[k0]), inv0, pn);
         pd = fma(fc[k0], inv0, pd);
-        pn = fma(un[1], inv1, pn);
+        pn = fma(fma(nC[k0 + 1], r, u0[k0 + 1]), inv1, pn);
         pd = fma(fc[k0 + 1], inv1, pd);
-        pn = fma(un[2], inv2, pn);
+        pn = fma(fma(nC[k0 + 2], r, u0[k0 + 2]), inv2, pn);
         pd = fma(fc[k0 + 2], inv2, pd);
-        pn = fma(un[3], inv3, pn);
+        pn = fma(fma(nC[k0 + 3], r, u0[k0 + 3]), inv3, pn);
         pd = fma(fc[k0 + 3], inv3, pd);
       }
     } else {
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
-        const double sum = fma(r, fma(r, sC[k], sb[k]), sA[k]);
-        const double un = fma(nC[k], Fv[k] + r, c1[k]);
-        const double inv = rcp_nr(sum);
-        pn = fma(un, inv, pn);
+        const double inv = rcp_nr(fma(r, fma(r, sC[k], sb[k]), sA[k]));
+        pn = fma(fma(nC[k], r, u0[k]), inv, pn);
         pd = fma(fc[k], inv, pd);
       }
     }
-    pn *= r;
-    pd *= r;
-    {
-      const double wn = wave_sum_lastrow(pn), wd = wave_sum_lastrow(pd);
-      if (lane == 63) {
-        xch[buf][wv][0] = wn;
-        xch[buf][wv][1] = wd;
+    const double v = wave_sum_pair(pn, pd);
+    double sn = lane_value(v, 31), sd = lane_value(v, 63);
+    if constexpr (W > 1) {
+      if (lane == 0) {
+        xch[buf][wv][0] = sn;
+        xch[buf][wv][1] = sd;
       }
-    }
-    __syncthreads();
-    double sn = 0, sd = 0;
+      __syncthreads();
+      sn = xch[buf][0][0];
+      sd = xch[buf][0][1];
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-      sn += xch[buf][w][0];
-      sd += xch[buf][w][1];
+      for (int w = 1; w < W; ++w) {
+        sn += xch[buf][w][0];
+        sd += xch[buf][w][1];
+      }
+      buf ^= 1;
     }
-    num += sn;
-    den += tF_sum + sd;
-    buf ^= 1;
-    freq = num * rcp_nr2(den);
-    again = (fabs(prev - freq) > kEPS) && (iters++ < 100);
+    num = fma(r, sn, num);
+    den = fma(r, sd, den + tF_sum);
+    again = (fabs(fma(pnum, den, -(num * pden))) > kEPS * (den * pden)) && (iters++ < 100);
+    pnum = num;
+    pden = den;
   } while (again);
+  const double freq = num / den;
   if (threadIdx.x == 0) {
     // non-finite or out-of-range result: a cell with vanishing weights (or f reaching 1);
     // the careful kernel redoes the site in the reference's log-space order
@@ -1118,17 +1165,19 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
     else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);
     else if (cfg_ni == 16 && cfg_b == 256) LAUNCH_NI(16, 256);
     else if (cfg_ni == 16 && cfg_b == 512) LAUNCH_NI(16, 512);
+    else if (cfg_ni == 8 && cfg_b == 64) LAUNCH_NI(8, 64);
     else if (cfg_ni == 8 && cfg_b == 128) LAUNCH_NI(8, 128);
     else if (cfg_ni == 8 && cfg_b == 256) LAUNCH_NI(8, 256);
     else if (cfg_ni == 8 && cfg_b == 512) LAUNCH_NI(8, 512);
     else if (cfg_ni == 4 && cfg_b == 256) LAUNCH_NI(4, 256);
     else if (cfg_ni == 4 && cfg_b == 512) LAUNCH_NI(4, 512);
     else return false;
-  } else if (I_tot <= 128) LAUNCH_NI(1, 128);
-  else if (I_tot <= 256) LAUNCH_NI(2, 128);
-  else if (I_tot <= 512) LAUNCH_NI(4, 128);
-  else if (I_tot <= 1024) LAUNCH_NI(8, 128);
-  else if (I_tot <= 2048) LAUNCH_NI(8, 256);
+  } else if (I_tot <= 64) LAUNCH_NI(1, 64);
+  else if (I_tot <= 128) LAUNCH_NI(2, 64);
+  else if (I_tot <= 256) LAUNCH_NI(4, 64);
+  else if (I_tot <= 512) LAUNCH_NI(8, 64);
+  else if (I_tot <= 1024) LAUNCH_NI(16, 64);
+  else if (I_tot <= 2048) LAUNCH_NI(16, 128);
   else if (I_tot <= 4096) LAUNCH_NI(16, 256);
   else if (I_tot <= 8192) LAUNCH_NI(16, 512);
   else redo = nullptr;  // more individuals than registers hold: stream every site

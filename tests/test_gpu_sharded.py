@@ -92,11 +92,12 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("I", [600, 1100, 2100, 4100, 8200])
+@pytest.mark.parametrize("I", [40, 100, 200, 400, 600, 1024, 1100, 2100, 4100, 8200])
 def test_est_maf_register_and_stream_variants(pkg, I):
-    """est_maf picks a kernel by the number of individuals (2..8 waves per site, 8 or 16
-    individuals per lane in registers; beyond 8192 the streaming kernel), as the
-    site-sharded frequency step of an N-GPU run needs: all must agree with the oracle."""
+    """est_maf picks a kernel by the number of individuals (one wave per site with 1..16
+    individuals per lane in registers up to 1024, then 2..8 waves per site; beyond 8192
+    the streaming kernel), as the site-sharded frequency step of an N-GPU run needs: all
+    must agree with the oracle."""
     import orclib
     S = 96 if I < 4000 else 24
     d = pkg.simulate.simulate(I, S, seed=I, missing_rate=0.05)
