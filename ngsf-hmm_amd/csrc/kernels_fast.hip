@@ -549,7 +549,7 @@ k_fast_deinterleave(const double* __restrict__ r_il, uint64_t I, uint64_t S, uin
 // site-major log GL -> linear emissions in the interleaved layout.
 // tile = (c, t) x 64 lanes (sites T apart) x 32 individuals
 __global__ void __launch_bounds__(256)
-k_fast_emission(const double* __restrict__ gl, const double* __restrict__ freq, uint64_t I,
+k_fast_emission(const double* __restrict__ gl_lin, const double* __restrict__ freq, uint64_t I,
                 uint64_t S, uint64_t T, uint32_t C, double2* __restrict__ e_il,
                 int* __restrict__ flags) {
   __shared__ double2 tile[32][65];
@@ -569,8 +569,8 @@ k_fast_emission(const double* __restrict__ gl, const double* __restrict__ freq, 
           flags[FLAG_INVALID_MAF] = 1;
           e = double2{__builtin_nan(""), __builtin_nan("")};
         } else {
-          const double* g = gl + (s * I + i) * 3;
-          const double p0 = exp(g[0]), p1 = exp(g[1]), p2 = exp(g[2]);
+          const double* g = gl_lin + (s * I + i) * 3;
+          const double p0 = g[0], p1 = g[1], p2 = g[2];
           // calc_HWE (gen_func.cpp:938-957) for F = 0 and F = 1; with F = 1 the
           // heterozygote weight is exp(-1e15) = 0
           const double om = 1 - maf;
@@ -592,6 +592,16 @@ k_fast_emission(const double* __restrict__ gl, const double* __restrict__ freq, 
       if (i < I) e_il[((i * C + c) * T + t) * 64 + tx] = tile[ii][tx];
     }
   }
+}
+
+// linear-space copy of the genotype likelihoods: they do not change during a run, and
+// both the emission refresh and est_maf would otherwise exponentiate all 3 I S of them
+// in every EM iteration
+__global__ void __launch_bounds__(256)
+k_fast_exp(const double* in, double* out, uint64_t n) {  // in == out allowed
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (uint64_t)gridDim.x * blockDim.x)
+    out[k] = exp(in[k]);
 }
 
 // largest finite distance (bit pattern order == value order for non-negative doubles)
@@ -763,6 +773,47 @@ __device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
   return v;
 }
 
+// ---- est_maf: certified interpolation of the per-pass sums -------------------
+// The reference's loop (gen_func.cpp:981-1006) is a running average: pass k evaluates
+// two sums over all individuals at the odds r_k of the current frequency and adds them
+// to num/den; r_k creeps towards its limit like 1/k, so nearly every site runs into the
+// 100-pass cap.  Both sums are rational functions of r whose poles all lie in Re r <= 0
+// (their denominators sA + r sb + r^2 sC have non-negative coefficients), hence analytic
+// in a disc of radius >= r around any r > 0: on an interval [lo, hi] with hi - lo <=
+// 0.55 lo, a 16-point Chebyshev interpolant reproduces them to rounding error (the
+// Bernstein-ellipse parameter is > 8; 8^-16 = 4e-15 before the constant, ~1e-15
+// measured).  So after a few exact passes the kernel evaluates the sums exactly at the 16
+// Chebyshev nodes of an interval ahead of r_k (as expensive as 16 passes), CHECKS the
+// interpolant against the next exact pass (relative 1e-13, else the site stays on exact
+// passes), and hands the site to k_fast_estmaf_interp, where one LANE per site runs the
+// remaining passes on the barycentric formula: the same recursion, same pass count,
+// same stopping rule, at ~1/60 of the cost per pass.  A pass whose stopping decision
+// would be closer than 1e-9 (relative) to the threshold, or whose r leaves the
+// interval, goes back to exact evaluation (one more build is allowed per site).
+constexpr int EN = 16;                  // Chebyshev nodes per interval
+constexpr int EST_SCALARS = 8;          // num, den, pnum, pden, iters, mid, half, tF
+constexpr int EST_FIELDS = EST_SCALARS + 2 * EN;
+enum : uint8_t { EST_DONE = 0, EST_INTERP = 1, EST_EXACT = 2 };
+constexpr int EST_K0 = 4;               // exact passes before the first interval
+constexpr int EST_MIN_GAIN = 24;        // build only if about this many passes remain
+constexpr double EST_DMAX = 0.5;        // interval length <= EST_DMAX * r ahead ...
+constexpr double EST_BACK = 0.1;        // ... plus this fraction of it behind
+constexpr double EST_MULT = 32.0;       // ... and about this many current steps
+constexpr double EST_TOL = 1e-13;       // interpolant vs exact pass, relative
+constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back to exact
+// cos((2j+1) pi/32) and (-1)^j sin((2j+1) pi/32): first-kind Chebyshev nodes and their
+// barycentric weights
+__constant__ double kChebC[EN] = {
+    0.9951847266721969,  0.9569403357322088,  0.881921264348355,   0.773010453362737,
+    0.6343932841636455,  0.47139673682599764, 0.2902846772544624,  0.0980171403295606,
+    -0.0980171403295606, -0.2902846772544624, -0.47139673682599764, -0.6343932841636455,
+    -0.773010453362737,  -0.881921264348355,  -0.9569403357322088, -0.9951847266721969};
+__constant__ double kChebW[EN] = {
+    0.0980171403295606,  -0.2902846772544624, 0.47139673682599764, -0.6343932841636455,
+    0.773010453362737,   -0.881921264348355,  0.9569403357322088,  -0.9951847266721969,
+    0.9951847266721969,  -0.9569403357322088, 0.881921264348355,   -0.773010453362737,
+    0.6343932841636455,  -0.47139673682599764, 0.2902846772544624, -0.0980171403295606};
+
 // W = BLOCK/64 waves per site, NI individuals per lane held in registers.  With
 //   A = (1-f)^2, b = (1-f) f, C = f^2
 // the weights w_g = p_g * HWE_g(f, F) of calc_HWE/post_prob (gen_func.cpp:920-957) are
@@ -772,31 +823,37 @@ __device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
 //   den-term = (2 w1 + (2-F)(w0 + w2)) / sum = (2-F) + F w1 / sum
 // Dividing every weight by (1-f)^2 leaves, in the odds r = f/(1-f),
 //   sum' = sA + r sb + r^2 sC,  num-term = r (u0 + r nC) / sum',  den-term = (2-F) + r fc / sum'
-// six constants per individual, 8 FP64 instructions per individual and pass with the
-// reciprocals taken four at a time, and the (2-F) part of the denominator a per-site
-// constant.  The <= 101 passes of the reference's do-while
-// (gen_func.cpp:981-1006) never touch memory again.  A site with a cell whose weights all
-// vanish (a called heterozygote at posterior IBD = 1, ...) ends with a non-finite
-// frequency, is flagged and redone by k_fast_estmaf_stream, which takes the
-// reference-order log-space route for such cells.
+// six constants per individual, 8 FP64 instructions per individual and evaluation with
+// the reciprocals taken four at a time, and the (2-F) part of the denominator a per-site
+// constant.  Nothing is read from memory again after the constants are formed.  A site
+// with a cell whose weights all vanish (a called heterozygote at posterior IBD = 1, ...)
+// ends with a non-finite frequency, is flagged and redone by k_fast_estmaf_stream, which
+// takes the reference-order log-space route for such cells.
 //
 // Up to 1024 individuals one wave holds the whole site (NI <= 16: 192 VGPRs of constants,
-// two waves per SIMD) and a pass is 128 + ~45 instructions; beyond that W waves share a
-// site (e.g. the site-sharded frequency step of a multi-GPU run), their partial sums meet
-// in LDS once per pass (double-buffered, one barrier) and are added in wave order, so the
-// result does not depend on scheduling.
+// two waves per SIMD) and an evaluation is 128 + ~45 instructions; beyond that W waves
+// share a site (e.g. the site-sharded frequency step of a multi-GPU run), their partial
+// sums meet in LDS once per evaluation (double-buffered, one barrier) and are added in
+// wave order, so the result does not depend on scheduling.
+//
+// fresh != 0: every site starts the loop; else only sites whose status is EST_EXACT
+// resume from `state`.  n_exact passes are evaluated exactly, then (allow_build) the
+// interval is built and checked; a site that ends here writes freq_out/redo.
 constexpr int ESTMAF_MAXW = 16;
 template <int NI, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
-              uint8_t* __restrict__ redo) {
+              uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
+              double* __restrict__ state, uint64_t state_stride, int fresh, int n_exact,
+              int allow_build) {
   constexpr int W = BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   constexpr uint64_t stride = BLOCK;
   const uint64_t site = blockIdx.x;
+  if (!fresh && status[site] != EST_EXACT) return;
   const double* gls = gl + site * I_tot * 3;
 
   double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
@@ -805,7 +862,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   for (int k = 0; k < NI; ++k) {
     const uint64_t i = (uint64_t)threadIdx.x + stride * k;
     if (i < I_tot) {
-      const double p0 = exp(gls[i * 3]), p1 = exp(gls[i * 3 + 1]), p2 = exp(gls[i * 3 + 2]);
+      const double p0 = gls[i * 3], p1 = gls[i * 3 + 1], p2 = gls[i * 3 + 2];  // linear GL
       const double F = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
       const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
       const double n2 = (2 - F) * p2;
@@ -831,52 +888,40 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     __syncthreads();
   }
 
-  int iters = 0;
-  int buf = 0;
   // The loop carries num and den only.  The odds of freq = num/den are num/(den - num):
   // one reciprocal on the serial path instead of two, and the reference's stopping rule
   // |prev - freq| > EPSILON (gen_func.cpp:1006) is tested cross-multiplied,
   // |num_prev den - num den_prev| > EPSILON den den_prev, which needs no quotient.
+  int iters = 0;
+  int buf = 0;
   double num = 0, den = 0;
   double pnum = 0.01, pden = 1.0;  // freq = 0.01 (gen_func.cpp:976)
-  bool again;
-  do {
-    const double r = pnum * rcp_nr2(pden - pnum);
+  if (!fresh) {
+    num = state[0 * state_stride + site];
+    den = state[1 * state_stride + site];
+    pnum = state[2 * state_stride + site];
+    pden = state[3 * state_stride + site];
+    iters = (int)state[4 * state_stride + site];
+  }
+  bool built = !allow_build;  // at most one interval per launch
+  int n_before = n_exact;     // exact passes before deciding on it
+  int node = -1;              // >= 0: this evaluation is Chebyshev node `node`
+  bool check = false, interp_ok = false;
+  double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;
+  for (;;) {
+    const double r = (node >= 0) ? fma(half, kChebC[node], mid) : pnum * rcp_nr2(pden - pnum);
     double pn = 0, pd = 0;
-    if constexpr (NI >= 8) {
-      // reciprocals eight at a time (Montgomery's trick): one v_rcp_f64 + Newton step and
-      // 21 multiplies instead of eight reciprocals; v_rcp_f64 is the slow instruction
-#pragma unroll
-      for (int k0 = 0; k0 < NI; k0 += 8) {
-        double sm[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sm[j] = fma(r, fma(r, sC[k0 + j], sb[k0 + j]), sA[k0 + j]);
-        const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
-        const double p45 = sm[4] * sm[5], p67 = sm[6] * sm[7];
-        const double pa = p01 * p23, pb = p45 * p67;
-        // a vanishing sum makes R infinite and the site's freq non-finite, which ends the
-        // loop (the comparison below is false for NaN) and flags the site after it
-        const double R = rcp_nr(pa * pb);
-        const double Ra = R * pb, Rb = R * pa;
-        const double r01 = Ra * p23, r23 = Ra * p01, r45 = Rb * p67, r67 = Rb * p45;
-        double inv[8];
-        inv[0] = r01 * sm[1]; inv[1] = r01 * sm[0];
-        inv[2] = r23 * sm[3]; inv[3] = r23 * sm[2];
-        inv[4] = r45 * sm[5]; inv[5] = r45 * sm[4];
-        inv[6] = r67 * sm[7]; inv[7] = r67 * sm[6];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          pn = fma(fma(nC[k0 + j], r, u0[k0 + j]), inv[j], pn);
-          pd = fma(fc[k0 + j], inv[j], pd);
-        }
-      }
-    } else if constexpr (NI >= 4) {
+    if constexpr (NI >= 4) {
+      // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step and
+      // 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
 #pragma unroll
       for (int k0 = 0; k0 < NI; k0 += 4) {
         double sm[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) sm[j] = fma(r, fma(r, sC[k0 + j], sb[k0 + j]), sA[k0 + j]);
         const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
+        // a vanishing sum makes R infinite and the site's freq non-finite, which ends the
+        // loop (the comparison below is false for NaN) and flags the site after it
         const double R = rcp_nr(p01 * p23);
         const double r01 = R * p23, r23 = R * p01;
         const double inv0 = r01 * sm[1], inv1 = r01 * sm[0];
@@ -915,20 +960,151 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       }
       buf ^= 1;
     }
+    if (node >= 0) {  // a node of the interval: lane `node` keeps its two values
+      if (lane == node) {
+        my_gn = sn;
+        my_gd = sd;
+      }
+      if (++node == EN) {
+        node = -1;
+        check = true;
+      }
+      continue;
+    }
+    if (check) {  // the pass after a build: exact sums in hand, compare the interpolant
+      const double t = r - fma(half, kChebC[lane & (EN - 1)], mid);
+      const double q = (lane < EN) ? kChebW[lane & (EN - 1)] / t : 0.0;
+      const double Sq = wave_sum_uniform(q);
+      const double bn = wave_sum_uniform(q * my_gn) / Sq, bd = wave_sum_uniform(q * my_gd) / Sq;
+      interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);
+      check = false;
+    }
     num = fma(r, sn, num);
     den = fma(r, sd, den + tF_sum);
-    again = (fabs(fma(pnum, den, -(num * pden))) > kEPS * (den * pden)) && (iters++ < 100);
+    const double lhs = fabs(fma(pnum, den, -(num * pden))), thr = kEPS * (den * pden);
+    const bool again = (lhs > thr) && (iters++ < 100);
+    rprev = r;
     pnum = num;
     pden = den;
-  } while (again);
-  const double freq = num / den;
+    if (!again) break;
+    if (interp_ok) {  // hand the site to k_fast_estmaf_interp
+      if (wv == 0) {
+        if (lane < EN) {
+          state[(EST_SCALARS + lane) * state_stride + site] = my_gn;
+          state[(EST_SCALARS + EN + lane) * state_stride + site] = my_gd;
+        }
+        if (lane == 0) {
+          state[0 * state_stride + site] = num;
+          state[1 * state_stride + site] = den;
+          state[2 * state_stride + site] = pnum;
+          state[3 * state_stride + site] = pden;
+          state[4 * state_stride + site] = (double)iters;
+          state[5 * state_stride + site] = mid;
+          state[6 * state_stride + site] = half;
+          state[7 * state_stride + site] = tF_sum;
+          status[site] = EST_INTERP;
+        }
+      }
+      return;
+    }
+    if (!built && --n_before <= 0) {
+      built = true;
+      // |delta freq| shrinks roughly like 1/k^2: about k (sqrt(|delta|/EPSILON) - 1)
+      // passes remain; an interval costs EN evaluations, so short tails stay exact
+      const double m_est = (double)iters * (sqrt(lhs / thr) - 1.0);
+      if (m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
+        const double rn = pnum * rcp_nr2(pden - pnum);
+        const double step = fabs(rn - rprev);
+        const double L = fmin(EST_DMAX * rn, fmax(EST_MULT * step, 1e-3 * rn));
+        double lo, hi;
+        if (rn >= rprev) {
+          lo = fma(-EST_BACK, L, rn);
+          hi = rn + L;
+        } else {
+          lo = rn - L;
+          hi = fma(EST_BACK, L, rn);
+        }
+        mid = 0.5 * (lo + hi);
+        half = 0.5 * (hi - lo);
+        // a degenerate interval (rn not finite or not positive) keeps the site exact
+        if (half > 0 && lo > 0 && hi < 1e300) node = 0;
+      }
+    }
+  }
   if (threadIdx.x == 0) {
     // non-finite or out-of-range result: a cell with vanishing weights (or f reaching 1);
     // the careful kernel redoes the site in the reference's log-space order
+    const double freq = num / den;
     const bool ok = freq >= 0 && freq < 1;
     freq_out[site] = freq;
     redo[site] = ok ? 0 : 1;
+    status[site] = EST_DONE;
   }
+}
+
+// The passes between a checked interval and either the end of the loop or the point
+// where exact evaluation is needed again: one lane per site, sums from the barycentric
+// formula on the 16 node values.
+__global__ void __launch_bounds__(256)
+k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+                     uint8_t* __restrict__ status, double* __restrict__ state,
+                     uint64_t state_stride) {
+  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= S_own || status[site] != EST_INTERP) return;
+  double num = state[0 * state_stride + site], den = state[1 * state_stride + site];
+  double pnum = state[2 * state_stride + site], pden = state[3 * state_stride + site];
+  int iters = (int)state[4 * state_stride + site];
+  const double mid = state[5 * state_stride + site], half = state[6 * state_stride + site];
+  const double tF_sum = state[7 * state_stride + site];
+  double gn[EN], gd[EN];
+#pragma unroll
+  for (int j = 0; j < EN; ++j) {
+    gn[j] = state[(EST_SCALARS + j) * state_stride + site];
+    gd[j] = state[(EST_SCALARS + EN + j) * state_stride + site];
+  }
+  uint8_t st = EST_EXACT;
+  for (;;) {
+    const double r = pnum * rcp_nr2(pden - pnum);  // the expression of k_fast_estmaf
+    if (!(fabs(r - mid) <= half)) break;           // left the interval (or not finite)
+    double Sq = 0, Sn = 0, Sd = 0;
+    bool hit = false;
+#pragma unroll
+    for (int j = 0; j < EN; ++j) {
+      const double t = r - fma(half, kChebC[j], mid);
+      hit |= (t == 0);
+      const double q = kChebW[j] / t;
+      Sq += q;
+      Sn = fma(q, gn[j], Sn);
+      Sd = fma(q, gd[j], Sd);
+    }
+    if (hit) break;  // exactly on a node: let the exact kernel evaluate this pass
+    const double sn = Sn / Sq, sd = Sd / Sq;
+    const double num2 = fma(r, sn, num), den2 = fma(r, sd, den + tF_sum);
+    const double lhs = fabs(fma(pnum, den2, -(num2 * pden))), thr = kEPS * (den2 * pden);
+    if (!(fabs(lhs - thr) >= EST_GUARD * thr)) break;  // too close to call (or not finite)
+    num = num2;
+    den = den2;
+    const bool again = (lhs > thr) && (iters++ < 100);
+    pnum = num;
+    pden = den;
+    if (!again) {
+      st = EST_DONE;
+      break;
+    }
+  }
+  if (st == EST_DONE) {
+    const double freq = num / den;
+    const bool ok = freq >= 0 && freq < 1;
+    freq_out[site] = freq;
+    redo[site] = ok ? 0 : 1;
+  } else {
+    state[0 * state_stride + site] = num;
+    state[1 * state_stride + site] = den;
+    state[2 * state_stride + site] = pnum;
+    state[3 * state_stride + site] = pden;
+    state[4 * state_stride + site] = (double)iters;
+  }
+  status[site] = st;
 }
 
 // any number of individuals: re-reads the (L2-resident) site row every pass
@@ -955,8 +1131,7 @@ k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ m
       const double bF = b * F;
       const double h0 = A + bF, h2 = Cq + bF;
       const double h1 = (F == 1) ? 0.0 : (2 * b - 2 * bF);
-      const double w0 = exp(gls[i * 3]) * h0, w1 = exp(gls[i * 3 + 1]) * h1,
-                   w2 = exp(gls[i * 3 + 2]) * h2;
+      const double w0 = gls[i * 3] * h0, w1 = gls[i * 3 + 1] * h1, w2 = gls[i * 3 + 2] * h2;
       const double sum = w0 + w1 + w2;
       const double tF = 2 - F;
       if (sum > 0) {
@@ -964,7 +1139,8 @@ k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ m
         pn += fma(w2, tF, w1) * inv;
         pd += fma(w0 + w2, tF, 2 * w1) * inv;
       } else {
-        const double2 tt = estmaf_term_logspace(gls + i * 3, freq, F);
+        const double lg[3] = {log(gls[i * 3]), log(gls[i * 3 + 1]), log(gls[i * 3 + 2])};
+        const double2 tt = estmaf_term_logspace(lg, freq, F);
         pn += tt.x;
         pd += tt.y;
       }
@@ -1010,6 +1186,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.r_il, cells)) return false;
+  if (!dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
   if (!dalloc(&fs.lane_ops, (size_t)I * fs.J * 5)) return false;
   if (!dalloc(&fs.bound, (size_t)I * fs.J * 4)) return false;
   return true;
@@ -1017,15 +1194,20 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
 
 void fast_destroy(FastState& fs) {
   void* ptrs[] = {fs.e_il, fs.pos_il, fs.r_il, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
-                  fs.grp_dev, fs.redo};
+                  fs.grp_dev, fs.redo, fs.est_status, fs.est_state, fs.gl_lin};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fs = FastState();
 }
 
+void fast_exp(hipStream_t st, const double* d_in, double* d_out, uint64_t n) {
+  if (n) hipLaunchKernelGGL(k_fast_exp, dim3(16384), dim3(256), 0, st, d_in, d_out, n);
+}
+
 bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* d_pos) {
   fs.d_gl = d_gl;
   fs.d_pos = d_pos;
+  fast_exp(st, d_gl, fs.gl_lin, fs.I * fs.S * 3);
   hipLaunchKernelGGL(k_fast_pos_interleave, dim3(1024), dim3(256), 0, st, d_pos, fs.S, fs.T, fs.C,
                      fs.pos_il);
   // the largest finite distance decides when the objective kernel may use its
@@ -1043,7 +1225,7 @@ bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* 
 bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
   const uint64_t n_it = (fs.I + 31) / 32;
   const uint64_t blocks = (uint64_t)fs.C * fs.T * n_it;
-  hipLaunchKernelGGL(k_fast_emission, dim3((unsigned)blocks), dim3(256), 0, st, fs.d_gl, d_freq,
+  hipLaunchKernelGGL(k_fast_emission, dim3((unsigned)blocks), dim3(256), 0, st, fs.gl_lin, d_freq,
                      fs.I, fs.S, fs.T, fs.C, reinterpret_cast<double2*>(fs.e_il), d_flags);
   return hipGetLastError() == hipSuccess;
 }
@@ -1147,40 +1329,67 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
   const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
   if (S_own > fs.redo_cap) {
     if (fs.redo) (void)hipFree(fs.redo);
-    fs.redo = nullptr;
+    if (fs.est_status) (void)hipFree(fs.est_status);
+    if (fs.est_state) (void)hipFree(fs.est_state);
+    fs.redo = fs.est_status = nullptr;
+    fs.est_state = nullptr;
     fs.redo_cap = 0;
     if (hipMalloc((void**)&fs.redo, S_own) != hipSuccess) return false;
+    if (hipMalloc((void**)&fs.est_status, S_own) != hipSuccess) return false;
+    if (hipMalloc((void**)&fs.est_state, S_own * EST_FIELDS * sizeof(double)) != hipSuccess)
+      return false;
     fs.redo_cap = S_own;
   }
-  // waves per site (W) and individuals per lane (NI): registers allow NI = 8 at three
-  // waves per SIMD and NI = 16 at two; a workgroup must fit one CU
-#define LAUNCH_NI(N, B)                                                                      \
+  // Interpolated passes (see k_fast_estmaf) unless NGHMM_ESTMAF_INTERP=0, which runs
+  // every pass exactly.
+  bool interp = true;
+  if (const char* env = std::getenv("NGHMM_ESTMAF_INTERP")) interp = std::atoi(env) != 0;
+  // waves per site (W) and individuals per lane (NI): 16 per lane at two waves per SIMD;
+  // a workgroup must fit one CU
+#define LAUNCH_NI(N, B)                                                                       \
   hipLaunchKernelGGL((k_fast_estmaf<N, B>), dim3((unsigned)S_own), dim3(B), 0, st, d_gl_sites, \
-                     d_marg_blocks, S_own, I_tot, I_blk, d_freq_out, fs.redo)
-  const uint8_t* redo = fs.redo;
+                     d_marg_blocks, S_own, I_tot, I_blk, d_freq_out, fs.redo, fs.est_status,  \
+                     fs.est_state, fs.redo_cap, fresh, n_exact, allow_build)
   int cfg_ni = 0, cfg_b = 0;
   if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
-  if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
-    if (cfg_ni == 16 && cfg_b == 64) LAUNCH_NI(16, 64);
-    else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);
-    else if (cfg_ni == 16 && cfg_b == 256) LAUNCH_NI(16, 256);
-    else if (cfg_ni == 16 && cfg_b == 512) LAUNCH_NI(16, 512);
-    else if (cfg_ni == 8 && cfg_b == 64) LAUNCH_NI(8, 64);
-    else if (cfg_ni == 8 && cfg_b == 128) LAUNCH_NI(8, 128);
-    else if (cfg_ni == 8 && cfg_b == 256) LAUNCH_NI(8, 256);
-    else if (cfg_ni == 8 && cfg_b == 512) LAUNCH_NI(8, 512);
-    else if (cfg_ni == 4 && cfg_b == 256) LAUNCH_NI(4, 256);
-    else if (cfg_ni == 4 && cfg_b == 512) LAUNCH_NI(4, 512);
-    else return false;
-  } else if (I_tot <= 64) LAUNCH_NI(1, 64);
-  else if (I_tot <= 128) LAUNCH_NI(2, 64);
-  else if (I_tot <= 256) LAUNCH_NI(4, 64);
-  else if (I_tot <= 512) LAUNCH_NI(8, 64);
-  else if (I_tot <= 1024) LAUNCH_NI(16, 64);
-  else if (I_tot <= 2048) LAUNCH_NI(16, 128);
-  else if (I_tot <= 4096) LAUNCH_NI(16, 256);
-  else if (I_tot <= 8192) LAUNCH_NI(16, 512);
-  else redo = nullptr;  // more individuals than registers hold: stream every site
+  auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
+    if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
+      if (cfg_ni == 16 && cfg_b == 64) LAUNCH_NI(16, 64);
+      else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);
+      else if (cfg_ni == 16 && cfg_b == 256) LAUNCH_NI(16, 256);
+      else if (cfg_ni == 16 && cfg_b == 512) LAUNCH_NI(16, 512);
+      else if (cfg_ni == 8 && cfg_b == 64) LAUNCH_NI(8, 64);
+      else if (cfg_ni == 8 && cfg_b == 128) LAUNCH_NI(8, 128);
+      else if (cfg_ni == 8 && cfg_b == 256) LAUNCH_NI(8, 256);
+      else if (cfg_ni == 8 && cfg_b == 512) LAUNCH_NI(8, 512);
+      else if (cfg_ni == 4 && cfg_b == 256) LAUNCH_NI(4, 256);
+      else if (cfg_ni == 4 && cfg_b == 512) LAUNCH_NI(4, 512);
+      else return false;
+    } else if (I_tot <= 64) LAUNCH_NI(1, 64);
+    else if (I_tot <= 128) LAUNCH_NI(2, 64);
+    else if (I_tot <= 256) LAUNCH_NI(4, 64);
+    else if (I_tot <= 512) LAUNCH_NI(8, 64);
+    else if (I_tot <= 1024) LAUNCH_NI(16, 64);
+    else if (I_tot <= 2048) LAUNCH_NI(16, 128);
+    else if (I_tot <= 4096) LAUNCH_NI(16, 256);
+    else LAUNCH_NI(16, 512);
+    return true;
+  };
+  const uint8_t* redo = fs.redo;
+  if (I_tot > 8192 && !cfg_ni) {
+    redo = nullptr;  // more individuals than registers hold: stream every site
+  } else if (!interp) {
+    if (!launch(1, 0, 0)) return false;
+  } else {
+    const dim3 igrid((unsigned)((S_own + 255) / 256));
+    if (!launch(1, EST_K0, 1)) return false;
+    hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
+                       fs.est_status, fs.est_state, fs.redo_cap);
+    if (!launch(0, 1, 1)) return false;  // sites that left their interval: one more
+    hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
+                       fs.est_status, fs.est_state, fs.redo_cap);
+    if (!launch(0, 0, 0)) return false;  // whatever is left finishes on exact passes
+  }
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
                      I_tot, I_blk, d_freq_out, redo);
 #undef LAUNCH_NI

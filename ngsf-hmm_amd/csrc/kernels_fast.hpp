@@ -17,6 +17,7 @@ struct FastState {
   uint64_t Spad = 0;  // J * T >= S
   const double* d_gl = nullptr;   // borrowed: site-major log GL [S][I][3]
   const double* d_pos = nullptr;  // borrowed: [S]
+  double* gl_lin = nullptr;       // exp(GL), site-major [S][I][3] (emission refresh, est_maf)
   double* e_il = nullptr;         // linear emissions, interleaved [I][C][T][64] x double2
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
   double* r_il = nullptr;         // forward odds, then posteriors, interleaved [I][C][T][64]
@@ -33,6 +34,8 @@ struct FastState {
   double dmax_finite = 0;         // largest finite distance of the loaded data
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;
+  uint8_t* est_status = nullptr;  // est_maf per-site state machine (see k_fast_estmaf):
+  double* est_state = nullptr;    // [EST_FIELDS][redo_cap] loop state + interval node values
 };
 
 bool fast_create(FastState& fs, uint64_t I, uint64_t S);
@@ -50,9 +53,11 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags)
 // forward + backward + posteriors; marg out is site-major [S][I]
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
                 double* d_ind_lkl, double* d_marg, int* d_flags);
-// est_maf on S_own sites: GL site-major log [S_own][I_tot][3], posteriors in rank
-// blocks [I_tot / I_blk][S_own][I_blk]
-bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
+// out = exp(in) elementwise (in == out allowed): linear genotype likelihoods
+void fast_exp(hipStream_t st, const double* d_in, double* d_out, uint64_t n);
+// est_maf on S_own sites: LINEAR GL site-major [S_own][I_tot][3] (fs.gl_lin, or a
+// site shard passed through fast_exp), posteriors in rank blocks [I_tot / I_blk][S_own][I_blk]
+bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_lin_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out);
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,

@@ -509,7 +509,10 @@ static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double
   int rc;
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
-    if (!fast_estmaf(h->fast, h->stream, d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out))
+    // fast mode reads linear-space GL: its own copy of the handle's GL, or the site
+    // shard, which the shard loaders exponentiate in place
+    const double* d_lin = (d_gl_sites == h->d_gl) ? h->fast.gl_lin : d_gl_sites;
+    if (!fast_estmaf(h->fast, h->stream, d_lin, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out))
       return NGHMM_ERR_HIP;
   } else {
     if (I_blk != I_tot) {
@@ -569,7 +572,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     HIP_TRY(hipEventCreate(&h->ev2b));
   }
   HIP_TRY(hipEventRecord(h->ev2a, h->stream2));
-  if (!fast_estmaf(h->fast, h->stream2, h->d_gl, h->d_marg, h->S, h->I, h->I, h->d_freq)) {
+  if (!fast_estmaf(h->fast, h->stream2, h->fast.gl_lin, h->d_marg, h->S, h->I, h->I, h->d_freq)) {
     set_error("fast_estmaf launch failed: %s", hipGetErrorString(hipGetLastError()));
     return NGHMM_ERR_HIP;
   }
@@ -671,6 +674,7 @@ int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
   if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_gl_shard, gl_site_shard, n * sizeof(double), hipMemcpyHostToDevice,
                          h->stream));
+  if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
 }
@@ -685,6 +689,7 @@ int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
   if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_gl_shard, d_gl_site_shard, n * sizeof(double),
                          hipMemcpyDeviceToDevice, h->stream));
+  if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
 }

@@ -167,10 +167,14 @@ def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alph
     p_read = torch.tensor([error, 0.5, 1.0 - error], device=device, dtype=f64)
     lp, lq = torch.log(p_read), torch.log1p(-p_read)
     state = (torch.rand((I,), generator=g, device=device) < indF).to(torch.int64)
+    # freq = "r": a uniform frequency per site (ngsF-HMMsim.R:127-133), else one value
+    site_freq = (torch.rand((S,), generator=g, device=device, dtype=f64) if isinstance(freq, str)
+                 else torch.full((S,), float(freq), device=device, dtype=f64))
     first = True
     for s0 in range(0, S, chunk_sites):
         s1 = min(S, s0 + chunk_sites)
         n = s1 - s0
+        freq = site_freq[None, s0:s1]
         X = torch.exp(-alpha * pos_dist_mb[s0:s1])                       # [n]
         redraw = torch.rand((I, n), generator=g, device=device, dtype=f64) >= X[None, :]
         if first:
