@@ -841,7 +841,7 @@ __constant__ double kChebW[EN] = {
 // interval is built and checked; a site that ends here writes freq_out/redo.
 constexpr int ESTMAF_MAXW = 16;
 template <int NI, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
               uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
@@ -856,29 +856,59 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   if (!fresh && status[site] != EST_EXACT) return;
   const double* gls = gl + site * I_tot * 3;
 
+  double tF_lane_out;
+  // The loads of eight slots (32 per lane) are issued before anything waits on them
+  // (out-of-range slots re-read the last individual and are masked afterwards): a wave
+  // has two memory round trips here, not NI of them.
   double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
-  double tF_lane = 0;
+  {
+    constexpr int NB = NI < 8 ? NI : 8;  // slots per batch of loads
+    const bool one_block = (I_blk == I_tot);
+    const uint32_t ib = (uint32_t)I_blk;
+    double tF_acc = 0;
 #pragma unroll
-  for (int k = 0; k < NI; ++k) {
-    const uint64_t i = (uint64_t)threadIdx.x + stride * k;
-    if (i < I_tot) {
-      const double p0 = gls[i * 3], p1 = gls[i * 3 + 1], p2 = gls[i * 3 + 2];  // linear GL
-      const double F = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
-      const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
-      const double n2 = (2 - F) * p2;
-      sA[k] = p0;
-      sb[k] = fma(F, p0 + p2, cc);
-      sC[k] = p2;
-      u0[k] = fma(n2, F, cc);
-      nC[k] = n2;
-      fc[k] = F * cc;
-      tF_lane += 2 - F;
-    } else {  // empty slot: sum' = 1, numerators 0: contributes nothing
-      sA[k] = 1;
-      sb[k] = sC[k] = u0[k] = nC[k] = fc[k] = 0;
+    for (int k0 = 0; k0 < NI; k0 += NB) {
+      double r0[NB], r1[NB], r2[NB], rF[NB];
+      uint64_t ic[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const uint64_t i = (uint64_t)threadIdx.x + stride * (k0 + j);
+        ic[j] = i < I_tot ? i : I_tot - 1;
+        r0[j] = gls[ic[j] * 3];
+        r1[j] = gls[ic[j] * 3 + 1];
+        r2[j] = gls[ic[j] * 3 + 2];
+      }
+      if (one_block) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rF[j] = marg_blocks[site * I_blk + ic[j]];
+      } else {  // posteriors arrive in rank blocks [I_tot / I_blk][S_own][I_blk]
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint32_t q = (uint32_t)ic[j] / ib;
+          rF[j] = marg_blocks[((uint64_t)q * S_own + site) * I_blk + ((uint32_t)ic[j] - q * ib)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int k = k0 + j;
+        const bool valid = (uint64_t)threadIdx.x + stride * k < I_tot;
+        const double p0 = r0[j], p1 = r1[j], p2 = r2[j], F = rF[j];  // linear GL
+        const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
+        const double n2 = (2 - F) * p2;
+        // empty slot: sum' = 1, numerators 0: contributes nothing
+        sA[k] = valid ? p0 : 1.0;
+        sb[k] = valid ? fma(F, p0 + p2, cc) : 0.0;
+        sC[k] = valid ? p2 : 0.0;
+        u0[k] = valid ? fma(n2, F, cc) : 0.0;
+        nC[k] = valid ? n2 : 0.0;
+        fc[k] = valid ? F * cc : 0.0;
+        tF_acc += valid ? 2 - F : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the next batch's loads out of this one
     }
+    tF_lane_out = tF_acc;
   }
-  double tF_sum = wave_sum_uniform(tF_lane);
+  double tF_sum = wave_sum_uniform(tF_lane_out);
   if constexpr (W > 1) {
     if (lane == 0) xch[1][wv][0] = tF_sum;
     __syncthreads();
