@@ -41,34 +41,54 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s me
 
 LIMITER_NOTES = {
     "est_maf": "FP64-VALU-issue bound, not HBM bound: the reference's est_maf makes ~100 passes "
-               "per site over in-register data (SQ_ACTIVE_INST_VALU ~38% per wave x 3 waves/SIMD, "
-               "profiles/r01_pmc_summary.json); HBM traffic is one read of GL + posteriors",
+               "per site; ~20 of them are evaluated over in-register data, the rest on a checked "
+               "Chebyshev interpolant of the per-pass sums (DESIGN.md section 4)",
     "lkl_batch": "objective of the L-BFGS-B M-step: one 16 B emission pair per site and individual "
                  "per round; FP64-VALU issue is saturated (~37% per wave x 3 waves per SIMD)",
     "forward": "E-step: operators, boundary vectors, forward odds, backward posteriors, "
                "de-interleave (five launches, timed together)",
 }
 
-_KERNEL_OF = {"lkl_batch": "k_fast_lkl_chunks", "est_maf": "k_fast_estmaf<8, 128>",
-              "emission": "k_fast_emission"}
+# kernels behind each timed family (names as profiles/summarize_pmc.py shortens them)
+_KERNELS_OF = {"lkl_batch": ["k_fast_lkl_chunks", "k_fast_lkl_finish"],
+               "est_maf": ["k_fast_estmaf<16, 64>", "k_fast_estmaf_interp", "k_fast_estmaf_stream"],
+               "emission": ["k_fast_emission"],
+               "forward": ["k_fast_chunk_ops", "k_fast_bounds", "k_fast_fwd_odds", "k_fast_bwd_post",
+                           "k_fast_deinterleave"]}
 
 
 def pmc_traffic(family, args, I, S, ind_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction).
     Only valid for the workload it was collected on (c3, fast mode); else None."""
-    if args.workload != "c3" or args.mode != "fast" or family not in _KERNEL_OF:
+    if args.workload != "c3" or args.mode != "fast" or family not in _KERNELS_OF:
         return None
     path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if not os.path.exists(path):
         return None
-    d = json.load(open(path)).get(_KERNEL_OF[family])
-    if not d or "hbm_bytes_per_launch" not in d:
+    summ = json.load(open(path))
+    if family == "lkl_batch":
+        d = summ.get("k_fast_lkl_chunks")
+        if not d or "hbm_bytes_per_launch" not in d:
+            return None
+        t = d["hbm_bytes_per_launch"]
+        if d.get("avg_individuals_per_launch"):
+            t *= ind_per_launch / d["avg_individuals_per_launch"]   # launches differ in width
+        return t
+    # a family that is several kernels per call: bytes of all of them per EM iteration of
+    # the PMC pass (k_fast_chunk_ops runs exactly once per iteration)
+    iters = (summ.get("k_fast_chunk_ops") or {}).get("launches_fetch_pass")
+    if not iters:
         return None
-    t = d["hbm_bytes_per_launch"]
-    if family == "lkl_batch" and d.get("avg_individuals_per_launch"):
-        t *= ind_per_launch / d["avg_individuals_per_launch"]   # launches differ in width
-    return t
+    t = 0.0
+    for k in _KERNELS_OF[family]:
+        d = summ.get(k)
+        if d and "hbm_bytes_per_launch" in d:
+            n = d["launches_fetch_pass"]
+            if k == "k_fast_emission":
+                n = iters            # the pass also holds the one-off initial refresh
+            t += d["hbm_bytes_per_launch"] * n / iters
+    return t or None
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
