@@ -55,6 +55,7 @@ constexpr double kINF = 1e15;
 constexpr double kEPS = 1e-5;
 constexpr int MAXP = 5;   // probe points per group (f(x) + 4 finite-difference probes)
 constexpr int RENORM = 8; // sites between rescalings
+constexpr int CK = 8;     // sites between forward checkpoints (== RENORM: stored right after a rescale)
 constexpr int UF = 4;     // prefetch depth (sites) of the E-step sweeps
 constexpr int NB = 4;     // objective kernel: load buffers in flight ...
 constexpr int UG = 2;     // ... of this many sites each (NB * UG == RENORM)
@@ -62,7 +63,7 @@ constexpr int UG = 2;     // ... of this many sites each (NB * UG == RENORM)
 struct GroupDesc {
   uint32_t ind;
   uint32_t np;
-  uint32_t shared3;  // points 0..2 share alpha, 3 and 4 have their own (the BFGS pattern)
+  uint32_t mode;     // 0 = general points, else fd_mode(nf, na, small): see lkl_run_fd
   uint32_t pad;
   double F[MAXP];
   double A[MAXP];
@@ -131,31 +132,222 @@ __device__ __forceinline__ void op_step(Op& m, double ce0, double ce1, double g0
   m.a11 = fma(g1, s1, ce1 * m.a11);
 }
 
-// exp(x) for |x| <= 1e-3 to < 1e-17 relative (x^6/720 is the first dropped term)
-__device__ __forceinline__ double exp_small(double x) {
-  return fma(x, fma(x, fma(x, fma(x, fma(x, 1.0 / 120, 1.0 / 24), 1.0 / 6), 0.5), 1.0), 1.0);
-}
-
 __device__ __forceinline__ double coanc(double alpha, double d) {
   // exp(-alpha d): 0 at chromosome starts (d = +inf), 1 on padding sites (d = 0)
   return exp_nonpos(-alpha * d);
 }
 
+// by-products of a forward walk that the E-step consumes (see "E-step" below)
+struct EmitPtrs {
+  double* __restrict__ lane_ops;  // [I][J][5]: operator of the whole lane-chunk
+  double2* __restrict__ ckpt;     // see "E-step" below
+};
+
+__device__ __forceinline__ void emit_checkpoint(double2* __restrict__ ck, uint64_t wave,
+                                                uint64_t nblk, uint64_t b, int lane, const Op& R) {
+  double2* o = ck + ((wave * nblk + b) * 2) * 64 + lane;
+  o[0] = double2{R.a00, R.a01};
+  o[64] = double2{R.a10, R.a11};
+}
+
+__device__ __forceinline__ void emit_lane_op(double* __restrict__ lane_ops, uint64_t wave, int lane,
+                                             const Op& R) {
+  double* out = lane_ops + (wave * 64 + lane) * 5;
+  out[0] = R.a00;
+  out[1] = R.a01;
+  out[2] = R.a10;
+  out[3] = R.a11;
+  out[4] = (double)R.ex;
+}
+
 // ---- objective: chunk operators of <= 5 points per individual ------------
+// exp(x) for |x| <= 1e-3 to < 1e-16 relative (x^5/120 is the first dropped term)
+__device__ __forceinline__ double exp_small4(double x) {
+  return fma(x, fma(x, fma(x, fma(x, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0);
+}
+
+// exp(y) for -2^-6 <= y <= 0 without range reduction (y^8/8! < 1e-19)
+__device__ __forceinline__ double exp_tiny7(double y) {
+  double p = 1.0 / 5040.0;
+  p = fma(p, y, 1.0 / 720.0);
+  p = fma(p, y, 1.0 / 120.0);
+  p = fma(p, y, 1.0 / 24.0);
+  p = fma(p, y, 1.0 / 6.0);
+  p = fma(p, y, 0.5);
+  p = fma(p, y, 1.0);
+  return fma(p, y, 1.0);
+}
+
+// GroupDesc::mode: 0 = general points; else the finite-difference pattern of
+// shared/bfgs.cpp:22-43 -- point 0 = x, then NF probes that differ from it in F only,
+// then NA probes that differ in alpha only, by so little that exp(-(alpha +- eh) d) =
+// exp(-alpha d) * exp(-+ eh d) with a tiny second argument.
+constexpr uint32_t FD_FLAG = 0x100, FD_SMALL = 0x200;
+__host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small) {
+  return FD_FLAG | (small ? FD_SMALL : 0u) | ((uint32_t)nf << 2) | (uint32_t)na;
+}
+
+// The main loop of one wave for the finite-difference pattern.  Per site and lane:
+// one exp (a degree-7 polynomial when alpha * d_max <= 2^-6: SMALL), the products shared
+// by all points, 12 instructions per F-probe and 20 per alpha-probe; one exponent (point
+// 0's) rescales all points, which are perturbations of each other.
+template <int NF, int NA, bool SMALL, bool EMIT>
+__device__ __forceinline__ void lkl_run_fd(const double2* __restrict__ ep,
+                                           const double* __restrict__ dp, uint64_t T,
+                                           const GroupDesc& G, Op (&R)[MAXP], EmitPtrs emit,
+                                           uint64_t wave, int lane) {
+  static_assert(NB * UG == CK && RENORM == CK, "checkpoints are stored right after a rescale");
+  constexpr int NPT = 1 + NF + NA;
+  const uint64_t nblk = T / CK;
+  const double al0 = G.A[0];
+  const double q1 = G.F[0], q0 = 1 - q1;
+  double rho0[NF > 0 ? NF : 1], rho1[NF > 0 ? NF : 1], dal[NA > 0 ? NA : 1];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    rho0[f] = (1 - G.F[1 + f]) / q0;
+    rho1[f] = G.F[1 + f] / q1;
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) dal[a] = al0 - G.A[1 + NF + a];
+  int exc = 0;
+  // Software pipeline: NB buffers of UG sites.  A buffer is refilled right after it
+  // has been consumed, i.e. (NB-1) groups = 6 sites before it is needed again, which
+  // covers HBM latency at two to three waves per SIMD.  T is a multiple of NB*UG and the
+  // arrays carry one group of slack at the end, so neither the prologue nor the refills
+  // need bound checks (values read past T are never used); sites past S are identity
+  // operators (e = 1, d = 0).
+  double2 eb[NB][UG];
+  double db[NB][UG];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const uint64_t t = (uint64_t)b * UG + u;
+      eb[b][u] = ep[t * 64];
+      db[b][u] = dp[t * 64];
+    }
+  }
+  for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
+        double c0;
+        if constexpr (SMALL) {
+          // chromosome starts are stored as d = 1e30: c = 0 there (the polynomial of the
+          // huge argument is finite; masking its bits keeps the loop body branch-free)
+          const uint64_t keep = (d < 1e30) ? ~0ull : 0ull;
+          c0 = ngh_from_bits(ngh_bits(exp_tiny7(-al0 * d)) & keep);
+        } else {
+          c0 = coanc(al0, d);
+        }
+        const double a0 = 1 - c0;
+        const double ce0 = c0 * e0, ce1 = c0 * e1;
+        const double eq0 = e0 * q0, eq1 = e1 * q1;
+        const double g0 = a0 * eq0, g1 = a0 * eq1;
+        op_step(R[0], ce0, ce1, g0, g1);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) op_step(R[1 + f], ce0, ce1, g0 * rho0[f], g1 * rho1[f]);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          // |x| <= 1e-3 on every finite distance (checked by the host); at d = 1e30 the
+          // polynomial is huge but finite and multiplies c0 = 0
+          const double m = exp_small4(dal[a] * d);
+          const double am = fma(-c0, m, 1.0);
+          op_step(R[1 + NF + a], ce0 * m, ce1 * m, am * eq0, am * eq1);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
+        eb[b][u] = ep[t * 64];
+        db[b][u] = dp[t * 64];
+      }
+    }
+    {  // rescale every point by point 0's exponent
+      const double mx = fmax(fmax(R[0].a00, R[0].a01), fmax(R[0].a10, R[0].a11));
+      const int e = exp_of(mx);
+      const double sc = __builtin_ldexp(1.0, -e);
+      exc += e;
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        R[p].a00 *= sc;
+        R[p].a01 *= sc;
+        R[p].a10 *= sc;
+        R[p].a11 *= sc;
+      }
+    }
+    if constexpr (EMIT) {  // first round of an M-step: point 0 is the E-step's forward walk
+      // (no bound check, to keep the loop one basic block: the store after the last block
+      // lands in the unused slot 0 of the next wave, or in the array's slack)
+      emit_checkpoint(emit.ckpt, wave, nblk, t0 / CK + 1, lane, R[0]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) R[p].ex = exc;
+}
+
+// ordered product of the 64 lanes' operators; lane 0 stores the wave's operator
+__device__ __forceinline__ void lkl_store_wave_op(Op r, int lane, double* __restrict__ out) {
+  renorm(r);
+  Op m = r;
+  for (int off = 1; off < 64; off <<= 1) {
+    const Op o = op_shfl_down(m, off);
+    if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
+  }
+  if (lane == 0) {
+    out[0] = m.a00;
+    out[1] = m.a01;
+    out[2] = m.a10;
+    out[3] = m.a11;
+    out[4] = (double)m.ex;
+  }
+}
+
+// One kernel per loop-body version (each gets its own register allocation); the host
+// sorts the groups of a round by mode and launches every version on its range
+// [g_begin, g_begin + gridDim.x / C).
+template <int NF, int NA, bool SMALL, bool EMIT>
+__global__ void __launch_bounds__(64)
+k_fast_lkl_fd(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
+              uint32_t C, const GroupDesc* __restrict__ groups, uint32_t g_begin,
+              double* __restrict__ part, EmitPtrs emit) {
+  const uint32_t g = g_begin + blockIdx.x / C;
+  const uint32_t c = blockIdx.x % C;
+  const int lane = threadIdx.x;
+  const GroupDesc& G = groups[g];
+  const uint64_t i = G.ind;
+  Op R[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) R[p] = Op{1.0, 0.0, 0.0, 1.0, 0};
+  const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
+  const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
+  lkl_run_fd<NF, NA, SMALL, EMIT>(ep, dp, T, G, R, emit, i * C + c, lane);
+  if constexpr (EMIT) {
+    Op r0 = R[0];
+    renorm(r0);
+    emit_lane_op(emit.lane_ops, i * C + c, lane, r0);
+  }
+#pragma unroll
+  for (int p = 0; p < 1 + NF + NA; ++p)
+    lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
+}
+
 template <int NP_MAX>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
-                  uint32_t C, const GroupDesc* __restrict__ groups, double* __restrict__ part) {
-  const uint32_t g = blockIdx.x / C;
+                  uint32_t C, const GroupDesc* __restrict__ groups, uint32_t g_begin,
+                  double* __restrict__ part, EmitPtrs emit) {
+  const uint32_t g = g_begin + blockIdx.x / C;
   const uint32_t c = blockIdx.x % C;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
   const uint32_t np = G.np;
-  const bool shared3 = G.shared3 != 0;
   const uint64_t i = G.ind;
 
-  double q0[NP_MAX], q1[NP_MAX], al[NP_MAX];
   Op R[NP_MAX];
+  double q0[NP_MAX], q1[NP_MAX], al[NP_MAX];
 #pragma unroll
   for (int p = 0; p < NP_MAX; ++p) {
     const double f = (p < (int)np) ? G.F[p] : 0.5;
@@ -167,102 +359,55 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
 
   const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
-
-  // The loop body exists in two versions (finite-difference pattern / general points)
-  // selected ONCE per wave, so that the unrolled body of eight sites is a single basic
-  // block the scheduler can overlap the exp chains of one site with the row updates of
-  // the previous ones in.
-  auto run = [&](auto tag) {
-  // Software pipeline: NB buffers of UG sites.  A buffer is refilled right after it
-    // has been consumed, i.e. (NB-1) groups = 6 sites before it is needed again, which
-    // covers HBM latency at two waves per SIMD (a one-group-ahead scheme stalled on
-    // every group: 2.4 TB/s instead of ~4).
-    double2 eb[NB][UG];
-    double db[NB][UG];
-    // T is a multiple of NB*UG and the arrays carry one group of slack at the end, so
-    // neither the prologue nor the refills need bound checks (values read past T are
-    // never used)
-  #pragma unroll
+  double2 eb[NB][UG];
+  double db[NB][UG];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const uint64_t t = (uint64_t)b * UG + u;
+      eb[b][u] = ep[t * 64];
+      db[b][u] = dp[t * 64];
+    }
+  }
+  for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
+#pragma unroll
     for (int b = 0; b < NB; ++b) {
-  #pragma unroll
+#pragma unroll
       for (int u = 0; u < UG; ++u) {
-        const uint64_t t = (uint64_t)b * UG + u;
+        const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
+#pragma unroll
+        for (int p = 0; p < NP_MAX; ++p) {
+          if (p < (int)np) {
+            const double cc = coanc(al[p], d);
+            const double a = 1 - cc;
+            op_step(R[p], cc * e0, cc * e1, a * e0 * q0[p], a * e1 * q1[p]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
         eb[b][u] = ep[t * 64];
         db[b][u] = dp[t * 64];
       }
     }
-    for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
-  #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-  #pragma unroll
-        for (int u = 0; u < UG; ++u) {
-          // sites past T are identity operators (e = 1, d = 0), so no bound check
-          const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
-        if constexpr (NP_MAX >= 5 && decltype(tag)::value) {
-            // the finite-difference pattern: points 0..2 share alpha; points 3 and 4 sit at
-            // alpha +- eh, so their c is c0 * exp(-+ eh d) with a tiny argument
-            const double c0 = coanc(al[0], d);
-            const double x3 = (al[0] - al[3]) * d, x4 = (al[0] - al[4]) * d;
-            // |x| <= 1e-3 on every finite distance is checked by the host before it marks
-            // a group shared3; chromosome starts are stored as d = 1e30, where c0 = 0 and
-            // exp_small stays finite, so the products are exactly 0 as they must be
-            const double c3 = c0 * exp_small(x3);
-            const double c4 = c0 * exp_small(x4);
-            const double a0 = 1 - c0;
-            const double ce0 = c0 * e0, ce1 = c0 * e1, ae0 = a0 * e0, ae1 = a0 * e1;
-            op_step(R[0], ce0, ce1, ae0 * q0[0], ae1 * q1[0]);
-            op_step(R[1], ce0, ce1, ae0 * q0[1], ae1 * q1[1]);
-            op_step(R[2], ce0, ce1, ae0 * q0[2], ae1 * q1[2]);
-            const double a3 = 1 - c3, a4 = 1 - c4;
-            op_step(R[3], c3 * e0, c3 * e1, a3 * e0 * q0[3], a3 * e1 * q1[3]);
-            op_step(R[4], c4 * e0, c4 * e1, a4 * e0 * q0[4], a4 * e1 * q1[4]);
-          } else {
-    #pragma unroll
-            for (int p = 0; p < NP_MAX; ++p) {
-              if (p < (int)np) {
-                const double cc = coanc(al[p], d);
-                const double a = 1 - cc;
-                op_step(R[p], cc * e0, cc * e1, a * e0 * q0[p], a * e1 * q1[p]);
-              }
-            }
-          }
-        }
-  #pragma unroll
-        for (int u = 0; u < UG; ++u) {
-          const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
-          eb[b][u] = ep[t * 64];
-          db[b][u] = dp[t * 64];
-        }
-      }
-  #pragma unroll
-      for (int p = 0; p < NP_MAX; ++p)
-        if (p < (int)np) renorm(R[p]);
-    }
-  };
-  if (shared3)
-    run(std::true_type{});
-  else
-    run(std::false_type{});
-  // ordered product over the 64 lanes
 #pragma unroll
-  for (int p = 0; p < NP_MAX; ++p) {
-    if (p < (int)np) {
-      renorm(R[p]);
-      Op m = R[p];
-      for (int off = 1; off < 64; off <<= 1) {
-        const Op o = op_shfl_down(m, off);
-        if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
-      }
-      if (lane == 0) {
-        double* out = part + (((uint64_t)g * C + c) * MAXP + p) * 5;
-        out[0] = m.a00;
-        out[1] = m.a01;
-        out[2] = m.a10;
-        out[3] = m.a11;
-        out[4] = (double)m.ex;
-      }
+    for (int p = 0; p < NP_MAX; ++p)
+      if (p < (int)np) renorm(R[p]);
+    if (emit.ckpt) {
+      const uint64_t b = t0 / CK + 1;
+      if (b < T / CK) emit_checkpoint(emit.ckpt, i * C + c, T / CK, b, lane, R[0]);
     }
   }
+  if (emit.lane_ops) {
+    Op r0 = R[0];
+    renorm(r0);
+    emit_lane_op(emit.lane_ops, i * C + c, lane, r0);
+  }
+#pragma unroll
+  for (int p = 0; p < NP_MAX; ++p)
+    if (p < (int)np) lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
 }
 
 // lkl = log( q . prod_c R_c . 1 )
@@ -292,11 +437,24 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
 }
 
 // ---- E-step ---------------------------------------------------------------
-// phase A: the operator of every lane-chunk, one point per individual
+// The E-step of a lane-chunk needs the forward vector at every site and the backward
+// vector at every site.  Storing either per site costs 8 B written and 8 B read back per
+// site and individual; instead the forward pass leaves a CHECKPOINT every CK sites -- the
+// 2x2 prefix operator of the lane-chunk up to there, 32 B per CK sites -- and the backward
+// sweep recomputes the forward vectors of a block of CK sites from its checkpoint, in
+// registers, before walking the block backwards (k_fast_bwd_recompute).  The prefix
+// operators do not depend on the vector entering the lane-chunk, so they are produced by
+// whichever kernel walks the chunk forward first: k_fast_chunk_ops for a stand-alone
+// E-step, or the first objective round of the M-step (same parameters, same emissions:
+// lkl_run_fd / k_fast_lkl_chunks with `emit`), which then replaces phase A altogether.
+//
+// checkpoint layout: ck[((i*C + c)*NBLK + b)*2 + h][64] of double2 = row h of the prefix
+// operator of sites [0, b*CK) of lane-chunk (c, lane); b = 0 (identity) is not stored.
+// phase A: the operator of every lane-chunk and its checkpoints, one point per individual
 __global__ void __launch_bounds__(64)
 k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
                  uint32_t C, const double* __restrict__ indF, const double* __restrict__ alpha,
-                 double* __restrict__ lane_ops) {
+                 EmitPtrs out) {
   const uint64_t i = blockIdx.x / C;
   const uint32_t c = blockIdx.x % C;
   const int lane = threadIdx.x;
@@ -305,6 +463,7 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
   Op R{1.0, 0.0, 0.0, 1.0, 0};
   const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
+  const uint64_t nblk = T / CK;
   double2 ecur[UF], enxt[UF];
   double dcur[UF], dnxt[UF];
 #pragma unroll
@@ -325,7 +484,11 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
       const double a = 1 - cc;
       op_step(R, cc * ecur[u].x, cc * ecur[u].y, a * ecur[u].x * q0, a * ecur[u].y * q1);
     }
-    if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) renorm(R);
+    if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) {
+      renorm(R);
+      const uint64_t b = (t0 + UF) / CK;  // checkpoint in front of block b
+      if (b < nblk) emit_checkpoint(out.ckpt, i * C + c, nblk, b, lane, R);
+    }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       ecur[u] = enxt[u];
@@ -333,12 +496,7 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
     }
   }
   renorm(R);
-  double* out = lane_ops + ((i * C + c) * 64 + lane) * 5;
-  out[0] = R.a00;
-  out[1] = R.a01;
-  out[2] = R.a10;
-  out[3] = R.a11;
-  out[4] = (double)R.ex;
+  emit_lane_op(out.lane_ops, i * C + c, lane, R);
 }
 
 // phase B: per individual, the vector entering every lane-chunk from the left
@@ -388,63 +546,17 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t I, uint64_t J,
   if (fabs(lf - lb) > 0.001) flags[FLAG_FW_BW] = 1;  // EM.cpp:167
 }
 
-// phase C: forward sweep of every lane-chunk, storing the filtered odds v1/v0
+// phase C: backward sweep with block-wise forward recomputation.  Posterior of the IBD
+// state, snapped like check_interv (gen_func.cpp:55-70), in the TILE-MAJOR layout
+//   post[(c*T + t)*I + i][lane]      (site (c*64 + lane)*T + t)
+// i.e. every wave-store is one contiguous 512 B segment and no transposition pass is
+// needed: est_maf reads this layout directly (k_fast_estmaf<.., TILE>).
 __global__ void __launch_bounds__(64)
-k_fast_fwd_odds(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
-                uint32_t C, const double* __restrict__ indF, const double* __restrict__ alpha,
-                const double* __restrict__ bound, double* __restrict__ r_il) {
-  const uint64_t i = blockIdx.x / C;
-  const uint32_t c = blockIdx.x % C;
-  const int lane = threadIdx.x;
-  const double f = indF[i], al = alpha[i];
-  const double q0 = 1 - f, q1 = f;
-  const uint64_t J = (uint64_t)C * 64;
-  const double* bd = bound + (i * J + (uint64_t)c * 64 + lane) * 4;
-  double v0 = bd[0], v1 = bd[1];
-  const uint64_t base = ((i * C + c) * T) * 64 + lane;
-  const double2* ep = e_il + base;
-  const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
-  double* rp = r_il + base;
-  double2 ecur[UF], enxt[UF];
-  double dcur[UF], dnxt[UF];
-#pragma unroll
-  for (int u = 0; u < UF; ++u) {
-    ecur[u] = ep[(uint64_t)u * 64];  // T is a multiple of 8; arrays carry a group of slack
-    dcur[u] = dp[(uint64_t)u * 64];
-  }
-  int exd = 0;
-  for (uint64_t t0 = 0; t0 < T; t0 += UF) {
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const uint64_t t = t0 + UF + u;
-      enxt[u] = ep[t * 64];
-      dnxt[u] = dp[t * 64];
-    }
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const uint64_t t = t0 + u;
-      const double cc = coanc(al, dcur[u]);
-      const double a = 1 - cc;
-      const double s = v0 + v1;
-      v0 = fma(a * q0, s, cc * v0) * ecur[u].x;
-      v1 = fma(a * q1, s, cc * v1) * ecur[u].y;
-      rp[t * 64] = v1 / v0;
-    }
-    if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) renorm2(v0, v1, exd);
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      ecur[u] = enxt[u];
-      dcur[u] = dnxt[u];
-    }
-  }
-}
-
-// phase D: backward sweep; posterior of the IBD state overwrites the odds
-__global__ void __launch_bounds__(64)
-k_fast_bwd_post(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
-                uint32_t C, uint64_t S, const double* __restrict__ indF,
-                const double* __restrict__ alpha, const double* __restrict__ bound,
-                double* __restrict__ r_il, int* __restrict__ flags) {
+k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict__ pos_il,
+                     uint64_t T, uint32_t C, uint64_t S, uint64_t I,
+                     const double* __restrict__ indF, const double* __restrict__ alpha,
+                     const double* __restrict__ bound, const double2* __restrict__ ckpt,
+                     double* __restrict__ post, int* __restrict__ flags) {
   const uint64_t i = blockIdx.x / C;
   const uint32_t c = blockIdx.x % C;
   const int lane = threadIdx.x;
@@ -453,80 +565,98 @@ k_fast_bwd_post(const double2* __restrict__ e_il, const double* __restrict__ pos
   const uint64_t J = (uint64_t)C * 64;
   const uint64_t j = (uint64_t)c * 64 + lane;
   const double* bd = bound + (i * J + j) * 4;
+  const double vin0 = bd[0], vin1 = bd[1];
   double w0 = bd[2], w1 = bd[3];
-  const uint64_t base = ((i * C + c) * T) * 64 + lane;
-  const double2* ep = e_il + base;
+  const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
-  double* rp = r_il + base;
+  double* pp = post + ((uint64_t)c * T * I + i) * 64 + lane;  // site step t at pp[t * I * 64]
+  const uint64_t nblk = T / CK;
+  const double2* ck = ckpt + ((i * C + c) * nblk * 2) * 64 + lane;
+  const uint64_t tstride = I * 64;
   bool nanflag = false;
   int exd = 0;
 
-  double2 ecur[UF], enxt[UF];
-  double dcur[UF], dnxt[UF], ocur[UF], onxt[UF];
+  double2 ecur[CK], enxt[CK];
+  double dcur[CK], dnxt[CK];
+  double2 r0c, r1c, r0n, r1n;  // rows of the prefix operator in front of the block
+  {
+    const uint64_t b = nblk - 1;
 #pragma unroll
-  for (int u = 0; u < UF; ++u) {
-    const bool v = (uint64_t)u < T;
-    const uint64_t t = T - 1 - (v ? u : 0);
-    ecur[u] = v ? ep[t * 64] : double2{1, 1};
-    dcur[u] = v ? dp[t * 64] : 0.0;
-    ocur[u] = v ? rp[t * 64] : 1.0;
+    for (int u = 0; u < CK; ++u) {
+      ecur[u] = ep[(b * CK + u) * 64];
+      dcur[u] = dp[(b * CK + u) * 64];
+    }
+    r0c = b ? ck[(b * 2) * 64] : double2{1.0, 0.0};
+    r1c = b ? ck[(b * 2 + 1) * 64] : double2{0.0, 1.0};
   }
-  for (uint64_t r0 = 0; r0 < T; r0 += UF) {
+  for (uint64_t b = nblk;;) {
+    --b;
+    if (b > 0) {  // the block in front: in flight while this one is computed
+      const uint64_t bn = b - 1;
 #pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const uint64_t r = r0 + UF + u;
-      const bool v = r < T;
-      const uint64_t t = T - 1 - (v ? r : 0);
-      enxt[u] = v ? ep[t * 64] : double2{1, 1};
-      dnxt[u] = v ? dp[t * 64] : 0.0;
-      onxt[u] = v ? rp[t * 64] : 1.0;
-    }
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const uint64_t r = r0 + u;
-      if (r < T) {
-        const uint64_t t = T - 1 - r;
-        const uint64_t s = j * T + t;
-        // posterior of state 1 at this site: odds * w1 / (w0 + odds * w1)
-        const double odds = ocur[u];
-        double g1;
-        if (odds == __builtin_huge_val()) {
-          g1 = (w1 > 0) ? 1.0 : __builtin_nan("");
-        } else {
-          const double x = odds * w1;
-          g1 = x / (w0 + x);
-        }
-        if (s < S) {
-          if (g1 != g1) nanflag = true;
-          // check_interv (gen_func.cpp:55-70)
-          if (g1 < kEPS) g1 = 0;
-          else if (g1 > 1 - kEPS) g1 = 1;
-          rp[t * 64] = g1;
-        }
-        // beta step: w'_k = c u_k + a (q . u),  u = e * w
-        const double cc = coanc(al, dcur[u]);
-        const double a = 1 - cc;
-        const double u0 = ecur[u].x * w0, u1 = ecur[u].y * w1;
-        const double sq = a * fma(q0, u0, q1 * u1);
-        w0 = fma(cc, u0, sq);
-        w1 = fma(cc, u1, sq);
+      for (int u = 0; u < CK; ++u) {
+        enxt[u] = ep[(bn * CK + u) * 64];
+        dnxt[u] = dp[(bn * CK + u) * 64];
       }
+      r0n = bn ? ck[(bn * 2) * 64] : double2{1.0, 0.0};
+      r1n = bn ? ck[(bn * 2 + 1) * 64] : double2{0.0, 1.0};
     }
-    if (((r0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) renorm2(w0, w1, exd);
+    // forward vectors of the block's sites, from the checkpoint
+    double v0 = fma(vin0, r0c.x, vin1 * r1c.x);
+    double v1 = fma(vin0, r0c.y, vin1 * r1c.y);
+    double f0[CK], f1[CK], cc[CK];
 #pragma unroll
-    for (int u = 0; u < UF; ++u) {
+    for (int u = 0; u < CK; ++u) {
+      cc[u] = coanc(al, dcur[u]);
+      const double a = 1 - cc[u];
+      const double sm = v0 + v1;
+      v0 = fma(a * q0, sm, cc[u] * v0) * ecur[u].x;
+      v1 = fma(a * q1, sm, cc[u] * v1) * ecur[u].y;
+      if (u == CK / 2 - 1) {  // the scale of (v0, v1) does not matter: keep it in range
+        int dummy = 0;
+        renorm2(v0, v1, dummy);
+      }
+      f0[u] = v0;
+      f1[u] = v1;
+    }
+    // backward through the block: posterior, then the beta step
+#pragma unroll
+    for (int u = CK - 1; u >= 0; --u) {
+      const uint64_t t = b * CK + u;
+      const double x0 = f0[u] * w0, x1 = f1[u] * w1;
+      double g1 = x1 / (x0 + x1);
+      if (j * T + t < S) {
+        if (g1 != g1) nanflag = true;
+        // check_interv (gen_func.cpp:55-70)
+        if (g1 < kEPS) g1 = 0;
+        else if (g1 > 1 - kEPS) g1 = 1;
+        pp[t * tstride] = g1;
+      }
+      // beta step: w'_k = c u_k + a (q . u),  u = e * w
+      const double a = 1 - cc[u];
+      const double u0 = ecur[u].x * w0, u1 = ecur[u].y * w1;
+      const double sq = a * fma(q0, u0, q1 * u1);
+      w0 = fma(cc[u], u0, sq);
+      w1 = fma(cc[u], u1, sq);
+    }
+    renorm2(w0, w1, exd);
+    if (b == 0) break;
+#pragma unroll
+    for (int u = 0; u < CK; ++u) {
       ecur[u] = enxt[u];
       dcur[u] = dnxt[u];
-      ocur[u] = onxt[u];
     }
+    r0c = r0n;
+    r1c = r1n;
   }
   if (nanflag) flags[FLAG_NAN] = 1;
 }
 
-// interleaved [I][C][T][64] -> site-major [S][I]; tile = (c, t) x 64 lanes x 64 individuals
+// tile-major posteriors -> site-major [S][I] (multi-GPU packing, host read-back, est_maf
+// with more individuals than one wave holds); tile = (c, t) x 64 lanes x 64 individuals
 __global__ void __launch_bounds__(256)
-k_fast_deinterleave(const double* __restrict__ r_il, uint64_t I, uint64_t S, uint64_t T,
-                    uint32_t C, double* __restrict__ marg) {
+k_fast_post_to_site_major(const double* __restrict__ post, uint64_t I, uint64_t S, uint64_t T,
+                          uint32_t C, double* __restrict__ marg) {
   __shared__ double tile[64][65];
   const uint64_t n_it = (I + 63) / 64;
   const uint64_t ct = blockIdx.x / n_it;  // c * T + t
@@ -535,7 +665,7 @@ k_fast_deinterleave(const double* __restrict__ r_il, uint64_t I, uint64_t S, uin
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int ii = ty; ii < 64; ii += 4) {
     const uint64_t i = i0 + ii;
-    if (i < I) tile[ii][tx] = r_il[((i * C + c) * T + t) * 64 + tx];
+    if (i < I) tile[ii][tx] = post[(ct * I + i) * 64 + tx];
   }
   __syncthreads();
   for (int ll = ty; ll < 64; ll += 4) {
@@ -840,19 +970,37 @@ __constant__ double kChebW[EN] = {
 // resume from `state`.  n_exact passes are evaluated exactly, then (allow_build) the
 // interval is built and checked; a site that ends here writes freq_out/redo.
 constexpr int ESTMAF_MAXW = 16;
-template <int NI, int BLOCK>
+// TILE: the posteriors are read from the E-step's tile-major layout post[(c*T + t)*I + i][l]
+// (site (c*64 + l)*T + t), one wave per site and eight sites with consecutive l per
+// workgroup: a lane's 8-byte loads are 512 B apart, but the 64 B sector around each is
+// used by the eight waves of the workgroup at about the same time, so HBM still sees every
+// byte once (this kernel is FP64-bound; the extra address traffic hides under it).
+constexpr int ESTMAF_TILE_SITES = 8;
+template <int NI, int BLOCK, bool TILE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
-              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* __restrict__ freq_out,
-              uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
-              double* __restrict__ state, uint64_t state_stride, int fresh, int n_exact,
-              int allow_build) {
-  constexpr int W = BLOCK / 64;
+              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+              double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+              uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
+              int fresh, int n_exact, int allow_build) {
+  static_assert(!TILE || BLOCK == 64 * ESTMAF_TILE_SITES, "TILE: independent waves, one per site");
+  constexpr int W = TILE ? 1 : BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  constexpr uint64_t stride = BLOCK;
-  const uint64_t site = blockIdx.x;
+  const int wv = TILE ? 0 : (threadIdx.x >> 6);
+  const uint32_t tix = TILE ? (uint32_t)lane : threadIdx.x;  // index among the site's threads
+  constexpr uint64_t stride = TILE ? 64 : BLOCK;
+  uint64_t site, tile_row = 0, tile_l = 0;
+  if constexpr (TILE) {
+    const uint64_t q = (uint64_t)blockIdx.x * ESTMAF_TILE_SITES + (threadIdx.x >> 6);
+    tile_row = q >> 6;                       // c * T + t
+    tile_l = q & 63;
+    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
+    site = (c * 64 + tile_l) * tile_T + t;
+    if (site >= S_own) return;               // padding of the interleaved layout
+  } else {
+    site = blockIdx.x;
+  }
   if (!fresh && status[site] != EST_EXACT) return;
   const double* gls = gl + site * I_tot * 3;
 
@@ -872,13 +1020,17 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       uint64_t ic[NB];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const uint64_t i = (uint64_t)threadIdx.x + stride * (k0 + j);
+        const uint64_t i = (uint64_t)tix + stride * (k0 + j);
         ic[j] = i < I_tot ? i : I_tot - 1;
         r0[j] = gls[ic[j] * 3];
         r1[j] = gls[ic[j] * 3 + 1];
         r2[j] = gls[ic[j] * 3 + 2];
       }
-      if (one_block) {
+      if constexpr (TILE) {
+        const double* row = marg_blocks + tile_row * I_tot * 64 + tile_l;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rF[j] = row[ic[j] * 64];
+      } else if (one_block) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) rF[j] = marg_blocks[site * I_blk + ic[j]];
       } else {  // posteriors arrive in rank blocks [I_tot / I_blk][S_own][I_blk]
@@ -891,7 +1043,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int k = k0 + j;
-        const bool valid = (uint64_t)threadIdx.x + stride * k < I_tot;
+        const bool valid = (uint64_t)tix + stride * k < I_tot;
         const double p0 = r0[j], p1 = r1[j], p2 = r2[j], F = rF[j];  // linear GL
         const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
         const double n2 = (2 - F) * p2;
@@ -1061,7 +1213,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       }
     }
   }
-  if (threadIdx.x == 0) {
+  if (tix == 0) {
     // non-finite or out-of-range result: a cell with vanishing weights (or f reaching 1);
     // the careful kernel redoes the site in the reference's log-space order
     const double freq = num / den;
@@ -1140,13 +1292,18 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
 // any number of individuals: re-reads the (L2-resident) site row every pass
 __global__ void __launch_bounds__(256)
 k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
-                     uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
+                     uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
                      double* __restrict__ freq_out, const uint8_t* __restrict__ redo) {
   const int lane = threadIdx.x & 63;
   const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (site >= S_own) return;
   if (redo && !redo[site]) return;
   const double* gls = gl + site * I_tot * 3;
+  // tile_T != 0: posteriors in the tile-major layout (see k_fast_estmaf<.., TILE>)
+  const uint64_t tj = tile_T ? site / tile_T : 0;  // lane-chunk c*64 + l; t = site - tj*T
+  const double* trow =
+      tile_T ? marg_blocks + (((tj >> 6) * tile_T + (site - tj * tile_T)) * I_tot) * 64 + (tj & 63)
+             : nullptr;
   int iters = 0;
   double num = 0, den = 0, freq = 0.01, prev;
   bool again;
@@ -1157,7 +1314,8 @@ k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ m
     const double A = om * om, Cq = freq * freq;
     double pn = 0, pd = 0;
     for (uint64_t i = lane; i < I_tot; i += 64) {
-      const double F = marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
+      const double F = trow ? trow[i * 64]
+                            : marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
       const double bF = b * F;
       const double h0 = A + bF, h2 = Cq + bF;
       const double h1 = (F == 1) ? 0.0 : (2 * b - 2 * bF);
@@ -1215,7 +1373,9 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
-  if (!dalloc(&fs.r_il, cells)) return false;
+  if (!dalloc(&fs.post, cells)) return false;
+  if (!dalloc(&fs.ckpt, cells / CK * 4 + 4 * 64)) return false;  // T is a multiple of CK; slack:
+                                                                 // see lkl_run_fd
   if (!dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
   if (!dalloc(&fs.lane_ops, (size_t)I * fs.J * 5)) return false;
   if (!dalloc(&fs.bound, (size_t)I * fs.J * 4)) return false;
@@ -1223,7 +1383,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
 }
 
 void fast_destroy(FastState& fs) {
-  void* ptrs[] = {fs.e_il, fs.pos_il, fs.r_il, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
+  void* ptrs[] = {fs.e_il, fs.pos_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
                   fs.grp_dev, fs.redo, fs.est_status, fs.est_state, fs.gl_lin};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1260,6 +1420,28 @@ bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_fre
   return hipGetLastError() == hipSuccess;
 }
 
+// Recognise the finite-difference pattern of one objective + gradient evaluation
+// (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
+// close enough for exp_small4 on every finite distance of this data set.
+static uint32_t fd_pattern(const GroupDesc& G, double dmax) {
+  if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
+  int nf = 0, na = 0;
+  for (uint32_t p = 1; p < G.np; ++p) {
+    if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
+      if (na) return 0;  // F probes come first
+      ++nf;
+    } else if (G.F[p] == G.F[0] && std::fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
+      ++na;
+    } else {
+      return 0;
+    }
+  }
+  const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
+                  (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
+  if (!ok) return 0;
+  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625);
+}
+
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
                       const double* h_F, const double* h_A) {
   fs.n_groups = 0;
@@ -1284,14 +1466,19 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    // the finite-difference pattern, with alpha probes close enough for exp_small on
-    // every finite distance of this data set
-    G.shared3 = (np == 5 && G.A[0] == G.A[1] && G.A[0] == G.A[2] &&
-                 std::fabs(G.A[0] - G.A[3]) * fs.dmax_finite <= 1e-3 &&
-                 std::fabs(G.A[0] - G.A[4]) * fs.dmax_finite <= 1e-3)
-                    ? 1u
-                    : 0u;
+    G.mode = fd_pattern(G, fs.dmax_finite);
     groups.push_back(G);
+  }
+  // one kernel per loop-body version: sort the groups by mode (stable, so still in
+  // individual order inside a mode) and remember the ranges
+  std::stable_sort(groups.begin(), groups.end(),
+                   [](const GroupDesc& a, const GroupDesc& b) { return a.mode < b.mode; });
+  fs.mode_ranges.clear();
+  for (uint32_t k = 0; k < groups.size();) {
+    uint32_t e = k;
+    while (e < groups.size() && groups[e].mode == groups[k].mode) ++e;
+    fs.mode_ranges.push_back({groups[k].mode, k, e - k});
+    k = e;
   }
   const uint32_t ng = (uint32_t)groups.size();
   const size_t gbytes = (size_t)ng * sizeof(GroupDesc);
@@ -1322,40 +1509,84 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
   return true;
 }
 
-bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags) {
+bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags, bool emit_estep) {
   const uint32_t ng = fs.n_groups;
   if (ng == 0) return true;
   const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(fs.grp_dev);
-  hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP>), dim3(ng * fs.C), dim3(64), 0, st,
-                     reinterpret_cast<const double2*>(fs.e_il), fs.pos_il, fs.T, fs.C, dg,
-                     fs.part);
+  const double2* e2 = reinterpret_cast<const double2*>(fs.e_il);
+  // first round of an M-step inside nghmm_iter_em: point 0 of every individual is the
+  // E-step's forward walk, whose lane operators and checkpoints it leaves behind
+  const EmitPtrs emit = emit_estep ? EmitPtrs{fs.lane_ops, reinterpret_cast<double2*>(fs.ckpt)}
+                                   : EmitPtrs{nullptr, nullptr};
+  for (const auto& r : fs.mode_ranges) {
+    const dim3 grid(r.count * fs.C), block(64);
+    switch (r.mode) {
+#define FD_LAUNCH(NF, NA, SM, EM)                                                             \
+  hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM>), grid, block, 0, st, e2, fs.pos_il, fs.T,  \
+                     fs.C, dg, r.begin, fs.part, emit)
+#define FD_CASE(NF, NA)                                     \
+  case fd_mode(NF, NA, false):                              \
+    if (emit_estep) FD_LAUNCH(NF, NA, false, true);         \
+    else FD_LAUNCH(NF, NA, false, false);                   \
+    break;                                                  \
+  case fd_mode(NF, NA, true):                               \
+    if (emit_estep) FD_LAUNCH(NF, NA, true, true);          \
+    else FD_LAUNCH(NF, NA, true, false);                    \
+    break;
+      FD_CASE(2, 2)
+      FD_CASE(1, 2)
+      FD_CASE(2, 1)
+      FD_CASE(1, 1)
+      FD_CASE(2, 0)
+      FD_CASE(0, 2)
+#undef FD_CASE
+#undef FD_LAUNCH
+      default:
+        hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP>), grid, block, 0, st, e2, fs.pos_il, fs.T, fs.C,
+                           dg, r.begin, fs.part, emit);
+    }
+  }
   hipLaunchKernelGGL(k_fast_lkl_finish, dim3((ng * MAXP + 63) / 64), dim3(64), 0, st, dg, ng, fs.C,
                      fs.part, d_lkl, d_flags);
   return hipGetLastError() == hipSuccess;
 }
 
+bool fast_lkl_covers_everyone(const FastState& fs) {
+  // one group per individual (points are grouped by individual, <= MAXP each; an M-step's
+  // first round has <= 5 points per individual, so groups == individuals iff all are there)
+  return fs.n_groups == fs.I;
+}
+
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
-                double* d_ind_lkl, double* d_marg, int* d_flags) {
+                double* d_ind_lkl, int* d_flags, bool have_forward_walk) {
   const double2* e2 = reinterpret_cast<const double2*>(fs.e_il);
+  double2* ck = reinterpret_cast<double2*>(fs.ckpt);
   const unsigned waves = (unsigned)(fs.I * fs.C);
-  hipLaunchKernelGGL(k_fast_chunk_ops, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
-                     d_indF, d_alpha, fs.lane_ops);
+  if (!have_forward_walk)
+    hipLaunchKernelGGL(k_fast_chunk_ops, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
+                       d_indF, d_alpha, EmitPtrs{fs.lane_ops, ck});
   hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)((fs.I + 63) / 64)), dim3(64), 0, st,
                      fs.lane_ops, fs.I, fs.J, d_indF, fs.bound, d_ind_lkl, d_flags);
-  hipLaunchKernelGGL(k_fast_fwd_odds, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
-                     d_indF, d_alpha, fs.bound, fs.r_il);
-  hipLaunchKernelGGL(k_fast_bwd_post, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
-                     fs.S, d_indF, d_alpha, fs.bound, fs.r_il, d_flags);
+  hipLaunchKernelGGL(k_fast_bwd_recompute, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
+                     fs.S, fs.I, d_indF, d_alpha, fs.bound, ck, fs.post, d_flags);
+  return hipGetLastError() == hipSuccess;
+}
+
+bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg) {
   const uint64_t n_it = (fs.I + 63) / 64;
-  hipLaunchKernelGGL(k_fast_deinterleave, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)), dim3(256),
-                     0, st, fs.r_il, fs.I, fs.S, fs.T, fs.C, d_marg);
+  hipLaunchKernelGGL(k_fast_post_to_site_major, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)),
+                     dim3(256), 0, st, fs.post, fs.I, fs.S, fs.T, fs.C, d_marg);
   return hipGetLastError() == hipSuccess;
 }
 
 bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
-                 double* d_freq_out) {
+                 double* d_freq_out, bool tile_major) {
   if (S_own == 0) return true;
+  // tile-major posteriors (the E-step's own layout) only for the handle's whole site range
+  // and one wave per site
+  if (tile_major && !(I_tot <= 1024 && I_blk == I_tot && S_own == fs.S)) return false;
+  const uint64_t tile_T = tile_major ? fs.T : 0;
   const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
   if (S_own > fs.redo_cap) {
     if (fs.redo) (void)hipFree(fs.redo);
@@ -1376,14 +1607,27 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
   if (const char* env = std::getenv("NGHMM_ESTMAF_INTERP")) interp = std::atoi(env) != 0;
   // waves per site (W) and individuals per lane (NI): 16 per lane at two waves per SIMD;
   // a workgroup must fit one CU
-#define LAUNCH_NI(N, B)                                                                       \
-  hipLaunchKernelGGL((k_fast_estmaf<N, B>), dim3((unsigned)S_own), dim3(B), 0, st, d_gl_sites, \
-                     d_marg_blocks, S_own, I_tot, I_blk, d_freq_out, fs.redo, fs.est_status,  \
-                     fs.est_state, fs.redo_cap, fresh, n_exact, allow_build)
+#define LAUNCH_NI(N, B)                                                                         \
+  hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B), 0, st,        \
+                     d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0, d_freq_out,   \
+                     fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
+                     allow_build)
+#define LAUNCH_TILE(N)                                                                          \
+  hipLaunchKernelGGL((k_fast_estmaf<N, 64 * ESTMAF_TILE_SITES, true>),                           \
+                     dim3((unsigned)(fs.Spad / ESTMAF_TILE_SITES)), dim3(64 * ESTMAF_TILE_SITES), \
+                     0, st, d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out, \
+                     fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
+                     allow_build)
   int cfg_ni = 0, cfg_b = 0;
   if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
   auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
-    if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
+    if (tile_major) {
+      if (I_tot <= 64) LAUNCH_TILE(1);
+      else if (I_tot <= 128) LAUNCH_TILE(2);
+      else if (I_tot <= 256) LAUNCH_TILE(4);
+      else if (I_tot <= 512) LAUNCH_TILE(8);
+      else LAUNCH_TILE(16);
+    } else if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
       if (cfg_ni == 16 && cfg_b == 64) LAUNCH_NI(16, 64);
       else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);
       else if (cfg_ni == 16 && cfg_b == 256) LAUNCH_NI(16, 256);
@@ -1406,7 +1650,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
     return true;
   };
   const uint8_t* redo = fs.redo;
-  if (I_tot > 8192 && !cfg_ni) {
+  if (I_tot > 8192 && !cfg_ni && !tile_major) {
     redo = nullptr;  // more individuals than registers hold: stream every site
   } else if (!interp) {
     if (!launch(1, 0, 0)) return false;
@@ -1421,8 +1665,9 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
     if (!launch(0, 0, 0)) return false;  // whatever is left finishes on exact passes
   }
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
-                     I_tot, I_blk, d_freq_out, redo);
+                     I_tot, I_blk, tile_T, d_freq_out, redo);
 #undef LAUNCH_NI
+#undef LAUNCH_TILE
   return hipGetLastError() == hipSuccess;
 }
 

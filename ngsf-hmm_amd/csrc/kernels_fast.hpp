@@ -20,7 +20,8 @@ struct FastState {
   double* gl_lin = nullptr;       // exp(GL), site-major [S][I][3] (emission refresh, est_maf)
   double* e_il = nullptr;         // linear emissions, interleaved [I][C][T][64] x double2
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
-  double* r_il = nullptr;         // forward odds, then posteriors, interleaved [I][C][T][64]
+  double* post = nullptr;         // posteriors, tile-major [C][T][I][64] (site (c*64+l)*T + t)
+  double* ckpt = nullptr;         // forward checkpoints [I][C][T/8][2][64] x double2
   double* lane_ops = nullptr;     // per-lane chunk operators [I][J][5]
   double* bound = nullptr;        // per-lane incoming forward/backward vectors [I][J][4]
   double* eprob_log = nullptr;    // lazily: log emissions site-major [S][I][2] (Viterbi, export)
@@ -31,6 +32,8 @@ struct FastState {
   size_t grp_cap = 0;
   std::vector<unsigned char> grp_host;
   uint32_t n_groups = 0;
+  struct ModeRange { uint32_t mode, begin, count; };
+  std::vector<ModeRange> mode_ranges;  // groups sorted by loop-body version
   double dmax_finite = 0;         // largest finite distance of the loaded data
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;
@@ -49,17 +52,25 @@ bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_fre
 // in point order
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
                       const double* h_F, const double* h_A);
-bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags);
-// forward + backward + posteriors; marg out is site-major [S][I]
+// emit_estep: the launch is the first round of an M-step (point 0 of every individual =
+// its current parameters) and leaves the E-step's lane operators and checkpoints behind
+bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
+                     bool emit_estep = false);
+bool fast_lkl_covers_everyone(const FastState& fs);
+// forward checkpoints (unless a preceding fast_lkl_launch(emit_estep) left them), boundary
+// vectors, backward sweep with posteriors into fs.post (tile-major)
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
-                double* d_ind_lkl, double* d_marg, int* d_flags);
+                double* d_ind_lkl, int* d_flags, bool have_forward_walk);
+// fs.post -> site-major [S][I]
+bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg);
 // out = exp(in) elementwise (in == out allowed): linear genotype likelihoods
 void fast_exp(hipStream_t st, const double* d_in, double* d_out, uint64_t n);
 // est_maf on S_own sites: LINEAR GL site-major [S_own][I_tot][3] (fs.gl_lin, or a
 // site shard passed through fast_exp), posteriors in rank blocks [I_tot / I_blk][S_own][I_blk]
+// or (tile_major) fs.post itself
 bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_lin_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
-                 double* d_freq_out);
+                 double* d_freq_out, bool tile_major = false);
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
                   const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags,
                   double* d_scratch, uint64_t chunk_sites);

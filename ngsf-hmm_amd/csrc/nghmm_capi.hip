@@ -59,8 +59,7 @@ struct nghmm_handle {
   uint64_t I = 0, S = 0;
   int device = 0, mode = NGHMM_MODE_EXACT;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // est_maf underneath the M-step rounds (nghmm_iter_em)
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2a = nullptr, ev2b = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool loaded = false;
 
   double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
@@ -81,6 +80,9 @@ struct nghmm_handle {
   double* d_gl_shard = nullptr;
 
   FastState fast;  // fast-mode layouts (kernels_fast.hip)
+  // fast mode keeps the posteriors tile-major (fast.post); the site-major copy d_marg is
+  // made on demand (host read-back, multi-GPU packing, est_maf beyond 1024 individuals)
+  bool marg_valid = false;
 
   std::vector<double> h_indF, h_alpha;
   double ms[NSLOTS] = {0, 0, 0, 0, 0, 0};
@@ -176,8 +178,39 @@ int ensure_tmp(nghmm_t* h) {
   return dev_alloc(&h->d_tmp, h->S * h->I * 2);
 }
 
+// site-major posteriors [S][I] in d_marg (fast mode: converted from the tile-major layout)
+int ensure_marg(nghmm_t* h) {
+  if (h->mode != NGHMM_MODE_FAST || h->marg_valid) return NGHMM_OK;
+  int rc;
+  if (!h->d_marg) {
+    if ((rc = dev_alloc(&h->d_marg, (size_t)h->I * h->S))) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_marg, 0, (size_t)h->I * h->S * sizeof(double), h->stream));
+  }
+  if (!fast_post_to_site_major(h->fast, h->stream, h->d_marg)) return NGHMM_ERR_HIP;
+  h->marg_valid = true;
+  return NGHMM_OK;
+}
+
+// fast-mode E-step; have_walk: an objective round just left the forward walk behind
+int fast_estep_impl(nghmm_t* h, double* ind_lkl, bool have_walk) {
+  int rc;
+  if ((rc = clear_flags(h))) return rc;
+  tic(h);
+  if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_flags, have_walk))
+    return NGHMM_ERR_HIP;
+  if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
+  h->ms[SLOT_BACKWARD] = 0;
+  h->launches[SLOT_BACKWARD] = 0;
+  h->marg_valid = false;
+  HIP_TRY(hipGetLastError());
+  if (ind_lkl)
+    HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+  return check_flags(h);
+}
+
 int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
-                   const double* alpha, double* lkl, bool accumulate) {
+                   const double* alpha, double* lkl, bool accumulate, bool* emit_estep = nullptr) {
   if (n_pts == 0) return NGHMM_OK;
   for (uint32_t p = 0; p < n_pts; ++p)
     if (ind[p] >= h->I) {
@@ -194,12 +227,17 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
       set_error("fast_lkl_prepare failed: %s", hipGetErrorString(hipGetLastError()));
       return NGHMM_ERR_HIP;
     }
-    tic(h);  // after the descriptor upload: the timed span is the two kernels
-    if (!fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags)) {
+    // *emit_estep in: the caller wants the E-step's forward walk as a by-product (first
+    // round of an M-step); out: whether every individual was in the batch, i.e. it was left
+    const bool emit = emit_estep && *emit_estep && fast_lkl_covers_everyone(h->fast);
+    if (emit_estep) *emit_estep = emit;
+    tic(h);  // after the descriptor upload: the timed span is the kernels
+    if (!fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags, emit)) {
       set_error("fast_lkl_launch failed: %s", hipGetErrorString(hipGetLastError()));
       return NGHMM_ERR_HIP;
     }
   } else {
+    if (emit_estep) *emit_estep = false;
     HIP_TRY(hipMemcpyAsync(h->d_pt_ind, ind, n_pts * sizeof(uint32_t), hipMemcpyHostToDevice,
                            h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_pt_F, F, n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -287,7 +325,6 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
     if ((rc = dev_alloc(&h->d_gl, cells * 3))) break;
     if ((rc = dev_alloc(&h->d_pos, n_sites))) break;
     if ((rc = dev_alloc(&h->d_freq, n_sites))) break;
-    if ((rc = dev_alloc(&h->d_marg, cells))) break;
     if ((rc = dev_alloc(&h->d_indF, n_ind))) break;
     if ((rc = dev_alloc(&h->d_alpha, n_ind))) break;
     if ((rc = dev_alloc(&h->d_ind_lkl, n_ind))) break;
@@ -295,8 +332,9 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
     if (mode == NGHMM_MODE_EXACT) {
       if ((rc = dev_alloc(&h->d_eprob, cells * 2))) break;
       if ((rc = dev_alloc(&h->d_fw, (cells + n_ind) * 2))) break;
+      if ((rc = dev_alloc(&h->d_marg, cells))) break;
+      if (hipMemset(h->d_marg, 0, cells * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     }
-    if (hipMemset(h->d_marg, 0, cells * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     if (hipMemset(h->d_freq, 0, n_sites * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     h->h_indF.assign(n_ind, 0.0);
     h->h_alpha.assign(n_ind, 0.0);
@@ -322,9 +360,6 @@ int nghmm_destroy(nghmm_t* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fast_destroy(h->fast);
-  if (h->ev2a) (void)hipEventDestroy(h->ev2a);
-  if (h->ev2b) (void)hipEventDestroy(h->ev2b);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -408,15 +443,9 @@ int nghmm_estep(nghmm_t* h, double* ind_lkl) {
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
+  if (h->mode == NGHMM_MODE_FAST) return fast_estep_impl(h, ind_lkl, false);
   if ((rc = clear_flags(h))) return rc;
-  if (h->mode == NGHMM_MODE_FAST) {
-    tic(h);
-    if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_marg, h->d_flags))
-      return NGHMM_ERR_HIP;
-    if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
-    h->ms[SLOT_BACKWARD] = 0;
-    h->launches[SLOT_BACKWARD] = 0;
-  } else {
+  {
     tic(h);
     launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr,
                          h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_fw, h->d_flags);
@@ -441,28 +470,44 @@ int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const doubl
   return lkl_batch_impl(h, n_pts, ind, F, alpha, lkl, false);
 }
 
-int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats) {
-  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+// indF/alpha M-step.  fuse_estep (fast mode, nghmm_iter_em): the E-step that the
+// reference runs BEFORE this M-step (EM.cpp:147-185) reads the same emissions and the
+// same parameters as the M-step's first objective evaluation f(x) (EM.cpp:449-464 at the
+// start values), and neither step writes anything the other reads.  So the first round
+// runs first and leaves the forward walk of every individual behind (lane operators and
+// checkpoints); the E-step then needs no forward pass over the emissions of its own.
+static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats,
+                           bool fuse_estep, double* ind_lkl) {
   int rc;
-  if ((rc = use_device(h))) return rc;
   if (stats) std::memset(stats, 0, sizeof *stats);
   h->ms[SLOT_LKL] = 0;
   h->launches[SLOT_LKL] = 0;
-  if (indF_fixed && alpha_fixed) return NGHMM_OK;  // EM.cpp:191-193
+  if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
+    return fuse_estep ? fast_estep_impl(h, ind_lkl, false) : NGHMM_OK;
 
   BfgsBatch batch;
   batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
   std::vector<uint32_t> ind;
   std::vector<double> F, A, lkl;
+  bool estep_pending = fuse_estep;
   while (!batch.done()) {
     const size_t n = batch.gather(ind, F, A);
     lkl.resize(n);
+    bool emit = estep_pending;
     if (n) {
-      if ((rc = lkl_batch_impl(h, (uint32_t)n, ind.data(), F.data(), A.data(), lkl.data(), true)))
+      if ((rc = lkl_batch_impl(h, (uint32_t)n, ind.data(), F.data(), A.data(), lkl.data(), true,
+                               &emit)))
         return rc;
+    } else {
+      emit = false;
+    }
+    if (estep_pending) {
+      if ((rc = fast_estep_impl(h, ind_lkl, emit))) return rc;
+      estep_pending = false;
     }
     batch.scatter(lkl.data());
   }
+  if (estep_pending && (rc = fast_estep_impl(h, ind_lkl, false))) return rc;
   batch.result(h->h_indF.data(), h->h_alpha.data());
   HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
                          h->stream));
@@ -476,6 +521,13 @@ int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_st
     stats->ind_rounds = batch.ind_rounds();
   }
   return NGHMM_OK;
+}
+
+int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  return mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, false, nullptr);
 }
 
 int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
@@ -512,7 +564,18 @@ static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double
     // fast mode reads linear-space GL: its own copy of the handle's GL, or the site
     // shard, which the shard loaders exponentiate in place
     const double* d_lin = (d_gl_sites == h->d_gl) ? h->fast.gl_lin : d_gl_sites;
-    if (!fast_estmaf(h->fast, h->stream, d_lin, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out))
+    bool tile_major = false;
+    if (!d_marg_blocks) {  // the handle's own posteriors of its whole site range
+      tile_major = I_tot <= 1024;
+      if (tile_major) {
+        d_marg_blocks = h->fast.post;
+      } else {
+        if ((rc = ensure_marg(h))) return rc;
+        d_marg_blocks = h->d_marg;
+      }
+    }
+    if (!fast_estmaf(h->fast, h->stream, d_lin, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out,
+                     tile_major))
       return NGHMM_ERR_HIP;
   } else {
     if (I_blk != I_tot) {
@@ -543,50 +606,25 @@ int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
     set_error("sharded handle: use nghmm_mstep_freq_sites_dev");
     return NGHMM_ERR_ARG;
   }
-  if ((rc = estmaf_and_refresh(h, h->d_gl, h->d_marg, h->S, h->I, h->I, h->d_freq))) return rc;
+  if ((rc = estmaf_and_refresh(h, h->d_gl, h->mode == NGHMM_MODE_FAST ? nullptr : h->d_marg, h->S,
+                               h->I, h->I, h->d_freq)))
+    return rc;
   return emission_impl(h);
 }
 
 int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, double* ind_lkl,
                   nghmm_mstep_stats* stats) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
-  if ((rc = nghmm_estep(h, ind_lkl))) return rc;
-  // The allele-frequency EM reads only the E-step's posteriors and the genotype
-  // likelihoods, and the indF/alpha M-step reads only the (old) emissions
-  // (EM.cpp:198-201 vs 224-257): the two are independent until the emission refresh.
-  // With NGHMM_OVERLAP=1 est_maf runs on a second, low-priority stream underneath the
-  // M-step's rounds.  Off by default: measured at 1000 x 1M it changes nothing
-  // (120.8 vs 121.4 ms per iteration) because both kernels already saturate FP64 issue,
-  // and separate timings are easier to read.
-  const bool overlap = h->mode == NGHMM_MODE_FAST && freq_est == 1 && h->I_tot == h->I &&
-                       !(indF_fixed && alpha_fixed) && std::getenv("NGHMM_OVERLAP");
-  if (!overlap) {
+  if ((rc = use_device(h))) return rc;
+  if (h->mode == NGHMM_MODE_FAST && !std::getenv("NGHMM_NO_FUSE")) {
+    // E-step and indF/alpha M-step share their first forward walk (mstep_indf_impl)
+    if ((rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl))) return rc;
+  } else {
+    if ((rc = nghmm_estep(h, ind_lkl))) return rc;
     if ((rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats))) return rc;
-    return nghmm_mstep_freq(h, freq_est);
   }
-  if (!h->stream2) {
-    int lo = 0, hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo));
-    HIP_TRY(hipEventCreate(&h->ev2a));
-    HIP_TRY(hipEventCreate(&h->ev2b));
-  }
-  HIP_TRY(hipEventRecord(h->ev2a, h->stream2));
-  if (!fast_estmaf(h->fast, h->stream2, h->fast.gl_lin, h->d_marg, h->S, h->I, h->I, h->d_freq)) {
-    set_error("fast_estmaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-    return NGHMM_ERR_HIP;
-  }
-  HIP_TRY(hipEventRecord(h->ev2b, h->stream2));
-  if ((rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats))) {
-    (void)hipStreamSynchronize(h->stream2);
-    return rc;
-  }
-  HIP_TRY(hipEventSynchronize(h->ev2b));
-  float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, h->ev2a, h->ev2b));  // overlapped: not additive with slot 3
-  h->ms[SLOT_ESTMAF] = ms;
-  h->launches[SLOT_ESTMAF] = 1;
-  return emission_impl(h);
+  return nghmm_mstep_freq(h, freq_est);
 }
 
 int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
@@ -623,6 +661,7 @@ int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
   int rc;
   if ((rc = use_device(h))) return rc;
   if ((rc = ensure_tmp(h))) return rc;
+  if ((rc = ensure_marg(h))) return rc;
   launch_transpose_f64(h->stream, h->d_marg, h->d_tmp, h->S, h->I);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(marg_ibd, h->d_tmp, (size_t)h->I * h->S * sizeof(double),
@@ -699,6 +738,7 @@ int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, do
   int rc;
   if ((rc = use_device(h))) return rc;
   // marg is site-major [S][I]: the slice of a destination rank is contiguous
+  if ((rc = ensure_marg(h))) return rc;
   launch_copy_f64(h->stream, h->d_marg + site_lo * h->I, d_out, (site_hi - site_lo) * h->I);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));

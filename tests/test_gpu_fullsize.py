@@ -118,3 +118,45 @@ def test_est_maf_properties_at_full_size(pkg, big):
     agree = ((post > 0.5) == (path[:8] == 1)).mean()
     assert agree > 0.98                            # decoding and posteriors tell the same story
     h.close()
+
+
+@pytest.mark.parametrize("n_ind,n_sites,kw", [
+    (1000, 200_000, {}),
+    (1000, 200_000, dict(freq="r")),
+    (1000, 100_000, dict(freq="r", depth=10.0)),
+    (2000, 50_000, dict(freq="r")),
+    (100, 200_000, dict(freq="r")),
+])
+def test_est_maf_interpolated_passes_equal_exact_passes(pkg, n_ind, n_sites, kw):
+    """est_maf runs most of its <= 101 passes per site on a checked Chebyshev interpolant of
+    the per-pass sums (k_fast_estmaf / k_fast_estmaf_interp); NGHMM_ESTMAF_INTERP=0 evaluates
+    every pass over all individuals.  Same recursion, same stopping rule: the frequencies
+    must agree far inside the 1e-9 parity tolerance, on fixed and on uniform site
+    frequencies, at low and high depth, and across the kernel's individuals-per-lane
+    variants.  Two consecutive frequency steps, so the second starts from posteriors of
+    refreshed emissions."""
+    import torch
+    gl, pos = pkg.simulate.simulate_torch(n_ind, n_sites, torch.device("cuda", 0), seed=1, **kw)
+    torch.cuda.synchronize()
+    hmm = pkg.NgsFHMM(n_ind, n_sites, mode=pkg.MODE_FAST)
+    hmm.load_device(gl.data_ptr(), pos.data_ptr())
+    del gl, pos
+    res = {}
+    try:
+        for interp in ("0", "1"):
+            os.environ["NGHMM_ESTMAF_INTERP"] = interp
+            hmm.set_params(np.full(n_ind, 0.1), np.full(n_ind, 0.01), np.full(n_sites, 0.1))
+            hmm.init_emission()
+            for _ in range(2):
+                hmm.estep()
+                hmm.mstep_freq(1)
+            res[interp] = hmm.freq.copy()
+    finally:
+        del os.environ["NGHMM_ESTMAF_INTERP"]
+        hmm.close()
+        torch.cuda.empty_cache()
+    f0, f1 = res["0"], res["1"]
+    rel = np.abs(f1 - f0) / np.abs(f0)
+    print(f"est_maf interp vs exact passes {n_ind} x {n_sites} {kw}: max rel diff {rel.max():.3e}, "
+          f"sites > 1e-12: {int((rel > 1e-12).sum())}")
+    assert rel.max() < 1e-10
