@@ -971,11 +971,12 @@ __constant__ double kChebW[EN] = {
 // interval is built and checked; a site that ends here writes freq_out/redo.
 constexpr int ESTMAF_MAXW = 16;
 // TILE: the posteriors are read from the E-step's tile-major layout post[(c*T + t)*I + i][l]
-// (site (c*64 + l)*T + t), one wave per site and eight sites with consecutive l per
-// workgroup: a lane's 8-byte loads are 512 B apart, but the 64 B sector around each is
-// used by the eight waves of the workgroup at about the same time, so HBM still sees every
-// byte once (this kernel is FP64-bound; the extra address traffic hides under it).
-constexpr int ESTMAF_TILE_SITES = 8;
+// (site (c*64 + l)*T + t), one wave per site.  A lane's 8-byte loads are then 512 B apart,
+// and the 64 B sector around each holds the posteriors of the eight sites l0..l0+7 of the
+// same individual.  Workgroups go round-robin to the 8 XCDs (each with its own L2), so the
+// blockIdx -> site map gives XCD x the sites l = 8x..8x+7 of every tile row, in eight
+// consecutive workgroups of that XCD: the sector is fetched from HBM once and hit in that
+// L2 seven times.
 template <int NI, int BLOCK, bool TILE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
 k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
@@ -983,21 +984,23 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
               double* __restrict__ freq_out, uint8_t* __restrict__ redo,
               uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
               int fresh, int n_exact, int allow_build) {
-  static_assert(!TILE || BLOCK == 64 * ESTMAF_TILE_SITES, "TILE: independent waves, one per site");
+  static_assert(!TILE || BLOCK == 64, "TILE: one wave per site");
   constexpr int W = TILE ? 1 : BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   const int lane = threadIdx.x & 63;
   const int wv = TILE ? 0 : (threadIdx.x >> 6);
   const uint32_t tix = TILE ? (uint32_t)lane : threadIdx.x;  // index among the site's threads
   constexpr uint64_t stride = TILE ? 64 : BLOCK;
-  uint64_t site, tile_row = 0, tile_l = 0;
+  uint64_t site;
+  const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[i * 64]
   if constexpr (TILE) {
-    const uint64_t q = (uint64_t)blockIdx.x * ESTMAF_TILE_SITES + (threadIdx.x >> 6);
-    tile_row = q >> 6;                       // c * T + t
-    tile_l = q & 63;
+    const uint64_t b = blockIdx.x, x = b & 7, k = b >> 3;
+    const uint64_t q = ((k >> 3) << 6) + (x << 3) + (k & 7);
+    const uint64_t tile_row = q >> 6, l = q & 63;  // tile_row = c * T + t
     const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
-    site = (c * 64 + tile_l) * tile_T + t;
-    if (site >= S_own) return;               // padding of the interleaved layout
+    site = (c * 64 + l) * tile_T + t;
+    if (site >= S_own) return;  // padding of the interleaved layout
+    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
   } else {
     site = blockIdx.x;
   }
@@ -1027,9 +1030,8 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
         r2[j] = gls[ic[j] * 3 + 2];
       }
       if constexpr (TILE) {
-        const double* row = marg_blocks + tile_row * I_tot * 64 + tile_l;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) rF[j] = row[ic[j] * 64];
+        for (int j = 0; j < NB; ++j) rF[j] = tile_col[ic[j] * 64];
       } else if (one_block) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) rF[j] = marg_blocks[site * I_blk + ic[j]];
@@ -1613,9 +1615,8 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                      fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
                      allow_build)
 #define LAUNCH_TILE(N)                                                                          \
-  hipLaunchKernelGGL((k_fast_estmaf<N, 64 * ESTMAF_TILE_SITES, true>),                           \
-                     dim3((unsigned)(fs.Spad / ESTMAF_TILE_SITES)), dim3(64 * ESTMAF_TILE_SITES), \
-                     0, st, d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out, \
+  hipLaunchKernelGGL((k_fast_estmaf<N, 64, true>), dim3((unsigned)fs.Spad), dim3(64), 0, st,    \
+                     d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,        \
                      fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
                      allow_build)
   int cfg_ni = 0, cfg_b = 0;

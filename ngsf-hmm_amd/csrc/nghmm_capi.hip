@@ -566,7 +566,7 @@ static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double
     const double* d_lin = (d_gl_sites == h->d_gl) ? h->fast.gl_lin : d_gl_sites;
     bool tile_major = false;
     if (!d_marg_blocks) {  // the handle's own posteriors of its whole site range
-      tile_major = I_tot <= 1024;
+      tile_major = I_tot <= 1024 && !std::getenv("NGHMM_ESTMAF_SITEMAJOR");  // tuning knob
       if (tile_major) {
         d_marg_blocks = h->fast.post;
       } else {
