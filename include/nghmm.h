@@ -122,6 +122,17 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
  * 2 = NGHMM_ERR_FREQ_EST2 (the reference aborts). */
 int nghmm_mstep_freq(nghmm_t* h, int freq_est);
 
+/* E-step + indF/alpha M-step of one EM iteration (EM.cpp:147-201) in one call.  In fast
+ * mode the two share a pass over the emissions: the M-step's first objective evaluation
+ * f(x) at the current parameters (EM.cpp:449-464) IS the E-step's forward walk, so it runs
+ * first and leaves the lane operators and checkpoints the E-step's backward sweep needs;
+ * results are those of nghmm_estep followed by nghmm_mstep_indf.  after_estep (may be
+ * NULL) is called once on the calling thread as soon as the posteriors are final, before
+ * the remaining objective rounds: a multi-GPU host starts its posterior exchange there. */
+typedef void (*nghmm_hook_fn)(void* user);
+int nghmm_estep_mstep(nghmm_t* h, int indF_fixed, int alpha_fixed, double* ind_lkl,
+                      nghmm_mstep_stats* stats, nghmm_hook_fn after_estep, void* user);
+
 /* One whole EM iteration = iter_EM (EM.cpp:139-289). */
 int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, double* ind_lkl,
                   nghmm_mstep_stats* stats);
@@ -150,7 +161,8 @@ int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard);
 /* same, from a device buffer */
 int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard);
 /* pack posteriors of the own individuals for destination rank r's site range:
- * d_out[(s - site_lo) * n_ind + i], s in [site_lo, site_hi) */
+ * d_out[(s - site_lo) * n_ind + i], s in [site_lo, site_hi); with [0, n_sites) the whole
+ * site-major matrix = the send buffer of all equal contiguous ranges at once */
 int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, double* d_out);
 /* d_marg_sites: [n_sites_own][n_ind_total] posteriors of the own site range (device);
  * runs est_maf on them, writes d_freq_out[n_sites_own] (device) */

@@ -477,13 +477,21 @@ int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const doubl
 // runs first and leaves the forward walk of every individual behind (lane operators and
 // checkpoints); the E-step then needs no forward pass over the emissions of its own.
 static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats,
-                           bool fuse_estep, double* ind_lkl) {
+                           bool fuse_estep, double* ind_lkl, nghmm_hook_fn after_estep = nullptr,
+                           void* user = nullptr) {
   int rc;
+  // the E-step inside the loop below, then the caller's hook (multi-GPU: start moving the
+  // posteriors while the remaining objective rounds run)
+  auto estep_then_hook = [&](bool have_walk) -> int {
+    int r = fast_estep_impl(h, ind_lkl, have_walk);
+    if (r == NGHMM_OK && after_estep) after_estep(user);
+    return r;
+  };
   if (stats) std::memset(stats, 0, sizeof *stats);
   h->ms[SLOT_LKL] = 0;
   h->launches[SLOT_LKL] = 0;
   if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
-    return fuse_estep ? fast_estep_impl(h, ind_lkl, false) : NGHMM_OK;
+    return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
 
   BfgsBatch batch;
   batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
@@ -502,12 +510,12 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
       emit = false;
     }
     if (estep_pending) {
-      if ((rc = fast_estep_impl(h, ind_lkl, emit))) return rc;
+      if ((rc = estep_then_hook(emit))) return rc;
       estep_pending = false;
     }
     batch.scatter(lkl.data());
   }
-  if (estep_pending && (rc = fast_estep_impl(h, ind_lkl, false))) return rc;
+  if (estep_pending && (rc = estep_then_hook(false))) return rc;
   batch.result(h->h_indF.data(), h->h_alpha.data());
   HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
                          h->stream));
@@ -612,18 +620,26 @@ int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
   return emission_impl(h);
 }
 
+int nghmm_estep_mstep(nghmm_t* h, int indF_fixed, int alpha_fixed, double* ind_lkl,
+                      nghmm_mstep_stats* stats, nghmm_hook_fn after_estep, void* user) {
+  if (!h || !h->loaded) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (h->mode == NGHMM_MODE_FAST && !std::getenv("NGHMM_NO_FUSE"))
+    return mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl, after_estep, user);
+  if ((rc = nghmm_estep(h, ind_lkl))) return rc;
+  if (after_estep) after_estep(user);
+  return nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats);
+}
+
 int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, double* ind_lkl,
                   nghmm_mstep_stats* stats) {
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  if (h->mode == NGHMM_MODE_FAST && !std::getenv("NGHMM_NO_FUSE")) {
-    // E-step and indF/alpha M-step share their first forward walk (mstep_indf_impl)
-    if ((rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl))) return rc;
-  } else {
-    if ((rc = nghmm_estep(h, ind_lkl))) return rc;
-    if ((rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats))) return rc;
-  }
+  // fast mode: E-step and indF/alpha M-step share their first forward walk (mstep_indf_impl)
+  if ((rc = nghmm_estep_mstep(h, indF_fixed, alpha_fixed, ind_lkl, stats, nullptr, nullptr)))
+    return rc;
   return nghmm_mstep_freq(h, freq_est);
 }
 
@@ -737,6 +753,14 @@ int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, do
   if (!h || !d_out || site_lo > site_hi || site_hi > h->S) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
+  if (h->mode == NGHMM_MODE_FAST && site_lo == 0 && site_hi == h->S) {
+    // every destination at once: the send buffer [rank][S_own][I] of equal contiguous site
+    // ranges IS the site-major matrix, so convert the tile-major posteriors straight into it
+    if (!fast_post_to_site_major(h->fast, h->stream, d_out)) return NGHMM_ERR_HIP;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NGHMM_OK;
+  }
   // marg is site-major [S][I]: the slice of a destination rank is contiguous
   if ((rc = ensure_marg(h))) return rc;
   launch_copy_f64(h->stream, h->d_marg + site_lo * h->I, d_out, (site_hi - site_lo) * h->I);

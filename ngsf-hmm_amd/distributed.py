@@ -104,6 +104,12 @@ class GpuBackend:
     def mstep_indf(self, indF_fixed, alpha_fixed):
         return self.hmm.mstep_indf(indF_fixed, alpha_fixed)
 
+    def estep_mstep(self, indF_fixed, alpha_fixed, after_estep):
+        """E-step + indF/alpha M-step sharing their first pass over the emissions
+        (nghmm_estep_mstep); after_estep() is called once the posteriors are final."""
+        st = self.hmm.estep_mstep(indF_fixed, alpha_fixed, after_estep)
+        return st, self.hmm.ind_lkl
+
     def pack_posteriors(self, lo, hi, out):
         self.hmm._check(self.hmm.lib.nghmm_pack_posteriors_dev(self.hmm.handle, lo, hi,
                                                                C.c_void_p(out.data_ptr())))
@@ -177,19 +183,30 @@ class ShardedEM:
         if self.world == 1:
             st, self.ind_lkl = self.backend.iter_em_local(freq_est, indF_fixed, alpha_fixed)
             return st
-        self.ind_lkl = self.backend.estep()
         # the posteriors are final after the E-step and the indF/alpha M-step neither reads
-        # nor writes them: start their all-to-all now and let it run under the M-step
-        work = self.start_posterior_exchange() if freq_est else None
-        st = self.backend.mstep_indf(indF_fixed, alpha_fixed)
+        # nor writes them: start their all-to-all then and let it run under the M-step
+        box = {}
+
+        def after_estep():
+            if freq_est:
+                box["work"] = self.start_posterior_exchange()
+
+        fused = getattr(self.backend, "estep_mstep", None)
+        if fused is not None:
+            st, self.ind_lkl = fused(indF_fixed, alpha_fixed, after_estep)
+        else:
+            self.ind_lkl = self.backend.estep()
+            after_estep()
+            st = self.backend.mstep_indf(indF_fixed, alpha_fixed)
         if freq_est:
-            self.finish_exchange_and_update_freq(work)
+            self.finish_exchange_and_update_freq(box.get("work"))
         return st
 
     def start_posterior_exchange(self):
         import torch.distributed as dist
-        for q, (lo, hi) in enumerate(self.ranges):
-            self.backend.pack_posteriors(lo, hi, self._send[q])
+        # equal contiguous site ranges: the send buffer [rank][S_own][I] is the whole
+        # site-major posterior matrix
+        self.backend.pack_posteriors(0, self.n_sites, self._send)
         self._sync()
         if _staged(self._send):
             all_to_all(self._recv, self._send)

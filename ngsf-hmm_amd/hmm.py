@@ -25,6 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 c_double_p = C.POINTER(C.c_double)
+HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)   # nghmm_hook_fn
 
 
 class NgsFHMMError(RuntimeError):
@@ -81,6 +82,7 @@ def load_library():
         "nghmm_mstep_indf": (i32, [vp, i32, i32, C.POINTER(MstepStats)]),
         "nghmm_bfgs_batch_host": (i32, [u64, dp, dp, i32, i32, vp, vp, C.POINTER(MstepStats)]),
         "nghmm_mstep_freq": (i32, [vp, i32]),
+        "nghmm_estep_mstep": (i32, [vp, i32, i32, dp, C.POINTER(MstepStats), HOOK_FN, vp]),
         "nghmm_iter_em": (i32, [vp, i32, i32, i32, dp, C.POINTER(MstepStats)]),
         "nghmm_viterbi": (i32, [vp, C.POINTER(C.c_uint8)]),
         "nghmm_get_posteriors": (i32, [vp, dp]),
@@ -111,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "nghmm_last_error", "nghmm_strerror", "nghmm_has_hip", "nghmm_create", "nghmm_destroy",
     "nghmm_load_gl", "nghmm_load_gl_device", "nghmm_set_params", "nghmm_get_params",
     "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
-    "nghmm_bfgs_batch_host", "nghmm_mstep_freq",
+    "nghmm_bfgs_batch_host", "nghmm_mstep_freq", "nghmm_estep_mstep",
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
     "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_load_gl_site_shard_dev",
     "nghmm_pack_posteriors_dev",
@@ -272,6 +274,28 @@ class NgsFHMM:
 
     def mstep_freq(self, freq_est=1):
         self._check(self.lib.nghmm_mstep_freq(self._h, int(freq_est)))
+
+    def estep_mstep(self, indF_fixed=False, alpha_fixed=False, after_estep=None):
+        """E-step and indF/alpha M-step of one iteration in one call (nghmm_estep_mstep);
+        ``after_estep()`` runs as soon as the posteriors are final.  An exception raised
+        in it is re-raised here after the call returns."""
+        st = MstepStats()
+        err = []
+
+        def _hook(_user):
+            try:
+                after_estep()
+            except BaseException as e:      # must not propagate through the C frame
+                err.append(e)
+
+        cb = HOOK_FN(_hook) if after_estep is not None else C.cast(None, HOOK_FN)
+        rc = self.lib.nghmm_estep_mstep(self._h, int(indF_fixed), int(alpha_fixed),
+                                        _dp(self.ind_lkl), C.byref(st), cb, None)
+        if err:
+            raise err[0]
+        self._check(rc)
+        self.last_stats = st
+        return st
 
     def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
         """One EM iteration (EM.cpp:139-289)."""

@@ -56,7 +56,8 @@ class OracleBackend:
     def load_site_shard_device(self, shard):
         self.gl_shard = shard.numpy().copy()                     # [S_own][I_tot][3]
     def pack_posteriors(self, lo, hi, out):
-        out.copy_(torch.from_numpy(np.ascontiguousarray(self.em.marg.T[lo:hi])))   # [sites][I_loc]
+        out.view(hi - lo, -1).copy_(
+            torch.from_numpy(np.ascontiguousarray(self.em.marg.T[lo:hi])))         # [sites][I_loc]
     def mstep_freq_sites(self, blocks, freq_out):
         b = blocks.numpy()                                       # [rank][S_own][I_loc]
         for s in range(self.S_own):

@@ -208,3 +208,55 @@ def test_fast_reference_fatal_errors(pkg):
         hmm.estep()
     assert ei.value.code in (-1, -4)
     hmm.close()
+
+
+@pytest.mark.parametrize("fixed", [(False, False), (True, False), (False, True), (True, True)])
+def test_fast_estep_mstep_shares_the_forward_walk(pkg, orc_libm, mid_sim, fixed):
+    """nghmm_estep_mstep runs the M-step's first objective round first and lets it leave
+    the E-step's forward walk (lane operators, checkpoints) behind.  Its E-step must be
+    the oracle's (1e-12 / 1e-9 as for nghmm_estep), its M-step that of nghmm_estep +
+    nghmm_mstep_indf on a second handle, and the after-E-step hook runs exactly once,
+    when the posteriors are final."""
+    d, gl = mid_sim
+    indF = np.linspace(0.01, 0.95, d.n_ind)
+    alpha = np.linspace(0.01, 8, d.n_ind)
+    a, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb, indF=indF, alpha=alpha)
+    b, _ = _pair(pkg, orc_libm, gl, d.pos_dist_mb, indF=indF, alpha=alpha)
+    em.init_emission(); a.init_emission(); b.init_emission()
+    assert em.estep() == 0
+    seen = []
+    st = a.estep_mstep(*fixed, after_estep=lambda: seen.append(a.marg_prob.copy()))
+    assert len(seen) == 1
+    np.testing.assert_allclose(a.ind_lkl, em.ind_lkl, rtol=1e-12)
+    np.testing.assert_allclose(seen[0], em.marg, rtol=RTOL, atol=1e-9)
+    np.testing.assert_array_equal(a.marg_prob, seen[0])      # later rounds leave them alone
+    b.estep()
+    st_b = b.mstep_indf(*fixed)
+    np.testing.assert_allclose(a.ind_lkl, b.ind_lkl, rtol=1e-13)
+    np.testing.assert_allclose(a.marg_prob, b.marg_prob, rtol=RTOL, atol=1e-10)
+    # same optimiser, objective values equal to rounding: same path to within its own noise
+    np.testing.assert_allclose(a.indF, b.indF, atol=2e-4)
+    np.testing.assert_allclose(a.alpha, b.alpha, rtol=2e-2, atol=2e-4)
+    if fixed[0]:
+        np.testing.assert_array_equal(a.indF, indF)
+    if fixed[1]:
+        np.testing.assert_array_equal(a.alpha, alpha)
+    assert (st.rounds == 0) == all(fixed)
+    assert abs(int(st_b.rounds) - int(st.rounds)) <= 2
+    # the frequency step reads the posteriors the fused E-step wrote
+    a.mstep_freq(1); b.mstep_freq(1)
+    np.testing.assert_allclose(a.freq, b.freq, rtol=1e-9)
+    a.close(); b.close()
+
+
+def test_fast_hook_exception_propagates(pkg, orc_libm, mid_sim):
+    d, gl = mid_sim
+    a, _ = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    a.init_emission()
+
+    def boom():
+        raise ValueError("from the hook")
+
+    with pytest.raises(ValueError, match="from the hook"):
+        a.estep_mstep(after_estep=boom)
+    a.close()
