@@ -187,15 +187,77 @@ __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small) {
   return FD_FLAG | (small ? FD_SMALL : 0u) | ((uint32_t)nf << 2) | (uint32_t)na;
 }
 
+// Where a forward walk gets its per-site inputs from.  Plain: the materialised linear
+// emissions e_il.  Fresh: the first walk after an allele-frequency update computes the
+// emissions itself from the interleaved linear genotype likelihoods and the new
+// frequencies (calc_emission, shared/HMM.cpp:144-154, in linear space: e_k = sum_g p_g
+// HWE_g(f, F = k)) and WRITES e_il for every later pass -- the separate refresh pass
+// (24 B read + 16 B written per site and individual) disappears into a kernel that is
+// FP64-bound anyway.
+struct LklArrays {
+  const double2* __restrict__ e_il;
+  const double* __restrict__ pos_il;
+  const double2* __restrict__ gl02_il;  // (p0, p2)
+  const double* __restrict__ gl1_il;    // p1
+  const double* __restrict__ freq_il;
+  double2* __restrict__ e_out;          // == e_il, written by the fresh walk
+};
+
+struct SrcPlain {
+  const double2* __restrict__ ep;
+  const double* __restrict__ dp;
+  struct Buf {
+    double2 e;
+    double d;
+  };
+  __device__ __forceinline__ SrcPlain(const LklArrays& A, uint64_t wave_base, uint64_t pos_base)
+      : ep(A.e_il + wave_base), dp(A.pos_il + pos_base) {}
+  __device__ __forceinline__ Buf load(uint64_t t) const { return Buf{ep[t * 64], dp[t * 64]}; }
+  __device__ __forceinline__ void get(const Buf& b, uint64_t, double& e0, double& e1,
+                                      double& d) const {
+    e0 = b.e.x;
+    e1 = b.e.y;
+    d = b.d;
+  }
+};
+
+struct SrcFresh {
+  const double2* __restrict__ g02;
+  const double* __restrict__ g1;
+  const double* __restrict__ fp;
+  const double* __restrict__ dp;
+  double2* __restrict__ eo;
+  struct Buf {
+    double2 p02;
+    double p1, f, d;
+  };
+  __device__ __forceinline__ SrcFresh(const LklArrays& A, uint64_t wave_base, uint64_t pos_base)
+      : g02(A.gl02_il + wave_base), g1(A.gl1_il + wave_base), fp(A.freq_il + pos_base),
+        dp(A.pos_il + pos_base), eo(A.e_out + wave_base) {}
+  __device__ __forceinline__ Buf load(uint64_t t) const {
+    return Buf{g02[t * 64], g1[t * 64], fp[t * 64], dp[t * 64]};
+  }
+  __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& e0, double& e1,
+                                      double& d) const {
+    // calc_HWE (gen_func.cpp:938-957) for F = 0 and F = 1, as in k_fast_emission
+    const double maf = b.f, om = 1 - maf;
+    const double bb = om * maf;
+    const double h00 = om * om, h02 = maf * maf;
+    e0 = fma(b.p02.x, h00, fma(b.p1, 2 * bb, b.p02.y * h02));
+    e1 = fma(b.p02.x, h00 + bb, b.p02.y * (h02 + bb));
+    d = b.d;
+    eo[t * 64] = double2{e0, e1};  // sites past T never get here
+  }
+};
+
 // The main loop of one wave for the finite-difference pattern.  Per site and lane:
 // one exp (a degree-7 polynomial when alpha * d_max <= 2^-6: SMALL), the products shared
 // by all points, 12 instructions per F-probe and 20 per alpha-probe; one exponent (point
 // 0's) rescales all points, which are perturbations of each other.
-template <int NF, int NA, bool SMALL, bool EMIT>
-__device__ __forceinline__ void lkl_run_fd(const double2* __restrict__ ep,
-                                           const double* __restrict__ dp, uint64_t T,
-                                           const GroupDesc& G, Op (&R)[MAXP], EmitPtrs emit,
-                                           uint64_t wave, int lane) {
+template <int NF, int NA, bool SMALL, bool EMIT, typename Src>
+__device__ __forceinline__ void lkl_run_fd(const Src& src, uint64_t T, const GroupDesc& G,
+                                           Op (&R)[MAXP], EmitPtrs emit, uint64_t wave,
+                                           int lane) {
   static_assert(NB * UG == CK && RENORM == CK, "checkpoints are stored right after a rescale");
   constexpr int NPT = 1 + NF + NA;
   const uint64_t nblk = T / CK;
@@ -216,23 +278,19 @@ __device__ __forceinline__ void lkl_run_fd(const double2* __restrict__ ep,
   // arrays carry one group of slack at the end, so neither the prologue nor the refills
   // need bound checks (values read past T are never used); sites past S are identity
   // operators (e = 1, d = 0).
-  double2 eb[NB][UG];
-  double db[NB][UG];
+  typename Src::Buf buf[NB][UG];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
 #pragma unroll
-    for (int u = 0; u < UG; ++u) {
-      const uint64_t t = (uint64_t)b * UG + u;
-      eb[b][u] = ep[t * 64];
-      db[b][u] = dp[t * 64];
-    }
+    for (int u = 0; u < UG; ++u) buf[b][u] = src.load((uint64_t)b * UG + u);
   }
   for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int u = 0; u < UG; ++u) {
-        const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
+        double e0, e1, d;
+        src.get(buf[b][u], t0 + (uint64_t)b * UG + u, e0, e1, d);
         double c0;
         if constexpr (SMALL) {
           // chromosome starts are stored as d = 1e30: c = 0 there (the polynomial of the
@@ -259,11 +317,7 @@ __device__ __forceinline__ void lkl_run_fd(const double2* __restrict__ ep,
         }
       }
 #pragma unroll
-      for (int u = 0; u < UG; ++u) {
-        const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
-        eb[b][u] = ep[t * 64];
-        db[b][u] = dp[t * 64];
-      }
+      for (int u = 0; u < UG; ++u) buf[b][u] = src.load(t0 + (uint64_t)(b + NB) * UG + u);
     }
     {  // rescale every point by point 0's exponent
       const double mx = fmax(fmax(R[0].a00, R[0].a01), fmax(R[0].a10, R[0].a11));
@@ -308,11 +362,11 @@ __device__ __forceinline__ void lkl_store_wave_op(Op r, int lane, double* __rest
 // One kernel per loop-body version (each gets its own register allocation); the host
 // sorts the groups of a round by mode and launches every version on its range
 // [g_begin, g_begin + gridDim.x / C).
-template <int NF, int NA, bool SMALL, bool EMIT>
+template <int NF, int NA, bool SMALL, bool EMIT, bool FRESH>
 __global__ void __launch_bounds__(64)
-k_fast_lkl_fd(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
-              uint32_t C, const GroupDesc* __restrict__ groups, uint32_t g_begin,
-              double* __restrict__ part, EmitPtrs emit) {
+k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
+              uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
+  static_assert(EMIT || !FRESH, "the fresh walk is the first round of an M-step");
   const uint32_t g = g_begin + blockIdx.x / C;
   const uint32_t c = blockIdx.x % C;
   const int lane = threadIdx.x;
@@ -321,9 +375,10 @@ k_fast_lkl_fd(const double2* __restrict__ e_il, const double* __restrict__ pos_i
   Op R[MAXP];
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) R[p] = Op{1.0, 0.0, 0.0, 1.0, 0};
-  const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
-  const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
-  lkl_run_fd<NF, NA, SMALL, EMIT>(ep, dp, T, G, R, emit, i * C + c, lane);
+  const uint64_t wave_base = ((i * C + c) * T) * 64 + lane;
+  const uint64_t pos_base = ((uint64_t)c * T) * 64 + lane;
+  using Src = std::conditional_t<FRESH, SrcFresh, SrcPlain>;
+  lkl_run_fd<NF, NA, SMALL, EMIT>(Src(arr, wave_base, pos_base), T, G, R, emit, i * C + c, lane);
   if constexpr (EMIT) {
     Op r0 = R[0];
     renorm(r0);
@@ -334,11 +389,10 @@ k_fast_lkl_fd(const double2* __restrict__ e_il, const double* __restrict__ pos_i
     lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
 }
 
-template <int NP_MAX>
+template <int NP_MAX, bool FRESH>
 __global__ void __launch_bounds__(64)
-k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
-                  uint32_t C, const GroupDesc* __restrict__ groups, uint32_t g_begin,
-                  double* __restrict__ part, EmitPtrs emit) {
+k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
+                  uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
   const uint32_t g = g_begin + blockIdx.x / C;
   const uint32_t c = blockIdx.x % C;
   const int lane = threadIdx.x;
@@ -357,25 +411,21 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
     R[p] = Op{1.0, 0.0, 0.0, 1.0, 0};
   }
 
-  const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
-  const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
-  double2 eb[NB][UG];
-  double db[NB][UG];
+  using Src = std::conditional_t<FRESH, SrcFresh, SrcPlain>;
+  const Src src(arr, ((i * C + c) * T) * 64 + lane, ((uint64_t)c * T) * 64 + lane);
+  typename Src::Buf buf[NB][UG];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
 #pragma unroll
-    for (int u = 0; u < UG; ++u) {
-      const uint64_t t = (uint64_t)b * UG + u;
-      eb[b][u] = ep[t * 64];
-      db[b][u] = dp[t * 64];
-    }
+    for (int u = 0; u < UG; ++u) buf[b][u] = src.load((uint64_t)b * UG + u);
   }
   for (uint64_t t0 = 0; t0 < T; t0 += NB * UG) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int u = 0; u < UG; ++u) {
-        const double e0 = eb[b][u].x, e1 = eb[b][u].y, d = db[b][u];
+        double e0, e1, d;
+        src.get(buf[b][u], t0 + (uint64_t)b * UG + u, e0, e1, d);
 #pragma unroll
         for (int p = 0; p < NP_MAX; ++p) {
           if (p < (int)np) {
@@ -386,11 +436,7 @@ k_fast_lkl_chunks(const double2* __restrict__ e_il, const double* __restrict__ p
         }
       }
 #pragma unroll
-      for (int u = 0; u < UG; ++u) {
-        const uint64_t t = t0 + (uint64_t)(b + NB) * UG + u;
-        eb[b][u] = ep[t * 64];
-        db[b][u] = dp[t * 64];
-      }
+      for (int u = 0; u < UG; ++u) buf[b][u] = src.load(t0 + (uint64_t)(b + NB) * UG + u);
     }
 #pragma unroll
     for (int p = 0; p < NP_MAX; ++p)
@@ -762,6 +808,71 @@ k_fast_pos_interleave(const double* __restrict__ pos, uint64_t S, uint64_t T, ui
     // as 1e30 (exp(-alpha 1e30) = 0 for every alpha >= 1e-15, and no inf*0 can arise)
     const double d = (s < S) ? pos[s] : 0.0;
     pos_il[k] = (d < 1e30) ? d : 1e30;
+  }
+}
+
+// freq[S] -> interleaved [C][T][64] for the fresh forward walk (padding: 0.5); flags an
+// allele frequency outside [0, 1] like calc_emission does (shared/HMM.cpp:145-146)
+__global__ void __launch_bounds__(256)
+k_fast_freq_interleave(const double* __restrict__ freq, uint64_t S, uint64_t T, uint32_t C,
+                       double* __restrict__ freq_il, int* __restrict__ flags) {
+  const uint64_t n = (uint64_t)C * T * 64;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t lane = k & 63, ct = k >> 6;
+    const uint64_t c = ct / T, t = ct % T;
+    const uint64_t s = (c * 64 + lane) * T + t;
+    double f = 0.5;
+    if (s < S) {
+      f = freq[s];
+      if (!(f >= 0 && f <= 1)) {
+        flags[FLAG_INVALID_MAF] = 1;
+        f = __builtin_nan("");
+      }
+    }
+    freq_il[k] = f;
+  }
+}
+
+// site-major linear GL [S][I][3] -> interleaved planes (p0, p2) and p1, layout of e_il;
+// padding sites get (1, 1, 1), which any frequency turns into the identity emission (1, 1).
+// tile = (c, t) x 64 lanes (sites T apart) x 32 individuals
+__global__ void __launch_bounds__(256)
+k_fast_gl_interleave(const double* __restrict__ gl_lin, uint64_t I, uint64_t S, uint64_t T,
+                     uint32_t C, double2* __restrict__ gl02_il, double* __restrict__ gl1_il) {
+  __shared__ double2 t02[32][65];
+  __shared__ double t1[32][65];
+  const uint64_t n_it = (I + 31) / 32;
+  const uint64_t ct = blockIdx.x / n_it;
+  const uint64_t i0 = (blockIdx.x % n_it) * 32;
+  const uint64_t c = ct / T, t = ct % T;
+  {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 individuals x 8
+    const uint64_t i = i0 + tx;
+    for (int ll = ty; ll < 64; ll += 8) {
+      const uint64_t s = (c * 64 + ll) * T + t;
+      double p0 = 1, p1 = 1, p2 = 1;
+      if (s < S && i < I) {
+        const double* g = gl_lin + (s * I + i) * 3;
+        p0 = g[0];
+        p1 = g[1];
+        p2 = g[2];
+      }
+      t02[tx][ll] = double2{p0, p2};
+      t1[tx][ll] = p1;
+    }
+  }
+  __syncthreads();
+  {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 lanes x 4
+    for (int ii = ty; ii < 32; ii += 4) {
+      const uint64_t i = i0 + ii;
+      if (i < I) {
+        const uint64_t o = ((i * C + c) * T + t) * 64 + tx;
+        gl02_il[o] = t02[ii][tx];
+        gl1_il[o] = t1[ii][tx];
+      }
+    }
   }
 }
 
@@ -1375,6 +1486,12 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.gl02_il, (cells + slack) * 2)) return false;
+  if (!dalloc(&fs.gl1_il, cells + slack)) return false;
+  if (!dalloc(&fs.freq_il, (size_t)fs.Spad + slack)) return false;
+  if (hipMemset(fs.gl02_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
+  if (hipMemset(fs.gl1_il + cells, 0, slack * sizeof(double)) != hipSuccess) return false;
+  if (hipMemset(fs.freq_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.post, cells)) return false;
   if (!dalloc(&fs.ckpt, cells / CK * 4 + 4 * 64)) return false;  // T is a multiple of CK; slack:
                                                                  // see lkl_run_fd
@@ -1385,7 +1502,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
 }
 
 void fast_destroy(FastState& fs) {
-  void* ptrs[] = {fs.e_il, fs.pos_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
+  void* ptrs[] = {fs.e_il, fs.pos_il, fs.gl02_il, fs.gl1_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
                   fs.grp_dev, fs.redo, fs.est_status, fs.est_state, fs.gl_lin};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1400,6 +1517,12 @@ bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* 
   fs.d_gl = d_gl;
   fs.d_pos = d_pos;
   fast_exp(st, d_gl, fs.gl_lin, fs.I * fs.S * 3);
+  {
+    const uint64_t n_it = (fs.I + 31) / 32;
+    hipLaunchKernelGGL(k_fast_gl_interleave, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)),
+                       dim3(256), 0, st, fs.gl_lin, fs.I, fs.S, fs.T, fs.C,
+                       reinterpret_cast<double2*>(fs.gl02_il), fs.gl1_il);
+  }
   hipLaunchKernelGGL(k_fast_pos_interleave, dim3(1024), dim3(256), 0, st, d_pos, fs.S, fs.T, fs.C,
                      fs.pos_il);
   // the largest finite distance decides when the objective kernel may use its
@@ -1414,11 +1537,22 @@ bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* 
   return hipGetLastError() == hipSuccess;
 }
 
-bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
+// After an allele-frequency update: the interleaved frequency table (and the MAF check);
+// the emissions themselves are refreshed either by fast_refresh_emissions or, for free, by
+// the next forward walk (fast_lkl_launch with fresh emissions).
+bool fast_refresh_freq_table(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
+  hipLaunchKernelGGL(k_fast_freq_interleave, dim3(1024), dim3(256), 0, st, d_freq, fs.S, fs.T, fs.C,
+                     fs.freq_il, d_flags);
+  fs.e_stale = true;
+  return hipGetLastError() == hipSuccess;
+}
+
+bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
   const uint64_t n_it = (fs.I + 31) / 32;
   const uint64_t blocks = (uint64_t)fs.C * fs.T * n_it;
   hipLaunchKernelGGL(k_fast_emission, dim3((unsigned)blocks), dim3(256), 0, st, fs.gl_lin, d_freq,
                      fs.I, fs.S, fs.T, fs.C, reinterpret_cast<double2*>(fs.e_il), d_flags);
+  fs.e_stale = false;
   return hipGetLastError() == hipSuccess;
 }
 
@@ -1515,25 +1649,32 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
   const uint32_t ng = fs.n_groups;
   if (ng == 0) return true;
   const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(fs.grp_dev);
-  const double2* e2 = reinterpret_cast<const double2*>(fs.e_il);
-  // first round of an M-step inside nghmm_iter_em: point 0 of every individual is the
-  // E-step's forward walk, whose lane operators and checkpoints it leaves behind
+  const LklArrays arr{reinterpret_cast<const double2*>(fs.e_il), fs.pos_il,
+                      reinterpret_cast<const double2*>(fs.gl02_il), fs.gl1_il, fs.freq_il,
+                      reinterpret_cast<double2*>(fs.e_il)};
+  // first round of an M-step inside nghmm_estep_mstep: point 0 of every individual is the
+  // E-step's forward walk, whose lane operators and checkpoints it leaves behind; if the
+  // emissions are stale (frequencies just updated) the same walk recomputes and stores them
   const EmitPtrs emit = emit_estep ? EmitPtrs{fs.lane_ops, reinterpret_cast<double2*>(fs.ckpt)}
                                    : EmitPtrs{nullptr, nullptr};
+  const bool fresh = emit_estep && fs.e_stale;
+  if (fs.e_stale && !fresh) return false;  // the caller refreshes the emissions first
   for (const auto& r : fs.mode_ranges) {
     const dim3 grid(r.count * fs.C), block(64);
     switch (r.mode) {
-#define FD_LAUNCH(NF, NA, SM, EM)                                                             \
-  hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM>), grid, block, 0, st, e2, fs.pos_il, fs.T,  \
-                     fs.C, dg, r.begin, fs.part, emit)
+#define FD_LAUNCH(NF, NA, SM, EM, FR)                                                          \
+  hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR>), grid, block, 0, st, arr, fs.T, fs.C, \
+                     dg, r.begin, fs.part, emit)
 #define FD_CASE(NF, NA)                                     \
   case fd_mode(NF, NA, false):                              \
-    if (emit_estep) FD_LAUNCH(NF, NA, false, true);         \
-    else FD_LAUNCH(NF, NA, false, false);                   \
+    if (fresh) FD_LAUNCH(NF, NA, false, true, true);        \
+    else if (emit_estep) FD_LAUNCH(NF, NA, false, true, false); \
+    else FD_LAUNCH(NF, NA, false, false, false);            \
     break;                                                  \
   case fd_mode(NF, NA, true):                               \
-    if (emit_estep) FD_LAUNCH(NF, NA, true, true);          \
-    else FD_LAUNCH(NF, NA, true, false);                    \
+    if (fresh) FD_LAUNCH(NF, NA, true, true, true);         \
+    else if (emit_estep) FD_LAUNCH(NF, NA, true, true, false); \
+    else FD_LAUNCH(NF, NA, true, false, false);             \
     break;
       FD_CASE(2, 2)
       FD_CASE(1, 2)
@@ -1544,10 +1685,15 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
 #undef FD_CASE
 #undef FD_LAUNCH
       default:
-        hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP>), grid, block, 0, st, e2, fs.pos_il, fs.T, fs.C,
-                           dg, r.begin, fs.part, emit);
+        if (fresh)
+          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, true>), grid, block, 0, st, arr, fs.T, fs.C,
+                             dg, r.begin, fs.part, emit);
+        else
+          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, false>), grid, block, 0, st, arr, fs.T, fs.C,
+                             dg, r.begin, fs.part, emit);
     }
   }
+  if (fresh) fs.e_stale = false;
   hipLaunchKernelGGL(k_fast_lkl_finish, dim3((ng * MAXP + 63) / 64), dim3(64), 0, st, dg, ng, fs.C,
                      fs.part, d_lkl, d_flags);
   return hipGetLastError() == hipSuccess;

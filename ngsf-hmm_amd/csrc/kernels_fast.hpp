@@ -20,6 +20,10 @@ struct FastState {
   double* gl_lin = nullptr;       // exp(GL), site-major [S][I][3] (emission refresh, est_maf)
   double* e_il = nullptr;         // linear emissions, interleaved [I][C][T][64] x double2
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
+  double* gl02_il = nullptr;      // linear GL (p0, p2), interleaved like e_il
+  double* gl1_il = nullptr;       // linear GL p1, interleaved [I][C][T][64]
+  double* freq_il = nullptr;      // allele frequencies, interleaved [C][T][64]
+  bool e_stale = true;            // e_il older than freq_il (refreshed lazily)
   double* post = nullptr;         // posteriors, tile-major [C][T][I][64] (site (c*64+l)*T + t)
   double* ckpt = nullptr;         // forward checkpoints [I][C][T/8][2][64] x double2
   double* lane_ops = nullptr;     // per-lane chunk operators [I][J][5]
@@ -45,8 +49,10 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S);
 void fast_destroy(FastState& fs);
 // (re)build the interleaved distance table; remembers the GL / distance pointers
 bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* d_pos);
+// after a frequency update: interleaved frequency table + MAF check; marks e_il stale
+bool fast_refresh_freq_table(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags);
 // linear-space emissions of every cell from freq, into the interleaved layout
-bool fast_refresh_site_tables(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags);
+bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags);
 // objective for host-side points: prepare() groups them by individual and uploads
 // the descriptors, launch() runs the two kernels; d_lkl (device) receives the values
 // in point order

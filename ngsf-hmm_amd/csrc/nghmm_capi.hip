@@ -178,6 +178,8 @@ int ensure_tmp(nghmm_t* h) {
   return dev_alloc(&h->d_tmp, h->S * h->I * 2);
 }
 
+int ensure_emissions(nghmm_t* h);
+
 // site-major posteriors [S][I] in d_marg (fast mode: converted from the tile-major layout)
 int ensure_marg(nghmm_t* h) {
   if (h->mode != NGHMM_MODE_FAST || h->marg_valid) return NGHMM_OK;
@@ -195,6 +197,7 @@ int ensure_marg(nghmm_t* h) {
 int fast_estep_impl(nghmm_t* h, double* ind_lkl, bool have_walk) {
   int rc;
   if ((rc = clear_flags(h))) return rc;
+  if (!have_walk && (rc = ensure_emissions(h))) return rc;
   tic(h);
   if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_flags, have_walk))
     return NGHMM_ERR_HIP;
@@ -231,6 +234,7 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     // round of an M-step); out: whether every individual was in the batch, i.e. it was left
     const bool emit = emit_estep && *emit_estep && fast_lkl_covers_everyone(h->fast);
     if (emit_estep) *emit_estep = emit;
+    if (!emit && (rc = ensure_emissions(h))) return rc;  // else the walk refreshes them itself
     tic(h);  // after the descriptor upload: the timed span is the kernels
     if (!fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags, emit)) {
       set_error("fast_lkl_launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -254,18 +258,36 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
   return check_flags(h);
 }
 
+// Emissions from the current frequencies (calc_emission, shared/HMM.cpp:144-154).  Fast
+// mode checks the frequencies and rebuilds its interleaved frequency table now, but leaves
+// the 16 B per site and individual of e_il to whoever reads them next: the first forward
+// walk of the next EM iteration recomputes them on its way (fast_lkl_launch), anything
+// else calls ensure_emissions.
 int emission_impl(nghmm_t* h) {
   int rc;
   if ((rc = clear_flags(h))) return rc;
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
-    if (!fast_refresh_site_tables(h->fast, h->stream, h->d_freq, h->d_flags)) return NGHMM_ERR_HIP;
+    if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags)) return NGHMM_ERR_HIP;
+    if (std::getenv("NGHMM_EAGER_EMISSION") &&
+        !fast_refresh_emissions(h->fast, h->stream, h->d_freq, h->d_flags))
+      return NGHMM_ERR_HIP;
   } else {
     launch_emission_exact(h->stream, h->d_gl, h->d_freq, h->d_eprob, h->S, h->I, h->d_flags);
   }
   if ((rc = toc(h, SLOT_EMISSION, false))) return rc;
   HIP_TRY(hipGetLastError());
   return check_flags(h);
+}
+
+int ensure_emissions(nghmm_t* h) {
+  if (h->mode != NGHMM_MODE_FAST || !h->fast.e_stale) return NGHMM_OK;
+  int rc;
+  tic(h);
+  if (!fast_refresh_emissions(h->fast, h->stream, h->d_freq, h->d_flags)) return NGHMM_ERR_HIP;
+  if ((rc = toc(h, SLOT_EMISSION, true))) return rc;
+  HIP_TRY(hipGetLastError());
+  return NGHMM_OK;
 }
 
 }  // namespace
@@ -692,6 +714,7 @@ int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
   if ((rc = use_device(h))) return rc;
   if ((rc = ensure_tmp(h))) return rc;
   if (h->mode == NGHMM_MODE_FAST) {
+    if ((rc = ensure_emissions(h))) return rc;
     if (!fast_export_emissions(h->fast, h->stream, h->d_tmp)) return NGHMM_ERR_HIP;
   } else {
     launch_transpose_pairs_f64(h->stream, h->d_eprob, h->d_tmp, h->S, h->I);
