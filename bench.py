@@ -41,54 +41,50 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s me
 
 LIMITER_NOTES = {
     "est_maf": "FP64-VALU-issue bound, not HBM bound: the reference's est_maf makes ~100 passes "
-               "per site; ~20 of them are evaluated over in-register data, the rest on a checked "
+               "per site; ~21 of them are evaluated over in-register data, the rest on a checked "
                "Chebyshev interpolant of the per-pass sums (DESIGN.md section 4)",
-    "lkl_batch": "objective of the L-BFGS-B M-step: one 16 B emission pair per site and individual "
-                 "per round; FP64-VALU issue is saturated (~37% per wave x 3 waves per SIMD)",
-    "forward": "E-step: operators, boundary vectors, forward odds, backward posteriors, "
-               "de-interleave (five launches, timed together)",
+    "lkl_batch": "objective rounds of the L-BFGS-B M-step.  Round 1 of an iteration is also the "
+                 "E-step's forward walk and the emission refresh (24 B GL read, 16 B emissions + "
+                 "4 B checkpoints written per site and individual: HBM-bound, ~5.5 TB/s); later "
+                 "rounds read 16 B per site and still-active individual and are FP64-VALU-issue "
+                 "bound (~92 instructions per site for 5 probe points)",
+    "forward": "E-step after the shared forward walk: boundary vectors + backward sweep with "
+               "block-wise forward recomputation (16 B emissions + 4 B checkpoints read, 8 B "
+               "posteriors written)",
 }
 
-# kernels behind each timed family (names as profiles/summarize_pmc.py shortens them)
-_KERNELS_OF = {"lkl_batch": ["k_fast_lkl_chunks", "k_fast_lkl_finish"],
-               "est_maf": ["k_fast_estmaf<16, 64>", "k_fast_estmaf_interp", "k_fast_estmaf_stream"],
-               "emission": ["k_fast_emission"],
-               "forward": ["k_fast_chunk_ops", "k_fast_bounds", "k_fast_fwd_odds", "k_fast_bwd_post",
-                           "k_fast_deinterleave"]}
 
-
-def pmc_traffic(family, args, I, S, ind_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction).
-    Only valid for the workload it was collected on (c3, fast mode); else None."""
-    if args.workload != "c3" or args.mode != "fast" or family not in _KERNELS_OF:
+def pmc_traffic(family, args, I, S, C, rounds, ind_rounds, K):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC
+    passes (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950
+    correction).  Only valid for the workload it was collected on (c3, fast mode); else None.
+    lkl_batch: the pass holds other iterations than the timed ones (more rounds early in a
+    run), so its bytes are re-weighted: measured bytes of a fresh first round x K iterations
+    + measured bytes per individual of a later round x the timed individual-rounds."""
+    if args.workload != "c3" or args.mode != "fast":
         return None
     path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if not os.path.exists(path):
         return None
     summ = json.load(open(path))
-    if family == "lkl_batch":
-        d = summ.get("k_fast_lkl_chunks")
-        if not d or "hbm_bytes_per_launch" not in d:
-            return None
-        t = d["hbm_bytes_per_launch"]
-        if d.get("avg_individuals_per_launch"):
-            t *= ind_per_launch / d["avg_individuals_per_launch"]   # launches differ in width
-        return t
-    # a family that is several kernels per call: bytes of all of them per EM iteration of
-    # the PMC pass (k_fast_chunk_ops runs exactly once per iteration)
-    iters = (summ.get("k_fast_chunk_ops") or {}).get("launches_fetch_pass")
-    if not iters:
+    if family != "lkl_batch":
+        f = summ.get("families", {}).get(family)
+        return f["hbm_bytes_per_em_iteration"] if f and f.get("hbm_bytes_per_em_iteration") else None
+    fresh_b = fresh_n = plain_b = plain_ind = 0.0
+    for k, d in summ.items():
+        if not k.startswith(("k_fast_lkl_fd<", "k_fast_lkl_chunks<")) or "hbm_bytes_per_launch" not in d:
+            continue
+        n = d["launches_fetch_pass"]
+        if k.endswith("true>"):        # <..., EMIT, FRESH = true>: a first round, all individuals
+            fresh_b += d["hbm_bytes_per_launch"] * n
+            fresh_n += n * (d["avg_grid_threads"] / 64.0 / C) / I
+        elif not k.endswith("true, false>"):   # later rounds
+            plain_b += d["hbm_bytes_per_launch"] * n
+            plain_ind += n * d["avg_grid_threads"] / 64.0 / C
+    if not fresh_n or not plain_ind or not rounds:
         return None
-    t = 0.0
-    for k in _KERNELS_OF[family]:
-        d = summ.get(k)
-        if d and "hbm_bytes_per_launch" in d:
-            n = d["launches_fetch_pass"]
-            if k == "k_fast_emission":
-                n = iters            # the pass also holds the one-off initial refresh
-            t += d["hbm_bytes_per_launch"] * n / iters
-    return t or None
+    total = fresh_b / fresh_n * K + plain_b / plain_ind * max(ind_rounds - I * K, 0)
+    return total / rounds
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
@@ -218,20 +214,24 @@ def main():
         K = max(args.steps, 1)
         units = float(I) * S * world * K
         # dominant kernel family by measured time, and its algorithmic traffic per launch
-        # (DESIGN.md section 5): objective = 16 B emission pair per site per individual
-        # still being optimised; est_maf = 24 B GL + 8 B posterior per site-individual;
-        # E-step (fast mode, 4 sweeps + de-interleave) = 88 B per site-individual
+        # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
+        # fast mode: the first objective round of an iteration (all I individuals) reads the
+        # 24 B GL and writes 16 B emissions + 4 B checkpoints; later rounds read 16 B per
+        # still-active individual; the E-step then reads 16 + 4 B and writes 8 B
+        fast = args.mode == "fast"
         algo = {
-            "lkl_batch": 16.0 * S * ind_rounds / max(launches["lkl_batch"], 1),
+            "lkl_batch": ((44.0 * S * I * K + 16.0 * S * max(ind_rounds - I * K, 0)) if fast
+                          else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
             "est_maf": 32.0 * S * I * world,
-            "forward": (88.0 if args.mode == "fast" else 40.0) * S * I,
+            "forward": (28.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
-            "emission": (40.0) * S * I,
+            "emission": (8.0 * S if fast else 40.0 * S * I),
         }
         dom = max(fam, key=lambda k: fam[k])
         avg_ms = fam[dom] / max(launches[dom], 1)
         achieved = algo[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = pmc_traffic(dom, args, I, S, ind_rounds / max(launches["lkl_batch"], 1))
+        traffic = pmc_traffic(dom, args, I, S, em.hmm.layout()[0], launches["lkl_batch"],
+                              ind_rounds, K)
         # every kernel family against the HBM roof (the dominant one is repeated above)
         fam_roof = {}
         for k in fam:

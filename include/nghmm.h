@@ -170,6 +170,10 @@ int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_sites, double* d
 /* install the gathered freq[S] (device pointer) and refresh the own emissions */
 int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all);
 
+/* Fast-mode layout of the site axis: every individual's sites are cut into 64 * waves
+ * runs of sites_per_lane sites; 0, 0 in exact mode.  Diagnostic. */
+int nghmm_fast_layout(nghmm_t* h, uint32_t* waves_per_individual, uint64_t* sites_per_lane);
+
 /* Device pointer + stream access for host-side plumbing (torch tensors, events). */
 void* nghmm_stream(nghmm_t* h);
 int nghmm_synchronize(nghmm_t* h);

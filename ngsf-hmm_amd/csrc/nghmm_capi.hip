@@ -817,6 +817,14 @@ int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all) {
   return emission_impl(h);
 }
 
+int nghmm_fast_layout(nghmm_t* h, uint32_t* waves_per_individual, uint64_t* sites_per_lane) {
+  if (!h) return NGHMM_ERR_ARG;
+  const bool fast = h->mode == NGHMM_MODE_FAST;
+  if (waves_per_individual) *waves_per_individual = fast ? h->fast.C : 0;
+  if (sites_per_lane) *sites_per_lane = fast ? h->fast.T : 0;
+  return NGHMM_OK;
+}
+
 void* nghmm_stream(nghmm_t* h) { return h ? (void*)h->stream : nullptr; }
 
 int nghmm_synchronize(nghmm_t* h) {

@@ -93,6 +93,7 @@ def load_library():
         "nghmm_pack_posteriors_dev": (i32, [vp, u64, u64, vp]),
         "nghmm_mstep_freq_sites_dev": (i32, [vp, vp, vp]),
         "nghmm_set_freq_dev": (i32, [vp, vp]),
+        "nghmm_fast_layout": (i32, [vp, C.POINTER(u32), C.POINTER(u64)]),
         "nghmm_stream": (vp, [vp]),
         "nghmm_synchronize": (i32, [vp]),
         "nghmm_kernel_ms": (i32, [vp, i32, dp, C.POINTER(u32)]),
@@ -117,7 +118,8 @@ EXPORTED_SYMBOLS = [
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
     "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_load_gl_site_shard_dev",
     "nghmm_pack_posteriors_dev",
-    "nghmm_mstep_freq_sites_dev", "nghmm_set_freq_dev", "nghmm_stream", "nghmm_synchronize",
+    "nghmm_mstep_freq_sites_dev", "nghmm_set_freq_dev", "nghmm_fast_layout", "nghmm_stream",
+    "nghmm_synchronize",
     "nghmm_kernel_ms",
 ]
 
@@ -274,6 +276,13 @@ class NgsFHMM:
 
     def mstep_freq(self, freq_est=1):
         self._check(self.lib.nghmm_mstep_freq(self._h, int(freq_est)))
+
+    def layout(self):
+        """(waves per individual, sites per lane) of the fast-mode site layout; (0, 0) in
+        exact mode."""
+        c, t = C.c_uint32(0), C.c_uint64(0)
+        self._check(self.lib.nghmm_fast_layout(self._h, C.byref(c), C.byref(t)))
+        return int(c.value), int(t.value)
 
     def estep_mstep(self, indF_fixed=False, alpha_fixed=False, after_estep=None):
         """E-step and indF/alpha M-step of one iteration in one call (nghmm_estep_mstep);

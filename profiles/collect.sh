@@ -46,9 +46,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3
   > /dev/null 2> $OUT/write.err
 filter "$(find $OUT/write -name '*counter_collection.csv' | head -1)" $OUT/pmc/write_size.csv
 echo "write pass done"
-C=$(python3 -c "print((8192 + 999) // 1000)")
 python3 profiles/summarize_pmc.py $OUT/pmc/sq_counters.csv $OUT/pmc/fetch_size.csv \
-  $OUT/pmc/write_size.csv $OUT/${TAG}_pmc_summary.json $C > $OUT/summary.txt
+  $OUT/pmc/write_size.csv $OUT/${TAG}_pmc_summary.json > $OUT/summary.txt
 # raw rocprof trees are large: keep only the summaries
 rm -rf $OUT/trace $OUT/sq $OUT/fetch $OUT/write
 ls -la $OUT $OUT/pmc

@@ -1,31 +1,41 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes (one directory per pass, CSV output) into a small JSON
-that bench.py reads for the `roofline.traffic` field.
+"""Summarise rocprofv3 --pmc passes (one CSV per pass, filtered to this library's kernels)
+into a small JSON that bench.py reads for the `roofline.traffic` field.
 
-HBM bytes per launch follow MI355X_MICROARCH.md section HBM / cdna_hip_programming.md
-section 7: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the
-bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled for kernels whose
-dominant loads are 16 B per lane (the interleaved emission stream); WRITE_SIZE is exact.
-Collected in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+HBM bytes follow MI355X_MICROARCH.md section HBM / cdna_hip_programming.md section 7:
+FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a
+wide (16 B/lane) coalesced streaming read, so it is doubled for kernels whose dominant
+loads are 16 B per lane (the interleaved emission / genotype-likelihood streams);
+WRITE_SIZE is exact.  Collected in separate passes (FETCH_SIZE and WRITE_SIZE do not fit
+one pass).
 
-usage: summarize_pmc.py <sq.csv> <fetch.csv> <write.csv> <out.json> [C]
+Per kernel (template arguments kept) and per timed FAMILY of bench.py (lkl_batch = every
+k_fast_lkl_* kernel, forward = the E-step's kernels, est_maf, emission): bytes per launch
+and, for families, bytes per EM iteration of the pass and per objective round.
+
+usage: summarize_pmc.py <sq.csv> <fetch.csv> <write.csv> <out.json>
 """
 import collections
 import csv
 import json
+import re
 import sys
+
+FAMILIES = {
+    "lkl_batch": ("k_fast_lkl_fd", "k_fast_lkl_chunks", "k_fast_lkl_finish"),
+    "forward": ("k_fast_chunk_ops", "k_fast_bounds", "k_fast_bwd_recompute"),
+    "est_maf": ("k_fast_estmaf",),
+    "emission": ("k_fast_emission", "k_fast_freq_interleave"),
+}
 
 
 def short(name):
-    n = name.split("::")[-1].split("(")[0]
-    if "GroupDesc const*, double" in name or "k_fast_lkl_chunks" in name:
-        return "k_fast_lkl_chunks"
-    if "k_fast_lkl_finish" in name or "GroupDesc const*, unsign" in name:
-        return "k_fast_lkl_finish"
-    return n.strip()
+    """'void nghmm::(anonymous namespace)::k_x<2, 2, true>(args...)' -> 'k_x<2, 2, true>'"""
+    m = re.search(r"(k_\w+(?:<[^>(]*>)?)\(", name)
+    return m.group(1) if m else name
 
 
-def per_kernel(path, counter=None):
+def per_kernel(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(set)
     grid = collections.defaultdict(float)
@@ -42,7 +52,6 @@ def per_kernel(path, counter=None):
 
 def main():
     sq, fetch, write, out = sys.argv[1:5]
-    C = int(sys.argv[5]) if len(sys.argv) > 5 else 8
     a_sq, n_sq, _ = per_kernel(sq)
     a_f, n_f, grid_f = per_kernel(fetch)
     a_w, n_w, _ = per_kernel(write)
@@ -70,9 +79,22 @@ def main():
         if "fetch_bytes_corrected_per_launch" in d:
             d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected_per_launch"] + d.get(
                 "write_bytes_per_launch", 0.0)
-        if k == "k_fast_lkl_chunks" and "avg_grid_threads" in d:
-            d["avg_individuals_per_launch"] = d["avg_grid_threads"] / 64.0 / C
         res[k] = d
+    # the backward sweep runs exactly once per EM iteration of the pass
+    iters = res.get("k_fast_bwd_recompute", {}).get("launches_fetch_pass", 0)
+    rounds = res.get("k_fast_lkl_finish", {}).get("launches_fetch_pass", 0)
+    fam = {}
+    for name, prefixes in FAMILIES.items():
+        tot = 0.0
+        for k, d in res.items():
+            if k.split("<")[0] in prefixes and "hbm_bytes_per_launch" in d:
+                tot += d["hbm_bytes_per_launch"] * d["launches_fetch_pass"]
+        fam[name] = {"hbm_bytes_in_pass": tot, "em_iterations_in_pass": iters,
+                     "hbm_bytes_per_em_iteration": tot / iters if iters else None}
+    if rounds:
+        fam["lkl_batch"]["objective_rounds_in_pass"] = rounds
+        fam["lkl_batch"]["hbm_bytes_per_round"] = fam["lkl_batch"]["hbm_bytes_in_pass"] / rounds
+    res["families"] = fam
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, d in res.items():
         print(k, {kk: (f"{vv:.4g}" if isinstance(vv, float) else vv) for kk, vv in d.items()})
