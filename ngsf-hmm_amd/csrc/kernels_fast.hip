@@ -546,24 +546,54 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
 }
 
 // phase B: per individual, the vector entering every lane-chunk from the left
-// (forward) and from the right (backward), the log-likelihood and the Fw/Bw check
+// (forward) and from the right (backward), the log-likelihood and the Fw/Bw check.
+// One wave per individual: lane l owns the C consecutive lane-chunks l*C .. l*C + C-1,
+// multiplies their operators, an ordered shuffle scan over the 64 lanes gives every lane
+// the product of everything to its left (right), and the lane then walks its own chunks.
+__device__ __forceinline__ Op op_shfl_up(const Op& m, int off) {
+  Op o;
+  o.a00 = __shfl_up(m.a00, off);
+  o.a01 = __shfl_up(m.a01, off);
+  o.a10 = __shfl_up(m.a10, off);
+  o.a11 = __shfl_up(m.a11, off);
+  o.ex = __shfl_up(m.ex, off);
+  return o;
+}
+
+__device__ __forceinline__ Op op_load(const double* __restrict__ m) {
+  return Op{m[0], m[1], m[2], m[3], (int)m[4]};
+}
+
 __global__ void __launch_bounds__(64)
-k_fast_bounds(const double* __restrict__ lane_ops, uint64_t I, uint64_t J,
+k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
               const double* __restrict__ indF, double* __restrict__ bound,
               double* __restrict__ ind_lkl, int* __restrict__ flags) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= I) return;
+  const uint64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
   const double f = indF[i];
   const double q0 = 1 - f, q1 = f;
   const double LN2 = 0.6931471805599453094;
-  const double* ops = lane_ops + i * J * 5;
-  double* bd = bound + i * J * 4;
-  double v0 = q0, v1 = q1;
-  int ex = 0;
-  for (uint64_t j = 0; j < J; ++j) {
-    bd[j * 4 + 0] = v0;
-    bd[j * 4 + 1] = v1;
-    const double* m = ops + j * 5;
+  const double* ops = lane_ops + (i * J + (uint64_t)lane * C) * 5;
+  double* bd = bound + (i * J + (uint64_t)lane * C) * 4;
+
+  Op L{1.0, 0.0, 0.0, 1.0, 0};
+  for (uint32_t k = 0; k < C; ++k) L = op_mul(L, op_load(ops + (uint64_t)k * 5));
+
+  // forward: product of the lanes to the left
+  Op P = L;
+  for (int off = 1; off < 64; off <<= 1) {
+    const Op o = op_shfl_up(P, off);
+    if (lane >= off) P = op_mul(o, P);
+  }
+  Op E = op_shfl_up(P, 1);
+  if (lane == 0) E = Op{1.0, 0.0, 0.0, 1.0, 0};
+  double v0 = fma(q0, E.a00, q1 * E.a10), v1 = fma(q0, E.a01, q1 * E.a11);
+  int ex = E.ex;
+  renorm2(v0, v1, ex);
+  for (uint32_t k = 0; k < C; ++k) {
+    bd[(uint64_t)k * 4 + 0] = v0;
+    bd[(uint64_t)k * 4 + 1] = v1;
+    const double* m = ops + (uint64_t)k * 5;
     const double n0 = fma(v0, m[0], v1 * m[2]);
     const double n1 = fma(v0, m[1], v1 * m[3]);
     v0 = n0;
@@ -571,14 +601,24 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t I, uint64_t J,
     ex += (int)m[4];
     renorm2(v0, v1, ex);
   }
-  const double lf = log(v0 + v1) + (double)ex * LN2;
-  double w0 = 1, w1 = 1;
-  int exb = 0;
-  for (uint64_t jj = J; jj > 0; --jj) {
-    const uint64_t j = jj - 1;
-    bd[j * 4 + 2] = w0;
-    bd[j * 4 + 3] = w1;
-    const double* m = ops + j * 5;
+  const double lf = __shfl(log(v0 + v1) + (double)ex * LN2, 63);  // lane 63 has walked it all
+
+  // backward: product of the lanes to the right
+  Op Sx = L;
+  for (int off = 1; off < 64; off <<= 1) {
+    const Op o = op_shfl_down(Sx, off);
+    if (lane + off < 64) Sx = op_mul(Sx, o);
+  }
+  Op X = op_shfl_down(Sx, 1);
+  if (lane == 63) X = Op{1.0, 0.0, 0.0, 1.0, 0};
+  double w0 = X.a00 + X.a01, w1 = X.a10 + X.a11;
+  int exb = X.ex;
+  renorm2(w0, w1, exb);
+  for (uint32_t kk = C; kk > 0; --kk) {
+    const uint32_t k = kk - 1;
+    bd[(uint64_t)k * 4 + 2] = w0;
+    bd[(uint64_t)k * 4 + 3] = w1;
+    const double* m = ops + (uint64_t)k * 5;
     const double n0 = fma(m[0], w0, m[1] * w1);
     const double n1 = fma(m[2], w0, m[3] * w1);
     w0 = n0;
@@ -586,10 +626,12 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t I, uint64_t J,
     exb += (int)m[4];
     renorm2(w0, w1, exb);
   }
-  const double lb = log(fma(q0, w0, q1 * w1)) + (double)exb * LN2;
-  ind_lkl[i] = lf;
-  if (lf != lf || lb != lb) flags[FLAG_INVALID_LKL] = 1;
-  if (fabs(lf - lb) > 0.001) flags[FLAG_FW_BW] = 1;  // EM.cpp:167
+  const double lb = __shfl(log(fma(q0, w0, q1 * w1)) + (double)exb * LN2, 0);
+  if (lane == 0) {
+    ind_lkl[i] = lf;
+    if (lf != lf || lb != lb) flags[FLAG_INVALID_LKL] = 1;
+    if (fabs(lf - lb) > 0.001) flags[FLAG_FW_BW] = 1;  // EM.cpp:167
+  }
 }
 
 // phase C: backward sweep with block-wise forward recomputation.  Posterior of the IBD
@@ -1713,8 +1755,8 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
   if (!have_forward_walk)
     hipLaunchKernelGGL(k_fast_chunk_ops, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
                        d_indF, d_alpha, EmitPtrs{fs.lane_ops, ck});
-  hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)((fs.I + 63) / 64)), dim3(64), 0, st,
-                     fs.lane_ops, fs.I, fs.J, d_indF, fs.bound, d_ind_lkl, d_flags);
+  hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J, fs.C,
+                     d_indF, fs.bound, d_ind_lkl, d_flags);
   hipLaunchKernelGGL(k_fast_bwd_recompute, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
                      fs.S, fs.I, d_indF, d_alpha, fs.bound, ck, fs.post, d_flags);
   return hipGetLastError() == hipSuccess;
