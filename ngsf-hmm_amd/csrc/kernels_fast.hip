@@ -1073,29 +1073,40 @@ __device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
 // same stopping rule, at ~1/60 of the cost per pass.  A pass whose stopping decision
 // would be closer than 1e-9 (relative) to the threshold, or whose r leaves the
 // interval, goes back to exact evaluation (one more build is allowed per site).
-constexpr int EN = 16;                  // Chebyshev nodes per interval
+#ifndef NGHMM_EST_EN
+#define NGHMM_EST_EN 16
+#endif
+constexpr int EN = NGHMM_EST_EN;        // Chebyshev nodes per interval
 constexpr int EST_SCALARS = 8;          // num, den, pnum, pden, iters, mid, half, tF
 constexpr int EST_FIELDS = EST_SCALARS + 2 * EN;
 enum : uint8_t { EST_DONE = 0, EST_INTERP = 1, EST_EXACT = 2 };
 constexpr int EST_K0 = 4;               // exact passes before the first interval
 constexpr int EST_MIN_GAIN = 24;        // build only if about this many passes remain
-constexpr double EST_DMAX = 0.5;        // interval length <= EST_DMAX * r ahead ...
+#ifndef NGHMM_EST_DMAX
+#define NGHMM_EST_DMAX 0.5
+#endif
+#ifndef NGHMM_EST_MULT
+#define NGHMM_EST_MULT 32.0
+#endif
+constexpr double EST_DMAX = NGHMM_EST_DMAX;  // interval length <= EST_DMAX * r ahead ...
 constexpr double EST_BACK = 0.1;        // ... plus this fraction of it behind
-constexpr double EST_MULT = 32.0;       // ... and about this many current steps
+constexpr double EST_MULT = NGHMM_EST_MULT;  // ... and about this many current steps
 constexpr double EST_TOL = 1e-13;       // interpolant vs exact pass, relative
 constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back to exact
-// cos((2j+1) pi/32) and (-1)^j sin((2j+1) pi/32): first-kind Chebyshev nodes and their
-// barycentric weights
-__constant__ double kChebC[EN] = {
-    0.9951847266721969,  0.9569403357322088,  0.881921264348355,   0.773010453362737,
-    0.6343932841636455,  0.47139673682599764, 0.2902846772544624,  0.0980171403295606,
-    -0.0980171403295606, -0.2902846772544624, -0.47139673682599764, -0.6343932841636455,
-    -0.773010453362737,  -0.881921264348355,  -0.9569403357322088, -0.9951847266721969};
-__constant__ double kChebW[EN] = {
-    0.0980171403295606,  -0.2902846772544624, 0.47139673682599764, -0.6343932841636455,
-    0.773010453362737,   -0.881921264348355,  0.9569403357322088,  -0.9951847266721969,
-    0.9951847266721969,  -0.9569403357322088, 0.881921264348355,   -0.773010453362737,
-    0.6343932841636455,  -0.47139673682599764, 0.2902846772544624, -0.0980171403295606};
+// cos((2j+1) pi/(2 EN)) and (-1)^j sin((2j+1) pi/(2 EN)): first-kind Chebyshev nodes and
+// their barycentric weights
+#if NGHMM_EST_EN == 8
+__constant__ double kChebC[EN] = {0.9807852804032304, 0.8314696123025452, 0.5555702330196023, 0.19509032201612833, -0.1950903220161282, -0.555570233019602, -0.8314696123025453, -0.9807852804032304};
+__constant__ double kChebW[EN] = {0.19509032201612825, -0.5555702330196022, 0.8314696123025452, -0.9807852804032304, 0.9807852804032304, -0.8314696123025455, 0.5555702330196022, -0.1950903220161286};
+#elif NGHMM_EST_EN == 12
+__constant__ double kChebC[EN] = {0.9914448613738104, 0.9238795325112867, 0.7933533402912352, 0.6087614290087207, 0.38268343236508984, 0.1305261922200517, -0.1305261922200516, -0.3826834323650895, -0.6087614290087207, -0.793353340291235, -0.9238795325112867, -0.9914448613738104};
+__constant__ double kChebW[EN] = {0.13052619222005157, -0.3826834323650898, 0.6087614290087207, -0.7933533402912352, 0.9238795325112867, -0.9914448613738104, 0.9914448613738104, -0.9238795325112868, 0.7933533402912352, -0.6087614290087209, 0.3826834323650899, -0.130526192220052};
+#elif NGHMM_EST_EN == 16
+__constant__ double kChebC[EN] = {0.9951847266721969, 0.9569403357322088, 0.881921264348355, 0.773010453362737, 0.6343932841636455, 0.4713967368259978, 0.29028467725446233, 0.09801714032956077, -0.09801714032956065, -0.29028467725446216, -0.4713967368259977, -0.6343932841636454, -0.773010453362737, -0.8819212643483549, -0.9569403357322088, -0.9951847266721968};
+__constant__ double kChebW[EN] = {0.0980171403295606, -0.29028467725446233, 0.47139673682599764, -0.6343932841636455, 0.773010453362737, -0.8819212643483549, 0.9569403357322089, -0.9951847266721968, 0.9951847266721969, -0.9569403357322089, 0.881921264348355, -0.7730104533627371, 0.6343932841636455, -0.47139673682599786, 0.2902846772544624, -0.09801714032956083};
+#else
+#error "NGHMM_EST_EN must be 8, 12 or 16"
+#endif
 
 // W = BLOCK/64 waves per site, NI individuals per lane held in registers.  With
 //   A = (1-f)^2, b = (1-f) f, C = f^2
@@ -1309,8 +1320,9 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       continue;
     }
     if (check) {  // the pass after a build: exact sums in hand, compare the interpolant
-      const double t = r - fma(half, kChebC[lane & (EN - 1)], mid);
-      const double q = (lane < EN) ? kChebW[lane & (EN - 1)] / t : 0.0;
+      const int nj = lane < EN ? lane : 0;
+      const double t = r - fma(half, kChebC[nj], mid);
+      const double q = (lane < EN) ? kChebW[nj] / t : 0.0;
       const double Sq = wave_sum_uniform(q);
       const double bn = wave_sum_uniform(q * my_gn) / Sq, bd = wave_sum_uniform(q * my_gd) / Sq;
       interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -515,15 +516,27 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
     return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
 
+  // NGHMM_TIMING=1: host-side wall time of the phases of this call on stderr
+  const bool timing = std::getenv("NGHMM_TIMING") != nullptr;
+  double t_gather = 0, t_lkl = 0, t_estep = 0, t_scatter = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(now() - t0).count();
+  };
   BfgsBatch batch;
+  auto t0 = now();
   batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
+  t_gather += since(t0);
   std::vector<uint32_t> ind;
   std::vector<double> F, A, lkl;
   bool estep_pending = fuse_estep;
   while (!batch.done()) {
+    t0 = now();
     const size_t n = batch.gather(ind, F, A);
     lkl.resize(n);
+    t_gather += since(t0);
     bool emit = estep_pending;
+    t0 = now();
     if (n) {
       if ((rc = lkl_batch_impl(h, (uint32_t)n, ind.data(), F.data(), A.data(), lkl.data(), true,
                                &emit)))
@@ -531,12 +544,23 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
     } else {
       emit = false;
     }
+    t_lkl += since(t0);
     if (estep_pending) {
+      t0 = now();
       if ((rc = estep_then_hook(emit))) return rc;
       estep_pending = false;
+      t_estep += since(t0);
     }
+    t0 = now();
     batch.scatter(lkl.data());
+    t_scatter += since(t0);
   }
+  if (timing)
+    std::fprintf(stderr,
+                 "[nghmm timing] mstep: gather %.3f ms, lkl calls %.3f ms (kernels %.3f), "
+                 "estep call %.3f ms (kernels %.3f), scatter %.3f ms, rounds %u\n",
+                 t_gather, t_lkl, h->ms[SLOT_LKL], t_estep, h->ms[SLOT_FORWARD], t_scatter,
+                 batch.rounds());
   if (estep_pending && (rc = estep_then_hook(false))) return rc;
   batch.result(h->h_indF.data(), h->h_alpha.data());
   HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,

@@ -43,7 +43,8 @@ class MstepStats(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libnghmm.so")
+    # NGHMM_LIB: another build of the same library (kernel tuning experiments)
+    return os.environ.get("NGHMM_LIB") or os.path.join(_HERE, "libnghmm.so")
 
 
 def build_library(verbose=False):
