@@ -125,8 +125,10 @@ def cpu_baseline(pkg, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: an EM run is 10-100 iterations (parse_args.cpp:17-18) and the first three of
+    # a run are not typical (L-BFGS-B needs 18, 13, 6 objective rounds there, then 4-5)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     ap.add_argument("--n_ind", type=int, default=None)
