@@ -19,6 +19,18 @@ def write_inputs(tmp, d, gl_raw):
     with gzip.open(paths["glf_gz"], "wt") as fh:
         for s in range(S):
             fh.write("\t".join(repr(float(v)) for v in gl_raw[s].reshape(-1)) + "\n")
+    # BEAGLE-style: marker + two allele columns, then 3 normal-space likelihoods per
+    # individual (BASELINE.json configs[2] input; the reader takes the LAST 3*I columns,
+    # shared/read_data.cpp:84, and --lkl without --loglkl takes their log, :89).  The header
+    # has no numeric token, so split() returns 0 fields and the line is skipped
+    # (gen_func.cpp:390-417, read_data.cpp:64).
+    paths["beagle_gz"] = os.path.join(tmp, "sim.beagle.gz")
+    with gzip.open(paths["beagle_gz"], "wt") as fh:
+        fh.write("marker\tallele1\tallele2\t" +
+                 "\t".join(f"Ind{i}" for i in range(I) for _ in range(3)) + "\n")
+        for s in range(S):
+            fh.write(f"chr{int(d.chrom[s])}_{int(d.pos[s])}\t0\t1\t" +
+                     "\t".join(repr(float(v)) for v in np.exp(gl_raw[s]).reshape(-1)) + "\n")
     paths["glf_bin"] = os.path.join(tmp, "sim.glf")
     gl_raw.astype("<f8").tofile(paths["glf_bin"])
     paths["geno_gz"] = os.path.join(tmp, "sim.geno.gz")
