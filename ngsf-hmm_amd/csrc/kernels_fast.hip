@@ -1670,6 +1670,17 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     fs.mode_ranges.push_back({groups[k].mode, k, e - k});
     k = e;
   }
+  if (std::getenv("NGHMM_DEBUG_MODES")) {  // which loop-body versions this round uses
+    std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
+    for (const auto& r : fs.mode_ranges) {
+      if (r.mode)
+        std::fprintf(stderr, " %uF%uA%s x%u", (r.mode >> 2) & 3, r.mode & 3,
+                     (r.mode & FD_SMALL) ? "s" : "", r.count);
+      else
+        std::fprintf(stderr, " general x%u", r.count);
+    }
+    std::fprintf(stderr, "\n");
+  }
   const uint32_t ng = (uint32_t)groups.size();
   const size_t gbytes = (size_t)ng * sizeof(GroupDesc);
   if (gbytes > fs.grp_cap) {

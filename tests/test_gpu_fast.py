@@ -260,3 +260,63 @@ def test_fast_hook_exception_propagates(pkg, orc_libm, mid_sim):
     with pytest.raises(ValueError, match="from the hook"):
         a.estep_mstep(after_estep=boom)
     a.close()
+
+
+@pytest.mark.parametrize("alpha0", [0.01, 0.7, 9.99])
+@pytest.mark.parametrize("pattern", ["2F2A", "1F2A", "2F1A", "1F1A", "2F0A", "0F2A"])
+def test_fast_objective_kernel_variants(pkg, orc_libm, mid_sim, pattern, alpha0):
+    """One objective kernel exists per finite-difference pattern of shared/bfgs.cpp:22-43
+    (two-sided / one-sided / absent probes of F and of alpha), each in a version for
+    alpha * d_max <= 2^-6 (polynomial exp) and a general one.  Every one of them against the
+    oracle's forward log-likelihood at 1e-12, and their finite differences -- what the
+    optimizer consumes -- against the oracle's.  alpha0 = 0.01 takes the small-argument
+    versions on this data (d_max ~ 0.3 Mb), 0.7 and 9.99 the general ones; 9.99 + 2 eh > 10
+    is the one-sided pattern at the upper bound."""
+    d, gl = mid_sim
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission(); hmm.init_emission()
+    nf, na = int(pattern[0]), int(pattern[2])
+    F0 = 0.3
+    ehF = (1e-8 * (abs(F0) + 1)) ** 0.67
+    ehA = (1e-8 * (abs(alpha0) + 1)) ** 0.67
+    pts = [(F0, alpha0)]
+    pts += [(F0 + ehF, alpha0), (F0 - ehF, alpha0)][:nf] if nf == 2 else [(F0 + 2 * ehF, alpha0)][:nf]
+    pts += [(F0, alpha0 + ehA), (F0, alpha0 - ehA)][:na] if na == 2 else [(F0, alpha0 - 2 * ehA)][:na]
+    npt = len(pts)
+    ind = np.repeat(np.arange(d.n_ind), npt)
+    F = np.tile([p[0] for p in pts], d.n_ind)
+    A = np.tile([p[1] for p in pts], d.n_ind)
+    got = hmm.lkl(ind, F, A)
+    e = em.e_prob
+    want = np.array([-orc_libm.lkl([F[p], A[p]], e[ind[p]], d.pos_dist_mb) for p in range(len(ind))])
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    for k in range(1, npt):                       # every probe's difference from f(x)
+        np.testing.assert_allclose(got[k::npt] - got[0::npt], want[k::npt] - want[0::npt],
+                                   rtol=1e-4, atol=2e-8)
+    hmm.close()
+
+
+def test_fast_fused_walk_through_the_general_kernel(pkg, orc_libm):
+    """A data set with one very long finite distance (2000 Mb): the alpha probes' exp(-+ eh d)
+    shortcut does not hold there (|eh d| > 1e-3), so every group takes the general objective
+    kernel -- which must then also play the E-step's forward walk and refresh the emissions
+    (nghmm_estep_mstep after a frequency update)."""
+    d = pkg.simulate.simulate(21, 3000, seed=5, n_chrom=2, missing_rate=0.02)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    pos = d.pos_dist_mb.copy()
+    pos[1234] = 2000.0
+    a, em = _pair(pkg, orc_libm, gl, pos, indF=0.2, alpha=0.5, freq=0.2)
+    em.init_emission(); a.init_emission()
+    for it in range(2):
+        assert em.estep() == 0
+        st = a.estep_mstep()
+        # (5e-12: the log-space oracle's own rounding over 3000 sites is ~1e-12 here)
+        np.testing.assert_allclose(a.ind_lkl, em.ind_lkl, rtol=5e-12)
+        np.testing.assert_allclose(a.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+        # continue the oracle from the GPU's parameters (teacher forcing), then both update
+        # the frequencies and, lazily on the GPU, the emissions
+        em.set_params(a.indF, a.alpha, None)
+        assert em.mstep_freq(1) == 0
+        a.mstep_freq(1)
+        np.testing.assert_allclose(a.freq, em.freq, rtol=RTOL)
+    a.close()
