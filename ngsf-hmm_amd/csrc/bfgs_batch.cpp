@@ -2,7 +2,10 @@
 #include "bfgs_batch.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+
+#include <omp.h>
 
 namespace nghmm {
 
@@ -10,12 +13,32 @@ namespace {
 constexpr double kINF = 1e15;  // shared/gen_func.hpp:15
 inline bool same_bits(const double* a, const double* b) { return std::memcmp(a, b, 16) == 0; }
 inline bool nonfinite(double v) { return std::isnan(v) || std::isinf(v); }
+
+// Host threads for the per-individual state machines (independent problems).  Bounded:
+// an 8-GPU node runs eight of these processes side by side.  NGHMM_HOST_THREADS overrides.
+int host_threads(uint64_t n_items) {
+  static const int cap = [] {
+    if (const char* env = std::getenv("NGHMM_HOST_THREADS")) {
+      const int v = std::atoi(env);
+      if (v >= 1) return v;
+    }
+    const int hw = omp_get_max_threads();
+    return hw < 8 ? hw : 8;
+  }();
+  // measured: at 1000 problems a round's host work (~0.1 ms) is not worth waking threads
+  // for; at 8000 it is 5 ms -> 1 ms on 8 threads
+  const uint64_t by_work = n_items / 512;
+  return (int)(by_work < 1 ? 1 : (by_work < (uint64_t)cap ? by_work : (uint64_t)cap));
+}
 }  // namespace
 
 void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, bool F_fixed,
                       bool alpha_fixed) {
-  probs_.clear();
-  probs_.resize(n_ind);
+  // the problems (and their solvers' work arrays) are reused from call to call
+  if (probs_.size() != n_ind) {
+    probs_.clear();
+    probs_.resize(n_ind);
+  }
   rounds_ = 0;
   points_ = 0;
   ref_calls_ = 0;
@@ -23,7 +46,7 @@ void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, b
   n_active_ = n_ind;
   for (uint64_t i = 0; i < n_ind; ++i) {
     Problem& p = probs_[i];
-    p.solver.reset(2, 10);  // MVAL, shared/bfgs.h:23
+    p.solver.configure(2, 10);  // MVAL, shared/bfgs.h:23; start() zeroes the work arrays
     p.x[0] = indF[i];
     p.x[1] = alpha[i];
     // EM.cpp:424-436
@@ -91,8 +114,10 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
   F.clear();
   alpha.clear();
   if (n_active_ == 0) return 0;
-  for (auto& p : probs_)
-    if (p.active) plan(p);
+  const int64_t np = (int64_t)probs_.size();
+#pragma omp parallel for schedule(static) num_threads(host_threads(n_active_))
+  for (int64_t i = 0; i < np; ++i)
+    if (probs_[i].active) plan(probs_[i]);
   for (int k = 0; k < 5; ++k) {
     for (size_t i = 0; i < probs_.size(); ++i) {
       Problem& p = probs_[i];
@@ -109,7 +134,7 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
   return ind.size();
 }
 
-void BfgsBatch::consume(Problem& p, const double* lkl) {
+void BfgsBatch::consume(Problem& p, const double* lkl, uint64_t& ref_calls, uint64_t& finished) {
   // objective = -forward log-likelihood; non-finite parameters give -INF... i.e.
   // lkl = INF and the function returns -lkl (EM.cpp:454-463)
   double fv[5] = {0, 0, 0, 0, 0};
@@ -145,7 +170,7 @@ void BfgsBatch::consume(Problem& p, const double* lkl) {
     if (p.x[i] >= p.ub[i] && g < 0.0) g = 0.0;
     p.grad[i] = g;
   }
-  ref_calls_ += calls;
+  ref_calls += calls;
   p.eval_x[0] = p.x[0];
   p.eval_x[1] = p.x[1];
   p.have_eval = true;
@@ -163,21 +188,27 @@ void BfgsBatch::consume(Problem& p, const double* lkl) {
       if (p.have_eval && same_bits(p.x, p.eval_x)) {
         // the START call asks for f and g at the point just evaluated
         // (bfgs.cpp:901,114-121): same x, same values.
-        ref_calls_ += calls;
+        ref_calls += calls;
         continue;
       }
       return;  // wants a new round
     }
     if (task == Lbfgsb::Task::NewX) continue;
     p.active = false;
-    --n_active_;
+    ++finished;
     return;
   }
 }
 
 void BfgsBatch::scatter(const double* lkl) {
-  for (auto& p : probs_)
-    if (p.active) consume(p, lkl);
+  const int64_t np = (int64_t)probs_.size();
+  uint64_t ref_calls = 0, finished = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ref_calls, finished) \
+    num_threads(host_threads(n_active_))
+  for (int64_t i = 0; i < np; ++i)
+    if (probs_[i].active) consume(probs_[i], lkl, ref_calls, finished);
+  ref_calls_ += ref_calls;
+  n_active_ -= finished;
 }
 
 void BfgsBatch::result(double* indF, double* alpha) const {

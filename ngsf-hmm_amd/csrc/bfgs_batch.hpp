@@ -63,7 +63,7 @@ class BfgsBatch {
   uint64_t points_ = 0, ref_calls_ = 0, ind_rounds_ = 0;
 
   void plan(Problem& p);
-  void consume(Problem& p, const double* lkl);
+  void consume(Problem& p, const double* lkl, uint64_t& ref_calls, uint64_t& finished);
 };
 
 }  // namespace nghmm

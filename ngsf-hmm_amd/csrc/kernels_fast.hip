@@ -1636,11 +1636,12 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
                       const double* h_F, const double* h_A) {
   fs.n_groups = 0;
   if (n_pts == 0) return true;
-  // group the points by individual (<= MAXP per group)
-  std::vector<uint32_t> order(n_pts);
-  for (uint32_t p = 0; p < n_pts; ++p) order[p] = p;
-  std::stable_sort(order.begin(), order.end(),
-                   [&](uint32_t a, uint32_t b) { return h_ind[a] < h_ind[b]; });
+  // group the points by individual (<= MAXP per group): stable counting sort on the
+  // individual index (the caller has checked ind < I)
+  std::vector<uint32_t> order(n_pts), start(fs.I + 1, 0);
+  for (uint32_t p = 0; p < n_pts; ++p) ++start[h_ind[p] + 1];
+  for (uint64_t i = 0; i < fs.I; ++i) start[i + 1] += start[i];
+  for (uint32_t p = 0; p < n_pts; ++p) order[start[h_ind[p]]++] = p;
   std::vector<GroupDesc> groups;
   groups.reserve(n_pts / 3 + 1);
   for (uint32_t k = 0; k < n_pts;) {

@@ -4,6 +4,8 @@
 // to right exactly as there; compile with -ffp-contract=off.
 #include "lbfgsb.hpp"
 
+#include <utility>
+
 #include <cmath>
 #include <cstring>
 
@@ -173,6 +175,35 @@ double machine_eps() {
 #define WT(i, j) wt_[((i) - 1) + (size_t)((j) - 1) * m_]
 #define WN(i, j) wn_[((i) - 1) + (size_t)((j) - 1) * 2 * m_]
 #define WN1(i, j) snd_[((i) - 1) + (size_t)((j) - 1) * 2 * m_]
+
+// A solver object reused for another minimisation: every scalar back to its initial value
+// (as a newly constructed object), the work arrays keep their storage.  start() sizes and
+// zeroes them.
+void Lbfgsb::configure(int n, int m) {
+  Lbfgsb fresh;
+  fresh.x_.swap(x_);
+  fresh.l_.swap(l_);
+  fresh.u_.swap(u_);
+  fresh.nbd_.swap(nbd_);
+  fresh.ws_.swap(ws_);
+  fresh.wy_.swap(wy_);
+  fresh.sy_.swap(sy_);
+  fresh.ss_.swap(ss_);
+  fresh.wt_.swap(wt_);
+  fresh.wn_.swap(wn_);
+  fresh.snd_.swap(snd_);
+  fresh.z_.swap(z_);
+  fresh.r_.swap(r_);
+  fresh.d_.swap(d_);
+  fresh.t_.swap(t_);
+  fresh.wa_.swap(wa_);
+  fresh.index_.swap(index_);
+  fresh.iwhere_.swap(iwhere_);
+  fresh.indx2_.swap(indx2_);
+  *this = std::move(fresh);
+  n_ = n;
+  m_ = m;
+}
 
 void Lbfgsb::reset(int n, int m) {
   n_ = n;

@@ -34,6 +34,9 @@ class Lbfgsb {
   Lbfgsb(int n, int m) { reset(n, m); }
 
   void reset(int n, int m);
+  // reuse this object for another problem of size (n, m): scalars as newly constructed,
+  // storage kept; follow with start()
+  void configure(int n, int m);
 
   // Begin a minimisation.  x0 is copied; bounds as in the reference:
   // nbd[i] = 0 none, 1 lower, 2 both, 3 upper (bfgs.h:27-33).

@@ -81,6 +81,7 @@ struct nghmm_handle {
   double* d_gl_shard = nullptr;
 
   FastState fast;  // fast-mode layouts (kernels_fast.hip)
+  BfgsBatch batch;  // one L-BFGS-B state machine per individual, storage reused across M-steps
   // fast mode keeps the posteriors tile-major (fast.post); the site-major copy d_marg is
   // made on demand (host read-back, multi-GPU packing, est_maf beyond 1024 individuals)
   bool marg_valid = false;
@@ -523,7 +524,7 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   auto since = [&](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(now() - t0).count();
   };
-  BfgsBatch batch;
+  BfgsBatch& batch = h->batch;
   auto t0 = now();
   batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
   t_gather += since(t0);
@@ -590,7 +591,7 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
   if (!indF || !alpha || !fn) return NGHMM_ERR_ARG;
   if (stats) std::memset(stats, 0, sizeof *stats);
   if (indF_fixed && alpha_fixed) return NGHMM_OK;
-  BfgsBatch batch;
+  static thread_local BfgsBatch batch;  // solver storage reused from call to call
   batch.begin(n_ind, indF, alpha, indF_fixed != 0, alpha_fixed != 0);
   std::vector<uint32_t> ind;
   std::vector<double> F, A, lkl;
