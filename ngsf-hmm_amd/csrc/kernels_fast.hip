@@ -367,8 +367,11 @@ __global__ void __launch_bounds__(64)
 k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
               uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
   static_assert(EMIT || !FRESH, "the fresh walk is the first round of an M-step");
-  const uint32_t g = g_begin + blockIdx.x / C;
-  const uint32_t c = blockIdx.x % C;
+  // chunk-major: the waves resident at a time walk the same few slices of the shared
+  // distance / frequency tables, which then stay in L2
+  const uint32_t n_g = gridDim.x / C;
+  const uint32_t g = g_begin + blockIdx.x % n_g;
+  const uint32_t c = blockIdx.x / n_g;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
   const uint64_t i = G.ind;
@@ -393,8 +396,11 @@ template <int NP_MAX, bool FRESH>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
                   uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
-  const uint32_t g = g_begin + blockIdx.x / C;
-  const uint32_t c = blockIdx.x % C;
+  // chunk-major: the waves resident at a time walk the same few slices of the shared
+  // distance / frequency tables, which then stay in L2
+  const uint32_t n_g = gridDim.x / C;
+  const uint32_t g = g_begin + blockIdx.x % n_g;
+  const uint32_t c = blockIdx.x / n_g;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
   const uint32_t np = G.np;
