@@ -21,14 +21,23 @@
 //    (c*64 + lane)*T + t.  Every load of the main loops is one contiguous
 //    1 KiB (double2 emissions) or 512 B segment per wave-instruction.
 //
-//  * MATERIALISED emissions (16 B per site-individual, refreshed once per EM
-//    iteration by the frequency step) rather than recomputing them from the
-//    24 B genotype likelihoods in every one of the ~10-25 passes of an iteration.
+//  * MATERIALISED emissions (16 B per site-individual) rather than recomputing them
+//    from the 24 B genotype likelihoods in every pass of an iteration; they are
+//    refreshed by the first forward walk after a frequency update, on its way.
 //
 //  * the <= 5 probe points of one individual's finite-difference gradient
-//    (shared/bfgs.cpp:22-43) share ONE pass over that individual's emissions.
+//    (shared/bfgs.cpp:22-43) share ONE pass over that individual's emissions, in a
+//    kernel specialised for the pattern of the points.
 //
-// HBM-bound by construction (no MFMA: there is no contraction longer than 2).
+//  * ONE forward walk per EM iteration serves the M-step's first objective round, the
+//    E-step (it leaves lane operators and a checkpoint every 8 sites; the backward
+//    sweep recomputes forward vectors block-wise) and the emission refresh.
+//
+//  * posteriors in the TILE-MAJOR layout [C][T][I][64] the backward sweep writes with
+//    contiguous stores; est_maf reads it in place.
+//
+// The streaming kernels are HBM-bound, the objective rounds and est_maf FP64-issue
+// bound (no MFMA: there is no contraction longer than 2).  DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
