@@ -269,7 +269,7 @@ def main():
                      "ind_rounds_per_iter": ind_rounds / K,
                      "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg)
         print(json.dumps(out))
     em.close()
