@@ -1095,7 +1095,10 @@ constexpr int EN = NGHMM_EST_EN;        // Chebyshev nodes per interval
 constexpr int EST_SCALARS = 8;          // num, den, pnum, pden, iters, mid, half, tF
 constexpr int EST_FIELDS = EST_SCALARS + 2 * EN;
 enum : uint8_t { EST_DONE = 0, EST_INTERP = 1, EST_EXACT = 2 };
-constexpr int EST_K0 = 4;               // exact passes before the first interval
+#ifndef NGHMM_EST_K0
+#define NGHMM_EST_K0 4
+#endif
+constexpr int EST_K0 = NGHMM_EST_K0;    // exact passes before the first interval
 constexpr int EST_MIN_GAIN = 24;        // build only if about this many passes remain
 #ifndef NGHMM_EST_DMAX
 #define NGHMM_EST_DMAX 0.5
