@@ -12,11 +12,16 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT/pmc
 export TMPDIR=/tmp
-BENCH="bench.py --steps 5 --warmup 2 --no_cpu_baseline"
+# no warm-up: the trace then holds exactly the kernels of the timed region (plus the one-off
+# load kernels, which have names of their own), so its averages can be set against bench.py's
+BENCH="bench.py --steps 7 --warmup 0 --no_cpu_baseline"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $BENCH \
   > $OUT/bench_under_trace.json 2> $OUT/trace.err
 cp "$(find $OUT/trace -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_c3_fast_kernel_stats.csv
+cp $OUT/bench_under_trace.json $OUT/${TAG}_bench_under_trace.json
+python3 profiles/reconcile.py $OUT/${TAG}_c3_fast_kernel_stats.csv $OUT/${TAG}_bench_under_trace.json \
+  > $OUT/${TAG}_trace_vs_bench.json
 echo "trace done"
 
 PMCBENCH="bench.py --steps 2 --warmup 1 --no_cpu_baseline"
