@@ -1169,6 +1169,9 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   static_assert(!TILE || BLOCK == 64, "TILE: one wave per site");
   constexpr int W = TILE ? 1 : BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
+  // W == 1: per-lane partial sums of the interval's nodes (see the build below); the pad
+  // makes lane j's reads of row j conflict-free
+  __shared__ double2 nodebuf[W == 1 ? EN : 1][W == 1 ? 65 : 1];
   const int lane = threadIdx.x & 63;
   const int wv = TILE ? 0 : (threadIdx.x >> 6);
   const uint32_t tix = TILE ? (uint32_t)lane : threadIdx.x;  // index among the site's threads
@@ -1274,9 +1277,10 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   int node = -1;              // >= 0: this evaluation is Chebyshev node `node`
   bool check = false, interp_ok = false;
   double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;
-  for (;;) {
-    const double r = (node >= 0) ? fma(half, kChebC[node], mid) : pnum * rcp_nr2(pden - pnum);
-    double pn = 0, pd = 0;
+  // this lane's part of the two per-pass sums at odds r
+  auto lane_sums = [&](double r, double& pn, double& pd) {
+    pn = 0;
+    pd = 0;
     if constexpr (NI >= 4) {
       // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step and
       // 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
@@ -1309,6 +1313,11 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
         pd = fma(fc[k], inv, pd);
       }
     }
+  };
+  for (;;) {
+    const double r = (node >= 0) ? fma(half, kChebC[node], mid) : pnum * rcp_nr2(pden - pnum);
+    double pn, pd;
+    lane_sums(r, pn, pd);
     const double v = wave_sum_pair(pn, pd);
     double sn = lane_value(v, 31), sd = lane_value(v, 63);
     if constexpr (W > 1) {
@@ -1394,7 +1403,41 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
         mid = 0.5 * (lo + hi);
         half = 0.5 * (hi - lo);
         // a degenerate interval (rn not finite or not positive) keeps the site exact
-        if (half > 0 && lo > 0 && hi < 1e300) node = 0;
+        if (half > 0 && lo > 0 && hi < 1e300) {
+          if constexpr (W == 1) {
+            // One wave holds the site: the node evaluations do not depend on each other,
+            // so every lane parks its partial sums in LDS and the 16 x 64 partials are
+            // added up once at the end -- no reduction tree (and its latency) per node.
+            // Lane q*16 + j adds quarter q of node j's partials; two shuffles join the
+            // quarters.
+#pragma unroll 1
+            for (int nd = 0; nd < EN; ++nd) {
+              double pn, pd;
+              lane_sums(fma(half, kChebC[nd], mid), pn, pd);
+              nodebuf[nd][lane] = double2{pn, pd};
+            }
+            __syncthreads();  // one wave: orders the LDS writes before the reads
+            const int j = lane & 15, q4 = lane >> 4;
+            double an = 0, ad = 0;
+            if (j < EN) {
+#pragma unroll
+              for (int l = 0; l < 16; ++l) {
+                const double2 t2 = nodebuf[j][q4 * 16 + l];
+                an += t2.x;
+                ad += t2.y;
+              }
+            }
+            an += __shfl_xor(an, 16);
+            ad += __shfl_xor(ad, 16);
+            an += __shfl_xor(an, 32);
+            ad += __shfl_xor(ad, 32);
+            my_gn = an;  // lanes 0..EN-1 hold node `lane` (every quarter has the total)
+            my_gd = ad;
+            check = true;
+          } else {
+            node = 0;
+          }
+        }
       }
     }
   }
