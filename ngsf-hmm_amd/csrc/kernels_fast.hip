@@ -1109,6 +1109,14 @@ constexpr int EST_MIN_GAIN = 24;        // build only if about this many passes 
 constexpr double EST_DMAX = NGHMM_EST_DMAX;  // interval length <= EST_DMAX * r ahead ...
 constexpr double EST_BACK = 0.1;        // ... plus this fraction of it behind
 constexpr double EST_MULT = NGHMM_EST_MULT;  // ... and about this many current steps
+#ifndef NGHMM_EST_FIT
+#define NGHMM_EST_FIT 0.6
+#endif
+#ifndef NGHMM_EST_KMAX
+#define NGHMM_EST_KMAX 32
+#endif
+constexpr double EST_FIT = NGHMM_EST_FIT;    // build once k * step <= EST_FIT * EST_DMAX * r ...
+constexpr int EST_KMAX = NGHMM_EST_KMAX;     // ... or after this many passes at the latest
 constexpr double EST_TOL = 1e-13;       // interpolant vs exact pass, relative
 constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back to exact
 // cos((2j+1) pi/(2 EN)) and (-1)^j sin((2j+1) pi/(2 EN)): first-kind Chebyshev nodes and
@@ -1384,13 +1392,22 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       return;
     }
     if (!built && --n_before <= 0) {
-      built = true;
       // |delta freq| shrinks roughly like 1/k^2: about k (sqrt(|delta|/EPSILON) - 1)
-      // passes remain; an interval costs EN evaluations, so short tails stay exact
+      // passes remain, and the odds still travel about k times their last step.  An
+      // interval costs EN evaluations, so short tails stay exact; and a site whose
+      // remaining travel does not fit into one interval yet (a frequency far from the
+      // 0.01 every site starts at) takes a few more exact passes first, rather than
+      // leaving its interval half way and paying for a second one.
       const double m_est = (double)iters * (sqrt(lhs / thr) - 1.0);
-      if (m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
-        const double rn = pnum * rcp_nr2(pden - pnum);
-        const double step = fabs(rn - rprev);
+      const double rn = pnum * rcp_nr2(pden - pnum);
+      const double step = fabs(rn - rprev);
+      const bool fits = (double)iters * step <= EST_FIT * EST_DMAX * rn;
+      if (!fits && iters < EST_KMAX && m_est >= EST_MIN_GAIN) {
+        n_before = 1;  // look again after the next exact pass
+      } else {
+        built = true;
+      }
+      if (built && m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
         const double L = fmin(EST_DMAX * rn, fmax(EST_MULT * step, 1e-3 * rn));
         double lo, hi;
         if (rn >= rprev) {
