@@ -80,6 +80,25 @@ int nghmm_destroy(nghmm_t* h);
  * its normalisation) and per-site distances in Mb, +inf at chromosome starts
  * (ngsF-HMM.cpp:75-86).  Host pointers. */
 int nghmm_load_gl(nghmm_t* h, const double* gl_site_major, const double* pos_dist_mb);
+/* Same from RAW genotype likelihoods as they come out of the input file, prepared on the
+ * device in the reference's operation order: conversion to log space, normalisation
+ * (shared/read_data.cpp:36-40,89-98), optional genotype calling and second normalisation
+ * (ngsF-HMM.cpp:101-117; call_geno, shared/gen_func.cpp:886-914, with its defaults).
+ * space: how the values are encoded, see below.  check_nan != 0: a NaN cell after the first
+ * normalisation returns NGHMM_ERR_NAN ("NaN found! Is the file format correct?",
+ * read_data.cpp:42-45: the reference checks binary input only). */
+enum {
+  NGHMM_GL_LOG = 0,          /* natural-log likelihoods (--loglkl, or called genotypes) */
+  NGHMM_GL_NORMAL_BINARY = 1, /* normal space, binary file: log 0 becomes -1e15 (conv_space) */
+  NGHMM_GL_NORMAL_TEXT = 2    /* normal space, text file: plain log (log 0 = -inf)         */
+};
+/* A cell the reader never filled (the reference lets an empty text line consume a site,
+ * read_data.cpp:60-61: its cells keep the initial -1e15 and see only the second
+ * normalisation): its FIRST value carries this quiet-NaN bit pattern. */
+#define NGHMM_GL_UNREAD_BITS 0x7ff8dead00000001ull
+int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw_site_major, int space, int call_geno,
+                      int check_nan, const double* pos_dist_mb);
+
 /* Same, from buffers already resident on the handle's device. */
 int nghmm_load_gl_device(nghmm_t* h, const double* d_gl_site_major, const double* d_pos_dist_mb);
 
@@ -144,6 +163,14 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path);
 /* Posterior of the IBD state from the last E-step, marg_prob[i][s][1], as
  * [I][S] doubles (host) -- what EM.cpp:347-353 prints. */
 int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd);
+/* Prepared genotype likelihoods [S][I][3] (natural log, normalised) back to the host:
+ * what nghmm_load_gl_raw made of its input. */
+int nghmm_get_gl(nghmm_t* h, double* gl_site_major);
+/* Genotype posteriors of the .geno output (EM.cpp:367-376) for the sites
+ * [site_begin, site_begin + n_sites): out[n_sites][n_ind][3] (host, normal space), with the
+ * path of the last nghmm_viterbi call as the prior's F (all zeros before the first call, like
+ * the reference's path[][] at an intermediate print_iter) and the current frequencies. */
+int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, double* out);
 /* Current emissions [I][S][2] (host); test/debug aid. */
 int nghmm_get_emissions(nghmm_t* h, double* e_prob);
 

@@ -51,7 +51,9 @@ struct Params {  // ngsF-HMM.hpp:13-52
   unsigned n_threads = 1, verbose = 1, seed = 0;
   int mode = NGHMM_MODE_FAST, device = 0;
 
-  std::vector<double> gl;        // [S][I][3] log, normalised
+  std::vector<double> gl;        // [S][I][3] raw values of the input file (freed after upload)
+  int gl_space = NGHMM_GL_LOG;   // their encoding (nghmm_load_gl_raw)
+  bool gl_check_nan = false;
   std::vector<double> pos_dist;  // [S] Mb
   std::vector<double> freq, indF, alpha, ind_lkl, marg;
   std::vector<uint8_t> path;
@@ -75,38 +77,6 @@ void check(int rc, const char* where) {
   if (rc == NGHMM_OK) return;
   const char* detail = nghmm_last_error();
   fatal(where, (detail && *detail) ? detail : nghmm_strerror(rc));
-}
-
-// --- the reference's logsum / post_prob / call_geno on the host (input preparation) ---
-double logsum3(const double* a) {  // gen_func.cpp:135-151
-  double M = a[0];
-  for (int i = 1; i < 3; i++) M = (a[i] >= M) ? a[i] : M;
-  if (M == -INFINITY) return -INFINITY;
-  double sum = 0;
-  for (int i = 0; i < 3; i++) sum += exp(a[i] - M);
-  return log(sum) + M;
-}
-
-void post_prob_self(double* g) {  // gen_func.cpp:920-932 with prior == NULL
-  const double norm = logsum3(g);
-  for (int k = 0; k < 3; k++) g[k] -= norm;
-}
-
-void call_geno(double* g) {  // gen_func.cpp:886-914, defaults (log scale, thresholds 0, miss 0)
-  int max_pos = 0, min_pos = 0;
-  double mx = -INFINITY, mn = INFINITY;
-  for (int k = 0; k < 3; k++) {
-    if (g[k] > mx) { mx = g[k]; max_pos = k; }
-    if (g[k] < mn) { mn = g[k]; min_pos = k; }
-  }
-  double max_pp = exp(g[max_pos]);
-  if (g[min_pos] == g[max_pos]) max_pp = -1;
-  if (max_pp < 0)
-    for (int k = 0; k < 3; k++) g[k] = log((double)1 / 3);
-  if (max_pp >= 0) {
-    for (int k = 0; k < 3; k++) g[k] = -kINF;
-    g[max_pos] = log(1);
-  }
 }
 
 // --- text parsing: tokens on the separators, non-numeric tokens dropped (gen_func.cpp:390-417) ---
@@ -169,15 +139,21 @@ void read_dist(Params& P) {
   for (auto& d : P.pos_dist) d /= 1e6;
 }
 
-// shared/read_data.cpp:13-116
+// shared/read_data.cpp:13-116: file -> RAW values [S][I][3] as the reference's reader sees
+// them.  Conversion to log space, the two normalisations and the optional genotype call
+// (read_data.cpp:36-40,89-98; ngsF-HMM.cpp:101-117) happen on the device
+// (nghmm_load_gl_raw); P.gl_space says how the values are encoded.
 void read_geno(Params& P) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   const uint64_t n_geno = P.in_lkl ? 3 : 1;
-  P.gl.assign((size_t)S * I * 3, -kINF);
+  double unread;
+  const uint64_t unread_bits = NGHMM_GL_UNREAD_BITS;
+  memcpy(&unread, &unread_bits, sizeof unread);
   gzFile fh = gzopen(P.in_geno, P.in_bin ? "rb" : "r");
   if (!fh) fatal(__FUNCTION__, "cannot open GENO file!");
   gzbuffer(fh, 1 << 20);
   if (P.in_bin) {
+    P.gl.resize((size_t)S * I * 3);
     for (uint64_t s = 0; s < S; s++) {
       double* row = &P.gl[s * I * 3];
       const int want = (int)(I * 3 * sizeof(double));
@@ -186,20 +162,11 @@ void read_geno(Params& P) {
                                 ? "GENO file at premature EOF. Check GENO file and number of sites!"
                                 : "cannot read binary GENO file. Check GENO file and number of sites!");
     }
-    bool nan_found = false;
-#pragma omp parallel for schedule(static) reduction(|| : nan_found)
-    for (uint64_t c2 = 0; c2 < (uint64_t)S * I; c2++) {
-      double* g = &P.gl[c2 * 3];
-      if (!P.in_loglkl)
-        for (int k = 0; k < 3; k++) {
-          g[k] = log(g[k]);
-          if (g[k] == -INFINITY) g[k] = -kINF;
-        }
-      post_prob_self(g);
-      if (std::isnan(g[0]) || std::isnan(g[1]) || std::isnan(g[2])) nan_found = true;
-    }
-    if (nan_found) fatal(__FUNCTION__, "NaN found! Is the file format correct?");
+    P.gl_space = P.in_loglkl ? NGHMM_GL_LOG : NGHMM_GL_NORMAL_BINARY;
+    P.gl_check_nan = true;  // read_data.cpp:42-45
   } else {
+    // a site whose line is empty keeps "unread" cells (read_data.cpp:60-61)
+    P.gl.assign((size_t)S * I * 3, unread);
     std::vector<char> buf(kBuffLen);
     std::vector<double> t;
     for (uint64_t s = 0; s < S; s++) {
@@ -222,33 +189,28 @@ void read_geno(Params& P) {
       for (uint64_t i = 0; i < I; i++) {
         double* g = &P.gl[(s * I + i) * 3];
         if (P.in_lkl) {
-          for (int k = 0; k < 3; k++) g[k] = P.in_loglkl ? ptr[i * 3 + k] : log(ptr[i * 3 + k]);
+          for (int k = 0; k < 3; k++) g[k] = ptr[i * 3 + k];
         } else {
           const int gg = (int)ptr[i];
           if (gg >= 0) {
             if (gg > 2)
               fatal(__FUNCTION__,
                     "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+            g[0] = g[1] = g[2] = -kINF;  // read_data.cpp:21
             g[gg] = log(1);
           } else {
             g[0] = g[1] = g[2] = log((double)1 / 3);
           }
         }
-        post_prob_self(g);
       }
     }
+    P.gl_space = (P.in_lkl && !P.in_loglkl) ? NGHMM_GL_NORMAL_TEXT : NGHMM_GL_LOG;
+    P.gl_check_nan = false;
   }
   char c;
   gzread(fh, &c, 1);
   if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
   gzclose(fh);
-  // ngsF-HMM.cpp:101-117: optional genotype calling, then a second normalisation
-#pragma omp parallel for schedule(static)
-  for (uint64_t c2 = 0; c2 < (uint64_t)S * I; c2++) {
-    double* g = &P.gl[c2 * 3];
-    if (P.call_geno) call_geno(g);
-    post_prob_self(g);
-  }
 }
 
 // GSL's gsl_rng_taus (Tausworthe, L'Ecuyer 1996), the only GSL generator the reference
@@ -351,22 +313,6 @@ bool init_values(Params& P, nghmm_t* h) {
   return estimate;
 }
 
-// gen_func.cpp:938-957 + 920-932 on the host, for the .geno posteriors (EM.cpp:367-376)
-void geno_posterior(const double* gl, double maf, double F, double* pp) {
-  double h[3];
-  h[0] = (1 - maf) * (1 - maf) + (1 - maf) * maf * F;
-  h[1] = 2 * (1 - maf) * maf - 2 * (1 - maf) * maf * F;
-  h[2] = maf * maf + (1 - maf) * maf * F;
-  for (int k = 0; k < 3; k++) {
-    h[k] = log(h[k]);
-    if (h[k] == -INFINITY) h[k] = -kINF;
-  }
-  if (F == 1) h[1] = -kINF;
-  for (int k = 0; k < 3; k++) pp[k] = gl[k] + h[k];
-  const double norm = logsum3(pp);
-  for (int k = 0; k < 3; k++) pp[k] = exp(pp[k] - norm);
-}
-
 // printf("%f") / printf("%.10f") through std::to_chars: the same correctly rounded
 // digits (checked against printf on 5M values incl. ties), ~10x faster, thread-safe
 inline char* put_fixed(char* p, double v, int prec) {
@@ -376,7 +322,7 @@ inline char* put_fixed(char* p, double v, int prec) {
 }
 
 // EM.cpp:293-380
-void print_iter(const Params& P) {
+void print_iter(const Params& P, nghmm_t* h) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   std::string name = std::string(P.out_prefix) + ".indF";
   FILE* fh = fopen(name.c_str(), "w");
@@ -445,11 +391,8 @@ void print_iter(const Params& P) {
   std::vector<double> blk(chunk * I * 3);
   for (uint64_t s0 = 0; s0 < S; s0 += chunk) {
     const uint64_t ns = (S - s0) < chunk ? (S - s0) : chunk;
-#pragma omp parallel for schedule(static)
-    for (uint64_t c2 = 0; c2 < ns * I; c2++) {
-      const uint64_t s = s0 + c2 / I, i = c2 % I;
-      geno_posterior(&P.gl[(s * I + i) * 3], P.freq[s], (double)P.path[i * S + s], &blk[c2 * 3]);
-    }
+    // EM.cpp:367-376 on the device, from the decoded path and the final frequencies
+    check(nghmm_geno_posteriors(h, s0, ns, blk.data()), "print_iter");
     fwrite(blk.data(), sizeof(double), ns * I * 3, fh);
   }
   fclose(fh);
@@ -582,7 +525,11 @@ int main(int argc, char** argv) {
 
   nghmm_t* h = nullptr;
   check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode), "nghmm_create");
-  check(nghmm_load_gl(h, P.gl.data(), P.pos_dist.data()), "nghmm_load_gl");
+  // conversion to log space, normalisation, --call_geno: on the device (read_geno, main)
+  check(nghmm_load_gl_raw(h, P.gl.data(), P.gl_space, P.call_geno ? 1 : 0, P.gl_check_nan ? 1 : 0,
+                          P.pos_dist.data()),
+        "read_geno");
+  std::vector<double>().swap(P.gl);  // the host does not need the likelihoods again
   const bool estimate_freq = init_values(P, h);
   if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
     check(nghmm_mstep_freq(h, 1), "init_output");
@@ -601,7 +548,7 @@ int main(int argc, char** argv) {
     if (P.log && (iter == 1 || iter % P.log == 0)) {
       if (P.verbose >= 1) printf("==> Printing current iteration parameters\n");
       sync_outputs(P, h, false);
-      print_iter(P);
+      print_iter(P, h);
     }
     const time_t iter_start = time(nullptr);
     iter++;
@@ -655,7 +602,7 @@ int main(int argc, char** argv) {
     printf("Final logLkl: %f\n", P.tot_lkl);
     printf("Printing final results\n");
   }
-  print_iter(P);
+  print_iter(P, h);
   if (P.verbose >= 1) printf("Freeing memory...\n");
   nghmm_destroy(h);
   if (P.verbose >= 1) printf("Done!\n");

@@ -14,6 +14,18 @@ enum Flag { FLAG_INVALID_LKL = 0, FLAG_FW_BW = 1, FLAG_INVALID_MAF = 2, FLAG_NAN
 // ---------------- exact mode (kernels_exact.hip) ----------------
 // All arrays site-major: gl [S][I][3], eprob [S][I][2], fw [S+1][I][2], marg [S][I].
 
+// input preparation in place: log conversion (space 0 log / 1 binary-file normal space /
+// 2 text-file normal space), post_prob, optional call_geno, post_prob
+// (shared/read_data.cpp:36-40,89-98; ngsF-HMM.cpp:101-117); FLAG_NAN on a NaN cell
+void launch_prepare_gl(hipStream_t st, double* gl, uint64_t n_cells, int space, int call_geno,
+                       int* flags);
+
+// genotype posteriors of the .geno output (EM.cpp:367-376) for sites s0 .. s0 + n_s from
+// the blocked Viterbi path; out [n_s][I][3]
+void launch_geno_post_exact(hipStream_t st, const double* gl, const double* freq,
+                            const uint8_t* path16, uint64_t I, uint64_t s0, uint64_t n_s,
+                            double* out);
+
 // e_prob[s][i][k] = calc_emission(gl[s][i], freq[s], k)   (shared/HMM.cpp:144-154)
 void launch_emission_exact(hipStream_t st, const double* gl, const double* freq, double* eprob,
                            uint64_t S, uint64_t I, int* flags);

@@ -33,6 +33,7 @@ namespace {
 
 constexpr double kINF = 1e15;      // shared/gen_func.hpp:15
 constexpr double kEPS = 1e-5;      // shared/gen_func.hpp:16
+constexpr uint64_t kUnreadBits = 0x7ff8dead00000001ull;  // NGHMM_GL_UNREAD (include/nghmm.h)
 #define NEG_INFINITY (-__builtin_huge_val())
 
 // shared/gen_func.cpp:135-151, n = 2.  max() there is the macro (a >= b ? a : b).
@@ -513,7 +514,109 @@ k_unblock_path(const uint8_t* __restrict__ path16, uint64_t S, uint64_t I,
   }
 }
 
+// Input preparation of one cell, in place, in the reference's operation order: conversion
+// to log space and normalisation (shared/read_data.cpp:36-40,89-98: conv_space + post_prob
+// with no prior, gen_func.cpp:123-130,920-932), optional genotype call with the defaults of
+// ngsF-HMM.cpp:105 (gen_func.cpp:886-914; array_max_pos / array_min_pos :73-98), second
+// normalisation (ngsF-HMM.cpp:117).  A NaN after the first normalisation is the reference's
+// "NaN found! Is the file format correct?" (read_data.cpp:42-45).
+__global__ void __launch_bounds__(256)
+k_prepare_gl(double* __restrict__ gl, uint64_t n_cells, int space, int call_geno,
+             int* __restrict__ flags) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    double g[3] = {gl[c * 3], gl[c * 3 + 1], gl[c * 3 + 2]};
+    // a cell the reader never filled (an empty text line still consumes a site,
+    // read_data.cpp:60-61): it keeps the initial -1e15 and sees only the second normalisation
+    const bool unread = ngh_bits(g[0]) == kUnreadBits;
+    if (unread) g[0] = g[1] = g[2] = -kINF;
+    if (unread) {
+    } else if (space == 1) {  // binary file: conv_space(log), log 0 -> -1e15 (read_data.cpp:36-37)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[k] = log_or_minf(g[k]);
+    } else if (space == 2) {  // text file: plain log (read_data.cpp:89)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[k] = det_log(g[k]);
+    }
+    double norm = unread ? 0.0 : logsum3(g[0], g[1], g[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] -= norm;
+    if (g[0] != g[0] || g[1] != g[1] || g[2] != g[2]) flags[FLAG_NAN] = 1;
+    if (call_geno) {
+      int max_pos = 0, min_pos = 0;
+      double mx = NEG_INFINITY, mn = __builtin_huge_val();
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (g[k] > mx) {
+          max_pos = k;
+          mx = g[k];
+        }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (g[k] < mn) {
+          min_pos = k;
+          mn = g[k];
+        }
+      double max_pp = det_exp(g[max_pos]);
+      if (g[min_pos] == g[max_pos]) max_pp = -1;  // missing data
+      if (max_pp < 0) {
+        const double u = det_log((double)1 / 3);
+        g[0] = g[1] = g[2] = u;
+      }
+      if (max_pp >= 0) {
+        g[0] = g[1] = g[2] = -kINF;
+        g[max_pos] = det_log(1.0);
+      }
+    }
+    norm = logsum3(g[0], g[1], g[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gl[c * 3 + k] = g[k] - norm;
+  }
+}
+
+// Genotype posteriors of the .geno output (EM.cpp:367-376): prior = calc_HWE(freq[s], F)
+// with F the decoded state of the cell, post_prob, back to normal space.  path16 is the
+// blocked Viterbi path [site/16][individual][16]; out [n_s][I][3] for sites s0 .. s0 + n_s.
+__global__ void __launch_bounds__(256)
+k_geno_post_exact(const double* __restrict__ gl, const double* __restrict__ freq,
+                  const uint8_t* __restrict__ path16, uint64_t I, uint64_t s0, uint64_t n_s,
+                  double* __restrict__ out) {
+  const uint64_t n = n_s * I;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = s0 + c / I, i = c % I;
+    const double F = (double)path16[((s >> 4) * I + i) * 16 + (s & 15)];
+    double h0, h1, h2;
+    hwe_log(freq[s], F, h0, h1, h2);
+    const double* g = gl + (s * I + i) * 3;
+    const double p0 = g[0] + h0, p1 = g[1] + h1, p2 = g[2] + h2;
+    const double norm = logsum3(p0, p1, p2);
+    out[c * 3 + 0] = det_exp(p0 - norm);
+    out[c * 3 + 1] = det_exp(p1 - norm);
+    out[c * 3 + 2] = det_exp(p2 - norm);
+  }
+}
+
 }  // namespace
+
+void launch_prepare_gl(hipStream_t st, double* gl, uint64_t n_cells, int space, int call_geno,
+                       int* flags) {
+  if (n_cells == 0) return;
+  uint64_t blocks = (n_cells + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_prepare_gl, dim3((unsigned)blocks), dim3(256), 0, st, gl, n_cells, space,
+                     call_geno, flags);
+}
+
+void launch_geno_post_exact(hipStream_t st, const double* gl, const double* freq,
+                            const uint8_t* path16, uint64_t I, uint64_t s0, uint64_t n_s,
+                            double* out) {
+  if (n_s == 0 || I == 0) return;
+  uint64_t blocks = (n_s * I + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_geno_post_exact, dim3((unsigned)blocks), dim3(256), 0, st, gl, freq, path16,
+                     I, s0, n_s, out);
+}
 
 void launch_emission_exact(hipStream_t st, const double* gl, const double* freq, double* eprob,
                            uint64_t S, uint64_t I, int* flags) {

@@ -74,6 +74,8 @@ struct nghmm_handle {
   uint8_t *d_bp = nullptr, *d_path_sites = nullptr, *d_path = nullptr;
   double* d_vit = nullptr;  // Viterbi scratch: transition logs of one site chunk + carry state
   double* d_tmp = nullptr;  // S*I*2 doubles, transposes for host read-back
+  double* d_geno = nullptr;  // .geno posteriors of one site chunk
+  size_t geno_cap = 0;
   uint32_t* d_passes = nullptr;
 
   // multi-GPU shard
@@ -380,7 +382,7 @@ int nghmm_destroy(nghmm_t* h) {
   void* ptrs[] = {h->d_gl, h->d_pos, h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
                   h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
                   h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
-                  h->d_gl_shard};
+                  h->d_gl_shard, h->d_geno};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fast_destroy(h->fast);
@@ -409,6 +411,39 @@ int nghmm_load_gl(nghmm_t* h, const double* gl, const double* pos) {
   HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return after_gl_load(h);
+}
+
+int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw, int space, int call_geno, int check_nan,
+                      const double* pos) {
+  if (!h || !gl_raw || !pos || space < NGHMM_GL_LOG || space > NGHMM_GL_NORMAL_TEXT)
+    return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t cells = (size_t)h->I * h->S;
+  HIP_TRY(hipMemcpyAsync(h->d_gl, gl_raw, cells * 3 * sizeof(double), hipMemcpyHostToDevice,
+                         h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if ((rc = clear_flags(h))) return rc;
+  launch_prepare_gl(h->stream, h->d_gl, cells, space, call_geno, h->d_flags);
+  HIP_TRY(hipGetLastError());
+  int f[NFLAGS];
+  HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (check_nan && f[FLAG_NAN]) {
+    set_error("NaN found! Is the file format correct?");
+    return NGHMM_ERR_NAN;
+  }
+  return after_gl_load(h);
+}
+
+int nghmm_get_gl(nghmm_t* h, double* gl) {
+  if (!h || !h->loaded || !gl) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  HIP_TRY(hipMemcpyAsync(gl, h->d_gl, (size_t)h->I * h->S * 3 * sizeof(double),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
 }
 
 int nghmm_load_gl_device(nghmm_t* h, const double* d_gl, const double* d_pos) {
@@ -729,6 +764,33 @@ int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(marg_ibd, h->d_tmp, (size_t)h->I * h->S * sizeof(double),
                          hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, double* out) {
+  if (!h || !h->loaded || !out || site_begin + n_sites > h->S) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if (!h->d_path_sites) {
+    // not decoded yet: the reference's path[][] is still all zeros then (an intermediate
+    // print_iter, EM.cpp:60-62)
+    const size_t blocked = viterbi_blocked_bytes(h->S, h->I);
+    if ((rc = dev_alloc(&h->d_path_sites, blocked))) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_path_sites, 0, blocked, h->stream));
+  }
+  const size_t n = (size_t)n_sites * h->I * 3;
+  if (n > h->geno_cap) {
+    if (h->d_geno) (void)hipFree(h->d_geno);
+    h->d_geno = nullptr;
+    h->geno_cap = 0;
+    if ((rc = dev_alloc(&h->d_geno, n))) return rc;
+    h->geno_cap = n;
+  }
+  launch_geno_post_exact(h->stream, h->d_gl, h->d_freq, h->d_path_sites, h->I, site_begin, n_sites,
+                         h->d_geno);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, h->d_geno, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
 }

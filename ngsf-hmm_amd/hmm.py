@@ -74,6 +74,9 @@ def load_library():
         "nghmm_create": (i32, [C.POINTER(vp), u64, u64, i32, i32]),
         "nghmm_destroy": (i32, [vp]),
         "nghmm_load_gl": (i32, [vp, dp, dp]),
+        "nghmm_load_gl_raw": (i32, [vp, dp, i32, i32, i32, dp]),
+        "nghmm_get_gl": (i32, [vp, dp]),
+        "nghmm_geno_posteriors": (i32, [vp, u64, u64, dp]),
         "nghmm_load_gl_device": (i32, [vp, vp, vp]),
         "nghmm_set_params": (i32, [vp, dp, dp, dp]),
         "nghmm_get_params": (i32, [vp, dp, dp, dp]),
@@ -113,7 +116,8 @@ def _dp(a):
 
 EXPORTED_SYMBOLS = [
     "nghmm_last_error", "nghmm_strerror", "nghmm_has_hip", "nghmm_create", "nghmm_destroy",
-    "nghmm_load_gl", "nghmm_load_gl_device", "nghmm_set_params", "nghmm_get_params",
+    "nghmm_load_gl", "nghmm_load_gl_raw", "nghmm_get_gl", "nghmm_geno_posteriors",
+    "nghmm_load_gl_device", "nghmm_set_params", "nghmm_get_params",
     "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
     "nghmm_bfgs_batch_host", "nghmm_mstep_freq", "nghmm_estep_mstep",
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
@@ -199,6 +203,34 @@ class NgsFHMM:
             raise NgsFHMMError(-10, f"load: shapes {gl.shape} {pos_dist.shape} do not match "
                                     f"({self.n_sites}, {self.n_ind}, 3)")
         self._check(self.lib.nghmm_load_gl(self._h, _dp(gl), _dp(pos_dist)))
+
+    def load_raw(self, gl_raw, pos_dist, space=0, call_geno=False, check_nan=False):
+        """Raw genotype likelihoods as read from the input file; conversion to log space,
+        normalisation and optional genotype calling happen on the device
+        (nghmm_load_gl_raw).  space: 0 log, 1 normal space from a binary file, 2 normal
+        space from a text file."""
+        gl_raw = np.ascontiguousarray(gl_raw, dtype=np.float64)
+        pos_dist = np.ascontiguousarray(pos_dist, dtype=np.float64)
+        if gl_raw.shape != (self.n_sites, self.n_ind, 3) or pos_dist.shape != (self.n_sites,):
+            raise NgsFHMMError(-10, f"load_raw: shapes {gl_raw.shape} {pos_dist.shape} do not "
+                                    f"match ({self.n_sites}, {self.n_ind}, 3)")
+        self._check(self.lib.nghmm_load_gl_raw(self._h, _dp(gl_raw), int(space), int(call_geno),
+                                               int(check_nan), _dp(pos_dist)))
+
+    @property
+    def gl(self):
+        """[S][I][3] prepared (natural-log, normalised) genotype likelihoods."""
+        out = np.empty((self.n_sites, self.n_ind, 3))
+        self._check(self.lib.nghmm_get_gl(self._h, _dp(out)))
+        return out
+
+    def geno_posteriors(self, site_begin=0, n_sites=None):
+        """[n_sites][I][3] genotype posteriors of the .geno output (EM.cpp:367-376), from the
+        path of the last viterbi() call."""
+        n = self.n_sites - site_begin if n_sites is None else n_sites
+        out = np.empty((n, self.n_ind, 3))
+        self._check(self.lib.nghmm_geno_posteriors(self._h, int(site_begin), int(n), _dp(out)))
+        return out
 
     def load_device(self, gl_ptr, pos_ptr):
         """Same as load() from raw device pointers (e.g. torch tensors' data_ptr())."""

@@ -79,6 +79,47 @@ static void conv_space_exp(double* geno, int n) {
   }
 }
 
+/* shared/gen_func.cpp:886-914 with the defaults the reference calls it with
+ * (ngsF-HMM.cpp:105; gen_func.hpp: log scale, both thresholds 0, miss_data 0);
+ * array_max_pos / array_min_pos: gen_func.cpp:73-98 (first maximum, first minimum) */
+void orc_call_geno(double geno[3]) {
+  int max_pos = 0, min_pos = 0;
+  double mx = -INFINITY, mn = INFINITY;
+  for (int g = 0; g < 3; g++)
+    if (geno[g] > mx) { max_pos = g; mx = geno[g]; }
+  for (int g = 0; g < 3; g++)
+    if (geno[g] < mn) { min_pos = g; mn = geno[g]; }
+  double max_pp = ORC_EXP(geno[max_pos]);
+  if (geno[min_pos] == geno[max_pos]) max_pp = -1; /* missing data */
+  if (max_pp < 0)
+    for (int g = 0; g < 3; g++) geno[g] = ORC_LOG((double)1 / 3);
+  if (max_pp >= 0) {
+    for (int g = 0; g < 3; g++) geno[g] = -ORC_INF;
+    geno[max_pos] = ORC_LOG(1);
+  }
+}
+
+/* What one cell goes through between the input file and the EM: read_geno's conversion
+ * to log space and first normalisation (shared/read_data.cpp:36-40,89-98), then the
+ * optional genotype call and the second normalisation (ngsF-HMM.cpp:101-117). */
+void orc_prepare_gl(double* gl, uint64_t n_cells, int space, int call_geno) {
+  for (uint64_t c = 0; c < n_cells; c++) {
+    double* g = gl + 3 * c;
+    unsigned long long bits;
+    memcpy(&bits, g, sizeof bits);
+    if (bits == 0x7ff8dead00000001ull) {             /* cell of an empty text line: */
+      g[0] = g[1] = g[2] = -ORC_INF;                 /* read_data.cpp:21,60-61 */
+    } else {
+      if (space == 1) conv_space_log(g, 3);          /* binary file: read_data.cpp:36-37 */
+      if (space == 2)                                /* text file: plain log, :89 */
+        for (int k = 0; k < 3; k++) g[k] = ORC_LOG(g[k]);
+      orc_post_prob(g, g, NULL);
+    }
+    if (call_geno) orc_call_geno(g);
+    orc_post_prob(g, g, NULL);
+  }
+}
+
 /* shared/gen_func.cpp:938-957.  pow(x,2) is x*x in the reference's -O3 build. */
 void orc_calc_hwe(double out[3], double maf, double F, int log_scale) {
   out[0] = (1 - maf) * (1 - maf) + (1 - maf) * maf * F;

@@ -54,6 +54,13 @@ double orc_calc_trans(int k, int l, double q_l, double alpha, double pos_dist);
 void orc_calc_hwe(double out[3], double maf, double F, int log_scale);
 /* shared/gen_func.cpp:920-932 (prior may be NULL) */
 void orc_post_prob(double pp[3], const double lkl[3], const double* prior);
+/* call_geno with the reference's defaults (gen_func.cpp:886-914) */
+void orc_call_geno(double geno[3]);
+/* input preparation of every cell: log conversion (space 0: already log; 1: normal space
+ * from a binary file, log 0 -> -1e15; 2: normal space from a text file, plain log),
+ * normalisation, optional genotype call, normalisation (read_data.cpp:36-40,89-98;
+ * ngsF-HMM.cpp:101-117); in place */
+void orc_prepare_gl(double* gl, uint64_t n_cells, int space, int call_geno);
 /* shared/gen_func.cpp:55-70; returns NaN flag through *is_nan */
 double orc_check_interv(double v, int* is_nan);
 /* shared/HMM.cpp:144-154; returns NaN and sets *bad if maf outside [0,1] */

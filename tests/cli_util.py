@@ -44,25 +44,15 @@ def write_inputs(tmp, d, gl_raw):
     return paths
 
 
-def host_normalise(orc_libm, gl, call_geno=False):
-    """What the host does to log GLs (shared/read_data.cpp:40,98 then ngsF-HMM.cpp:101-117):
-    post_prob, optional call_geno, post_prob again -- with libm, cell by cell."""
-    import ctypes as C
-    out = np.ascontiguousarray(gl, dtype=np.float64).copy()
-    flat = out.reshape(-1, 3)
-    dp = C.POINTER(C.c_double)
-    for r in flat:
-        p = r.ctypes.data_as(dp)
-        orc_libm.lib.orc_post_prob(p, p, None)
-        if call_geno:
-            if r.min() == r.max():
-                r[:] = np.log(1.0 / 3.0)
-            else:
-                k = int(np.argmax(r))
-                r[:] = -1e15
-                r[k] = 0.0
-        orc_libm.lib.orc_post_prob(p, p, None)
-    return out
+def raw_called_genotypes(geno):
+    """What the reader makes of a called-genotype file (shared/read_data.cpp:21,91-97):
+    [S][I][3] with log(1) at the called genotype, -1e15 elsewhere, log(1/3) x 3 if missing."""
+    S, I = geno.shape
+    raw = np.full((S, I, 3), -1e15)
+    for g in range(3):
+        raw[..., g][geno == g] = 0.0
+    raw[geno < 0] = np.log(1.0 / 3.0)
+    return raw
 
 
 def expected_files(tot_lkl, indF, alpha, freq, ind_lkl, path, marg, geno_post):

@@ -52,6 +52,8 @@ class Oracle:
             "orc_calc_trans": (d, [i32, i32, d, d, d]),
             "orc_calc_hwe": (None, [dp, d, d, i32]),
             "orc_post_prob": (None, [dp, dp, dp]),
+            "orc_call_geno": (None, [dp]),
+            "orc_prepare_gl": (None, [dp, u64, i32, i32]),
             "orc_check_interv": (d, [d, ip]),
             "orc_calc_emission": (d, [dp, d, i32, ip]),
             "orc_est_maf": (d, [u64, dp, dp, ip]),
@@ -98,6 +100,13 @@ class Oracle:
         bad = C.c_int(0)
         v = self.lib.orc_calc_emission(_dp(gl), maf, k, C.byref(bad))
         return v, bool(bad.value)
+
+    def prepare_gl(self, gl_raw, space=0, call_geno=False):
+        """Input preparation of every cell (read_data.cpp:36-40,89-98; ngsF-HMM.cpp:101-117):
+        raw [..., 3] values -> normalised natural-log likelihoods (a new array)."""
+        out = np.ascontiguousarray(gl_raw, dtype=np.float64).copy()
+        self.lib.orc_prepare_gl(_dp(out), out.size // 3, int(space), int(call_geno))
+        return out
 
     def est_maf(self, gl_site, indF):
         gl_site = np.ascontiguousarray(gl_site, dtype=np.float64)

@@ -31,10 +31,7 @@ def _oracle_outputs(orc_det, orc_libm, gl, d, freq0, indF0, alpha0, min_iters, m
     assert em.init_emission() == 0
     n = em.run(freq_est=freq_est, indF_fixed=indF_fixed, min_iters=min_iters, max_iters=max_iters)
     path = em.viterbi()
-    # the host computes the .geno posteriors with libm (EM.cpp:367-376)
-    em_l = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
-    em_l.set_params(em.indF, em.alpha, em.freq)
-    gp = em_l.geno_post(path)
+    gp = em.geno_post(path)              # .geno posteriors (EM.cpp:367-376), on the device too
     return n, cli_util.expected_files(em.tot_lkl, em.indF, em.alpha, em.freq, em.ind_lkl, path,
                                       em.marg, gp)
 
@@ -51,15 +48,16 @@ CASES = [
 @pytest.mark.parametrize("name,flags,key,call,called", CASES)
 def test_cli_outputs_byte_identical(pkg, orc_det, orc_libm, data, name, flags, key, call, called):
     d, paths, tmp = data
+    # the raw values as the host's reader sees them; their preparation (log, normalisation,
+    # genotype calling) runs on the device with the exact-mode arithmetic = the det oracle's
+    space = 0
     if called:
-        raw = np.full((S, I, 3), -1e15)
-        for g in range(3):
-            raw[..., g][d.geno == g] = 0.0
+        raw = cli_util.raw_called_genotypes(d.geno)
     elif name == "GL_beagle":
-        raw = np.log(np.exp(d.gl))       # what the reader sees: log of the printed likelihoods
+        raw, space = np.exp(d.gl), 2      # normal-space values of a text file: plain log
     else:
         raw = d.gl
-    gl = cli_util.host_normalise(orc_libm, raw, call_geno=call)
+    gl = orc_det.prepare_gl(raw, space, call_geno=call)
     out = os.path.join(tmp, "out_" + name)
     r = cli_util.run_cli(["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I,
                           "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
@@ -76,7 +74,6 @@ def test_cli_fixed_parameters_and_fast_mode(pkg, orc_det, orc_libm, data):
     """examples/test.sh 'indF_fixed' configuration; fast mode must agree to print precision
     on freq/posteriors (no optimizer in the loop to amplify anything)."""
     d, paths, tmp = data
-    gl = cli_util.host_normalise(orc_libm, d.gl)
     for mode in ("exact", "fast"):
         out = os.path.join(tmp, "fixed_" + mode)
         cli_util.run_cli(["--geno", paths["glf_gz"], "--loglkl", "--pos", paths["pos_gz"],
@@ -95,7 +92,7 @@ def test_cli_fixed_parameters_and_fast_mode(pkg, orc_det, orc_libm, data):
 def test_cli_freq_e_initialisation(pkg, orc_det, orc_libm, data):
     """--freq e: initial frequencies from est_maf with F = 0 (parse_args.cpp:312-318)."""
     d, paths, tmp = data
-    gl = cli_util.host_normalise(orc_libm, d.gl)
+    gl = orc_det.prepare_gl(d.gl)
     out = os.path.join(tmp, "freq_e")
     cli_util.run_cli(["--geno", paths["glf_bin"], "--loglkl", "--pos", paths["pos_gz"], "--n_ind",
                       I, "--n_sites", S, "--freq", "e", "--freq_est", 0, "--indF", "0.1,0.2",

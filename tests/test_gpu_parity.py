@@ -217,3 +217,59 @@ def test_golden_fixture(pkg):
     assert np.array_equal(hmm.viterbi(), g["libm_path"])
     np.testing.assert_allclose(hmm.ind_lkl, g["libm_ind_lkl"], rtol=RTOL)
     hmm.close()
+
+
+@pytest.mark.parametrize("space,call", [(0, False), (0, True), (1, False), (1, True), (2, False)])
+def test_input_preparation_on_device_bitwise(pkg, orc_det, small_sim, space, call):
+    """nghmm_load_gl_raw: conversion to log space, the two normalisations and the optional
+    genotype call of shared/read_data.cpp:36-40,89-98 / ngsF-HMM.cpp:101-117 on the device,
+    bit for bit the det oracle's, for log-scale input, normal-space input with the binary
+    reader's log 0 -> -1e15 and with the text reader's plain log; zeros, ties (missing data)
+    and cells the text reader never filled included."""
+    d, _ = small_sim
+    rng = np.random.default_rng(space * 2 + call)
+    raw = d.gl + rng.normal(size=d.gl.shape[:2] + (1,))      # not normalised
+    raw[3, 1] = np.log(1.0 / 3.0)                              # missing data: all equal
+    raw[5, 2] = [0.0, -np.inf, -np.inf] if space == 0 else [0.0, -50.0, -60.0]
+    if space:
+        raw = np.exp(raw)
+        raw[7, 0] = [0.0, 0.0, 1.0]                            # log 0
+    unread = np.frombuffer(np.uint64(0x7ff8dead00000001).tobytes(), dtype=np.float64)[0]
+    raw[9, 3] = unread                                         # an empty text line's cell
+    want = orc_det.prepare_gl(raw, space, call)
+    with pkg.NgsFHMM(d.n_ind, d.n_sites, mode=pkg.MODE_EXACT) as hmm:
+        hmm.load_raw(raw, d.pos_dist_mb, space=space, call_geno=call)
+        got = hmm.gl
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.all(np.abs(np.exp(want[:3]).sum(-1) - 1) < 1e-12)
+
+
+def test_input_preparation_nan_check(pkg, small_sim):
+    d, gl = small_sim
+    raw = gl.copy()
+    raw[2, 2, 1] = np.nan
+    with pkg.NgsFHMM(d.n_ind, d.n_sites, mode=pkg.MODE_EXACT) as hmm:
+        hmm.load_raw(raw, d.pos_dist_mb, check_nan=False)      # text reader: no check
+        with pytest.raises(pkg.NgsFHMMError, match="NaN found"):
+            hmm.load_raw(raw, d.pos_dist_mb, check_nan=True)   # binary reader: read_data.cpp:42-45
+
+
+def test_geno_posteriors_bitwise(pkg, orc_det, small_sim):
+    """nghmm_geno_posteriors = the .geno output of EM.cpp:367-376, bit for bit the det
+    oracle's, whole range and a chunk; before any decoding the path counts as all zeros."""
+    d, gl = small_sim
+    em = orclib.OracleEM(orc_det, gl, d.pos_dist_mb)
+    em.set_params(0.1, 0.2, 0.1)
+    em.init_emission()
+    assert em.iterate() == 0
+    with pkg.NgsFHMM(d.n_ind, d.n_sites, mode=pkg.MODE_EXACT) as hmm:
+        hmm.load(gl, d.pos_dist_mb)
+        hmm.set_params(0.1, 0.2, 0.1)
+        hmm.init_emission()
+        hmm.iter_EM()
+        zero = np.zeros((d.n_ind, d.n_sites), dtype=np.uint8)
+        assert np.array_equal(hmm.geno_posteriors(), em.geno_post(zero))
+        path = hmm.viterbi()
+        want = em.geno_post(em.viterbi())
+        assert np.array_equal(hmm.geno_posteriors(), want)
+        assert np.array_equal(hmm.geno_posteriors(17, 40), want[17:57])

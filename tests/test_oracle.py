@@ -182,3 +182,30 @@ def test_em_loop_control(orc_libm, small_sim):
     em2.set_params(0.1, 0.2, 0.1)
     em2.init_emission()
     assert em2.run(min_iters=1, max_iters=2, min_epsilon=1e30) >= 1
+
+
+def test_prepare_gl_against_a_numpy_restatement(orc_libm):
+    """orc_prepare_gl (input preparation, read_data.cpp:36-40,89-98; ngsF-HMM.cpp:101-117)
+    against the formulas written out in numpy: post_prob = g - logsum(g) twice, call_geno
+    (gen_func.cpp:886-914 with its defaults) in between."""
+    rng = np.random.default_rng(5)
+    raw = np.log(rng.dirichlet([1, 1, 1], size=(40, 7))) + rng.normal(size=(40, 7, 1))
+    raw[0, 0] = np.log(1 / 3)
+
+    def post_prob(g):
+        m = g.max(-1, keepdims=True)
+        return g - (np.log(np.exp(g - m).sum(-1, keepdims=True)) + m)
+
+    a = orc_libm.prepare_gl(raw, 0, False)
+    np.testing.assert_allclose(a, post_prob(post_prob(raw)), rtol=0, atol=1e-14)
+    b = orc_libm.prepare_gl(raw, 0, True)
+    called = post_prob(raw)
+    k = called.argmax(-1)
+    want = np.full_like(called, -1e15)
+    np.put_along_axis(want, k[..., None], 0.0, axis=-1)
+    want[0, 0] = np.log(1 / 3)                       # all equal: missing data
+    np.testing.assert_allclose(b, post_prob(want), rtol=0, atol=1e-14)
+    c = orc_libm.prepare_gl(np.exp(raw), 2, False)   # text reader: plain log first
+    np.testing.assert_allclose(c, a, rtol=0, atol=1e-14)
+    z = orc_libm.prepare_gl(np.array([[0.0, 0.0, 1.0]]), 1, False)   # binary reader: log 0 -> -1e15
+    assert z[0, 2] == 0.0 and z[0, 0] == -1e15
