@@ -320,3 +320,26 @@ def test_fast_fused_walk_through_the_general_kernel(pkg, orc_libm):
         a.mstep_freq(1)
         np.testing.assert_allclose(a.freq, em.freq, rtol=RTOL)
     a.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 70), (3, 17), (65, 1030), (130, 2049), (1025, 300)])
+def test_fast_ragged_shapes_fused_iteration(pkg, orc_libm, shape):
+    """Two whole fast-mode EM iterations (shared forward walk, lazily refreshed emissions,
+    tile-major posteriors read by est_maf; beyond 1024 individuals the site-major copy) on
+    shapes that do not fill waves, lanes or checkpoint blocks: E-step and frequency step of
+    each iteration against the oracle continued from the GPU's indF/alpha."""
+    I, S = shape
+    d = pkg.simulate.simulate(I, S, seed=I * 1000 + S + 1, missing_rate=0.1,
+                              n_chrom=2 if S > 10 else 1)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    em.init_emission(); hmm.init_emission()
+    for it in range(2):
+        assert em.estep() == 0
+        hmm.iter_EM()
+        np.testing.assert_allclose(hmm.ind_lkl, em.ind_lkl, rtol=1e-11)
+        np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+        em.set_params(hmm.indF, hmm.alpha, None)
+        assert em.mstep_freq(1) == 0
+        np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
+    hmm.close()
