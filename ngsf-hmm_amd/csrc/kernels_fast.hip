@@ -1499,7 +1499,7 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
     for (int j = 0; j < EN; ++j) {
       const double t = r - fma(half, kChebC[j], mid);
       hit |= (t == 0);
-      const double q = kChebW[j] / t;
+      const double q = kChebW[j] * rcp_nr2(t);  // full precision, half a division's cost
       Sq += q;
       Sn = fma(q, gn[j], Sn);
       Sd = fma(q, gd[j], Sd);
