@@ -170,6 +170,21 @@ __device__ __forceinline__ void emit_lane_op(double* __restrict__ lane_ops, uint
 }
 
 // ---- objective: chunk operators of <= 5 points per individual ------------
+// 1/x to full precision (v_rcp_f64 + two Newton steps); 1/0 = inf as in IEEE
+__device__ __forceinline__ double rcp_nr2(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
+// 1/x to ~46 bits: v_rcp_f64 (about 23 bits) + one Newton step; x in (0, 3]
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
 // exp(x) for |x| <= 1e-3 to < 1e-16 relative (x^5/120 is the first dropped term)
 __device__ __forceinline__ double exp_small4(double x) {
   return fma(x, fma(x, fma(x, fma(x, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0);
@@ -727,7 +742,7 @@ k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict_
     for (int u = CK - 1; u >= 0; --u) {
       const uint64_t t = b * CK + u;
       const double x0 = f0[u] * w0, x1 = f1[u] * w1;
-      double g1 = x1 / (x0 + x1);
+      double g1 = x1 * rcp_nr2(x0 + x1);  // 0/0 (no probability mass) stays NaN
       if (j * T + t < S) {
         if (g1 != g1) nanflag = true;
         // check_interv (gen_func.cpp:55-70)
@@ -1029,21 +1044,6 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {
   v += dpp_move<0x141>(v);  // row_half_mirror
   v += dpp_move<0x140>(v);  // row_mirror: every lane now holds its 16-lane row total
   return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
-}
-
-// 1/x to full precision (two Newton steps); x finite and > 0
-__device__ __forceinline__ double rcp_nr2(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(r, fma(-x, r, 1.0), r);
-  r = fma(r, fma(-x, r, 1.0), r);
-  return r;
-}
-
-// 1/x to ~46 bits: v_rcp_f64 (about 23 bits) + one Newton step; x in (0, 3]
-__device__ __forceinline__ double rcp_nr(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(r, fma(-x, r, 1.0), r);
-  return r;
 }
 
 // Sums of two per-lane values over the wave in ONE reduction tree: the first step swaps
