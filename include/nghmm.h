@@ -171,6 +171,15 @@ int nghmm_get_gl(nghmm_t* h, double* gl_site_major);
  * path of the last nghmm_viterbi call as the prior's F (all zeros before the first call, like
  * the reference's path[][] at an intermediate print_iter) and the current frequencies. */
 int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, double* out);
+/* The posterior lines of the .ibd file (EM.cpp:347-353) as text, formatted on the device:
+ * for the individuals [ind_begin, ind_begin + n_ind) one line each of n_sites values
+ * printed like printf("%f") -- "d.dddddd", the digits glibc prints -- separated by tabs and
+ * ended by a newline, i.e. exactly 9 * n_sites bytes per individual; out (host) receives
+ * n_ind * 9 * n_sites bytes. */
+int nghmm_format_posteriors(nghmm_t* h, uint64_t ind_begin, uint64_t n_ind, char* out);
+/* The formatter behind it, for caller-supplied values in [0, 1] (host): rows lines of cols
+ * "%f" values, 9 * rows * cols bytes.  NGHMM_ERR_ARG if a value is outside [0, 1]. */
+int nghmm_format_fixed6(nghmm_t* h, const double* values, uint64_t rows, uint64_t cols, char* out);
 /* Current emissions [I][S][2] (host); test/debug aid. */
 int nghmm_get_emissions(nghmm_t* h, double* e_prob);
 

@@ -55,7 +55,7 @@ struct Params {  // ngsF-HMM.hpp:13-52
   int gl_space = NGHMM_GL_LOG;   // their encoding (nghmm_load_gl_raw)
   bool gl_check_nan = false;
   std::vector<double> pos_dist;  // [S] Mb
-  std::vector<double> freq, indF, alpha, ind_lkl, marg;
+  std::vector<double> freq, indF, alpha, ind_lkl;
   std::vector<uint8_t> path;
   double tot_lkl = 0, prev_tot_lkl = 0;
 };
@@ -360,26 +360,18 @@ void print_iter(const Params& P, nghmm_t* h) {
     line[S] = '\n';
     fwrite(line.data(), 1, S + 1, fh);
   }
-  // posterior lines: formatted in parallel, one batch of individuals at a time
-  const int nt = omp_get_max_threads();
-  std::vector<std::vector<char>> bufs(nt);
-  std::vector<size_t> lens(nt);
-  for (uint64_t i0 = 0; i0 < I; i0 += nt) {
-    const int nb = (int)((I - i0) < (uint64_t)nt ? (I - i0) : nt);
-#pragma omp parallel for schedule(static, 1)
-    for (int b2 = 0; b2 < nb; b2++) {
-      std::vector<char>& bf = bufs[b2];
-      bf.resize(S * 12 + 64);
-      char* p = bf.data();
-      const double* m = &P.marg[(i0 + b2) * S];
-      for (uint64_t s = 0; s < S; s++) {
-        if (s) *p++ = '\t';
-        p = put_fixed(p, m[s], 6);
-      }
-      *p++ = '\n';
-      lens[b2] = p - bf.data();
+  // posterior lines (EM.cpp:347-353): printf("%f") text formatted on the device, a batch of
+  // individuals (<= 256 MB of text) at a time
+  {
+    uint64_t batch = (256ull << 20) / (9 * S);
+    if (batch < 1) batch = 1;
+    if (batch > I) batch = I;
+    std::vector<char> text(batch * 9 * S);
+    for (uint64_t i0 = 0; i0 < I; i0 += batch) {
+      const uint64_t nb = (I - i0) < batch ? (I - i0) : batch;
+      check(nghmm_format_posteriors(h, i0, nb, text.data()), "print_iter");
+      fwrite(text.data(), 1, nb * 9 * S, fh);
     }
-    for (int b2 = 0; b2 < nb; b2++) fwrite(bufs[b2].data(), 1, lens[b2], fh);
   }
   fclose(fh);
 
@@ -400,8 +392,6 @@ void print_iter(const Params& P, nghmm_t* h) {
 
 void sync_outputs(Params& P, nghmm_t* h, bool with_viterbi) {
   check(nghmm_get_params(h, P.indF.data(), P.alpha.data(), P.freq.data()), "print_iter");
-  P.marg.resize((size_t)P.n_ind * P.n_sites);
-  check(nghmm_get_posteriors(h, P.marg.data()), "print_iter");
   P.path.resize((size_t)P.n_ind * P.n_sites, 0);
   if (with_viterbi) check(nghmm_viterbi(h, P.path.data()), "viterbi");
 }

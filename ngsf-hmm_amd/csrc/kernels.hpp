@@ -64,6 +64,10 @@ void launch_transpose_u8(hipStream_t st, const uint8_t* in, uint8_t* out, uint64
 // eprob [S][I][2] -> out [I][S][2]
 void launch_transpose_pairs_f64(hipStream_t st, const double* in, double* out, uint64_t rows,
                                 uint64_t cols);
+// "%f" text of rows x cols values in [0, 1]: 9 bytes per value (8 characters + tab, newline
+// after the last value of a row); *bad = 1 if a value is outside [0, 1]
+void launch_format_fixed6(hipStream_t st, const double* in, uint64_t rows, uint64_t cols, char* out,
+                          int* bad);
 // out[(s - lo) * I + i] = marg[s][i] for s in [lo, hi): a contiguous slice copy in site-major
 void launch_copy_f64(hipStream_t st, const double* in, double* out, uint64_t n);
 

@@ -76,6 +76,9 @@ struct nghmm_handle {
   double* d_tmp = nullptr;  // S*I*2 doubles, transposes for host read-back
   double* d_geno = nullptr;  // .geno posteriors of one site chunk
   size_t geno_cap = 0;
+  char* d_text = nullptr;    // formatted posterior lines of one batch of individuals
+  size_t text_cap = 0;
+  bool tmp_is_posteriors = false;  // d_tmp holds the [I][S] posteriors of the last E-step
   uint32_t* d_passes = nullptr;
 
   // multi-GPU shard
@@ -209,6 +212,7 @@ int fast_estep_impl(nghmm_t* h, double* ind_lkl, bool have_walk) {
   h->ms[SLOT_BACKWARD] = 0;
   h->launches[SLOT_BACKWARD] = 0;
   h->marg_valid = false;
+  h->tmp_is_posteriors = false;
   HIP_TRY(hipGetLastError());
   if (ind_lkl)
     HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
@@ -382,7 +386,7 @@ int nghmm_destroy(nghmm_t* h) {
   void* ptrs[] = {h->d_gl, h->d_pos, h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
                   h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
                   h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
-                  h->d_gl_shard, h->d_geno};
+                  h->d_gl_shard, h->d_geno, h->d_text};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fast_destroy(h->fast);
@@ -510,6 +514,7 @@ int nghmm_estep(nghmm_t* h, double* ind_lkl) {
                          h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_fw, h->d_flags);
     if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
     tic(h);
+    h->tmp_is_posteriors = false;
     launch_backward_exact(h->stream, h->d_eprob, h->d_pos, h->d_fw, h->S, h->I, h->d_indF,
                           h->d_alpha, h->d_ind_lkl, h->d_marg, h->d_flags);
     if ((rc = toc(h, SLOT_BACKWARD, false))) return rc;
@@ -754,17 +759,90 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   return NGHMM_OK;
 }
 
+// [I][S] posteriors of the last E-step in d_tmp (transposed once per E-step)
+static int posteriors_ind_major(nghmm_t* h) {
+  int rc;
+  if ((rc = ensure_tmp(h))) return rc;
+  if (h->tmp_is_posteriors) return NGHMM_OK;
+  if ((rc = ensure_marg(h))) return rc;
+  launch_transpose_f64(h->stream, h->d_marg, h->d_tmp, h->S, h->I);
+  HIP_TRY(hipGetLastError());
+  h->tmp_is_posteriors = true;
+  return NGHMM_OK;
+}
+
 int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
   if (!h || !marg_ibd) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  if ((rc = ensure_tmp(h))) return rc;
-  if ((rc = ensure_marg(h))) return rc;
-  launch_transpose_f64(h->stream, h->d_marg, h->d_tmp, h->S, h->I);
-  HIP_TRY(hipGetLastError());
+  if ((rc = posteriors_ind_major(h))) return rc;
   HIP_TRY(hipMemcpyAsync(marg_ibd, h->d_tmp, (size_t)h->I * h->S * sizeof(double),
                          hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_format_posteriors(nghmm_t* h, uint64_t ind_begin, uint64_t n_ind, char* out) {
+  if (!h || !h->loaded || !out || ind_begin + n_ind > h->I) return NGHMM_ERR_ARG;
+  if (n_ind == 0) return NGHMM_OK;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if ((rc = posteriors_ind_major(h))) return rc;
+  const size_t bytes = (size_t)n_ind * 9 * h->S;
+  if (bytes > h->text_cap) {
+    if (h->d_text) (void)hipFree(h->d_text);
+    h->d_text = nullptr;
+    h->text_cap = 0;
+    if ((rc = dev_alloc(&h->d_text, bytes))) return rc;
+    h->text_cap = bytes;
+  }
+  if ((rc = clear_flags(h))) return rc;
+  launch_format_fixed6(h->stream, h->d_tmp + ind_begin * h->S, n_ind, h->S, h->d_text, h->d_flags);
+  HIP_TRY(hipGetLastError());
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, h->d_flags, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(out, h->d_text, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (bad) {
+    set_error("nghmm_format_posteriors: a posterior outside [0, 1]");
+    return NGHMM_ERR_ARG;
+  }
+  return NGHMM_OK;
+}
+
+int nghmm_format_fixed6(nghmm_t* h, const double* values, uint64_t rows, uint64_t cols, char* out) {
+  if (!h || !values || !out) return NGHMM_ERR_ARG;
+  if (rows == 0 || cols == 0) return NGHMM_OK;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t n = (size_t)rows * cols;
+  double* d_in = nullptr;
+  char* d_out = nullptr;
+  if ((rc = dev_alloc(&d_in, n))) return rc;
+  if ((rc = dev_alloc(&d_out, n * 9))) {
+    (void)hipFree(d_in);
+    return rc;
+  }
+  int bad = 0;
+  hipError_t e = hipMemcpyAsync(d_in, values, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(h->d_flags, 0, NFLAGS * sizeof(int), h->stream);
+  if (e == hipSuccess) {
+    launch_format_fixed6(h->stream, d_in, rows, cols, d_out, h->d_flags);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, h->d_flags, sizeof bad, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 9, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) {
+    set_error("nghmm_format_fixed6: %s", hipGetErrorString(e));
+    return NGHMM_ERR_HIP;
+  }
+  if (bad) {
+    set_error("nghmm_format_fixed6: a value outside [0, 1]");
+    return NGHMM_ERR_ARG;
+  }
   return NGHMM_OK;
 }
 
@@ -802,8 +880,10 @@ int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
   if ((rc = ensure_tmp(h))) return rc;
   if (h->mode == NGHMM_MODE_FAST) {
     if ((rc = ensure_emissions(h))) return rc;
+    h->tmp_is_posteriors = false;
     if (!fast_export_emissions(h->fast, h->stream, h->d_tmp)) return NGHMM_ERR_HIP;
   } else {
+    h->tmp_is_posteriors = false;
     launch_transpose_pairs_f64(h->stream, h->d_eprob, h->d_tmp, h->S, h->I);
   }
   HIP_TRY(hipGetLastError());

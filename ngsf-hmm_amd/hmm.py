@@ -77,6 +77,8 @@ def load_library():
         "nghmm_load_gl_raw": (i32, [vp, dp, i32, i32, i32, dp]),
         "nghmm_get_gl": (i32, [vp, dp]),
         "nghmm_geno_posteriors": (i32, [vp, u64, u64, dp]),
+        "nghmm_format_posteriors": (i32, [vp, u64, u64, C.c_char_p]),
+        "nghmm_format_fixed6": (i32, [vp, dp, u64, u64, C.c_char_p]),
         "nghmm_load_gl_device": (i32, [vp, vp, vp]),
         "nghmm_set_params": (i32, [vp, dp, dp, dp]),
         "nghmm_get_params": (i32, [vp, dp, dp, dp]),
@@ -117,6 +119,7 @@ def _dp(a):
 EXPORTED_SYMBOLS = [
     "nghmm_last_error", "nghmm_strerror", "nghmm_has_hip", "nghmm_create", "nghmm_destroy",
     "nghmm_load_gl", "nghmm_load_gl_raw", "nghmm_get_gl", "nghmm_geno_posteriors",
+    "nghmm_format_posteriors", "nghmm_format_fixed6",
     "nghmm_load_gl_device", "nghmm_set_params", "nghmm_get_params",
     "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
     "nghmm_bfgs_batch_host", "nghmm_mstep_freq", "nghmm_estep_mstep",
@@ -231,6 +234,23 @@ class NgsFHMM:
         out = np.empty((n, self.n_ind, 3))
         self._check(self.lib.nghmm_geno_posteriors(self._h, int(site_begin), int(n), _dp(out)))
         return out
+
+    def format_fixed6(self, values):
+        """printf("%f") of a [rows][cols] array of values in [0, 1], on the device: tab-separated,
+        one line per row, as bytes."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        rows, cols = v.shape
+        buf = C.create_string_buffer(rows * cols * 9)
+        self._check(self.lib.nghmm_format_fixed6(self._h, _dp(v), rows, cols, buf))
+        return buf.raw
+
+    def format_posteriors(self, ind_begin=0, n_ind=None):
+        """The .ibd file's posterior lines of individuals [ind_begin, ind_begin + n_ind) as
+        bytes: "%f" values, tab-separated, one line per individual (EM.cpp:347-353)."""
+        n = self.n_ind - ind_begin if n_ind is None else n_ind
+        buf = C.create_string_buffer(n * 9 * self.n_sites)
+        self._check(self.lib.nghmm_format_posteriors(self._h, int(ind_begin), int(n), buf))
+        return buf.raw
 
     def load_device(self, gl_ptr, pos_ptr):
         """Same as load() from raw device pointers (e.g. torch tensors' data_ptr())."""

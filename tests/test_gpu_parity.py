@@ -273,3 +273,37 @@ def test_geno_posteriors_bitwise(pkg, orc_det, small_sim):
         want = em.geno_post(em.viterbi())
         assert np.array_equal(hmm.geno_posteriors(), want)
         assert np.array_equal(hmm.geno_posteriors(17, 40), want[17:57])
+
+
+def test_device_formatting_is_printf(pkg, orc_det, small_sim):
+    """The .ibd posterior lines formatted on the device are byte for byte what printf("%f")
+    writes: on the E-step's posteriors, and on values chosen to stress the rounding -- exact
+    ties (j/128 * ... = k + 0.5 in units of 1e-6: ties to even), neighbours of ties, values
+    next to 0 and 1, the snapping thresholds, random values."""
+    d, gl = small_sim
+    with pkg.NgsFHMM(d.n_ind, d.n_sites, mode=pkg.MODE_EXACT) as hmm:
+        hmm.load(gl, d.pos_dist_mb)
+        hmm.set_params(0.1, 0.2, 0.1)
+        hmm.init_emission()
+        hmm.estep()
+        post = hmm.marg_prob
+        want = "".join("\t".join("%f" % v for v in row) + "\n" for row in post).encode()
+        assert hmm.format_posteriors() == want
+        assert hmm.format_posteriors(3, 2) == "".join(
+            "\t".join("%f" % v for v in row) + "\n" for row in post[3:5]).encode()
+
+        rng = np.random.default_rng(0)
+        ties = np.arange(0, 129) / 128.0                   # j/128 = (j * 7812.5) e-6: exact ties
+        near = np.concatenate([np.nextafter(ties, 0.0), np.nextafter(ties, 1.0)])
+        edge = np.array([0.0, 1.0, 1e-5, 1 - 1e-5, 5e-7, 4.9999999e-7, 5.0000001e-7, 0.9999995,
+                         0.99999949, 0.99999951, 1 - 2.0 ** -53, 2.0 ** -60, 0.5, 0.1234565,
+                         0.1234575, 0.0000015, 0.0000025])
+        dec = np.round(rng.uniform(0, 1, 20000), 6) + rng.choice([0.0, 5e-7, -5e-7], 20000)
+        vals = np.clip(np.concatenate([ties, near, edge, dec, rng.uniform(0, 1, 50000),
+                                       rng.uniform(0, 1, 5000) ** 8]), 0.0, 1.0)
+        vals = vals[:(len(vals) // 7) * 7].reshape(-1, 7)
+        got = hmm.format_fixed6(vals)
+        want = "".join("\t".join("%f" % v for v in row) + "\n" for row in vals).encode()
+        assert got == want
+        with pytest.raises(pkg.NgsFHMMError):
+            hmm.format_fixed6(np.array([[0.5, 1.5]]))
