@@ -399,6 +399,8 @@ int nghmm_destroy(nghmm_t* h) {
 
 static int after_gl_load(nghmm_t* h) {
   h->loaded = true;
+  h->marg_valid = false;  // nothing derived from earlier data survives a (re)load
+  h->tmp_is_posteriors = false;
   if (h->mode == NGHMM_MODE_FAST) {
     if (!fast_load(h->fast, h->stream, h->d_gl, h->d_pos)) return NGHMM_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(h->stream));
