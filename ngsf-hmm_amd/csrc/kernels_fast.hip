@@ -771,25 +771,49 @@ k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict_
 }
 
 // tile-major posteriors -> site-major [S][I] (multi-GPU packing, host read-back, est_maf
-// with more individuals than one wave holds); tile = (c, t) x 64 lanes x 64 individuals
+// with more individuals than one wave holds); tile = (c, t) x 64 lanes x 64 individuals,
+// 16-byte accesses on both sides: a thread reads two lanes of one individual and writes
+// two individuals of one site (I even; odd I takes the 8-byte path)
+template <bool PAIRS>
 __global__ void __launch_bounds__(256)
 k_fast_post_to_site_major(const double* __restrict__ post, uint64_t I, uint64_t S, uint64_t T,
                           uint32_t C, double* __restrict__ marg) {
-  __shared__ double tile[64][65];
-  const uint64_t n_it = (I + 63) / 64;
+  constexpr int TI = 64;
+  __shared__ double tile[64][TI + 2];  // [lane][individual]
+  const uint64_t n_it = (I + TI - 1) / TI;
   const uint64_t ct = blockIdx.x / n_it;  // c * T + t
-  const uint64_t i0 = (blockIdx.x % n_it) * 64;
+  const uint64_t i0 = (blockIdx.x % n_it) * TI;
   const uint64_t c = ct / T, t = ct % T;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int ii = ty; ii < 64; ii += 4) {
-    const uint64_t i = i0 + ii;
-    if (i < I) tile[ii][tx] = post[(ct * I + i) * 64 + tx];
-  }
-  __syncthreads();
-  for (int ll = ty; ll < 64; ll += 4) {
-    const uint64_t s = (c * 64 + ll) * T + t;
-    const uint64_t i = i0 + tx;
-    if (s < S && i < I) marg[s * I + i] = tile[tx][ll];
+  if constexpr (PAIRS) {
+    const int lp = threadIdx.x & 31, ty = threadIdx.x >> 5;  // lane pair, 8 individuals a pass
+    for (int ii = ty; ii < TI; ii += 8) {
+      const uint64_t i = i0 + ii;
+      if (i < I) {
+        const double2 v = *reinterpret_cast<const double2*>(post + (ct * I + i) * 64 + 2 * lp);
+        tile[2 * lp][ii] = v.x;
+        tile[2 * lp + 1][ii] = v.y;
+      }
+    }
+    __syncthreads();
+    const int ip = threadIdx.x & 31, tz = threadIdx.x >> 5;  // individual pair, 8 sites a pass
+    for (int ll = tz; ll < 64; ll += 8) {
+      const uint64_t s = (c * 64 + ll) * T + t;
+      const uint64_t i = i0 + 2 * ip;
+      if (s < S && i < I)  // I even: i + 1 < I as well, and s * I + i is even
+        *reinterpret_cast<double2*>(marg + s * I + i) = double2{tile[ll][2 * ip], tile[ll][2 * ip + 1]};
+    }
+  } else {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int ii = ty; ii < TI; ii += 4) {
+      const uint64_t i = i0 + ii;
+      if (i < I) tile[tx][ii] = post[(ct * I + i) * 64 + tx];
+    }
+    __syncthreads();
+    for (int ll = ty; ll < 64; ll += 4) {
+      const uint64_t s = (c * 64 + ll) * T + t;
+      const uint64_t i = i0 + tx;
+      if (s < S && i < I) marg[s * I + i] = tile[ll][tx];
+    }
   }
 }
 
@@ -1866,8 +1890,15 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
 
 bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg) {
   const uint64_t n_it = (fs.I + 63) / 64;
-  hipLaunchKernelGGL(k_fast_post_to_site_major, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)),
-                     dim3(256), 0, st, fs.post, fs.I, fs.S, fs.T, fs.C, d_marg);
+  const dim3 grid((unsigned)((uint64_t)fs.C * fs.T * n_it)), block(256);
+  // 16-byte stores need s * I + i even for even i, i.e. an even number of individuals, and
+  // a 16-byte aligned destination
+  if (fs.I % 2 == 0 && (reinterpret_cast<uintptr_t>(d_marg) & 15) == 0)
+    hipLaunchKernelGGL((k_fast_post_to_site_major<true>), grid, block, 0, st, fs.post, fs.I, fs.S,
+                       fs.T, fs.C, d_marg);
+  else
+    hipLaunchKernelGGL((k_fast_post_to_site_major<false>), grid, block, 0, st, fs.post, fs.I, fs.S,
+                       fs.T, fs.C, d_marg);
   return hipGetLastError() == hipSuccess;
 }
 
