@@ -1204,6 +1204,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   // W == 1: per-lane partial sums of the interval's nodes (see the build below); the pad
   // makes lane j's reads of row j conflict-free
   __shared__ double2 nodebuf[W == 1 ? EN : 1][W == 1 ? 65 : 1];
+  __shared__ double2 xnode[W > 1 ? EN : 1][W > 1 ? W : 1];  // W > 1: per-wave node sums
   const int lane = threadIdx.x & 63;
   const int wv = TILE ? 0 : (threadIdx.x >> 6);
   const uint32_t tix = TILE ? (uint32_t)lane : threadIdx.x;  // index among the site's threads
@@ -1306,7 +1307,6 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
   }
   bool built = !allow_build;  // at most one interval per launch
   int n_before = n_exact;     // exact passes before deciding on it
-  int node = -1;              // >= 0: this evaluation is Chebyshev node `node`
   bool check = false, interp_ok = false;
   double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;
   // this lane's part of the two per-pass sums at odds r
@@ -1347,7 +1347,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     }
   };
   for (;;) {
-    const double r = (node >= 0) ? fma(half, kChebC[node], mid) : pnum * rcp_nr2(pden - pnum);
+    const double r = pnum * rcp_nr2(pden - pnum);
     double pn, pd;
     lane_sums(r, pn, pd);
     const double v = wave_sum_pair(pn, pd);
@@ -1366,17 +1366,6 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
         sd += xch[buf][w][1];
       }
       buf ^= 1;
-    }
-    if (node >= 0) {  // a node of the interval: lane `node` keeps its two values
-      if (lane == node) {
-        my_gn = sn;
-        my_gd = sd;
-      }
-      if (++node == EN) {
-        node = -1;
-        check = true;
-      }
-      continue;
     }
     if (check) {  // the pass after a build: exact sums in hand, compare the interpolant
       const int nj = lane < EN ? lane : 0;
@@ -1476,7 +1465,30 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
             my_gd = ad;
             check = true;
           } else {
-            node = 0;
+            // several waves per site: every wave reduces its own part of each node and the
+            // waves' parts meet in LDS once for the whole interval (one barrier instead of
+            // one per node), added in wave order
+#pragma unroll 1
+            for (int nd = 0; nd < EN; ++nd) {
+              double pn, pd;
+              lane_sums(fma(half, kChebC[nd], mid), pn, pd);
+              const double v = wave_sum_pair(pn, pd);
+              const double sn = lane_value(v, 31), sd = lane_value(v, 63);
+              if (lane == 0) xnode[nd][wv] = double2{sn, sd};
+            }
+            __syncthreads();
+            double an = 0, ad = 0;
+            if (lane < EN) {
+#pragma unroll
+              for (int w = 0; w < W; ++w) {
+                const double2 t2 = xnode[lane][w];
+                an += t2.x;
+                ad += t2.y;
+              }
+            }
+            my_gn = an;
+            my_gd = ad;
+            check = true;
           }
         }
       }
