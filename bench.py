@@ -170,7 +170,9 @@ def main():
     mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
 
     # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
-    gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank)
+    # every rank simulates its own individuals on the same sites
+    gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank,
+                                          pos_seed=None if world == 1 else 777)
     torch.cuda.synchronize()
 
     dd = importlib.import_module("ngsf-hmm_amd.distributed")
@@ -224,7 +226,7 @@ def main():
         algo = {
             "lkl_batch": ((44.0 * S * I * K + 16.0 * S * max(ind_rounds - I * K, 0)) if fast
                           else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
-            "est_maf": 32.0 * S * I * world,
+            "est_maf": 32.0 * S * I,   # N > 1: S/N own sites x N*I individuals per rank
             "forward": (28.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
             "emission": (8.0 * S if fast else 40.0 * S * I),

@@ -146,7 +146,7 @@ def called_genotype_gl(geno: np.ndarray) -> np.ndarray:
 
 
 def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alpha=0.01,
-                   depth=2.0, error=0.01, seed=12345, chunk_sites: int = 20000):
+                   depth=2.0, error=0.01, seed=12345, chunk_sites: int = 20000, pos_seed=None):
     """The same data model generated directly on a GPU with torch, in chunks of sites, for
     benchmark-sized inputs (1000 x 1M = 24 GB of doubles never touches the host).
 
@@ -160,7 +160,14 @@ def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alph
     g.manual_seed(int(seed))
     I, S = n_ind, n_sites
     f64 = torch.float64
-    gaps = torch.normal(1e5, 1e5 / 3.0, (S,), generator=g, device=device, dtype=f64).to(torch.int64)
+    # pos_seed: the site positions (and site frequencies) from a generator of their own, so
+    # that the ranks of a multi-GPU run, which simulate different individuals (seed), share
+    # one set of sites
+    gs = g
+    if pos_seed is not None:
+        gs = torch.Generator(device=device)
+        gs.manual_seed(int(pos_seed))
+    gaps = torch.normal(1e5, 1e5 / 3.0, (S,), generator=gs, device=device, dtype=f64).to(torch.int64)
     gaps.clamp_(min=1)
     pos_dist_mb = gaps.to(f64) / 1e6     # cumulative positions: d_0 = pos_0 - 0
     gl = torch.empty((S, I, 3), device=device, dtype=f64)
@@ -168,7 +175,7 @@ def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alph
     lp, lq = torch.log(p_read), torch.log1p(-p_read)
     state = (torch.rand((I,), generator=g, device=device) < indF).to(torch.int64)
     # freq = "r": a uniform frequency per site (ngsF-HMMsim.R:127-133), else one value
-    site_freq = (torch.rand((S,), generator=g, device=device, dtype=f64) if isinstance(freq, str)
+    site_freq = (torch.rand((S,), generator=gs, device=device, dtype=f64) if isinstance(freq, str)
                  else torch.full((S,), float(freq), device=device, dtype=f64))
     first = True
     for s0 in range(0, S, chunk_sites):
