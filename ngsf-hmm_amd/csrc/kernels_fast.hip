@@ -1198,17 +1198,16 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
               double* __restrict__ freq_out, uint8_t* __restrict__ redo,
               uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
               int fresh, int n_exact, int allow_build) {
-  static_assert(!TILE || BLOCK == 64, "TILE: one wave per site");
-  constexpr int W = TILE ? 1 : BLOCK / 64;
+  constexpr int W = BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   // W == 1: per-lane partial sums of the interval's nodes (see the build below); the pad
   // makes lane j's reads of row j conflict-free
   __shared__ double2 nodebuf[W == 1 ? EN : 1][W == 1 ? 65 : 1];
   __shared__ double2 xnode[W > 1 ? EN : 1][W > 1 ? W : 1];  // W > 1: per-wave node sums
   const int lane = threadIdx.x & 63;
-  const int wv = TILE ? 0 : (threadIdx.x >> 6);
-  const uint32_t tix = TILE ? (uint32_t)lane : threadIdx.x;  // index among the site's threads
-  constexpr uint64_t stride = TILE ? 64 : BLOCK;
+  const int wv = threadIdx.x >> 6;
+  const uint32_t tix = threadIdx.x;  // index among the site's threads
+  constexpr uint64_t stride = BLOCK;
   uint64_t site;
   const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[i * 64]
   if constexpr (TILE) {
@@ -1919,8 +1918,8 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                  double* d_freq_out, bool tile_major) {
   if (S_own == 0) return true;
   // tile-major posteriors (the E-step's own layout) only for the handle's whole site range
-  // and one wave per site
-  if (tile_major && !(I_tot <= 1024 && I_blk == I_tot && S_own == fs.S)) return false;
+  // and individuals that fit the registers of one workgroup
+  if (tile_major && !(I_tot <= 8192 && I_blk == I_tot && S_own == fs.S)) return false;
   const uint64_t tile_T = tile_major ? fs.T : 0;
   const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
   if (S_own > fs.redo_cap) {
@@ -1947,8 +1946,8 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
                      d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0, d_freq_out,   \
                      fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
                      allow_build)
-#define LAUNCH_TILE(N)                                                                          \
-  hipLaunchKernelGGL((k_fast_estmaf<N, 64, true>), dim3((unsigned)fs.Spad), dim3(64), 0, st,    \
+#define LAUNCH_TILE(N, B)                                                                       \
+  hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)fs.Spad), dim3(B), 0, st,      \
                      d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,        \
                      fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
                      allow_build)
@@ -1956,11 +1955,14 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
   if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
   auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
     if (tile_major) {
-      if (I_tot <= 64) LAUNCH_TILE(1);
-      else if (I_tot <= 128) LAUNCH_TILE(2);
-      else if (I_tot <= 256) LAUNCH_TILE(4);
-      else if (I_tot <= 512) LAUNCH_TILE(8);
-      else LAUNCH_TILE(16);
+      if (I_tot <= 64) LAUNCH_TILE(1, 64);
+      else if (I_tot <= 128) LAUNCH_TILE(2, 64);
+      else if (I_tot <= 256) LAUNCH_TILE(4, 64);
+      else if (I_tot <= 512) LAUNCH_TILE(8, 64);
+      else if (I_tot <= 1024) LAUNCH_TILE(16, 64);
+      else if (I_tot <= 2048) LAUNCH_TILE(16, 128);
+      else if (I_tot <= 4096) LAUNCH_TILE(16, 256);
+      else LAUNCH_TILE(16, 512);
     } else if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
       if (cfg_ni == 16 && cfg_b == 64) LAUNCH_NI(16, 64);
       else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);

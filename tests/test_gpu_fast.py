@@ -322,12 +322,14 @@ def test_fast_fused_walk_through_the_general_kernel(pkg, orc_libm):
     a.close()
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (1, 70), (3, 17), (65, 1030), (130, 2049), (1025, 300)])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 70), (3, 17), (65, 1030), (130, 2049), (1025, 300),
+                                   (4100, 40)])
 def test_fast_ragged_shapes_fused_iteration(pkg, orc_libm, shape):
     """Two whole fast-mode EM iterations (shared forward walk, lazily refreshed emissions,
-    tile-major posteriors read by est_maf; beyond 1024 individuals the site-major copy) on
-    shapes that do not fill waves, lanes or checkpoint blocks: E-step and frequency step of
-    each iteration against the oracle continued from the GPU's indF/alpha."""
+    tile-major posteriors read by est_maf, with one and with two waves per site) on
+    shapes that do not fill waves, lanes or checkpoint blocks (4100 individuals: est_maf
+    through the site-major copy): E-step and frequency step of each iteration against the
+    oracle continued from the GPU's indF/alpha."""
     I, S = shape
     d = pkg.simulate.simulate(I, S, seed=I * 1000 + S + 1, missing_rate=0.1,
                               n_chrom=2 if S > 10 else 1)
