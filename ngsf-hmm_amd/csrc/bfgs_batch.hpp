@@ -12,6 +12,7 @@
 // bit-identical to running findmax_bfgs on the same objective values.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
