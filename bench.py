@@ -191,7 +191,7 @@ def main():
 
     for _ in range(args.warmup):
         em.iter_EM()
-    fam = {k: 0.0 for k in ("emission", "forward", "backward", "lkl_batch", "est_maf")}
+    fam = {k: 0.0 for k in ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first")}
     launches = dict.fromkeys(fam, 0)
     rounds = points = ind_rounds = ref_calls = 0
     barrier()
@@ -230,8 +230,9 @@ def main():
             "forward": (28.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
             "emission": (8.0 * S if fast else 40.0 * S * I),
+            "lkl_first": 44.0 * S * I,
         }
-        dom = max(fam, key=lambda k: fam[k])
+        dom = max((k for k in fam if k != "lkl_first"), key=lambda k: fam[k])
         avg_ms = fam[dom] / max(launches[dom], 1)
         achieved = algo[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = pmc_traffic(dom, args, I, S, em.hmm.layout()[0], launches["lkl_batch"],
@@ -243,6 +244,33 @@ def main():
                 gbs = algo[k] / (fam[k] / launches[k] * 1e-3) / 1e9
                 fam_roof[k] = {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
                                "avg_launch_ms": fam[k] / launches[k], "launches": launches[k]}
+        # the objective family split into its HBM-bound first round (also forward walk and
+        # emission refresh) and its FP64-issue-bound later rounds; FP64 vector issue peak =
+        # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction (78.6 TFLOP/s FMA)
+        fp64_peak = 256 * 4 * 2.4e9 / 4
+        if fast and launches["lkl_first"] and fam["lkl_batch"] > fam["lkl_first"] > 0:
+            later_ms = fam["lkl_batch"] - fam["lkl_first"]
+            later_ind_rounds = max(ind_rounds - I * launches["lkl_first"], 0)
+            winstr = 91.5 * S * later_ind_rounds / 64.0       # per site
+            fam_roof["lkl_later_rounds"] = {
+                "achieved_GBps": 16.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9,
+                "frac": 16.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms_per_em_iteration": later_ms / K,
+                "fp64_issue": {"wave_instr_per_s": winstr / (later_ms * 1e-3), "peak": fp64_peak,
+                               "frac": winstr / (later_ms * 1e-3) / fp64_peak,
+                               "instr_per_site": 91.5}}
+            if "est_maf" in fam_roof:
+                # per site: 21 evaluations (4 exact passes, 16 interval nodes, the check) of
+                # 8.06 instructions per individual + ~45, and ~22 per individual to set up
+                i_tot = I * world
+                ni = min(16, -(-i_tot // 64))
+                waves = max(1, -(-i_tot // 1024))
+                per_site = waves * (21 * (8.06 * ni + 45) + 22 * ni)
+                sites = S / world
+                rate = per_site * sites * launches["est_maf"] / (fam["est_maf"] * 1e-3)
+                fam_roof["est_maf"]["fp64_issue"] = {"wave_instr_per_s": rate, "peak": fp64_peak,
+                                                     "frac": rate / fp64_peak,
+                                                     "instr_per_site": per_site}
         out = {
             "metric": "site-ind updates/sec (EM iterations x individuals x sites / s), 1M sites x 1k ind",
             "value": units / dt,
@@ -266,7 +294,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo[dom],
                          "note": LIMITER_NOTES.get(dom, "")},
             "roofline_all_kernels": fam_roof,
-            "per_step_kernel_ms": {k: fam[k] / K for k in fam},
+            "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
             "bfgs": {"rounds_per_iter": rounds / K, "points_per_iter": points / K,
                      "ind_rounds_per_iter": ind_rounds / K,
                      "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},

@@ -215,8 +215,9 @@ void* nghmm_stream(nghmm_t* h);
 int nghmm_synchronize(nghmm_t* h);
 /* HIP-event timing of the last call of each kernel family, in milliseconds:
  * 0 emission, 1 forward(store), 2 backward+posterior, 3 lkl_batch (sum over rounds of
- * the last mstep_indf or the last lkl_batch call), 4 est_maf+emission, 5 viterbi.
- * Also the launch count behind slot 3. */
+ * the last mstep_indf or the last lkl_batch call), 4 est_maf+emission, 5 viterbi, 6 the
+ * part of slot 3 spent in the round that doubled as the E-step's forward walk
+ * (nghmm_estep_mstep).  Also the launch count behind each slot. */
 int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches);
 
 #ifdef __cplusplus

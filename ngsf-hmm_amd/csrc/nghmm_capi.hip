@@ -52,7 +52,7 @@ void set_error(const char* fmt, ...) {
   } while (0)
 
 enum Slot { SLOT_EMISSION = 0, SLOT_FORWARD = 1, SLOT_BACKWARD = 2, SLOT_LKL = 3, SLOT_ESTMAF = 4,
-            SLOT_VITERBI = 5, NSLOTS = 6 };
+            SLOT_VITERBI = 5, SLOT_LKL_FIRST = 6, NSLOTS = 7 };
 
 }  // namespace
 
@@ -92,8 +92,8 @@ struct nghmm_handle {
   bool marg_valid = false;
 
   std::vector<double> h_indF, h_alpha;
-  double ms[NSLOTS] = {0, 0, 0, 0, 0, 0};
-  uint32_t launches[NSLOTS] = {0, 0, 0, 0, 0, 0};
+  double ms[NSLOTS] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t launches[NSLOTS] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -259,7 +259,12 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind,
                          h->d_pt_F, h->d_pt_A, h->d_pt_lkl, nullptr, h->d_flags);
   }
+  const double ms_before = accumulate ? h->ms[SLOT_LKL] : 0.0;
   if ((rc = toc(h, SLOT_LKL, accumulate))) return rc;
+  if (emit_estep && *emit_estep) {  // the round that doubles as the E-step's forward walk
+    h->ms[SLOT_LKL_FIRST] = h->ms[SLOT_LKL] - ms_before;
+    h->launches[SLOT_LKL_FIRST] = 1;
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(lkl, h->d_pt_lkl, n_pts * sizeof(double), hipMemcpyDeviceToHost,
                          h->stream));
@@ -556,6 +561,8 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   if (stats) std::memset(stats, 0, sizeof *stats);
   h->ms[SLOT_LKL] = 0;
   h->launches[SLOT_LKL] = 0;
+  h->ms[SLOT_LKL_FIRST] = 0;
+  h->launches[SLOT_LKL_FIRST] = 0;
   if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
     return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
 

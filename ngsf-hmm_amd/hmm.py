@@ -151,7 +151,7 @@ def bfgs_batch_host(indF, alpha, objective, indF_fixed=False, alpha_fixed=False)
 
 
 KERNEL_SLOTS = {"emission": 0, "forward": 1, "backward": 2, "lkl_batch": 3, "est_maf": 4,
-                "viterbi": 5}
+                "viterbi": 5, "lkl_first": 6}
 
 
 class NgsFHMM:
