@@ -1633,8 +1633,12 @@ bool dalloc(T** p, size_t n) {
 bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   fs.I = I;
   fs.S = S;
-  // enough waves to fill 256 CUs several times over, but at least 16 sites per lane
-  uint64_t C = (8192 + I - 1) / I;
+  // Waves per individual.  The objective rounds run 4 waves per SIMD = 4096 at a time and
+  // all their waves take equally long, so a launch of n waves wastes the unfilled part of
+  // its last batch: ~32k waves per 1000 individuals keep that below 2 % (measured at
+  // 1000 x 1M: FP64 issue 51 % -> 57 % of peak from C = 9 to C = 32).  At least 16 sites
+  // per lane.
+  uint64_t C = (32768 + I - 1) / I;
   if (const char* env = std::getenv("NGHMM_FAST_C")) {  // tuning knob: waves per individual
     const long v = std::atol(env);
     if (v >= 1) C = (uint64_t)v;
