@@ -9,10 +9,19 @@ values of examples/test.sh "normal" (--freq 0.1 --indF 0.1,0.2), inputs resident
 HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W [--workload c3|c2|tiny] [--mode fast|exact]
+                   [--scaling strong|weak]
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns
-its own 1000 individuals for all sites (weak scaling) and the frequency step is
-site-sharded: posteriors move by an RCCL all-to-all, frequencies by an all-gather.
+N > 1 = one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / WORLD_SIZE in
+the environment) the process IS a rank; started plainly (`python bench.py --gpus N`) it
+launches the N ranks itself as a child `python -m torch.distributed.run ...` BEFORE any
+GPU call and relays the child's JSON line and exit code.  A rank exits non-zero when the
+process group's size is not --gpus.
+
+--scaling strong (the default; BASELINE.json configs[3]): the workload's individuals are
+SHARDED over the ranks (1000 / N per GPU, all sites), the frequency step is site-sharded
+(S / N sites x all individuals per GPU): posteriors move by an RCCL all-to-all,
+frequencies by an all-gather.  --scaling weak: every rank owns the workload's full number
+of individuals.
 
 Prints ONE JSON line on rank 0.
 """
@@ -87,39 +96,92 @@ def pmc_traffic(family, args, I, S, C, rounds, ind_rounds, K):
     return total / rounds
 
 
-def cpu_baseline(pkg, seconds_budget=20.0):
+def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
     """The oracle (libm build = the reference's arithmetic; its L-BFGS-B core is pinned
     bit for bit to the reference object) timed on this box's host cores on a bounded
     sample of the same workload: per-individual phases threaded like the reference's
-    pool, the frequency loop serial as in the reference (EM.cpp:224)."""
+    pool, the frequency loop serial as in the reference (EM.cpp:224).  `improved_cpu`:
+    the same sample with the frequency loop threaded over sites too (BASELINE.md section 4:
+    what a maintainer could get from the CPU without changing the arithmetic).
+    full_c2: additionally one EM iteration of BASELINE.json configs[1] (100 x 100k) in
+    full, about a minute on a 256-thread host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     cores = os.cpu_count() or 1
-    n_ind, n_sites = 100, 4000
-    d = pkg.simulate.simulate(n_ind, n_sites, seed=777)
-    gl = pkg.simulate.normalise_log_gl(d.gl)
     orc = orclib.Oracle("libm")
-    em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
-    em.set_params(0.1, 0.2, 0.1)
-    em.init_emission()
-    t0 = time.time()
-    iters = 0
-    while iters < 3 and (time.time() - t0) < seconds_budget:
-        rc = em.iterate(n_threads=min(cores, n_ind))
-        assert rc == 0
-        iters += 1
-    dt = time.time() - t0
-    return {
-        "value": n_ind * n_sites * iters / dt,
+
+    def timed(n_ind, n_sites, max_iters, budget, thread_freq):
+        d = pkg.simulate.simulate(n_ind, n_sites, seed=777)
+        gl = pkg.simulate.normalise_log_gl(d.gl)
+        em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
+        em.set_params(0.1, 0.2, 0.1)
+        em.init_emission()
+        thr = min(cores, n_sites if thread_freq else n_ind)
+        t0 = time.time()
+        iters = 0
+        while iters < max_iters and (time.time() - t0) < budget:
+            rc = em.iterate(n_threads=thr, thread_freq=thread_freq)
+            assert rc == 0
+            iters += 1
+        dt = time.time() - t0
+        res = (n_ind * n_sites * iters / dt, iters, dt, thr, em.lkl_calls / (n_ind * iters),
+               em.maf_passes / (n_sites * iters))
+        em.close()
+        return res
+
+    n_ind, n_sites = 100, 4000
+    v, iters, dt, thr, fw, mp = timed(n_ind, n_sites, 3, seconds_budget, False)
+    out = {
+        "value": v,
         "unit": "site-ind updates/s",
-        "cores": min(cores, n_ind),
+        "cores": thr,
         "kind": "port",
         "sample": f"{n_ind} ind x {n_sites} sites, {iters} EM iterations in {dt:.1f} s, oracle libm "
-                  f"build, per-individual phases on {min(cores, n_ind)} threads, allele-frequency "
+                  f"build, per-individual phases on {thr} threads, allele-frequency "
                   f"loop serial as in the reference (EM.cpp:224)",
-        "forward_passes_per_ind_iter": em.lkl_calls / (n_ind * iters),
-        "est_maf_passes_per_site": em.maf_passes / (n_sites * iters),
+        "forward_passes_per_ind_iter": fw,
+        "est_maf_passes_per_site": mp,
     }
+    v2, it2, dt2, thr2, _, _ = timed(n_ind, n_sites, 3, seconds_budget / 2, True)
+    out["improved_cpu"] = {
+        "value": v2, "unit": "site-ind updates/s", "cores": thr2,
+        "sample": f"same {n_ind} x {n_sites} sample, {it2} iterations in {dt2:.1f} s, allele-frequency "
+                  f"loop threaded over sites as well ({thr2} threads): not the reference's "
+                  f"behaviour (its loop is serial, EM.cpp:224), same arithmetic"}
+    if full_c2:
+        v3, it3, dt3, thr3, _, _ = timed(100, 100_000, 1, 1e9, False)
+        out["configs1_full"] = {
+            "value": v3, "unit": "site-ind updates/s", "cores": thr3,
+            "sample": f"BASELINE configs[1] in full: 100 ind x 100k sites, {it3} EM iteration in "
+                      f"{dt3:.1f} s, frequency loop serial as in the reference"}
+    return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N rank
+    processes as a CHILD (never exec: this process may not have touched the GPU, and it has
+    not -- device_count() does not initialise it) and relay its output and exit code."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < args.gpus and "NGHMM_BENCH_BACKEND" not in env:
+        # fewer GPUs than ranks (a one-GPU box): functional run only -- every rank on cuda:0,
+        # collectives through gloo staged on the host; the line says so
+        if n_dev < 1 or args.gpus > 4:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+        env["NGHMM_BENCH_BACKEND"] = "gloo"
+        env["NGHMM_BENCH_ONE_GPU"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+           str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
 
 
 def main():
@@ -134,7 +196,16 @@ def main():
     ap.add_argument("--n_ind", type=int, default=None)
     ap.add_argument("--n_sites", type=int, default=None)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_full_c2", action="store_true",
+                    help="cpu_baseline also times BASELINE configs[1] (100 x 100k) in full")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: shard the workload's individuals over the ranks (strong, "
+                         "BASELINE configs[3]) or give every rank the full number (weak)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)       # does not return
 
     import torch
     import torch.distributed as dist
@@ -143,6 +214,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # NGHMM_BENCH_BACKEND=gloo + NGHMM_BENCH_ONE_GPU=1: functional test of the
@@ -156,6 +230,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, "
+                             f"--gpus says {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)
@@ -167,6 +244,12 @@ def main():
     if args.n_sites:
         wl["n_sites"] = args.n_sites
     I, S = wl["n_ind"], wl["n_sites"]
+    strong = args.scaling == "strong"
+    if world > 1 and strong:
+        if I % world or S % world:
+            raise SystemExit(f"--scaling strong: {I} individuals / {S} sites do not divide by {world}")
+        I //= world           # per rank; the job's total stays wl["n_ind"]
+    I_tot = I * world
     mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
 
     # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
@@ -216,7 +299,7 @@ def main():
 
     if rank == 0:
         K = max(args.steps, 1)
-        units = float(I) * S * world * K
+        units = float(I_tot) * S * K
         # dominant kernel family by measured time, and its algorithmic traffic per launch
         # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
         # fast mode: the first objective round of an iteration (all I individuals) reads the
@@ -226,7 +309,7 @@ def main():
         algo = {
             "lkl_batch": ((44.0 * S * I * K + 16.0 * S * max(ind_rounds - I * K, 0)) if fast
                           else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
-            "est_maf": 32.0 * S * I,   # N > 1: S/N own sites x N*I individuals per rank
+            "est_maf": 32.0 * (S / world) * I_tot,   # S/N own sites x all individuals per rank
             "forward": (28.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
             "emission": (8.0 * S if fast else 40.0 * S * I),
@@ -262,7 +345,7 @@ def main():
             if "est_maf" in fam_roof:
                 # per site: 21 evaluations (4 exact passes, 16 interval nodes, the check) of
                 # 8.06 instructions per individual + ~45, and ~22 per individual to set up
-                i_tot = I * world
+                i_tot = I_tot
                 ni = min(16, -(-i_tot // 64))
                 waves = max(1, -(-i_tot // 1024))
                 per_site = waves * (21 * (8.06 * ni + 45) + 22 * ni)
@@ -281,17 +364,29 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # total work fixed as N grows (strong: this run is a point of the 1/2/4/8 series
+            # over the same 1000 x 1M job) or per-GPU work fixed (weak)
+            "scaling": args.scaling,
+            "ranks": world,
+            "collectives": (None if world == 1 else
+                            ("rccl (nccl backend)" if backend == "nccl" else
+                             f"{backend}, all ranks on one GPU: functional run, not a measurement")),
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "n_ind_per_gpu": I, "n_sites": S,
-                       "mode": args.mode, "freq_est": 1,
-                       "sharding": "individuals per GPU; site-sharded allele-frequency step"},
+            "config": {"workload": wl["name"], "n_ind_total": I_tot, "n_ind_per_gpu": I,
+                       "n_sites": S, "mode": args.mode, "freq_est": 1,
+                       "sharding": (None if world == 1 else
+                                    f"{I} of {I_tot} individuals per GPU for all sites; allele-"
+                                    f"frequency step on {S // world} sites x all individuals per "
+                                    f"GPU (all-to-all of posteriors, all-gather of frequencies)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": launches[dom],
                          "algorithmic_bytes_per_launch": algo[dom],
+                         "traffic_source": ("committed rocprofv3 --pmc passes of this workload "
+                                            "(profiles/), not measured in this run"
+                                            if traffic is not None else None),
                          "note": LIMITER_NOTES.get(dom, "")},
             "roofline_all_kernels": fam_roof,
             "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
@@ -300,7 +395,7 @@ def main():
                      "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},
         }
         if not args.no_cpu_baseline and world == 1:   # on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(pkg)
+            out["cpu_baseline"] = cpu_baseline(pkg, full_c2=args.cpu_full_c2)
         print(json.dumps(out))
     em.close()
     if world > 1:

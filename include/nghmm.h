@@ -52,7 +52,15 @@ enum {
   NGHMM_MODE_EXACT = 0,
   /* Linear-space, chunk-parallel scan over sites with rescaling (the
    * throughput path); per-call results within 1e-9 relative of exact mode. */
-  NGHMM_MODE_FAST = 1
+  NGHMM_MODE_FAST = 1,
+  /* OR-ed into the mode: the genotype likelihoods are CALLED GENOTYPES (--call_geno, or a
+   * called-genotype input file; ngsF-HMM.cpp:101-117, shared/read_data.cpp:88-98,
+   * shared/gen_func.cpp:886-914), of which every cell is one of four -- genotype 0, 1, 2
+   * or missing -- and is kept as a 2-bit code (0.25 B instead of 24 B per site and
+   * individual).  Results equal those of an unpacked handle given the same cells: bit for bit
+   * in exact mode.  A loader that meets a cell which is not a called genotype returns
+   * NGHMM_ERR_ARG. */
+  NGHMM_GENO_PACKED = 0x10
 };
 
 /* Statistics of one indF/alpha M-step (shared/bfgs.cpp rounds). */
@@ -101,6 +109,25 @@ int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw_site_major, int space, in
 
 /* Same, from buffers already resident on the handle's device. */
 int nghmm_load_gl_device(nghmm_t* h, const double* d_gl_site_major, const double* d_pos_dist_mb);
+
+/* Chunked loading, for inputs that should never exist in one piece on the host (the file
+ * goes to the device a block of sites at a time; read_geno, shared/read_data.cpp:13-116,
+ * holds the whole matrix): nghmm_load_begin with the distances, then every site exactly once
+ * in chunks [site_begin, site_begin + n_sites) of any size and order, then nghmm_load_end.
+ *   nghmm_load_gl_raw_sites      raw likelihoods [n_sites][I][3] as nghmm_load_gl_raw takes them
+ *   nghmm_load_gl_raw_sites_dev  the same from a device buffer (left unmodified)
+ *   nghmm_load_geno_sites        called genotypes [n_sites][I] as the reader sees them, -1
+ *                                (missing), 0, 1, 2 (shared/read_data.cpp:88-98); a value > 2 is
+ *                                NGHMM_ERR_ARG ("Genotypes must be coded as {-1,0,1,2} !")
+ * The whole-matrix loaders above are these three calls in a row. */
+int nghmm_load_begin(nghmm_t* h, const double* pos_dist_mb);
+int nghmm_load_begin_dev(nghmm_t* h, const double* d_pos_dist_mb);
+int nghmm_load_gl_raw_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites,
+                            const double* gl_raw, int space, int call_geno, int check_nan);
+int nghmm_load_gl_raw_sites_dev(nghmm_t* h, uint64_t site_begin, uint64_t n_sites,
+                                const double* d_gl_raw, int space, int call_geno, int check_nan);
+int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const int8_t* geno);
+int nghmm_load_end(nghmm_t* h);
 
 /* indF[I], alpha[I], freq[S]; NULL leaves a vector unchanged (parse_args.cpp:245-363). */
 int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const double* freq);
@@ -196,6 +223,12 @@ int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uin
 int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard);
 /* same, from a device buffer */
 int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard);
+/* packed handles: the own individuals' genotype codes of the sites [site_lo, site_hi) as one
+ * byte per cell (0, 1, 2, 3 = missing), d_out[(s - site_lo) * n_ind + i] (device) -- what the
+ * host exchanges once to build the site shards -- and the static site-shard copy from such
+ * bytes, [n_sites_own][n_ind_total] (device) */
+int nghmm_get_geno_codes_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, uint8_t* d_out);
+int nghmm_load_geno_site_shard_dev(nghmm_t* h, const uint8_t* d_codes_bytes);
 /* pack posteriors of the own individuals for destination rank r's site range:
  * d_out[(s - site_lo) * n_ind + i], s in [site_lo, site_hi); with [0, n_sites) the whole
  * site-major matrix = the send buffer of all equal contiguous ranges at once */

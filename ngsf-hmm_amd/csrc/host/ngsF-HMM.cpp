@@ -329,7 +329,7 @@ void print_iter(const Params& P, nghmm_t* h) {
   if (!fh) fatal(__FUNCTION__, "cannot open INDF output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
   fprintf(fh, "%.10f\n", P.tot_lkl);
-  for (uint16_t i = 0; i < I; i++) {  // (sic) uint16_t as in the reference
+  for (uint64_t i = 0; i < I; i++) {  // the reference's uint16_t index never ends for I >= 65536
     if (P.indF[i] < kEPSILON)
       fprintf(fh, "%.5f\tNA\n", (double)0);
     else if (P.indF[i] > 1 - kEPSILON)
@@ -410,7 +410,9 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       {"min_epsilon", required_argument, nullptr, 'E'},
       {"n_threads", required_argument, nullptr, 'x'}, {"verbose", required_argument, nullptr, 'V'},
       {"seed", required_argument, nullptr, 'S'},      {"mode", required_argument, nullptr, 1000},
-      {"device", required_argument, nullptr, 1001},   {0, 0, 0, 0}};
+      {"device", required_argument, nullptr, 1001},   {"taus_kat", required_argument, nullptr, 1002},
+      {0, 0, 0, 0}};
+  long taus_kat = 0;
   P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
   int c;
   while ((c = getopt_long_only(argc, argv, "g:Z:lLn:s:Gf:F:e:i:IAo:X:b:m:M:E:x:V:S:", long_options,
@@ -444,8 +446,16 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
         else fatal(__FUNCTION__, "invalid --mode (exact|fast)!");
         break;
       case 1001: P.device = atoi(optarg); break;
+      case 1002: taus_kat = atol(optarg); break;
       default: exit(-1);
     }
+  if (taus_kat > 0) {  // known-answer check of the generator: the N-th raw output for --seed
+    Taus rng(P.seed);
+    uint32_t v = 0;
+    for (long k = 0; k < taus_kat; k++) v = rng.next();
+    printf("%u\n", v);
+    exit(0);
+  }
   if (P.in_freq.empty()) P.in_freq = "r";
   if (P.in_indF.empty()) P.in_indF = "0.01-0.001";
   if (P.verbose >= 1) {

@@ -5,11 +5,14 @@
 
 #include <cstdint>
 
+#include "glview.hpp"
+
 namespace nghmm {
 
 // Error flags raised by kernels (device int[NFLAGS]); the C ABI maps them to the
 // reference's fatal messages.
-enum Flag { FLAG_INVALID_LKL = 0, FLAG_FW_BW = 1, FLAG_INVALID_MAF = 2, FLAG_NAN = 3, NFLAGS = 8 };
+enum Flag { FLAG_INVALID_LKL = 0, FLAG_FW_BW = 1, FLAG_INVALID_MAF = 2, FLAG_NAN = 3,
+            FLAG_NOT_PACKABLE = 4, FLAG_BAD_GENO = 5, NFLAGS = 8 };
 
 // ---------------- exact mode (kernels_exact.hip) ----------------
 // All arrays site-major: gl [S][I][3], eprob [S][I][2], fw [S+1][I][2], marg [S][I].
@@ -20,14 +23,32 @@ enum Flag { FLAG_INVALID_LKL = 0, FLAG_FW_BW = 1, FLAG_INVALID_MAF = 2, FLAG_NAN
 void launch_prepare_gl(hipStream_t st, double* gl, uint64_t n_cells, int space, int call_geno,
                        int* flags);
 
+// ---- called genotypes as 2-bit codes (glview.hpp) ----
+// prepared dense cells [n_cells][3] -> codes at cell index cell0 + c (codes zeroed beforehand);
+// table = [3][3] prepared likelihoods of the called classes; *uniform_bits (initially ~0)
+// learns the one value all uniform cells share; FLAG_NOT_PACKABLE on any other cell
+void launch_pack_cells(hipStream_t st, const double* gl, uint64_t n_cells, uint64_t cell0,
+                       const double* table, uint32_t* codes, unsigned long long* uniform_bits,
+                       int* flags);
+// reader genotypes (-1 missing, 0, 1, 2) -> codes; FLAG_BAD_GENO on a value > 2
+void launch_pack_geno(hipStream_t st, const int8_t* geno, uint64_t n_cells, uint64_t cell0,
+                      uint32_t* codes, int* flags);
+// reader genotypes -> the raw likelihoods of shared/read_data.cpp:21,88-98 (dense [n_cells][3])
+void launch_expand_geno(hipStream_t st, const int8_t* geno, uint64_t n_cells, double log_third,
+                        double* gl, int* flags);
+void launch_unpack_cells(hipStream_t st, const GlView& gl, uint64_t n_cells, double* out);
+void launch_codes_to_bytes(hipStream_t st, const uint32_t* codes, uint64_t cell0, uint64_t n_cells,
+                           uint8_t* out);
+void launch_bytes_to_codes(hipStream_t st, const uint8_t* in, uint64_t n_cells, uint32_t* codes);
+
 // genotype posteriors of the .geno output (EM.cpp:367-376) for sites s0 .. s0 + n_s from
 // the blocked Viterbi path; out [n_s][I][3]
-void launch_geno_post_exact(hipStream_t st, const double* gl, const double* freq,
+void launch_geno_post_exact(hipStream_t st, const GlView& gl, const double* freq,
                             const uint8_t* path16, uint64_t I, uint64_t s0, uint64_t n_s,
                             double* out);
 
 // e_prob[s][i][k] = calc_emission(gl[s][i], freq[s], k)   (shared/HMM.cpp:144-154)
-void launch_emission_exact(hipStream_t st, const double* gl, const double* freq, double* eprob,
+void launch_emission_exact(hipStream_t st, const GlView& gl, const double* freq, double* eprob,
                            uint64_t S, uint64_t I, int* flags);
 
 // forward recursion (shared/HMM.cpp:6-28) for n_pts (individual, F, alpha) points;
@@ -43,7 +64,7 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
 
 // est_maf per site (shared/gen_func.cpp:974-1009): gl_sites [S_own][I_tot][3],
 // marg_sites [S_own][I_tot] -> freq_out[S_own]; passes_out (nullable) counts passes.
-void launch_estmaf_exact(hipStream_t st, const double* gl_sites, const double* marg_sites,
+void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out);
 
 // Viterbi (shared/HMM.cpp:98-125): bp [viterbi_blocked_bytes + I] scratch bytes, path_sites

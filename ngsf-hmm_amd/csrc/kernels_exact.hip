@@ -23,6 +23,7 @@
 #include <cstdint>
 
 #include "detmath.h"
+#include "glview.hpp"
 #include "kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -104,14 +105,15 @@ constexpr int U = 4;  // sites per prefetch group
 
 // ------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_emission_exact(const double* __restrict__ gl, const double* __restrict__ freq,
+k_emission_exact(const GlView gl, const double* __restrict__ freq,
                  double* __restrict__ eprob, uint64_t S, uint64_t I, int* __restrict__ flags) {
   const uint64_t n = S * I;
   for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n;
        c += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s = c / I;
     const double maf = freq[s];
-    const double g0 = gl[c * 3], g1 = gl[c * 3 + 1], g2 = gl[c * 3 + 2];
+    double g0, g1, g2;
+    gl_fetch(gl, c, g0, g1, g2);
     double e0, e1;
     if (maf < 0 || maf > 1) {
       flags[FLAG_INVALID_MAF] = 1;
@@ -298,12 +300,11 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 // individual order by all lanes redundantly, so the running sums are wave-uniform
 // and round exactly as the reference's `for i` loop (gen_func.cpp:984-1003).
 __global__ void __launch_bounds__(256)
-k_estmaf_exact(const double* __restrict__ gl, const double* __restrict__ marg, uint64_t S_own,
+k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
                uint64_t I, double* __restrict__ freq_out, uint32_t* __restrict__ passes_out) {
   const int lane = threadIdx.x & 63;
   const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (site >= S_own) return;
-  const double* gls = gl + site * I * 3;
   const double* ms = marg + site * I;
 
   int iters = 0;
@@ -319,7 +320,8 @@ k_estmaf_exact(const double* __restrict__ gl, const double* __restrict__ marg, u
       double tn = 0, td = 0;
       if (i < I) {
         const double F = ms[i];
-        const double g0 = gls[i * 3], g1 = gls[i * 3 + 1], g2 = gls[i * 3 + 2];
+        double g0, g1, g2;
+        gl_fetch(gl, site * I + i, g0, g1, g2);
         double h0, h1, h2;
         hwe_log(freq, F, h0, h1, h2);
         double p0 = g0 + h0, p1 = g1 + h1, p2 = g2 + h2;  // post_prob, gen_func.cpp:920-932
@@ -578,7 +580,7 @@ k_prepare_gl(double* __restrict__ gl, uint64_t n_cells, int space, int call_geno
 // with F the decoded state of the cell, post_prob, back to normal space.  path16 is the
 // blocked Viterbi path [site/16][individual][16]; out [n_s][I][3] for sites s0 .. s0 + n_s.
 __global__ void __launch_bounds__(256)
-k_geno_post_exact(const double* __restrict__ gl, const double* __restrict__ freq,
+k_geno_post_exact(const GlView gl, const double* __restrict__ freq,
                   const uint8_t* __restrict__ path16, uint64_t I, uint64_t s0, uint64_t n_s,
                   double* __restrict__ out) {
   const uint64_t n = n_s * I;
@@ -588,12 +590,121 @@ k_geno_post_exact(const double* __restrict__ gl, const double* __restrict__ freq
     const double F = (double)path16[((s >> 4) * I + i) * 16 + (s & 15)];
     double h0, h1, h2;
     hwe_log(freq[s], F, h0, h1, h2);
-    const double* g = gl + (s * I + i) * 3;
-    const double p0 = g[0] + h0, p1 = g[1] + h1, p2 = g[2] + h2;
+    double g0, g1, g2;
+    gl_fetch(gl, s * I + i, g0, g1, g2);
+    const double p0 = g0 + h0, p1 = g1 + h1, p2 = g2 + h2;
     const double norm = logsum3(p0, p1, p2);
     out[c * 3 + 0] = det_exp(p0 - norm);
     out[c * 3 + 1] = det_exp(p1 - norm);
     out[c * 3 + 2] = det_exp(p2 - norm);
+  }
+}
+
+
+// ---- called genotypes as 2-bit codes (glview.hpp) ---------------------------------------
+// Classifies prepared cells: class g = the cell equals, bit for bit, the prepared likelihoods
+// of called genotype g (table rows 0..2: what k_prepare_gl makes of a one-hot cell); class 3 =
+// three equal values (missing data, or a cell --call_geno leaves uniform).  All class-3 cells
+// of a data set must carry the same value: the first one seen is recorded in *uniform_bits
+// (initially ~0) and every other is compared with it.  Anything else raises flags[FLAG_NAN + 1]
+// ("not packable").  codes must be zeroed before the first chunk (atomicOr: chunks of sites
+// need not start on a word boundary).
+__global__ void __launch_bounds__(256)
+k_pack_cells(const double* __restrict__ gl, uint64_t n_cells, uint64_t cell0,
+             const double* __restrict__ table, uint32_t* __restrict__ codes,
+             unsigned long long* __restrict__ uniform_bits, int* __restrict__ flags) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t b0 = ngh_bits(gl[c * 3]), b1 = ngh_bits(gl[c * 3 + 1]),
+                   b2 = ngh_bits(gl[c * 3 + 2]);
+    uint32_t code = 4;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      if (b0 == ngh_bits(table[g * 3]) && b1 == ngh_bits(table[g * 3 + 1]) &&
+          b2 == ngh_bits(table[g * 3 + 2]))
+        code = g;
+    if (code == 4 && b0 == b1 && b1 == b2 && gl[c * 3] == gl[c * 3]) {
+      const unsigned long long old = atomicCAS(uniform_bits, ~0ull, (unsigned long long)b0);
+      if (old == ~0ull || old == b0) code = 3;
+    }
+    if (code == 4) {
+      flags[FLAG_NOT_PACKABLE] = 1;
+      code = 3;
+    }
+    const uint64_t k = cell0 + c;
+    atomicOr(&codes[k >> 4], code << ((uint32_t)(k & 15) * 2));
+  }
+}
+
+// genotype codes as the reader sees them (-1 missing, 0, 1, 2) -> 2-bit codes
+__global__ void __launch_bounds__(256)
+k_pack_geno(const int8_t* __restrict__ geno, uint64_t n_cells, uint64_t cell0,
+            uint32_t* __restrict__ codes, int* __restrict__ flags) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const int g = geno[c];
+    if (g > 2) flags[FLAG_BAD_GENO] = 1;  // "Genotypes must be coded as {-1,0,1,2} !"
+    const uint32_t code = (g < 0 || g > 2) ? 3u : (uint32_t)g;
+    const uint64_t k = cell0 + c;
+    atomicOr(&codes[k >> 4], code << ((uint32_t)(k & 15) * 2));
+  }
+}
+
+// the raw likelihoods the reference's reader builds from a called genotype
+// (shared/read_data.cpp:21,88-98): log(1) at the genotype, -1e15 elsewhere; missing: the
+// caller's log(1/3) three times
+__global__ void __launch_bounds__(256)
+k_expand_geno(const int8_t* __restrict__ geno, uint64_t n_cells, double log_third,
+              double* __restrict__ gl, int* __restrict__ flags) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    const int g = geno[c];
+    if (g > 2) flags[FLAG_BAD_GENO] = 1;
+    double v0 = -kINF, v1 = -kINF, v2 = -kINF;
+    if (g < 0 || g > 2) v0 = v1 = v2 = log_third;
+    else if (g == 0) v0 = 0.0;
+    else if (g == 1) v1 = 0.0;
+    else v2 = 0.0;
+    gl[c * 3] = v0;
+    gl[c * 3 + 1] = v1;
+    gl[c * 3 + 2] = v2;
+  }
+}
+
+// any view -> dense [cells][3] (host read-back of the prepared likelihoods) or int8 codes
+__global__ void __launch_bounds__(256)
+k_unpack_cells(const GlView gl, uint64_t n_cells, double* __restrict__ out) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (uint64_t)gridDim.x * blockDim.x) {
+    double g0, g1, g2;
+    gl_fetch(gl, c, g0, g1, g2);
+    out[c * 3] = g0;
+    out[c * 3 + 1] = g1;
+    out[c * 3 + 2] = g2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_codes_to_bytes(const uint32_t* __restrict__ codes, uint64_t cell0, uint64_t n_cells,
+                 uint8_t* __restrict__ out) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (uint64_t)gridDim.x * blockDim.x)
+    out[c] = (uint8_t)gl_code(codes, cell0 + c);
+}
+
+__global__ void __launch_bounds__(256)
+k_bytes_to_codes(const uint8_t* __restrict__ in, uint64_t n_cells, uint32_t* __restrict__ codes) {
+  // one thread per output word (the destination starts at cell 0)
+  const uint64_t n_words = (n_cells + 15) / 16;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words;
+       w += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t c = w * 16 + j;
+      if (c < n_cells) v |= (uint32_t)(in[c] & 3) << (2 * j);
+    }
+    codes[w] = v;
   }
 }
 
@@ -608,7 +719,54 @@ void launch_prepare_gl(hipStream_t st, double* gl, uint64_t n_cells, int space, 
                      call_geno, flags);
 }
 
-void launch_geno_post_exact(hipStream_t st, const double* gl, const double* freq,
+
+static unsigned grid_for(uint64_t n) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  return (unsigned)(blocks ? blocks : 1);
+}
+
+void launch_pack_cells(hipStream_t st, const double* gl, uint64_t n_cells, uint64_t cell0,
+                       const double* table, uint32_t* codes, unsigned long long* uniform_bits,
+                       int* flags) {
+  if (n_cells == 0) return;
+  hipLaunchKernelGGL(k_pack_cells, dim3(grid_for(n_cells)), dim3(256), 0, st, gl, n_cells, cell0,
+                     table, codes, uniform_bits, flags);
+}
+
+void launch_pack_geno(hipStream_t st, const int8_t* geno, uint64_t n_cells, uint64_t cell0,
+                      uint32_t* codes, int* flags) {
+  if (n_cells == 0) return;
+  hipLaunchKernelGGL(k_pack_geno, dim3(grid_for(n_cells)), dim3(256), 0, st, geno, n_cells, cell0,
+                     codes, flags);
+}
+
+void launch_expand_geno(hipStream_t st, const int8_t* geno, uint64_t n_cells, double log_third,
+                        double* gl, int* flags) {
+  if (n_cells == 0) return;
+  hipLaunchKernelGGL(k_expand_geno, dim3(grid_for(n_cells)), dim3(256), 0, st, geno, n_cells,
+                     log_third, gl, flags);
+}
+
+void launch_unpack_cells(hipStream_t st, const GlView& gl, uint64_t n_cells, double* out) {
+  if (n_cells == 0) return;
+  hipLaunchKernelGGL(k_unpack_cells, dim3(grid_for(n_cells)), dim3(256), 0, st, gl, n_cells, out);
+}
+
+void launch_codes_to_bytes(hipStream_t st, const uint32_t* codes, uint64_t cell0, uint64_t n_cells,
+                           uint8_t* out) {
+  if (n_cells == 0) return;
+  hipLaunchKernelGGL(k_codes_to_bytes, dim3(grid_for(n_cells)), dim3(256), 0, st, codes, cell0,
+                     n_cells, out);
+}
+
+void launch_bytes_to_codes(hipStream_t st, const uint8_t* in, uint64_t n_cells, uint32_t* codes) {
+  if (n_cells == 0) return;
+  hipLaunchKernelGGL(k_bytes_to_codes, dim3(grid_for((n_cells + 15) / 16)), dim3(256), 0, st, in,
+                     n_cells, codes);
+}
+
+void launch_geno_post_exact(hipStream_t st, const GlView& gl, const double* freq,
                             const uint8_t* path16, uint64_t I, uint64_t s0, uint64_t n_s,
                             double* out) {
   if (n_s == 0 || I == 0) return;
@@ -618,7 +776,7 @@ void launch_geno_post_exact(hipStream_t st, const double* gl, const double* freq
                      I, s0, n_s, out);
 }
 
-void launch_emission_exact(hipStream_t st, const double* gl, const double* freq, double* eprob,
+void launch_emission_exact(hipStream_t st, const GlView& gl, const double* freq, double* eprob,
                            uint64_t S, uint64_t I, int* flags) {
   const uint64_t n = S * I;
   if (n == 0) return;
@@ -644,7 +802,7 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
                      fw, S, I, indF, alpha, ind_lkl, marg, flags);
 }
 
-void launch_estmaf_exact(hipStream_t st, const double* gl_sites, const double* marg_sites,
+void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out) {
   if (S_own == 0) return;
   hipLaunchKernelGGL(k_estmaf_exact, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,

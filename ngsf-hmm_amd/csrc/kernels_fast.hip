@@ -225,6 +225,8 @@ struct LklArrays {
   const double* __restrict__ gl1_il;    // p1
   const double* __restrict__ freq_il;
   double2* __restrict__ e_out;          // == e_il, written by the fresh walk
+  const uint32_t* __restrict__ geno_il; // packed handle: 2-bit codes, 16 sites of a lane per word
+  double u_lin;                         // packed handle: linear likelihood of a uniform cell
 };
 
 struct SrcPlain {
@@ -273,6 +275,50 @@ struct SrcFresh {
     eo[t * 64] = double2{e0, e1};  // sites past T never get here
   }
 };
+
+// Fresh walk of a PACKED handle (called genotypes, glview.hpp): the cell is a 2-bit code, 16
+// consecutive sites of a lane share one 32-bit word, and the linear likelihoods are exactly
+// (1,0,0), (0,1,0), (0,0,1) or (u,u,u): the emission of SrcFresh::get collapses to a select
+// among four per-site values.  0.25 B read instead of 24 B per site and individual.
+struct SrcFreshPacked {
+  const uint32_t* __restrict__ gw;
+  const double* __restrict__ fp;
+  const double* __restrict__ dp;
+  double2* __restrict__ eo;
+  double u;
+  struct Buf {
+    uint32_t w;
+    double f, d;
+  };
+  __device__ __forceinline__ SrcFreshPacked(const LklArrays& A, uint64_t wave_base,
+                                            uint64_t pos_base)
+      : gw(A.geno_il + (((wave_base & ~63ull) >> 4) + (wave_base & 63))), fp(A.freq_il + pos_base),
+        dp(A.pos_il + pos_base), eo(A.e_out + wave_base), u(A.u_lin) {}
+  __device__ __forceinline__ Buf load(uint64_t t) const {
+    return Buf{gw[(t >> 4) * 64], fp[t * 64], dp[t * 64]};
+  }
+  __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& e0, double& e1,
+                                      double& d) const {
+    const uint32_t code = (b.w >> ((uint32_t)(t & 15) * 2)) & 3u;
+    const double maf = b.f, om = 1 - maf;
+    const double bb = om * maf;
+    const double h00 = om * om, h02 = maf * maf;
+    // the four classes through SrcFresh's formula with p in {0, 1} (exact) or p = (u, u, u)
+    const double u0 = fma(u, h00, fma(u, 2 * bb, u * h02));
+    const double u1 = fma(u, h00 + bb, u * (h02 + bb));
+    e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
+    e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
+    d = b.d;
+    eo[t * 64] = double2{e0, e1};
+  }
+};
+
+// which per-site source a forward walk reads: the materialised emissions, or (first walk
+// after a frequency update) the dense / packed likelihoods
+enum { SRC_PLAIN = 0, SRC_FRESH = 1, SRC_FRESH_PACKED = 2 };
+template <int SRC>
+using SrcOf = std::conditional_t<SRC == SRC_PLAIN, SrcPlain,
+                                 std::conditional_t<SRC == SRC_FRESH, SrcFresh, SrcFreshPacked>>;
 
 // The main loop of one wave for the finite-difference pattern.  Per site and lane:
 // one exp (a degree-7 polynomial when alpha * d_max <= 2^-6: SMALL), the products shared
@@ -386,11 +432,11 @@ __device__ __forceinline__ void lkl_store_wave_op(Op r, int lane, double* __rest
 // One kernel per loop-body version (each gets its own register allocation); the host
 // sorts the groups of a round by mode and launches every version on its range
 // [g_begin, g_begin + gridDim.x / C).
-template <int NF, int NA, bool SMALL, bool EMIT, bool FRESH>
+template <int NF, int NA, bool SMALL, bool EMIT, int SRC>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
               uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
-  static_assert(EMIT || !FRESH, "the fresh walk is the first round of an M-step");
+  static_assert(EMIT || SRC == SRC_PLAIN, "the fresh walk is the first round of an M-step");
   // chunk-major: the waves resident at a time walk the same few slices of the shared
   // distance / frequency tables, which then stay in L2
   const uint32_t n_g = gridDim.x / C;
@@ -404,7 +450,7 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
   for (int p = 0; p < MAXP; ++p) R[p] = Op{1.0, 0.0, 0.0, 1.0, 0};
   const uint64_t wave_base = ((i * C + c) * T) * 64 + lane;
   const uint64_t pos_base = ((uint64_t)c * T) * 64 + lane;
-  using Src = std::conditional_t<FRESH, SrcFresh, SrcPlain>;
+  using Src = SrcOf<SRC>;
   lkl_run_fd<NF, NA, SMALL, EMIT>(Src(arr, wave_base, pos_base), T, G, R, emit, i * C + c, lane);
   if constexpr (EMIT) {
     Op r0 = R[0];
@@ -416,7 +462,7 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
     lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
 }
 
-template <int NP_MAX, bool FRESH>
+template <int NP_MAX, int SRC>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
                   uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
@@ -441,7 +487,7 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
     R[p] = Op{1.0, 0.0, 0.0, 1.0, 0};
   }
 
-  using Src = std::conditional_t<FRESH, SrcFresh, SrcPlain>;
+  using Src = SrcOf<SRC>;
   const Src src(arr, ((i * C + c) * T) * 64 + lane, ((uint64_t)c * T) * 64 + lane);
   typename Src::Buf buf[NB][UG];
 #pragma unroll
@@ -509,7 +555,9 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
   }
   const double l = log(v0 + v1) + (double)ex * 0.6931471805599453094;
   lkl_out[G.out_idx[p]] = l;
-  if (l != l) flags[FLAG_INVALID_LKL] = 1;
+  // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left in
+  // linear space; the host re-evaluates such points with the general kernel
+  if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
 }
 
 // ---- E-step ---------------------------------------------------------------
@@ -866,6 +914,54 @@ k_fast_emission(const double* __restrict__ gl_lin, const double* __restrict__ fr
   }
 }
 
+// packed handle: codes and frequencies are both interleaved already, so the refresh is a
+// straight elementwise pass (no transposition); same expressions as SrcFreshPacked::get
+__global__ void __launch_bounds__(256)
+k_fast_emission_packed(const uint32_t* __restrict__ geno_il, const double* __restrict__ freq_il,
+                       uint64_t I, uint64_t T, uint32_t C, double u, double2* __restrict__ e_il) {
+  const uint64_t n = I * C * T * 64;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t lane = k & 63, wt = k >> 6;  // wt = (i*C + c)*T + t
+    const uint64_t t = wt % T, wv = wt / T;
+    const uint64_t c = wv % C;
+    const uint32_t w = geno_il[(wv * (T >> 4) + (t >> 4)) * 64 + lane];
+    const uint32_t code = (w >> ((uint32_t)(t & 15) * 2)) & 3u;
+    const double maf = freq_il[(c * T + t) * 64 + lane], om = 1 - maf;
+    const double bb = om * maf;
+    const double h00 = om * om, h02 = maf * maf;
+    const double u0 = fma(u, h00, fma(u, 2 * bb, u * h02));
+    const double u1 = fma(u, h00 + bb, u * (h02 + bb));
+    const double e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
+    const double e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
+    e_il[k] = double2{e0, e1};
+  }
+}
+
+// site-major codes [S][I] (2 bits per cell) -> interleaved words [I][C][T/16][64]: word
+// (i, c, tb, lane) holds the codes of sites (c*64 + lane)*T + tb*16 .. + 15.  Padding sites
+// get code 0, which the padding frequency 0 turns into the identity emission (1, 1).
+__global__ void __launch_bounds__(256)
+k_fast_geno_interleave(const uint32_t* __restrict__ codes, uint64_t cell0, uint64_t I, uint64_t S,
+                       uint64_t T, uint32_t C, uint32_t* __restrict__ geno_il) {
+  const uint64_t TB = T >> 4;
+  const uint64_t n = I * C * TB * 64;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t lane = k & 63, r = k >> 6;
+    const uint64_t tb = r % TB, wv = r / TB;
+    const uint64_t c = wv % C, i = wv / C;
+    const uint64_t s0 = (c * 64 + lane) * T + tb * 16;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t s = s0 + j;
+      if (s < S) w |= gl_code(codes, cell0 + s * I + i) << (2 * j);
+    }
+    geno_il[k] = w;
+  }
+}
+
 // linear-space copy of the genotype likelihoods: they do not change during a run, and
 // both the emission refresh and est_maf would otherwise exponentiate all 3 I S of them
 // in every EM iteration
@@ -907,7 +1003,9 @@ k_fast_pos_interleave(const double* __restrict__ pos, uint64_t S, uint64_t T, ui
   }
 }
 
-// freq[S] -> interleaved [C][T][64] for the fresh forward walk (padding: 0.5); flags an
+// freq[S] -> interleaved [C][T][64] for the fresh forward walk (padding: 0, which makes both
+// the dense padding likelihoods (1, 1, 1) and the packed padding code 0 the identity emission
+// (1, 1) exactly); flags an
 // allele frequency outside [0, 1] like calc_emission does (shared/HMM.cpp:145-146)
 __global__ void __launch_bounds__(256)
 k_fast_freq_interleave(const double* __restrict__ freq, uint64_t S, uint64_t T, uint32_t C,
@@ -918,10 +1016,11 @@ k_fast_freq_interleave(const double* __restrict__ freq, uint64_t S, uint64_t T, 
     const uint64_t lane = k & 63, ct = k >> 6;
     const uint64_t c = ct / T, t = ct % T;
     const uint64_t s = (c * 64 + lane) * T + t;
-    double f = 0.5;
+    double f = 0.0;
     if (s < S) {
       f = freq[s];
-      if (!(f >= 0 && f <= 1)) {
+      if (f < 0 || f > 1) {  // the reference's predicate (HMM.cpp:145): NaN passes, and
+                             // surfaces later as "invalid Lkl found!" like in exact mode
         flags[FLAG_INVALID_MAF] = 1;
         f = __builtin_nan("");
       }
@@ -1193,7 +1292,7 @@ constexpr int ESTMAF_MAXW = 16;
 // L2 seven times.
 template <int NI, int BLOCK, bool TILE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
-k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
+k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
               double* __restrict__ freq_out, uint8_t* __restrict__ redo,
               uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
@@ -1222,7 +1321,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
     site = blockIdx.x;
   }
   if (!fresh && status[site] != EST_EXACT) return;
-  const double* gls = gl + site * I_tot * 3;
+  const uint64_t cell_s = site * I_tot;  // first cell of the site's row
 
   double tF_lane_out;
   // The loads of eight slots (32 per lane) are issued before anything waits on them
@@ -1242,9 +1341,7 @@ k_fast_estmaf(const double* __restrict__ gl, const double* __restrict__ marg_blo
       for (int j = 0; j < NB; ++j) {
         const uint64_t i = (uint64_t)tix + stride * (k0 + j);
         ic[j] = i < I_tot ? i : I_tot - 1;
-        r0[j] = gls[ic[j] * 3];
-        r1[j] = gls[ic[j] * 3 + 1];
-        r2[j] = gls[ic[j] * 3 + 2];
+        gl_fetch(gl, cell_s + ic[j], r0[j], r1[j], r2[j]);
       }
       if constexpr (TILE) {
 #pragma unroll
@@ -1571,14 +1668,14 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
 
 // any number of individuals: re-reads the (L2-resident) site row every pass
 __global__ void __launch_bounds__(256)
-k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ marg_blocks,
+k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
                      uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
                      double* __restrict__ freq_out, const uint8_t* __restrict__ redo) {
   const int lane = threadIdx.x & 63;
   const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (site >= S_own) return;
   if (redo && !redo[site]) return;
-  const double* gls = gl + site * I_tot * 3;
+  const uint64_t cell_s = site * I_tot;
   // tile_T != 0: posteriors in the tile-major layout (see k_fast_estmaf<.., TILE>)
   const uint64_t tj = tile_T ? site / tile_T : 0;  // lane-chunk c*64 + l; t = site - tj*T
   const double* trow =
@@ -1599,7 +1696,9 @@ k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ m
       const double bF = b * F;
       const double h0 = A + bF, h2 = Cq + bF;
       const double h1 = (F == 1) ? 0.0 : (2 * b - 2 * bF);
-      const double w0 = gls[i * 3] * h0, w1 = gls[i * 3 + 1] * h1, w2 = gls[i * 3 + 2] * h2;
+      double p0, p1, p2;
+      gl_fetch(gl, cell_s + i, p0, p1, p2);
+      const double w0 = p0 * h0, w1 = p1 * h1, w2 = p2 * h2;
       const double sum = w0 + w1 + w2;
       const double tF = 2 - F;
       if (sum > 0) {
@@ -1607,7 +1706,12 @@ k_fast_estmaf_stream(const double* __restrict__ gl, const double* __restrict__ m
         pn += fma(w2, tF, w1) * inv;
         pd += fma(w0 + w2, tF, 2 * w1) * inv;
       } else {
-        const double lg[3] = {log(gls[i * 3]), log(gls[i * 3 + 1]), log(gls[i * 3 + 2])};
+        // a called genotype's impossible classes are -1e15 in the reference (read_data.cpp:21),
+        // not -inf: the packed view knows it holds such cells
+        double lg[3] = {log(p0), log(p1), log(p2)};
+        if (!gl.dense)
+          for (int k = 0; k < 3; ++k)
+            if (lg[k] == -__builtin_huge_val()) lg[k] = -kINF;
         const double2 tt = estmaf_term_logspace(lg, freq, F);
         pn += tt.x;
         pd += tt.y;
@@ -1630,9 +1734,10 @@ bool dalloc(T** p, size_t n) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
-bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
+bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   fs.I = I;
   fs.S = S;
+  fs.packed = packed;
   // Waves per individual.  The objective rounds run 4 waves per SIMD = 4096 at a time and
   // all their waves take equally long, so a launch of n waves wastes the unfilled part of
   // its last batch: ~32k waves per 1000 individuals keep that below 2 % (measured at
@@ -1650,6 +1755,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   fs.J = 64 * C;
   fs.T = (S + fs.J - 1) / fs.J;
   fs.T = (fs.T + 7) & ~7ull;  // whole prefetch groups: the main loops need no bound checks
+  if (packed) fs.T = (fs.T + 15) & ~15ull;  // 16 sites of a lane per code word
   fs.Spad = fs.J * fs.T;
   const size_t cells = (size_t)I * fs.Spad;
   const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
@@ -1657,24 +1763,34 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S) {
   if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
-  if (!dalloc(&fs.gl02_il, (cells + slack) * 2)) return false;
-  if (!dalloc(&fs.gl1_il, cells + slack)) return false;
+  if (packed) {
+    const size_t words = cells / 16 + slack;
+    if (!dalloc(&fs.geno_il, words)) return false;
+    if (hipMemset(fs.geno_il, 0, words * sizeof(uint32_t)) != hipSuccess) return false;
+    if (!dalloc(&fs.cls_lin, (size_t)12)) return false;
+  } else {
+    if (!dalloc(&fs.gl02_il, (cells + slack) * 2)) return false;
+    if (!dalloc(&fs.gl1_il, cells + slack)) return false;
+    if (hipMemset(fs.gl02_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
+    if (hipMemset(fs.gl1_il + cells, 0, slack * sizeof(double)) != hipSuccess) return false;
+  }
   if (!dalloc(&fs.freq_il, (size_t)fs.Spad + slack)) return false;
-  if (hipMemset(fs.gl02_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
-  if (hipMemset(fs.gl1_il + cells, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (hipMemset(fs.freq_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.post, cells)) return false;
+  // the reference starts from marg_prob = 0 (parse_args.cpp:403-405): `--freq e` and a
+  // `--log` print before the first E-step read the posteriors
+  if (hipMemset(fs.post, 0, cells * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.ckpt, cells / CK * 4 + 4 * 64)) return false;  // T is a multiple of CK; slack:
                                                                  // see lkl_run_fd
-  if (!dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
+  if (!packed && !dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
   if (!dalloc(&fs.lane_ops, (size_t)I * fs.J * 5)) return false;
   if (!dalloc(&fs.bound, (size_t)I * fs.J * 4)) return false;
   return true;
 }
 
 void fast_destroy(FastState& fs) {
-  void* ptrs[] = {fs.e_il, fs.pos_il, fs.gl02_il, fs.gl1_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.eprob_log, fs.part,
-                  fs.grp_dev, fs.redo, fs.est_status, fs.est_state, fs.gl_lin};
+  void* ptrs[] = {fs.e_il, fs.pos_il, fs.gl02_il, fs.gl1_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.part,
+                  fs.grp_dev, fs.redo, fs.est_status, fs.est_state, fs.gl_lin, fs.geno_il, fs.cls_lin};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fs = FastState();
@@ -1684,11 +1800,27 @@ void fast_exp(hipStream_t st, const double* d_in, double* d_out, uint64_t n) {
   if (n) hipLaunchKernelGGL(k_fast_exp, dim3(16384), dim3(256), 0, st, d_in, d_out, n);
 }
 
-bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* d_pos) {
-  fs.d_gl = d_gl;
+GlView fast_gl_lin(const FastState& fs) {
+  return fs.packed ? gl_packed(fs.gl_log.codes, fs.cls_lin, fs.gl_log.cell0) : gl_dense(fs.gl_lin);
+}
+
+bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double* d_pos) {
+  fs.gl_log = gl_log;
   fs.d_pos = d_pos;
-  fast_exp(st, d_gl, fs.gl_lin, fs.I * fs.S * 3);
-  {
+  fs.e_stale = true;
+  if (fs.packed) {
+    if (gl_log.dense) return false;
+    // linear class table = exp of the prepared log table, as gl_lin is of the dense GL
+    fast_exp(st, gl_log.table, fs.cls_lin, 12);
+    double t[12];
+    if (hipMemcpyAsync(t, fs.cls_lin, sizeof t, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    fs.u_lin = t[9];
+    hipLaunchKernelGGL(k_fast_geno_interleave, dim3(8192), dim3(256), 0, st, gl_log.codes,
+                       gl_log.cell0, fs.I, fs.S, fs.T, fs.C, fs.geno_il);
+  } else {
+    if (!gl_log.dense) return false;
+    fast_exp(st, gl_log.dense + gl_log.cell0 * 3, fs.gl_lin, fs.I * fs.S * 3);
     const uint64_t n_it = (fs.I + 31) / 32;
     hipLaunchKernelGGL(k_fast_gl_interleave, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)),
                        dim3(256), 0, st, fs.gl_lin, fs.I, fs.S, fs.T, fs.C,
@@ -1719,6 +1851,12 @@ bool fast_refresh_freq_table(FastState& fs, hipStream_t st, const double* d_freq
 }
 
 bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
+  if (fs.packed) {  // the interleaved frequency table is current (fast_refresh_freq_table)
+    hipLaunchKernelGGL(k_fast_emission_packed, dim3(16384), dim3(256), 0, st, fs.geno_il, fs.freq_il,
+                       fs.I, fs.T, fs.C, fs.u_lin, reinterpret_cast<double2*>(fs.e_il));
+    fs.e_stale = false;
+    return hipGetLastError() == hipSuccess;
+  }
   const uint64_t n_it = (fs.I + 31) / 32;
   const uint64_t blocks = (uint64_t)fs.C * fs.T * n_it;
   hipLaunchKernelGGL(k_fast_emission, dim3((unsigned)blocks), dim3(256), 0, st, fs.gl_lin, d_freq,
@@ -1730,12 +1868,19 @@ bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq,
 // Recognise the finite-difference pattern of one objective + gradient evaluation
 // (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
 // close enough for exp_small4 on every finite distance of this data set.
-static uint32_t fd_pattern(const GroupDesc& G, double dmax) {
+static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T) {
   if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
   int nf = 0, na = 0;
   for (uint32_t p = 1; p < G.np; ++p) {
     if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
       if (na) return 0;  // F probes come first
+      // The pattern kernel rescales all points by point 0's exponent.  A site that forces
+      // the non-IBD state (a called heterozygote: e1 = 0) multiplies an F probe's operator by
+      // rho0 = (1 - F_p) / (1 - F_0) relative to point 0's; with F_0 at its upper bound that
+      // is ~1e10 per such site and would overflow within a lane-chunk.  Keep rho0^T inside
+      // the double range, else the general kernel (an exponent per point) takes the group.
+      const double rho0 = (1 - G.F[p]) / (1 - G.F[0]);
+      if (!(std::fabs(std::log(rho0)) * (double)T <= 600.0)) return 0;
       ++nf;
     } else if (G.F[p] == G.F[0] && std::fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
       ++na;
@@ -1750,7 +1895,7 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax) {
 }
 
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
-                      const double* h_F, const double* h_A) {
+                      const double* h_F, const double* h_A, bool force_general) {
   fs.n_groups = 0;
   if (n_pts == 0) return true;
   // group the points by individual (<= MAXP per group): stable counting sort on the
@@ -1774,7 +1919,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    G.mode = fd_pattern(G, fs.dmax_finite);
+    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T);
     groups.push_back(G);
   }
   // one kernel per loop-body version: sort the groups by mode (stable, so still in
@@ -1834,7 +1979,7 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
   const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(fs.grp_dev);
   const LklArrays arr{reinterpret_cast<const double2*>(fs.e_il), fs.pos_il,
                       reinterpret_cast<const double2*>(fs.gl02_il), fs.gl1_il, fs.freq_il,
-                      reinterpret_cast<double2*>(fs.e_il)};
+                      reinterpret_cast<double2*>(fs.e_il), fs.geno_il, fs.u_lin};
   // first round of an M-step inside nghmm_estep_mstep: point 0 of every individual is the
   // E-step's forward walk, whose lane operators and checkpoints it leaves behind; if the
   // emissions are stale (frequencies just updated) the same walk recomputes and stores them
@@ -1848,16 +1993,18 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
 #define FD_LAUNCH(NF, NA, SM, EM, FR)                                                          \
   hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR>), grid, block, 0, st, arr, fs.T, fs.C, \
                      dg, r.begin, fs.part, emit)
-#define FD_CASE(NF, NA)                                     \
-  case fd_mode(NF, NA, false):                              \
-    if (fresh) FD_LAUNCH(NF, NA, false, true, true);        \
-    else if (emit_estep) FD_LAUNCH(NF, NA, false, true, false); \
-    else FD_LAUNCH(NF, NA, false, false, false);            \
-    break;                                                  \
-  case fd_mode(NF, NA, true):                               \
-    if (fresh) FD_LAUNCH(NF, NA, true, true, true);         \
-    else if (emit_estep) FD_LAUNCH(NF, NA, true, true, false); \
-    else FD_LAUNCH(NF, NA, true, false, false);             \
+#define FD_CASE(NF, NA)                                                \
+  case fd_mode(NF, NA, false):                                         \
+    if (fresh && fs.packed) FD_LAUNCH(NF, NA, false, true, SRC_FRESH_PACKED); \
+    else if (fresh) FD_LAUNCH(NF, NA, false, true, SRC_FRESH);         \
+    else if (emit_estep) FD_LAUNCH(NF, NA, false, true, SRC_PLAIN);    \
+    else FD_LAUNCH(NF, NA, false, false, SRC_PLAIN);                   \
+    break;                                                             \
+  case fd_mode(NF, NA, true):                                          \
+    if (fresh && fs.packed) FD_LAUNCH(NF, NA, true, true, SRC_FRESH_PACKED); \
+    else if (fresh) FD_LAUNCH(NF, NA, true, true, SRC_FRESH);          \
+    else if (emit_estep) FD_LAUNCH(NF, NA, true, true, SRC_PLAIN);     \
+    else FD_LAUNCH(NF, NA, true, false, SRC_PLAIN);                    \
     break;
       FD_CASE(2, 2)
       FD_CASE(1, 2)
@@ -1868,12 +2015,15 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
 #undef FD_CASE
 #undef FD_LAUNCH
       default:
-        if (fresh)
-          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, true>), grid, block, 0, st, arr, fs.T, fs.C,
-                             dg, r.begin, fs.part, emit);
+        if (fresh && fs.packed)
+          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_FRESH_PACKED>), grid, block, 0, st, arr,
+                             fs.T, fs.C, dg, r.begin, fs.part, emit);
+        else if (fresh)
+          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_FRESH>), grid, block, 0, st, arr, fs.T,
+                             fs.C, dg, r.begin, fs.part, emit);
         else
-          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, false>), grid, block, 0, st, arr, fs.T, fs.C,
-                             dg, r.begin, fs.part, emit);
+          hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_PLAIN>), grid, block, 0, st, arr, fs.T,
+                             fs.C, dg, r.begin, fs.part, emit);
     }
   }
   if (fresh) fs.e_stale = false;
@@ -1917,7 +2067,7 @@ bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg) {
   return hipGetLastError() == hipSuccess;
 }
 
-bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
+bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out, bool tile_major) {
   if (S_own == 0) return true;
@@ -2011,19 +2161,18 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_sites,
   return hipGetLastError() == hipSuccess;
 }
 
-static bool ensure_eprob_log(FastState& fs) {
-  if (fs.eprob_log) return true;
-  return dalloc(&fs.eprob_log, (size_t)fs.I * fs.S * 2);
-}
 
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
                   const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags,
                   double* d_scratch, uint64_t chunk_sites) {
   // Decoding runs once per analysis and must give the reference's path, ties and
-  // its in-place update included: use the exact-mode kernels on log emissions.
-  if (!ensure_eprob_log(fs)) return false;
-  launch_emission_exact(st, fs.d_gl, d_freq, fs.eprob_log, fs.S, fs.I, d_flags);
-  launch_viterbi_exact(st, fs.eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites,
+  // its in-place update included: use the exact-mode kernels on log emissions.  The
+  // site-major log emissions [S][I][2] take the place of the interleaved linear ones in
+  // e_il (never smaller: I * Spad * 2 doubles), which the next reader recomputes.
+  double* eprob_log = fs.e_il;
+  fs.e_stale = true;
+  launch_emission_exact(st, fs.gl_log, d_freq, eprob_log, fs.S, fs.I, d_flags);
+  launch_viterbi_exact(st, eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites,
                        d_scratch, chunk_sites);
   return hipGetLastError() == hipSuccess;
 }

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "glview.hpp"
+
 namespace nghmm {
 
 struct FastState {
@@ -15,8 +17,14 @@ struct FastState {
   uint32_t C = 0;     // waves (chunks of 64 lanes) per individual
   uint64_t J = 0;     // 64 * C lane-chunks per individual
   uint64_t Spad = 0;  // J * T >= S
-  const double* d_gl = nullptr;   // borrowed: site-major log GL [S][I][3]
+  GlView gl_log;                  // borrowed: site-major log GL [S][I] cells (dense or packed)
   const double* d_pos = nullptr;  // borrowed: [S]
+  // packed handle (called genotypes as 2-bit codes, glview.hpp): no dense copy of the
+  // likelihoods exists; the fresh forward walk reads geno_il, est_maf the site-major codes
+  bool packed = false;
+  uint32_t* geno_il = nullptr;    // codes interleaved [I][C][T/16][64]: 16 sites of a lane per word
+  double* cls_lin = nullptr;      // [4][3] linear likelihoods of the four classes (device)
+  double u_lin = 0;               // linear likelihood of a uniform (missing) cell, host copy
   double* gl_lin = nullptr;       // exp(GL), site-major [S][I][3] (emission refresh, est_maf)
   double* e_il = nullptr;         // linear emissions, interleaved [I][C][T][64] x double2
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
@@ -28,7 +36,6 @@ struct FastState {
   double* ckpt = nullptr;         // forward checkpoints [I][C][T/8][2][64] x double2
   double* lane_ops = nullptr;     // per-lane chunk operators [I][J][5]
   double* bound = nullptr;        // per-lane incoming forward/backward vectors [I][J][4]
-  double* eprob_log = nullptr;    // lazily: log emissions site-major [S][I][2] (Viterbi, export)
   // objective batches
   double* part = nullptr;         // [groups][C][5 points][5]
   size_t part_cap = 0;
@@ -45,10 +52,10 @@ struct FastState {
   double* est_state = nullptr;    // [EST_FIELDS][redo_cap] loop state + interval node values
 };
 
-bool fast_create(FastState& fs, uint64_t I, uint64_t S);
+bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed = false);
 void fast_destroy(FastState& fs);
 // (re)build the interleaved distance table; remembers the GL / distance pointers
-bool fast_load(FastState& fs, hipStream_t st, const double* d_gl, const double* d_pos);
+bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double* d_pos);
 // after a frequency update: interleaved frequency table + MAF check; marks e_il stale
 bool fast_refresh_freq_table(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags);
 // linear-space emissions of every cell from freq, into the interleaved layout
@@ -56,8 +63,9 @@ bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq,
 // objective for host-side points: prepare() groups them by individual and uploads
 // the descriptors, launch() runs the two kernels; d_lkl (device) receives the values
 // in point order
+// force_general: every group through the general kernel (one exponent per point)
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
-                      const double* h_F, const double* h_A);
+                      const double* h_F, const double* h_A, bool force_general = false);
 // emit_estep: the launch is the first round of an M-step (point 0 of every individual =
 // its current parameters) and leaves the E-step's lane operators and checkpoints behind
 bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
@@ -71,10 +79,11 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
 bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg);
 // out = exp(in) elementwise (in == out allowed): linear genotype likelihoods
 void fast_exp(hipStream_t st, const double* d_in, double* d_out, uint64_t n);
-// est_maf on S_own sites: LINEAR GL site-major [S_own][I_tot][3] (fs.gl_lin, or a
-// site shard passed through fast_exp), posteriors in rank blocks [I_tot / I_blk][S_own][I_blk]
-// or (tile_major) fs.post itself
-bool fast_estmaf(FastState& fs, hipStream_t st, const double* d_gl_lin_sites,
+// est_maf on S_own sites: LINEAR GL site-major [S_own][I_tot] cells (fast_gl_lin(), or a
+// site shard passed through fast_exp; packed: codes + fs.cls_lin), posteriors in rank blocks
+// [I_tot / I_blk][S_own][I_blk] or (tile_major) fs.post itself
+GlView fast_gl_lin(const FastState& fs);
+bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_lin_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out, bool tile_major = false);
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,

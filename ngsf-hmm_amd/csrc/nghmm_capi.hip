@@ -85,6 +85,21 @@ struct nghmm_handle {
   uint64_t I_tot = 0, ind_begin = 0, site_begin = 0, S_own = 0;
   double* d_gl_shard = nullptr;
 
+  // packed handle (NGHMM_GENO_PACKED): called genotypes as 2-bit codes (glview.hpp); d_gl
+  // does not exist
+  bool packed = false;
+  uint32_t* d_codes = nullptr;        // [S][I] cells, 16 per word
+  uint32_t* d_codes_shard = nullptr;  // [S_own][I_tot] cells of the frequency step's site range
+  double* d_cls_log = nullptr;        // [4][3] prepared log likelihoods of the four classes
+  unsigned long long* d_uniform = nullptr;  // the one value every uniform cell carries (~0: none yet)
+  // chunked loading (nghmm_load_begin .. nghmm_load_end)
+  uint64_t lkl_redone = 0;            // objective points re-evaluated by the general kernel
+  bool loading = false;
+  double* d_stage = nullptr;          // staging buffer of one chunk of raw likelihoods
+  size_t stage_cap = 0;
+  int8_t* d_stage8 = nullptr;         // ... of one chunk of reader genotypes
+  size_t stage8_cap = 0;
+
   FastState fast;  // fast-mode layouts (kernels_fast.hip)
   BfgsBatch batch;  // one L-BFGS-B state machine per individual, storage reused across M-steps
   // fast mode keeps the posteriors tile-major (fast.post); the site-major copy d_marg is
@@ -180,6 +195,11 @@ int ensure_points(nghmm_t* h, size_t n) {
   return NGHMM_OK;
 }
 
+// the handle's own genotype likelihoods (log space), and those of its frequency-step site range
+GlView own_gl(const nghmm_t* h) {
+  return h->packed ? gl_packed(h->d_codes, h->d_cls_log) : gl_dense(h->d_gl);
+}
+
 int ensure_tmp(nghmm_t* h) {
   if (h->d_tmp) return NGHMM_OK;
   return dev_alloc(&h->d_tmp, h->S * h->I * 2);
@@ -268,7 +288,38 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(lkl, h->d_pt_lkl, n_pts * sizeof(double), hipMemcpyDeviceToHost,
                          h->stream));
-  return check_flags(h);
+  rc = check_flags(h);
+  if (rc == NGHMM_ERR_INVALID_LKL && h->mode == NGHMM_MODE_FAST) {
+    // Points whose value is not finite: the pattern kernels share one scale among the points
+    // of a group and can overflow when a probe's likelihood is many orders away from point
+    // 0's; the general kernel carries an exponent per point.  (By-products of an emitting
+    // round come from point 0 alone and stay valid.)
+    std::vector<uint32_t> bad, bind;
+    std::vector<double> bF, bA;
+    for (uint32_t p = 0; p < n_pts; ++p)
+      if (!std::isfinite(lkl[p])) {
+        bad.push_back(p);
+        bind.push_back(ind[p]);
+        bF.push_back(F[p]);
+        bA.push_back(alpha[p]);
+      }
+    if (bad.empty()) return rc;
+    g_last_error.clear();
+    if ((rc = clear_flags(h))) return rc;
+    if (!fast_lkl_prepare(h->fast, h->stream, (uint32_t)bad.size(), bind.data(), bF.data(),
+                          bA.data(), true) ||
+        !fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags, false)) {
+      set_error("objective re-evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+      return NGHMM_ERR_HIP;
+    }
+    std::vector<double> redo(bad.size());
+    HIP_TRY(hipMemcpyAsync(redo.data(), h->d_pt_lkl, bad.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream));
+    rc = check_flags(h);
+    for (size_t k = 0; k < bad.size(); ++k) lkl[bad[k]] = redo[k];
+    h->lkl_redone += bad.size();
+  }
+  return rc;
 }
 
 // Emissions from the current frequencies (calc_emission, shared/HMM.cpp:144-154).  Fast
@@ -286,7 +337,7 @@ int emission_impl(nghmm_t* h) {
         !fast_refresh_emissions(h->fast, h->stream, h->d_freq, h->d_flags))
       return NGHMM_ERR_HIP;
   } else {
-    launch_emission_exact(h->stream, h->d_gl, h->d_freq, h->d_eprob, h->S, h->I, h->d_flags);
+    launch_emission_exact(h->stream, own_gl(h), h->d_freq, h->d_eprob, h->S, h->I, h->d_flags);
   }
   if ((rc = toc(h, SLOT_EMISSION, false))) return rc;
   HIP_TRY(hipGetLastError());
@@ -327,6 +378,9 @@ const char* nghmm_strerror(int code) {
 int nghmm_has_hip(void) { return 1; }
 
 int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, int mode) {
+  g_last_error.clear();
+  const bool packed = (mode & NGHMM_GENO_PACKED) != 0;
+  mode &= ~NGHMM_GENO_PACKED;
   if (!out || n_ind == 0 || n_sites == 0 || n_ind > 0xffffffffull ||
       (mode != NGHMM_MODE_EXACT && mode != NGHMM_MODE_FAST)) {
     set_error("nghmm_create: bad argument");
@@ -349,6 +403,7 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
   h->S = n_sites;
   h->device = device;
   h->mode = mode;
+  h->packed = packed;
   h->I_tot = n_ind;
   h->S_own = n_sites;
   int rc = NGHMM_OK;
@@ -357,13 +412,30 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     const size_t cells = (size_t)n_ind * n_sites;
-    if ((rc = dev_alloc(&h->d_gl, cells * 3))) break;
+    if (packed) {
+      if ((rc = dev_alloc(&h->d_codes, cells / 16 + 2))) break;
+      if ((rc = dev_alloc(&h->d_cls_log, (size_t)12))) break;
+      if ((rc = dev_alloc(&h->d_uniform, (size_t)1))) break;
+      if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
+      // the prepared likelihoods of the four classes: what the reference's reader and its two
+      // normalisations make of a called genotype 0 / 1 / 2 and of a missing one
+      // (shared/read_data.cpp:21,88-98; ngsF-HMM.cpp:117); row 3 is replaced by the value the
+      // data's own uniform cells carry, if they carry another (--call_geno: det_log(1/3))
+      const double u = std::log((double)1 / 3), ninf = -1e15;
+      const double proto[12] = {0.0, ninf, ninf, ninf, 0.0, ninf, ninf, ninf, 0.0, u, u, u};
+      if (hipMemcpy(h->d_cls_log, proto, sizeof proto, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemset(h->d_flags, 0, NFLAGS * sizeof(int)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+      launch_prepare_gl(h->stream, h->d_cls_log, 4, NGHMM_GL_LOG, 0, h->d_flags);
+      if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    } else {
+      if ((rc = dev_alloc(&h->d_gl, cells * 3))) break;
+      if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
+    }
     if ((rc = dev_alloc(&h->d_pos, n_sites))) break;
     if ((rc = dev_alloc(&h->d_freq, n_sites))) break;
     if ((rc = dev_alloc(&h->d_indF, n_ind))) break;
     if ((rc = dev_alloc(&h->d_alpha, n_ind))) break;
     if ((rc = dev_alloc(&h->d_ind_lkl, n_ind))) break;
-    if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
     if (mode == NGHMM_MODE_EXACT) {
       if ((rc = dev_alloc(&h->d_eprob, cells * 2))) break;
       if ((rc = dev_alloc(&h->d_fw, (cells + n_ind) * 2))) break;
@@ -373,7 +445,7 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
     if (hipMemset(h->d_freq, 0, n_sites * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     h->h_indF.assign(n_ind, 0.0);
     h->h_alpha.assign(n_ind, 0.0);
-    if (mode == NGHMM_MODE_FAST && !fast_create(h->fast, n_ind, n_sites)) { rc = NGHMM_ERR_NOMEM; break; }
+    if (mode == NGHMM_MODE_FAST && !fast_create(h->fast, n_ind, n_sites, packed)) { rc = NGHMM_ERR_NOMEM; break; }
   } while (0);
   if (rc != NGHMM_OK) {
     if (g_last_error.empty()) set_error("nghmm_create failed (%d)", rc);
@@ -391,7 +463,8 @@ int nghmm_destroy(nghmm_t* h) {
   void* ptrs[] = {h->d_gl, h->d_pos, h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
                   h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
                   h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
-                  h->d_gl_shard, h->d_geno, h->d_text};
+                  h->d_gl_shard, h->d_geno, h->d_text, h->d_codes, h->d_codes_shard, h->d_cls_log,
+                  h->d_uniform, h->d_stage, h->d_stage8};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fast_destroy(h->fast);
@@ -404,39 +477,53 @@ int nghmm_destroy(nghmm_t* h) {
 
 static int after_gl_load(nghmm_t* h) {
   h->loaded = true;
+  h->loading = false;
   h->marg_valid = false;  // nothing derived from earlier data survives a (re)load
   h->tmp_is_posteriors = false;
+  if (h->packed) {
+    // the value the data's uniform cells carry becomes row 3 of the class table
+    unsigned long long bits = ~0ull;
+    HIP_TRY(hipMemcpyAsync(&bits, h->d_uniform, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bits != ~0ull) {
+      double u;
+      std::memcpy(&u, &bits, sizeof u);
+      const double row[3] = {u, u, u};
+      HIP_TRY(hipMemcpyAsync(h->d_cls_log + 9, row, sizeof row, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  }
   if (h->mode == NGHMM_MODE_FAST) {
-    if (!fast_load(h->fast, h->stream, h->d_gl, h->d_pos)) return NGHMM_ERR_HIP;
+    if (!fast_load(h->fast, h->stream, own_gl(h), h->d_pos)) return NGHMM_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   return NGHMM_OK;
 }
 
-int nghmm_load_gl(nghmm_t* h, const double* gl, const double* pos) {
-  if (!h || !gl || !pos) return NGHMM_ERR_ARG;
+static int ensure_stage(nghmm_t* h, size_t doubles) {
+  if (doubles <= h->stage_cap) return NGHMM_OK;
+  if (h->d_stage) (void)hipFree(h->d_stage);
+  h->d_stage = nullptr;
+  h->stage_cap = 0;
   int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t cells = (size_t)h->I * h->S;
-  HIP_TRY(hipMemcpyAsync(h->d_gl, gl, cells * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return after_gl_load(h);
+  if ((rc = dev_alloc(&h->d_stage, doubles))) return rc;
+  h->stage_cap = doubles;
+  return NGHMM_OK;
 }
 
-int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw, int space, int call_geno, int check_nan,
-                      const double* pos) {
-  if (!h || !gl_raw || !pos || space < NGHMM_GL_LOG || space > NGHMM_GL_NORMAL_TEXT)
-    return NGHMM_ERR_ARG;
+static int ensure_stage8(nghmm_t* h, size_t bytes) {
+  if (bytes <= h->stage8_cap) return NGHMM_OK;
+  if (h->d_stage8) (void)hipFree(h->d_stage8);
+  h->d_stage8 = nullptr;
+  h->stage8_cap = 0;
   int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t cells = (size_t)h->I * h->S;
-  HIP_TRY(hipMemcpyAsync(h->d_gl, gl_raw, cells * 3 * sizeof(double), hipMemcpyHostToDevice,
-                         h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if ((rc = clear_flags(h))) return rc;
-  launch_prepare_gl(h->stream, h->d_gl, cells, space, call_geno, h->d_flags);
-  HIP_TRY(hipGetLastError());
+  if ((rc = dev_alloc(&h->d_stage8, bytes))) return rc;
+  h->stage8_cap = bytes;
+  return NGHMM_OK;
+}
+
+// flags a chunk loader looks at after its kernels
+static int check_load_flags(nghmm_t* h, bool check_nan) {
   int f[NFLAGS];
   HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -444,33 +531,238 @@ int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw, int space, int call_geno
     set_error("NaN found! Is the file format correct?");
     return NGHMM_ERR_NAN;
   }
+  if (f[FLAG_BAD_GENO]) {
+    set_error("wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+    return NGHMM_ERR_ARG;
+  }
+  if (f[FLAG_NOT_PACKABLE]) {
+    set_error("a cell is not a called genotype (one-hot or uniform likelihoods): a packed handle "
+              "(NGHMM_GENO_PACKED) needs --call_geno or called-genotype input");
+    return NGHMM_ERR_ARG;
+  }
+  return NGHMM_OK;
+}
+
+// One chunk of sites [site_begin, site_begin + n_sites) from d_src (device; dense [n][I][3]):
+// optional preparation, then into d_gl or, packed, into the codes.  d_src may be the staging
+// buffer or the caller's; `prepare` works in place on a copy when the handle is packed.
+static int ingest_chunk(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* d_src,
+                        bool src_is_scratch, bool prepare, int space, int call_geno,
+                        int check_nan) {
+  int rc;
+  const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
+  if ((rc = clear_flags(h))) return rc;
+  if (!h->packed) {
+    double* dst = h->d_gl + cell0 * 3;
+    if (d_src != dst)
+      HIP_TRY(hipMemcpyAsync(dst, d_src, n_cells * 3 * sizeof(double), hipMemcpyDeviceToDevice,
+                             h->stream));
+    if (prepare) launch_prepare_gl(h->stream, dst, n_cells, space, call_geno, h->d_flags);
+  } else {
+    const double* cells = d_src;
+    if (prepare) {
+      if (!src_is_scratch) {  // never modify the caller's buffer
+        if ((rc = ensure_stage(h, n_cells * 3))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->d_stage, d_src, n_cells * 3 * sizeof(double),
+                               hipMemcpyDeviceToDevice, h->stream));
+        cells = h->d_stage;
+      }
+      launch_prepare_gl(h->stream, const_cast<double*>(cells), n_cells, space, call_geno, h->d_flags);
+    }
+    launch_pack_cells(h->stream, cells, n_cells, cell0, h->d_cls_log, h->d_codes, h->d_uniform,
+                      h->d_flags);
+  }
+  HIP_TRY(hipGetLastError());
+  return check_load_flags(h, check_nan != 0);
+}
+
+// sites per chunk when a whole-matrix loader feeds a packed handle through the staging buffer
+static uint64_t stage_sites(const nghmm_t* h) {
+  uint64_t n = (256ull << 20) / (h->I * 24);
+  if (n < 1) n = 1;
+  return n < h->S ? n : h->S;
+}
+
+int nghmm_load_begin(nghmm_t* h, const double* pos) {
+  g_last_error.clear();
+  if (!h || !pos) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->packed) {
+    HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->loaded = false;
+  h->loading = true;
+  return NGHMM_OK;
+}
+
+static int load_begin_dev(nghmm_t* h, const double* d_pos) {
+  HIP_TRY(hipMemcpyAsync(h->d_pos, d_pos, h->S * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->packed) {
+    HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
+  }
+  h->loaded = false;
+  h->loading = true;
+  return NGHMM_OK;
+}
+
+int nghmm_load_begin_dev(nghmm_t* h, const double* d_pos) {
+  g_last_error.clear();
+  if (!h || !d_pos) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  if ((rc = load_begin_dev(h, d_pos))) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+static int load_sites_impl(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* src,
+                           bool src_on_device, bool prepare, int space, int call_geno,
+                           int check_nan) {
+  if (!h || !h->loading || !src || site_begin + n_sites > h->S ||
+      space < NGHMM_GL_LOG || space > NGHMM_GL_NORMAL_TEXT) {
+    set_error("chunk loader: bad argument, or nghmm_load_begin has not been called");
+    return NGHMM_ERR_ARG;
+  }
+  if (n_sites == 0) return NGHMM_OK;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const uint64_t n_cells = n_sites * h->I;
+  if (src_on_device)
+    return ingest_chunk(h, site_begin, n_sites, src, false, prepare, space, call_geno, check_nan);
+  double* dst = h->packed ? nullptr : h->d_gl + site_begin * h->I * 3;
+  if (h->packed) {
+    if ((rc = ensure_stage(h, n_cells * 3))) return rc;
+    dst = h->d_stage;
+  }
+  HIP_TRY(hipMemcpyAsync(dst, src, n_cells * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return ingest_chunk(h, site_begin, n_sites, dst, true, prepare, space, call_geno, check_nan);
+}
+
+int nghmm_load_gl_raw_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* gl_raw,
+                            int space, int call_geno, int check_nan) {
+  g_last_error.clear();
+  return load_sites_impl(h, site_begin, n_sites, gl_raw, false, true, space, call_geno, check_nan);
+}
+
+int nghmm_load_gl_raw_sites_dev(nghmm_t* h, uint64_t site_begin, uint64_t n_sites,
+                                const double* d_gl_raw, int space, int call_geno, int check_nan) {
+  g_last_error.clear();
+  return load_sites_impl(h, site_begin, n_sites, d_gl_raw, true, true, space, call_geno, check_nan);
+}
+
+int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const int8_t* geno) {
+  g_last_error.clear();
+  if (!h || !h->loading || !geno || site_begin + n_sites > h->S) {
+    set_error("nghmm_load_geno_sites: bad argument, or nghmm_load_begin has not been called");
+    return NGHMM_ERR_ARG;
+  }
+  if (n_sites == 0) return NGHMM_OK;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
+  if ((rc = ensure_stage8(h, n_cells))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_stage8, geno, n_cells, hipMemcpyHostToDevice, h->stream));
+  if ((rc = clear_flags(h))) return rc;
+  if (h->packed) {
+    // the reader's missing genotype is log(1/3) x 3 (read_data.cpp:94), prepared: row 3 of the
+    // class table as nghmm_create left it; a data set has ONE uniform value
+    unsigned long long cur = ~0ull, want = 0;
+    double u = 0;
+    HIP_TRY(hipMemcpyAsync(&cur, h->d_uniform, sizeof cur, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&u, h->d_cls_log + 9, sizeof u, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(&want, &u, sizeof want);
+    if (cur == ~0ull)
+      HIP_TRY(hipMemcpyAsync(h->d_uniform, &want, sizeof want, hipMemcpyHostToDevice, h->stream));
+    else if (cur != want) {
+      set_error("nghmm_load_geno_sites: mixed with likelihood chunks whose uniform cells differ");
+      return NGHMM_ERR_ARG;
+    }
+    launch_pack_geno(h->stream, h->d_stage8, n_cells, cell0, h->d_codes, h->d_flags);
+  } else {
+    double* dst = h->d_gl + cell0 * 3;
+    launch_expand_geno(h->stream, h->d_stage8, n_cells, std::log((double)1 / 3), dst, h->d_flags);
+    launch_prepare_gl(h->stream, dst, n_cells, NGHMM_GL_LOG, 0, h->d_flags);
+  }
+  HIP_TRY(hipGetLastError());
+  return check_load_flags(h, false);
+}
+
+int nghmm_load_end(nghmm_t* h) {
+  g_last_error.clear();
+  if (!h || !h->loading) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
   return after_gl_load(h);
 }
 
+// whole-matrix loaders = one begin, chunks, end
+static int load_whole(nghmm_t* h, const double* gl, bool on_device, bool prepare, int space,
+                      int call_geno, int check_nan) {
+  int rc;
+  // a dense handle takes the matrix in one piece; a packed one through the staging buffer
+  const uint64_t step = (h->packed && !(on_device && !prepare)) ? stage_sites(h) : h->S;
+  for (uint64_t s0 = 0; s0 < h->S; s0 += step) {
+    const uint64_t ns = (h->S - s0) < step ? (h->S - s0) : step;
+    if ((rc = load_sites_impl(h, s0, ns, gl + s0 * h->I * 3, on_device, prepare, space, call_geno,
+                              check_nan)))
+      return rc;
+  }
+  return after_gl_load(h);
+}
+
+int nghmm_load_gl(nghmm_t* h, const double* gl, const double* pos) {
+  g_last_error.clear();
+  if (!h || !gl || !pos) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = nghmm_load_begin(h, pos))) return rc;
+  return load_whole(h, gl, false, false, NGHMM_GL_LOG, 0, 0);
+}
+
+int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw, int space, int call_geno, int check_nan,
+                      const double* pos) {
+  g_last_error.clear();
+  if (!h || !gl_raw || !pos || space < NGHMM_GL_LOG || space > NGHMM_GL_NORMAL_TEXT)
+    return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = nghmm_load_begin(h, pos))) return rc;
+  return load_whole(h, gl_raw, false, true, space, call_geno, check_nan);
+}
+
 int nghmm_get_gl(nghmm_t* h, double* gl) {
+  g_last_error.clear();
   if (!h || !h->loaded || !gl) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  HIP_TRY(hipMemcpyAsync(gl, h->d_gl, (size_t)h->I * h->S * 3 * sizeof(double),
-                         hipMemcpyDeviceToHost, h->stream));
+  const size_t cells = (size_t)h->I * h->S;
+  const double* src = h->d_gl;
+  if (h->packed) {  // test / debug aid: unpack through the staging buffer
+    if ((rc = ensure_stage(h, cells * 3))) return rc;
+    launch_unpack_cells(h->stream, own_gl(h), cells, h->d_stage);
+    HIP_TRY(hipGetLastError());
+    src = h->d_stage;
+  }
+  HIP_TRY(hipMemcpyAsync(gl, src, cells * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
 }
 
 int nghmm_load_gl_device(nghmm_t* h, const double* d_gl, const double* d_pos) {
+  g_last_error.clear();
   if (!h || !d_gl || !d_pos) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  const size_t cells = (size_t)h->I * h->S;
-  HIP_TRY(hipMemcpyAsync(h->d_gl, d_gl, cells * 3 * sizeof(double), hipMemcpyDeviceToDevice,
-                         h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_pos, d_pos, h->S * sizeof(double), hipMemcpyDeviceToDevice,
-                         h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return after_gl_load(h);
+  if ((rc = load_begin_dev(h, d_pos))) return rc;
+  return load_whole(h, d_gl, true, false, NGHMM_GL_LOG, 0, 0);
 }
 
 int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const double* freq) {
+  g_last_error.clear();
   if (!h) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -490,6 +782,7 @@ int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const 
 }
 
 int nghmm_get_params(nghmm_t* h, double* indF, double* alpha, double* freq) {
+  g_last_error.clear();
   if (!h) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -503,6 +796,7 @@ int nghmm_get_params(nghmm_t* h, double* indF, double* alpha, double* freq) {
 }
 
 int nghmm_emission(nghmm_t* h) {
+  g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -510,6 +804,7 @@ int nghmm_emission(nghmm_t* h) {
 }
 
 int nghmm_estep(nghmm_t* h, double* ind_lkl) {
+  g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -535,6 +830,7 @@ int nghmm_estep(nghmm_t* h, double* ind_lkl) {
 
 int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
                     const double* alpha, double* lkl) {
+  g_last_error.clear();
   if (!h || !h->loaded || (n_pts && (!ind || !F || !alpha || !lkl))) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -628,6 +924,7 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
 }
 
 int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats) {
+  g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -637,6 +934,7 @@ int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_st
 int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
                           int alpha_fixed, nghmm_objective_fn fn, void* user,
                           nghmm_mstep_stats* stats) {
+  g_last_error.clear();
   if (!indF || !alpha || !fn) return NGHMM_ERR_ARG;
   if (stats) std::memset(stats, 0, sizeof *stats);
   if (indF_fixed && alpha_fixed) return NGHMM_OK;
@@ -660,14 +958,19 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
   return NGHMM_OK;
 }
 
-static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double* d_marg_blocks,
-                              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, double* d_freq_out) {
+// est_maf on the handle's own sites and individuals (shard = false) or on its frequency-step
+// site range over all ranks' individuals (shard = true: the static site-shard copy of the
+// likelihoods, posteriors in rank blocks)
+static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_blocks, uint64_t S_own,
+                              uint64_t I_tot, uint64_t I_blk, double* d_freq_out) {
   int rc;
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
     // fast mode reads linear-space GL: its own copy of the handle's GL, or the site
-    // shard, which the shard loaders exponentiate in place
-    const double* d_lin = (d_gl_sites == h->d_gl) ? h->fast.gl_lin : d_gl_sites;
+    // shard, which the shard loaders exponentiate in place (packed: the linear class table)
+    const GlView lin = !shard ? fast_gl_lin(h->fast)
+                       : h->packed ? gl_packed(h->d_codes_shard, h->fast.cls_lin)
+                                   : gl_dense(h->d_gl_shard);
     bool tile_major = false;
     if (!d_marg_blocks) {  // the handle's own posteriors of its whole site range
       // measured at 10^9 site-individuals: in place 13.6 vs 14.4 ms via the site-major copy
@@ -680,7 +983,7 @@ static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double
         d_marg_blocks = h->d_marg;
       }
     }
-    if (!fast_estmaf(h->fast, h->stream, d_lin, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out,
+    if (!fast_estmaf(h->fast, h->stream, lin, d_marg_blocks, S_own, I_tot, I_blk, d_freq_out,
                      tile_major))
       return NGHMM_ERR_HIP;
   } else {
@@ -688,7 +991,10 @@ static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double
       set_error("exact-mode est_maf expects one posterior block");
       return NGHMM_ERR_ARG;
     }
-    launch_estmaf_exact(h->stream, d_gl_sites, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr);
+    const GlView lg = !shard ? own_gl(h)
+                      : h->packed ? gl_packed(h->d_codes_shard, h->d_cls_log)
+                                  : gl_dense(h->d_gl_shard);
+    launch_estmaf_exact(h->stream, lg, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr);
   }
   if ((rc = toc(h, SLOT_ESTMAF, false))) return rc;
   HIP_TRY(hipGetLastError());
@@ -696,6 +1002,7 @@ static int estmaf_and_refresh(nghmm_t* h, const double* d_gl_sites, const double
 }
 
 int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
+  g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -712,7 +1019,7 @@ int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
     set_error("sharded handle: use nghmm_mstep_freq_sites_dev");
     return NGHMM_ERR_ARG;
   }
-  if ((rc = estmaf_and_refresh(h, h->d_gl, h->mode == NGHMM_MODE_FAST ? nullptr : h->d_marg, h->S,
+  if ((rc = estmaf_and_refresh(h, false, h->mode == NGHMM_MODE_FAST ? nullptr : h->d_marg, h->S,
                                h->I, h->I, h->d_freq)))
     return rc;
   return emission_impl(h);
@@ -720,6 +1027,7 @@ int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
 
 int nghmm_estep_mstep(nghmm_t* h, int indF_fixed, int alpha_fixed, double* ind_lkl,
                       nghmm_mstep_stats* stats, nghmm_hook_fn after_estep, void* user) {
+  g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -732,6 +1040,7 @@ int nghmm_estep_mstep(nghmm_t* h, int indF_fixed, int alpha_fixed, double* ind_l
 
 int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, double* ind_lkl,
                   nghmm_mstep_stats* stats) {
+  g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -742,6 +1051,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
 }
 
 int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
+  g_last_error.clear();
   if (!h || !h->loaded || !path) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -765,6 +1075,8 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   launch_unblock_path(h->stream, h->d_path_sites, h->S, h->I, h->d_path);
   if ((rc = toc(h, SLOT_VITERBI, false))) return rc;
   HIP_TRY(hipGetLastError());
+  // fast mode recomputes the log emissions first: "invalid MAF!" (HMM.cpp:145-146)
+  if (h->mode == NGHMM_MODE_FAST && (rc = check_flags(h))) return rc;
   HIP_TRY(hipMemcpyAsync(path, h->d_path, cells, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
@@ -783,7 +1095,8 @@ static int posteriors_ind_major(nghmm_t* h) {
 }
 
 int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
-  if (!h || !marg_ibd) return NGHMM_ERR_ARG;
+  g_last_error.clear();
+  if (!h || !h->loaded || !marg_ibd) return NGHMM_ERR_ARG;  // zeros before the first E-step
   int rc;
   if ((rc = use_device(h))) return rc;
   if ((rc = posteriors_ind_major(h))) return rc;
@@ -794,6 +1107,7 @@ int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
 }
 
 int nghmm_format_posteriors(nghmm_t* h, uint64_t ind_begin, uint64_t n_ind, char* out) {
+  g_last_error.clear();
   if (!h || !h->loaded || !out || ind_begin + n_ind > h->I) return NGHMM_ERR_ARG;
   if (n_ind == 0) return NGHMM_OK;
   int rc;
@@ -822,6 +1136,7 @@ int nghmm_format_posteriors(nghmm_t* h, uint64_t ind_begin, uint64_t n_ind, char
 }
 
 int nghmm_format_fixed6(nghmm_t* h, const double* values, uint64_t rows, uint64_t cols, char* out) {
+  g_last_error.clear();
   if (!h || !values || !out) return NGHMM_ERR_ARG;
   if (rows == 0 || cols == 0) return NGHMM_OK;
   int rc;
@@ -858,6 +1173,7 @@ int nghmm_format_fixed6(nghmm_t* h, const double* values, uint64_t rows, uint64_
 }
 
 int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, double* out) {
+  g_last_error.clear();
   if (!h || !h->loaded || !out || site_begin + n_sites > h->S) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -876,7 +1192,7 @@ int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, dou
     if ((rc = dev_alloc(&h->d_geno, n))) return rc;
     h->geno_cap = n;
   }
-  launch_geno_post_exact(h->stream, h->d_gl, h->d_freq, h->d_path_sites, h->I, site_begin, n_sites,
+  launch_geno_post_exact(h->stream, own_gl(h), h->d_freq, h->d_path_sites, h->I, site_begin, n_sites,
                          h->d_geno);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, h->d_geno, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -885,6 +1201,7 @@ int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, dou
 }
 
 int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
+  g_last_error.clear();
   if (!h || !e_prob) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -908,6 +1225,7 @@ int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
 
 int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uint64_t site_begin,
                        uint64_t n_sites_own) {
+  g_last_error.clear();
   if (!h || n_ind_total < h->I || ind_begin + h->I > n_ind_total ||
       site_begin + n_sites_own > h->S || n_ind_total % h->I != 0) {
     set_error("nghmm_shard_config: inconsistent shard (equal individuals per rank required)");
@@ -921,7 +1239,12 @@ int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uin
 }
 
 int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
+  g_last_error.clear();
   if (!h || !gl_site_shard) return NGHMM_ERR_ARG;
+  if (h->packed) {
+    set_error("packed handle: use nghmm_load_geno_site_shard_dev");
+    return NGHMM_ERR_ARG;
+  }
   int rc;
   if ((rc = use_device(h))) return rc;
   const size_t n = (size_t)h->S_own * h->I_tot * 3;
@@ -935,8 +1258,40 @@ int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
   return NGHMM_OK;
 }
 
+int nghmm_get_geno_codes_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, uint8_t* d_out) {
+  g_last_error.clear();
+  if (!h || !h->packed || !h->loaded || !d_out || site_lo > site_hi || site_hi > h->S)
+    return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  launch_codes_to_bytes(h->stream, h->d_codes, site_lo * h->I, (site_hi - site_lo) * h->I, d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
+int nghmm_load_geno_site_shard_dev(nghmm_t* h, const uint8_t* d_codes_bytes) {
+  g_last_error.clear();
+  if (!h || !h->packed || !d_codes_bytes) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t n = (size_t)h->S_own * h->I_tot;
+  if (h->d_codes_shard) (void)hipFree(h->d_codes_shard);
+  h->d_codes_shard = nullptr;
+  if ((rc = dev_alloc(&h->d_codes_shard, n / 16 + 2))) return rc;
+  launch_bytes_to_codes(h->stream, d_codes_bytes, n, h->d_codes_shard);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NGHMM_OK;
+}
+
 int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
+  g_last_error.clear();
   if (!h || !d_gl_site_shard) return NGHMM_ERR_ARG;
+  if (h->packed) {
+    set_error("packed handle: use nghmm_load_geno_site_shard_dev");
+    return NGHMM_ERR_ARG;
+  }
   int rc;
   if ((rc = use_device(h))) return rc;
   const size_t n = (size_t)h->S_own * h->I_tot * 3;
@@ -951,6 +1306,7 @@ int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
 }
 
 int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, double* d_out) {
+  g_last_error.clear();
   if (!h || !d_out || site_lo > site_hi || site_hi > h->S) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -971,7 +1327,9 @@ int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, do
 }
 
 int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_blocks, double* d_freq_out) {
-  if (!h || !d_marg_blocks || !d_freq_out || !h->d_gl_shard) return NGHMM_ERR_ARG;
+  g_last_error.clear();
+  if (!h || !d_marg_blocks || !d_freq_out || !(h->packed ? (void*)h->d_codes_shard : (void*)h->d_gl_shard))
+    return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
   if (h->mode != NGHMM_MODE_FAST && h->I_tot != h->I) {
@@ -979,14 +1337,14 @@ int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_blocks, double* 
     set_error("exact-mode sharded est_maf is not available; use NGHMM_MODE_FAST");
     return NGHMM_ERR_ARG;
   }
-  if ((rc = estmaf_and_refresh(h, h->d_gl_shard, d_marg_blocks, h->S_own, h->I_tot, h->I,
-                               d_freq_out)))
+  if ((rc = estmaf_and_refresh(h, true, d_marg_blocks, h->S_own, h->I_tot, h->I, d_freq_out)))
     return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NGHMM_OK;
 }
 
 int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all) {
+  g_last_error.clear();
   if (!h || !d_freq_all) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
@@ -1006,6 +1364,7 @@ int nghmm_fast_layout(nghmm_t* h, uint32_t* waves_per_individual, uint64_t* site
 void* nghmm_stream(nghmm_t* h) { return h ? (void*)h->stream : nullptr; }
 
 int nghmm_synchronize(nghmm_t* h) {
+  g_last_error.clear();
   if (!h) return NGHMM_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -20,6 +20,7 @@ import numpy as np
 
 MODE_EXACT = 0
 MODE_FAST = 1
+GENO_PACKED = 0x10   # OR-ed into the mode: called genotypes kept as 2-bit codes
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -80,6 +81,14 @@ def load_library():
         "nghmm_format_posteriors": (i32, [vp, u64, u64, C.c_char_p]),
         "nghmm_format_fixed6": (i32, [vp, dp, u64, u64, C.c_char_p]),
         "nghmm_load_gl_device": (i32, [vp, vp, vp]),
+        "nghmm_load_begin": (i32, [vp, dp]),
+        "nghmm_load_begin_dev": (i32, [vp, vp]),
+        "nghmm_load_gl_raw_sites": (i32, [vp, u64, u64, dp, i32, i32, i32]),
+        "nghmm_load_gl_raw_sites_dev": (i32, [vp, u64, u64, vp, i32, i32, i32]),
+        "nghmm_load_geno_sites": (i32, [vp, u64, u64, C.POINTER(C.c_int8)]),
+        "nghmm_load_end": (i32, [vp]),
+        "nghmm_get_geno_codes_dev": (i32, [vp, u64, u64, vp]),
+        "nghmm_load_geno_site_shard_dev": (i32, [vp, vp]),
         "nghmm_set_params": (i32, [vp, dp, dp, dp]),
         "nghmm_get_params": (i32, [vp, dp, dp, dp]),
         "nghmm_emission": (i32, [vp]),
@@ -120,7 +129,10 @@ EXPORTED_SYMBOLS = [
     "nghmm_last_error", "nghmm_strerror", "nghmm_has_hip", "nghmm_create", "nghmm_destroy",
     "nghmm_load_gl", "nghmm_load_gl_raw", "nghmm_get_gl", "nghmm_geno_posteriors",
     "nghmm_format_posteriors", "nghmm_format_fixed6",
-    "nghmm_load_gl_device", "nghmm_set_params", "nghmm_get_params",
+    "nghmm_load_gl_device", "nghmm_load_begin", "nghmm_load_begin_dev", "nghmm_load_gl_raw_sites",
+    "nghmm_load_gl_raw_sites_dev", "nghmm_load_geno_sites", "nghmm_load_end",
+    "nghmm_get_geno_codes_dev", "nghmm_load_geno_site_shard_dev",
+    "nghmm_set_params", "nghmm_get_params",
     "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
     "nghmm_bfgs_batch_host", "nghmm_mstep_freq", "nghmm_estep_mstep",
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
@@ -251,6 +263,34 @@ class NgsFHMM:
         buf = C.create_string_buffer(n * 9 * self.n_sites)
         self._check(self.lib.nghmm_format_posteriors(self._h, int(ind_begin), int(n), buf))
         return buf.raw
+
+    def load_chunks(self, pos_dist, chunks, space=0, call_geno=False, check_nan=False):
+        """Chunked loading (nghmm_load_begin / _sites / _end): ``chunks`` yields
+        ``(site_begin, array)`` with raw likelihoods [n][I][3] (float64) or reader genotypes
+        [n][I] (int8: -1 missing, 0, 1, 2)."""
+        pos_dist = np.ascontiguousarray(pos_dist, dtype=np.float64)
+        self._check(self.lib.nghmm_load_begin(self._h, _dp(pos_dist)))
+        for s0, a in chunks:
+            if a.dtype == np.int8:
+                a = np.ascontiguousarray(a)
+                self._check(self.lib.nghmm_load_geno_sites(
+                    self._h, int(s0), a.shape[0], a.ctypes.data_as(C.POINTER(C.c_int8))))
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                self._check(self.lib.nghmm_load_gl_raw_sites(
+                    self._h, int(s0), a.shape[0], _dp(a), int(space), int(call_geno),
+                    int(check_nan)))
+        self._check(self.lib.nghmm_load_end(self._h))
+
+    def load_chunks_device(self, pos_ptr, chunks, space=0, call_geno=False):
+        """The same from device buffers: ``chunks`` yields (site_begin, n_sites, data_ptr) of
+        raw likelihoods [n][I][3]."""
+        self._check(self.lib.nghmm_load_begin_dev(self._h, C.c_void_p(pos_ptr)))
+        for s0, n, ptr in chunks:
+            self._check(self.lib.nghmm_load_gl_raw_sites_dev(self._h, int(s0), int(n),
+                                                             C.c_void_p(ptr), int(space),
+                                                             int(call_geno), 0))
+        self._check(self.lib.nghmm_load_end(self._h))
 
     def load_device(self, gl_ptr, pos_ptr):
         """Same as load() from raw device pointers (e.g. torch tensors' data_ptr())."""

@@ -145,14 +145,16 @@ def called_genotype_gl(geno: np.ndarray) -> np.ndarray:
     return normalise_log_gl(out)
 
 
-def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alpha=0.01,
-                   depth=2.0, error=0.01, seed=12345, chunk_sites: int = 20000, pos_seed=None):
-    """The same data model generated directly on a GPU with torch, in chunks of sites, for
-    benchmark-sized inputs (1000 x 1M = 24 GB of doubles never touches the host).
+def simulate_torch_chunks(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alpha=0.01,
+                          depth=2.0, error=0.01, seed=12345, chunk_sites: int = 20000,
+                          pos_seed=None, n_chrom: int = 1):
+    """The same data model generated directly on a GPU with torch, a chunk of sites at a time.
 
-    Returns (gl [S][I][3] float64 normalised natural-log GL, pos_dist_mb [S]) as device
-    tensors.  One chromosome; distances as the reader derives them (first site: absolute
-    position).  Not bit-compatible with :func:`simulate` (different RNG); same distributions.
+    Returns (pos_dist_mb [S] device tensor, generator of (site_begin, gl_chunk [n][I][3]))
+    with gl_chunk float64 normalised natural-log GL.  n_chrom > 1: equal runs of sites whose
+    first distance is +inf, as the reader derives it at a chromosome change
+    (shared/read_data.cpp:203-210).  Not bit-compatible with :func:`simulate` (different
+    RNG); same distributions.
     """
     import torch
 
@@ -170,38 +172,65 @@ def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alph
     gaps = torch.normal(1e5, 1e5 / 3.0, (S,), generator=gs, device=device, dtype=f64).to(torch.int64)
     gaps.clamp_(min=1)
     pos_dist_mb = gaps.to(f64) / 1e6     # cumulative positions: d_0 = pos_0 - 0
-    gl = torch.empty((S, I, 3), device=device, dtype=f64)
+    if n_chrom > 1:
+        per_chr = -(-S // n_chrom)
+        pos_dist_mb[per_chr::per_chr] = float("inf")
     p_read = torch.tensor([error, 0.5, 1.0 - error], device=device, dtype=f64)
     lp, lq = torch.log(p_read), torch.log1p(-p_read)
-    state = (torch.rand((I,), generator=g, device=device) < indF).to(torch.int64)
+    state0 = (torch.rand((I,), generator=g, device=device) < indF).to(torch.int64)
     # freq = "r": a uniform frequency per site (ngsF-HMMsim.R:127-133), else one value
     site_freq = (torch.rand((S,), generator=gs, device=device, dtype=f64) if isinstance(freq, str)
                  else torch.full((S,), float(freq), device=device, dtype=f64))
-    first = True
-    for s0 in range(0, S, chunk_sites):
-        s1 = min(S, s0 + chunk_sites)
-        n = s1 - s0
-        freq = site_freq[None, s0:s1]
-        X = torch.exp(-alpha * pos_dist_mb[s0:s1])                       # [n]
-        redraw = torch.rand((I, n), generator=g, device=device, dtype=f64) >= X[None, :]
-        if first:
-            redraw[:, 0] = True
-            first = False
-        draws = (torch.rand((I, n), generator=g, device=device) < indF).to(torch.int64)
-        idx = torch.where(redraw, torch.arange(n, device=device)[None, :], -1)
-        idx = torch.cummax(idx, dim=1).values
-        path = torch.where(idx >= 0, torch.gather(draws, 1, idx.clamp(min=0)), state[:, None])
-        state = path[:, -1].clone()
-        h1 = (torch.rand((I, n), generator=g, device=device) < freq).to(torch.int64)
-        h2 = (torch.rand((I, n), generator=g, device=device) < freq).to(torch.int64)
-        h1 = torch.where(path == 1, h2, h1)
-        geno = h1 + h2                                                    # [I][n]
-        dep = torch.poisson(torch.full((I, n), float(depth), device=device, dtype=f64), generator=g)
-        nA = torch.binomial(dep, p_read[geno], generator=g)
-        ll = nA[..., None] * lp + (dep - nA)[..., None] * lq             # [I][n][3]
-        ll = ll - torch.logsumexp(ll, dim=2, keepdim=True)
-        ll = torch.round(ll, decimals=10)
-        ll = ll - torch.logsumexp(ll, dim=2, keepdim=True)               # the reader's post_prob
-        gl[s0:s1] = ll.permute(1, 0, 2)
-        del X, redraw, draws, idx, path, h1, h2, geno, dep, nA, ll
+
+    def chunks():
+        state = state0
+        first = True
+        for s0 in range(0, S, chunk_sites):
+            s1 = min(S, s0 + chunk_sites)
+            n = s1 - s0
+            fr = site_freq[None, s0:s1]
+            X = torch.exp(-alpha * pos_dist_mb[s0:s1])                       # [n]; 0 at chr starts
+            redraw = torch.rand((I, n), generator=g, device=device, dtype=f64) >= X[None, :]
+            if first:
+                redraw[:, 0] = True
+                first = False
+            draws = (torch.rand((I, n), generator=g, device=device) < indF).to(torch.int64)
+            idx = torch.where(redraw, torch.arange(n, device=device)[None, :], -1)
+            idx = torch.cummax(idx, dim=1).values
+            path = torch.where(idx >= 0, torch.gather(draws, 1, idx.clamp(min=0)), state[:, None])
+            state = path[:, -1].clone()
+            h1 = (torch.rand((I, n), generator=g, device=device) < fr).to(torch.int64)
+            h2 = (torch.rand((I, n), generator=g, device=device) < fr).to(torch.int64)
+            h1 = torch.where(path == 1, h2, h1)
+            geno = h1 + h2                                                    # [I][n]
+            dep = torch.poisson(torch.full((I, n), float(depth), device=device, dtype=f64),
+                                generator=g)
+            nA = torch.binomial(dep, p_read[geno], generator=g)
+            ll = nA[..., None] * lp + (dep - nA)[..., None] * lq             # [I][n][3]
+            ll = ll - torch.logsumexp(ll, dim=2, keepdim=True)
+            ll = torch.round(ll, decimals=10)
+            ll = ll - torch.logsumexp(ll, dim=2, keepdim=True)               # the reader's post_prob
+            out = ll.permute(1, 0, 2).contiguous()
+            del X, redraw, draws, idx, path, h1, h2, geno, dep, nA, ll
+            yield s0, out
+
+    return pos_dist_mb, chunks()
+
+
+def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alpha=0.01,
+                   depth=2.0, error=0.01, seed=12345, chunk_sites: int = 20000, pos_seed=None,
+                   n_chrom: int = 1):
+    """:func:`simulate_torch_chunks` collected into one tensor, for benchmark-sized inputs
+    (1000 x 1M = 24 GB of doubles never touches the host).  Returns (gl [S][I][3],
+    pos_dist_mb [S]) as device tensors."""
+    import torch
+
+    pos_dist_mb, chunks = simulate_torch_chunks(n_ind, n_sites, device, freq=freq, indF=indF,
+                                                alpha=alpha, depth=depth, error=error, seed=seed,
+                                                chunk_sites=chunk_sites, pos_seed=pos_seed,
+                                                n_chrom=n_chrom)
+    gl = torch.empty((n_sites, n_ind, 3), device=device, dtype=torch.float64)
+    for s0, c in chunks:
+        gl[s0:s0 + c.shape[0]] = c
+        del c
     return gl, pos_dist_mb

@@ -183,3 +183,50 @@ def brute_force_posterior(q, alpha, e, pos):
             if z[s + 1] == 1:
                 m[s] += p
     return [v / tot for v in m]
+
+
+class Taus:
+    """GSL's gsl_rng_taus (L'Ecuyer 1996 three-component Tausworthe generator), the only GSL
+    generator the reference uses (parse_args.cpp:232-233), restated from the published
+    recurrence; known answer (GSL's own test): seed 1, 10 000th output 2733957125."""
+    M = 0xFFFFFFFF
+
+    def __init__(self, seed):
+        s = seed & self.M
+        if s == 0:
+            s = 1
+        self.s1 = (69069 * s) & self.M
+        self.s2 = (69069 * self.s1) & self.M
+        self.s3 = (69069 * self.s2) & self.M
+        for _ in range(6):
+            self.next()
+
+    @staticmethod
+    def _step(s, a, b, c, d):
+        M = 0xFFFFFFFF
+        return ((((s & c) << d) & M) ^ ((((s << a) & M) ^ s) >> b)) & M
+
+    def next(self):
+        self.s1 = self._step(self.s1, 13, 19, 4294967294, 12)
+        self.s2 = self._step(self.s2, 2, 25, 4294967288, 4)
+        self.s3 = self._step(self.s3, 3, 11, 4294967280, 17)
+        return self.s1 ^ self.s2 ^ self.s3
+
+    def uniform(self):
+        return self.next() / 4294967296.0
+
+
+def random_initial_values(seed, n_ind, n_sites, indF_random=True, freq_random=True):
+    """parse_args.cpp:248-254 and :305-310: one generator; indF_i then alpha_i per individual
+    in [1e-6, 1 - 1e-6], then one frequency per site in [0.01, 0.49]."""
+    rng = Taus(seed)
+    f_min, f_max = 0.000001, 1 - 0.000001
+    indF, alpha = [], []
+    if indF_random:
+        for _ in range(n_ind):
+            indF.append(f_min + rng.uniform() * (f_max - f_min))
+            alpha.append(f_min + rng.uniform() * (f_max - f_min))
+    q_min = 0.01
+    q_max = 0.5 - q_min
+    freq = [q_min + rng.uniform() * (q_max - q_min) for _ in range(n_sites)] if freq_random else []
+    return indF, alpha, freq

@@ -51,3 +51,25 @@ def test_corrupt_binary_size(binary, pkg, tmp_path):
     r = cli_util.run_cli(["--geno", p["glf_bin"], "--pos", p["pos_gz"], "--n_ind", 3,
                           "--n_sites", 21, "--out", tmp_path / "o", "--verbose", 0], check=False)
     assert "invalid/corrupt genotype input file!" in r.stderr
+
+
+def test_taus_known_answer(binary):
+    """gsl_rng_taus as restated in the host (host/ngsF-HMM.cpp) and in tests/pyref.py: GSL's
+    own known answer -- seed 1, 10 000th output 2733957125 -- plus the
+    seed-0 rule (0 is replaced by 1) and agreement of the two restatements on other seeds."""
+    import pyref
+    def cli(seed, n):
+        r = cli_util.run_cli(["--seed", seed, "--taus_kat", n, "--verbose", 0])
+        return int(r.stdout.split()[-1])
+    t = pyref.Taus(1)
+    v = 0
+    for _ in range(10000):
+        v = t.next()
+    assert v == 2733957125
+    assert cli(1, 10000) == 2733957125
+    assert cli(0, 10000) == 2733957125          # seed 0 -> 1
+    for seed, n in ((12345, 1), (12345, 777), (4294967295, 50)):
+        t = pyref.Taus(seed)
+        for _ in range(n):
+            v = t.next()
+        assert cli(seed, n) == v

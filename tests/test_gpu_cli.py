@@ -101,3 +101,141 @@ def test_cli_freq_e_initialisation(pkg, orc_det, orc_libm, data):
     want = [orc_det.est_maf(gl[s], np.zeros(I))[0] for s in range(S)]
     got = [float(x) for x in open(out + ".indF").read().split("\n")[1 + I:1 + I + S]]
     assert got == [float("%f" % w) for w in want]
+
+
+def test_cli_freq_e_and_log_in_fast_mode(pkg, orc_det, orc_libm, data):
+    """Fast mode before its first E-step: the posteriors must be the reference's initial
+    zeros (parse_args.cpp:403-405), not whatever the allocation held.  (1) --freq e =
+    est_maf with F = 0; (2) --log N prints at iteration 0 (EM.cpp:59-63): posterior lines
+    of 0.000000, paths of '0'."""
+    d, paths, tmp = data
+    gl = orc_libm.prepare_gl(d.gl)
+    # a few handles first, so that the next allocation recycles used device memory
+    for _ in range(2):
+        with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as h:
+            h.load(gl, d.pos_dist_mb); h.set_params(0.3, 0.2, 0.2); h.init_emission(); h.estep()
+    out = os.path.join(tmp, "freq_e_fast")
+    cli_util.run_cli(["--geno", paths["glf_bin"], "--loglkl", "--pos", paths["pos_gz"], "--n_ind",
+                      I, "--n_sites", S, "--freq", "e", "--freq_est", 0, "--indF", "0.1,0.2",
+                      "--indF_fixed", "--alpha_fixed", "--out", out, "--min_iters", 1,
+                      "--max_iters", 2, "--mode", "fast", "--verbose", 0])
+    want = np.array([orc_libm.est_maf(gl[s], np.zeros(I))[0] for s in range(S)])
+    got = np.array([float(x) for x in open(out + ".indF").read().split("\n")[1 + I:1 + I + S]])
+    assert np.abs(got - want).max() < 1e-6          # the file holds 6 decimals
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as h:
+        h.load(gl, d.pos_dist_mb)
+        h.set_params(0.1, 0.2, 0.1)
+        h.mstep_freq(1)                              # posteriors still 0
+        np.testing.assert_allclose(h.freq, want, rtol=1e-9)
+        assert not h.marg_prob.any()
+        assert h.format_posteriors(0, 2) == (b"\t".join([b"0.000000"] * S) + b"\n") * 2
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_cli_log_prints_initial_state(pkg, data, mode):
+    """--log 5 with --max_iters 2: intermediate prints at iteration 0 (before any E-step:
+    posteriors and paths are the initial zeros) and at iteration 1 (EM.cpp:59-63: iter == 1
+    always prints); the run must succeed and leave complete final files."""
+    d, paths, tmp = data
+    out = os.path.join(tmp, "log_" + mode)
+    r = cli_util.run_cli(["--geno", paths["glf_gz"], "--loglkl", "--pos", paths["pos_gz"], "--n_ind",
+                          I, "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
+                          "--min_iters", 1, "--max_iters", 2, "--mode", mode, "--log", 5,
+                          "--verbose", 1])
+    assert r.stdout.count("==> Printing current iteration parameters") == 2
+    ibd = open(out + ".ibd").read().split("\n")
+    assert len(ibd) == 1 + 2 * I + 1 and all(len(l) == S for l in ibd[1:1 + I])
+
+
+def test_cli_random_initial_values(pkg, data):
+    """The reference's DEFAULT start (--freq r, and --indF r): gsl_rng_taus seeded with
+    --seed, indF_i / alpha_i interleaved, then one frequency per site
+    (parse_args.cpp:232-233,248-254,305-310).  With everything fixed the output files
+    print the initial values; the generator itself has its known-answer test in
+    tests/test_cli_cpu.py."""
+    import pyref
+    d, paths, tmp = data
+    for seed in (12345, 1):
+        out = os.path.join(tmp, f"rand_{seed}")
+        cli_util.run_cli(["--geno", paths["glf_gz"], "--loglkl", "--pos", paths["pos_gz"],
+                          "--n_ind", I, "--n_sites", S, "--freq", "r", "--freq_est", 0, "--indF",
+                          "r", "--indF_fixed", "--alpha_fixed", "--out", out, "--min_iters", 1,
+                          "--max_iters", 2, "--mode", "fast", "--seed", seed, "--verbose", 0])
+        indF, alpha, freq = pyref.random_initial_values(seed, I, S)
+        lines = open(out + ".indF").read().split("\n")
+        assert lines[1:1 + I] == ["%.5f\t%f" % (f, a) for f, a in zip(indF, alpha)]
+        assert lines[1 + I:1 + I + S] == ["%f" % f for f in freq]
+    # --freq r alone (the reference's default): the generator is consumed by the
+    # frequencies only
+    out = os.path.join(tmp, "rand_freq_only")
+    cli_util.run_cli(["--geno", paths["glf_gz"], "--loglkl", "--pos", paths["pos_gz"], "--n_ind",
+                      I, "--n_sites", S, "--freq_est", 0, "--indF_fixed", "--alpha_fixed",
+                      "--out", out, "--min_iters", 1, "--max_iters", 2, "--seed", 7,
+                      "--verbose", 0])
+    _, _, freq = pyref.random_initial_values(7, I, S, indF_random=False)
+    lines = open(out + ".indF").read().split("\n")
+    assert lines[1:1 + I] == ["%.5f\t%f" % (0.01, 0.001)] * I     # default --indF 0.01-0.001
+    assert lines[1 + I:1 + I + S] == ["%f" % f for f in freq]
+
+
+# ---- examples/test.sh part A: its five configurations x three input types at its size ----
+TS_I, TS_S = 10, 10000
+TS_CONFIGS = {   # examples/test.sh:40-53 (FREQ = 0.2, INDF = 0.5, ALPHA = 0.01)
+    "TRUE": (["--freq", 0.2, "--freq_est", 0, "--indF", "0.5,0.01", "--indF_fixed"],
+             dict(freq0=0.2, indF0=0.5, alpha0=0.01, freq_est=0, indF_fixed=True)),
+    "BEST": (["--freq", 0.2, "--indF", "0.5,0.01"],
+             dict(freq0=0.2, indF0=0.5, alpha0=0.01)),
+    "freq_fixed": (["--freq", 0.2, "--freq_est", 0, "--indF", "0.1,0.2"],
+                   dict(freq0=0.2, indF0=0.1, alpha0=0.2, freq_est=0)),
+    "indF_fixed": (["--freq", 0.1, "--indF", "0.5,0.01", "--indF_fixed"],
+                   dict(freq0=0.1, indF0=0.5, alpha0=0.01, indF_fixed=True)),
+    "normal": (["--freq", 0.1, "--indF", "0.1,0.2"], dict(freq0=0.1, indF0=0.1, alpha0=0.2)),
+}
+TS_TYPES = {     # examples/test.sh:28-38
+    "TG": ("geno_gz", [], False),
+    "GL": ("glf_gz", ["--loglkl"], False),
+    "GL_CG": ("glf_gz", ["--loglkl", "--call_geno"], True),
+}
+
+
+@pytest.fixture(scope="module")
+def testsh_data(pkg, tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("testsh"))
+    # test.sh:10-23: --freq 0.2 --site_pos r --indF 0.5 --alpha 0.01 --depth 2 --error 0.01
+    d = pkg.simulate.simulate(TS_I, TS_S, seed=12345, freq=0.2, indF=0.5, alpha=0.01, depth=2.0,
+                              error=0.01)
+    return d, cli_util.write_inputs(tmp, d, d.gl), tmp
+
+
+@pytest.mark.parametrize("typ", list(TS_TYPES))
+@pytest.mark.parametrize("cfg", list(TS_CONFIGS))
+def test_examples_test_sh_matrix(pkg, orc_det, orc_libm, testsh_data, cfg, typ):
+    """BASELINE.json configs[0]: the reference's own regression matrix (examples/test.sh:
+    TRUE, BEST, freq_fixed, indF_fixed, normal x TG, GL, GL_CG at 10 x 10 000, --log 1,
+    --n_threads 10, --seed 12345).  Its md5s pin outputs of inputs that need R to
+    regenerate, so the comparison is against the files print_iter would write from the
+    oracle's results (byte for byte, exact mode).  Deviation, stated: the runs are capped
+    at 6 iterations (--min_iters 3 --max_iters 6) to keep the suite short."""
+    d, paths, tmp = testsh_data
+    key, flags, call = TS_TYPES[typ]
+    args, okw = TS_CONFIGS[cfg]
+    raw = cli_util.raw_called_genotypes(d.geno) if typ == "TG" else d.gl
+    gl = orc_det.prepare_gl(raw, 0, call_geno=call)
+    out = os.path.join(tmp, f"testF-HMM.{cfg}.{typ}")
+    r = cli_util.run_cli(["--verbose", 2, "--n_threads", TS_I, "--seed", 12345, "--geno",
+                          paths[key], *flags, "--n_ind", TS_I, "--n_sites", TS_S, "--pos",
+                          paths["pos_gz"], *args, "--out", out, "--log", 1, "--min_iters", 3,
+                          "--max_iters", 6, "--mode", "exact"])
+    em = orclib.OracleEM(orc_det, gl, d.pos_dist_mb)
+    em.set_params(okw["indF0"], okw["alpha0"], okw["freq0"])
+    assert em.init_emission() == 0
+    n = em.run(freq_est=okw.get("freq_est", 1), indF_fixed=okw.get("indF_fixed", False),
+               min_iters=3, max_iters=6, n_threads=TS_I)
+    path = em.viterbi(n_threads=TS_I)
+    f_indF, f_ibd, f_geno = cli_util.expected_files(em.tot_lkl, em.indF, em.alpha, em.freq,
+                                                    em.ind_lkl, path, em.marg, em.geno_post(path))
+    assert f"Iteration {n}:" in r.stdout and f"Iteration {n + 1}:" not in r.stdout
+    assert r.stdout.count("==> Printing current iteration parameters") == n   # --log 1
+    assert open(out + ".indF", "rb").read() == f_indF
+    assert open(out + ".ibd", "rb").read() == f_ibd
+    assert open(out + ".geno", "rb").read() == f_geno

@@ -71,25 +71,43 @@ def test_two_shards_equal_one_handle(pkg):
 
 
 def test_bench_multi_rank_path_on_one_gpu(pkg):
-    """bench.py --gpus 2 end to end (torch.distributed.run, 2 ranks, ShardedEM with the
-    all-to-all / all-gather exchange), both ranks on cuda:0 with the gloo backend staging
-    collectives through the host.  Functional check only; the measured multi-GPU
-    configuration uses nccl (= RCCL) and is run by the driver on an 8-GPU node."""
+    """`python bench.py --gpus 2` as the driver starts it (no torch.distributed environment):
+    bench.py launches the two ranks itself before any GPU call; on this one-GPU box both
+    ranks share cuda:0 and the collectives go through gloo staged on the host (the line says
+    so).  Strong scaling is the default: the workload's individuals are sharded, and the
+    sharded run must reproduce the N = 1 job (same data seeds are not shared between the two
+    runs, so the check is on the bookkeeping: total individuals, sites, positive rate).
+    Functional check only; the measured multi-GPU configuration uses nccl (= RCCL) and is
+    run by the driver on an 8-GPU node."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NGHMM_BENCH_BACKEND="gloo", NGHMM_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny",
-           "--no_cpu_baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
+
+    def run(*extra):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
+               "--workload", "tiny", "--no_cpu_baseline", *extra]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run()
+    two = run("--gpus", "2")
+    assert one["n_gpus"] == 1 and one["ranks"] == 1 and one["config"]["n_ind_per_gpu"] == 64
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["n_ind_total"] == 64 and two["config"]["n_ind_per_gpu"] == 32
+    assert "gloo" in two["collectives"] and two["value"] > 0
+    weak = run("--gpus", "2", "--scaling", "weak")
+    assert weak["config"]["n_ind_total"] == 128 and weak["scaling"] == "weak"
+    # a rank count that does not match --gpus is an error, not a silent N = 1 run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--workload", "tiny", "--no_cpu_baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE is 1" in bad.stderr
 
 
 @pytest.mark.parametrize("I", [40, 100, 200, 400, 600, 1024, 1100, 2100, 4100, 8200])
