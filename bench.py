@@ -8,7 +8,8 @@ x 1,000,000 sites, --freq_est 1 (the reference aborts on --freq_est 2), starting
 values of examples/test.sh "normal" (--freq 0.1 --indF 0.1,0.2), inputs resident in
 HBM before the timed region.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|tiny] [--mode fast|exact]
+  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c5|c5share|tiny|tinycg]
+                   [--mode fast|exact]
                    [--scaling strong|weak]
 
 N > 1 = one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / WORLD_SIZE in
@@ -43,6 +44,16 @@ WORKLOADS = {
                name="100 ind x 100k sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
                     "--freq 0.1 --indF 0.1,0.2"),
     "tiny": dict(n_ind=64, n_sites=20_000, name="64 ind x 20k sites (smoke)"),
+    # BASELINE.json configs[4]: needs 8 GPUs (625 individuals x 5M sites each, 29 B per cell
+    # packed); c5share is exactly one GPU's share of it, without the exchange
+    "c5": dict(n_ind=5000, n_sites=5_000_000, n_chrom=25, call_geno=True,
+               name="5000 ind x 5M sites, 25 chromosomes, --call_geno (2-bit packed), "
+                    "synthetic log-GL, --freq_est 1, --freq 0.1 --indF 0.1,0.2"),
+    "c5share": dict(n_ind=625, n_sites=5_000_000, n_chrom=25, call_geno=True,
+                    name="625 ind x 5M sites (one GPU's share of 5000 x 5M over 8), 25 chromosomes, "
+                         "--call_geno (2-bit packed), --freq_est 1, --freq 0.1 --indF 0.1,0.2"),
+    "tinycg": dict(n_ind=64, n_sites=20_000, n_chrom=4, call_geno=True,
+                   name="64 ind x 20k sites, 4 chromosomes, --call_geno (2-bit packed) (smoke)"),
 }
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
@@ -251,17 +262,29 @@ def main():
         I //= world           # per rank; the job's total stays wl["n_ind"]
     I_tot = I * world
     mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
+    call_geno = bool(wl.get("call_geno"))
+    if call_geno:
+        mode |= pkg.GENO_PACKED
+    if I * S * (29.5 if call_geno else 100.0) > 270e9:
+        raise SystemExit(f"workload {args.workload}: {I} x {S} per GPU does not fit one MI355X "
+                         f"(use more ranks: --gpus 8)")
 
     # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
     # every rank simulates its own individuals on the same sites
-    gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank,
-                                          pos_seed=None if world == 1 else 777)
-    torch.cuda.synchronize()
-
     dd = importlib.import_module("ngsf-hmm_amd.distributed")
     em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world)
-    em.load_device(gl, pos)
-    del gl
+    if call_geno:   # a block of sites at a time, called and packed on the way in
+        pos, chunks = pkg.simulate.simulate_torch_chunks(
+            I, S, device, seed=12345 + rank, pos_seed=None if world == 1 else 777,
+            n_chrom=wl.get("n_chrom", 1), chunk_sites=50_000)
+        em.load_chunks_device(pos, chunks, space=0, call_geno=True)
+    else:
+        gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank,
+                                              pos_seed=None if world == 1 else 777,
+                                              n_chrom=wl.get("n_chrom", 1))
+        torch.cuda.synchronize()
+        em.load_device(gl, pos)
+        del gl
     torch.cuda.empty_cache()
     em.set_params(0.1, 0.2, 0.1)
     em.init_emission()
@@ -306,14 +329,15 @@ def main():
         # 24 B GL and writes 16 B emissions + 4 B checkpoints; later rounds read 16 B per
         # still-active individual; the E-step then reads 16 + 4 B and writes 8 B
         fast = args.mode == "fast"
+        glb = 0.25 if call_geno else 24.0     # bytes of genotype likelihoods per cell
         algo = {
-            "lkl_batch": ((44.0 * S * I * K + 16.0 * S * max(ind_rounds - I * K, 0)) if fast
+            "lkl_batch": (((glb + 20.0) * S * I * K + 16.0 * S * max(ind_rounds - I * K, 0)) if fast
                           else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
-            "est_maf": 32.0 * (S / world) * I_tot,   # S/N own sites x all individuals per rank
+            "est_maf": (glb + 8.0) * (S / world) * I_tot,   # S/N own sites x all individuals per rank
             "forward": (28.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
-            "emission": (8.0 * S if fast else 40.0 * S * I),
-            "lkl_first": 44.0 * S * I,
+            "emission": (8.0 * S if fast else (glb + 16.0) * S * I),
+            "lkl_first": (glb + 20.0) * S * I,
         }
         dom = max((k for k in fam if k != "lkl_first"), key=lambda k: fam[k])
         avg_ms = fam[dom] / max(launches[dom], 1)

@@ -42,7 +42,8 @@ enum {
                                  shared/gen_func.cpp:1030-1031) */
   NGHMM_ERR_ARG = -10,        /* bad argument / call order */
   NGHMM_ERR_HIP = -11,        /* HIP runtime error */
-  NGHMM_ERR_NOMEM = -12
+  NGHMM_ERR_NOMEM = -12,
+  NGHMM_ERR_NOT_PACKABLE = -13 /* a packed handle met a cell that is not a called genotype */
 };
 
 /* Arithmetic mode of a handle. */

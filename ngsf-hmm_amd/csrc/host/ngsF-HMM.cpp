@@ -51,9 +51,7 @@ struct Params {  // ngsF-HMM.hpp:13-52
   unsigned n_threads = 1, verbose = 1, seed = 0;
   int mode = NGHMM_MODE_FAST, device = 0;
 
-  std::vector<double> gl;        // [S][I][3] raw values of the input file (freed after upload)
-  int gl_space = NGHMM_GL_LOG;   // their encoding (nghmm_load_gl_raw)
-  bool gl_check_nan = false;
+  bool no_pack = false;          // --no_pack: never keep called genotypes as 2-bit codes
   std::vector<double> pos_dist;  // [S] Mb
   std::vector<double> freq, indF, alpha, ind_lkl;
   std::vector<uint8_t> path;
@@ -139,78 +137,121 @@ void read_dist(Params& P) {
   for (auto& d : P.pos_dist) d /= 1e6;
 }
 
-// shared/read_data.cpp:13-116: file -> RAW values [S][I][3] as the reference's reader sees
-// them.  Conversion to log space, the two normalisations and the optional genotype call
-// (read_data.cpp:36-40,89-98; ngsF-HMM.cpp:101-117) happen on the device
-// (nghmm_load_gl_raw); P.gl_space says how the values are encoded.
-void read_geno(Params& P) {
+// shared/read_data.cpp:13-116: file -> device, a block of sites at a time (the whole matrix
+// never exists on the host).  The host hands over the RAW values as the reference's reader sees
+// them; conversion to log space, the two normalisations and the optional genotype call
+// (read_data.cpp:36-40,89-98; ngsF-HMM.cpp:101-117) run on the device
+// (nghmm_load_gl_raw_sites).  A packed handle (called genotypes as 2-bit codes) takes a
+// called-genotype file as plain genotype values (nghmm_load_geno_sites).  Returns NGHMM_OK, or
+// NGHMM_ERR_NOT_PACKABLE when a packed handle cannot represent the input (the caller then
+// repeats the load with an unpacked handle).
+int load_geno(Params& P, nghmm_t* h, bool packed) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   const uint64_t n_geno = P.in_lkl ? 3 : 1;
   double unread;
   const uint64_t unread_bits = NGHMM_GL_UNREAD_BITS;
   memcpy(&unread, &unread_bits, sizeof unread);
+  check(nghmm_load_begin(h, P.pos_dist.data()), "read_geno");
   gzFile fh = gzopen(P.in_geno, P.in_bin ? "rb" : "r");
   if (!fh) fatal(__FUNCTION__, "cannot open GENO file!");
   gzbuffer(fh, 1 << 20);
+  uint64_t block = (64ull << 20) / (I * 24);  // sites per block: about 64 MB of likelihoods
+  if (block < 1) block = 1;
+  if (block > S) block = S;
+  int rc = NGHMM_OK;
   if (P.in_bin) {
-    P.gl.resize((size_t)S * I * 3);
-    for (uint64_t s = 0; s < S; s++) {
-      double* row = &P.gl[s * I * 3];
-      const int want = (int)(I * 3 * sizeof(double));
-      if (gzread(fh, row, want) != want)
-        fatal(__FUNCTION__, gzeof(fh)
-                                ? "GENO file at premature EOF. Check GENO file and number of sites!"
-                                : "cannot read binary GENO file. Check GENO file and number of sites!");
+    std::vector<double> buf((size_t)block * I * 3);
+    const int space = P.in_loglkl ? NGHMM_GL_LOG : NGHMM_GL_NORMAL_BINARY;
+    for (uint64_t s0 = 0; s0 < S && rc == NGHMM_OK; s0 += block) {
+      const uint64_t ns = (S - s0) < block ? (S - s0) : block;
+      for (uint64_t s = 0; s < ns; s++) {
+        const int want = (int)(I * 3 * sizeof(double));
+        if (gzread(fh, &buf[s * I * 3], want) != want)
+          fatal(__FUNCTION__, gzeof(fh)
+                                  ? "GENO file at premature EOF. Check GENO file and number of sites!"
+                                  : "cannot read binary GENO file. Check GENO file and number of sites!");
+      }
+      // NaN check: read_data.cpp:42-45 (binary input only)
+      rc = nghmm_load_gl_raw_sites(h, s0, ns, buf.data(), space, P.call_geno ? 1 : 0, 1);
     }
-    P.gl_space = P.in_loglkl ? NGHMM_GL_LOG : NGHMM_GL_NORMAL_BINARY;
-    P.gl_check_nan = true;  // read_data.cpp:42-45
   } else {
-    // a site whose line is empty keeps "unread" cells (read_data.cpp:60-61)
-    P.gl.assign((size_t)S * I * 3, unread);
+    const bool as_codes = packed && !P.in_lkl;  // called genotypes straight to 2-bit codes
+    const int space = (P.in_lkl && !P.in_loglkl) ? NGHMM_GL_NORMAL_TEXT : NGHMM_GL_LOG;
+    std::vector<double> dbuf(as_codes ? 0 : (size_t)block * I * 3);
+    std::vector<int8_t> gbuf(as_codes ? (size_t)block * I : 0);
     std::vector<char> buf(kBuffLen);
     std::vector<double> t;
-    for (uint64_t s = 0; s < S; s++) {
+    uint64_t s0 = 0, filled = 0;  // the block covers sites [s0, s0 + filled)
+    auto flush = [&]() {
+      if (!filled || rc != NGHMM_OK) return;
+      rc = as_codes ? nghmm_load_geno_sites(h, s0, filled, gbuf.data())
+                    : nghmm_load_gl_raw_sites(h, s0, filled, dbuf.data(), space,
+                                              P.call_geno ? 1 : 0, 0);
+      s0 += filled;
+      filled = 0;
+    };
+    for (uint64_t s = 0; s < S && rc == NGHMM_OK;) {
       if (gzgets(fh, buf.data(), (int)kBuffLen) == nullptr)
         fatal(__FUNCTION__, gzeof(fh)
                                 ? "GENO file at premature EOF. Check GENO file and number of sites!"
                                 : "cannot read GZip GENO file. Check GENO file and number of sites!");
       chomp(buf.data());
-      if (buf[0] == '\0') continue;  // (sic) an empty line still consumes a site, as in the reference
-      const size_t n_fields = split_doubles(buf.data(), " \t", t);
-      if (!n_fields || (s == 0 && n_fields < I * n_geno)) {
-        fprintf(stderr, "> Header found! Skipping line...\n");
-        if (s != 0) warn(__FUNCTION__, " header found but not on first line. Is this an error?");
-        s--;
-        continue;
-      }
-      if (n_fields < I * n_geno)
-        fatal(__FUNCTION__, "wrong GENO file format. Less fields than expected!");
-      const double* ptr = t.data() + (n_fields - I * n_geno);  // last I*n_geno columns
-      for (uint64_t i = 0; i < I; i++) {
-        double* g = &P.gl[(s * I + i) * 3];
-        if (P.in_lkl) {
-          for (int k = 0; k < 3; k++) g[k] = ptr[i * 3 + k];
-        } else {
-          const int gg = (int)ptr[i];
-          if (gg >= 0) {
-            if (gg > 2)
-              fatal(__FUNCTION__,
-                    "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
-            g[0] = g[1] = g[2] = -kINF;  // read_data.cpp:21
-            g[gg] = log(1);
+      double* row = as_codes ? nullptr : &dbuf[filled * I * 3];
+      if (buf[0] == '\0') {
+        // (sic) an empty line still consumes a site, as in the reference (read_data.cpp:60-61):
+        // its cells stay "unread", which 2-bit codes cannot express
+        if (as_codes) {
+          rc = NGHMM_ERR_NOT_PACKABLE;
+          break;
+        }
+        for (uint64_t k = 0; k < I * 3; k++) row[k] = unread;
+      } else {
+        const size_t n_fields = split_doubles(buf.data(), " \t", t);
+        if (!n_fields || (s == 0 && n_fields < I * n_geno)) {
+          fprintf(stderr, "> Header found! Skipping line...\n");
+          if (s != 0) warn(__FUNCTION__, " header found but not on first line. Is this an error?");
+          continue;
+        }
+        if (n_fields < I * n_geno)
+          fatal(__FUNCTION__, "wrong GENO file format. Less fields than expected!");
+        const double* ptr = t.data() + (n_fields - I * n_geno);  // last I*n_geno columns
+        for (uint64_t i = 0; i < I; i++) {
+          if (P.in_lkl) {
+            for (int k = 0; k < 3; k++) row[i * 3 + k] = ptr[i * 3 + k];
           } else {
-            g[0] = g[1] = g[2] = log((double)1 / 3);
+            const int gg = (int)ptr[i];
+            if (gg > 2)
+              fatal(__FUNCTION__, "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+            if (as_codes) {
+              gbuf[filled * I + i] = (int8_t)(gg < 0 ? -1 : gg);
+            } else if (gg >= 0) {
+              double* g = row + i * 3;
+              g[0] = g[1] = g[2] = -kINF;  // read_data.cpp:21
+              g[gg] = log(1);
+            } else {
+              double* g = row + i * 3;
+              g[0] = g[1] = g[2] = log((double)1 / 3);
+            }
           }
         }
       }
+      s++;
+      if (++filled == block) flush();
     }
-    P.gl_space = (P.in_lkl && !P.in_loglkl) ? NGHMM_GL_NORMAL_TEXT : NGHMM_GL_LOG;
-    P.gl_check_nan = false;
+    flush();
   }
+  if (rc == NGHMM_ERR_NOT_PACKABLE) {
+    gzclose(fh);
+    return rc;
+  }
+  check(rc, "read_geno");
   char c;
   gzread(fh, &c, 1);
   if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
   gzclose(fh);
+  rc = nghmm_load_end(h);
+  if (rc != NGHMM_ERR_NOT_PACKABLE) check(rc, "read_geno");
+  return rc;
 }
 
 // GSL's gsl_rng_taus (Tausworthe, L'Ecuyer 1996), the only GSL generator the reference
@@ -411,6 +452,7 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       {"n_threads", required_argument, nullptr, 'x'}, {"verbose", required_argument, nullptr, 'V'},
       {"seed", required_argument, nullptr, 'S'},      {"mode", required_argument, nullptr, 1000},
       {"device", required_argument, nullptr, 1001},   {"taus_kat", required_argument, nullptr, 1002},
+      {"no_pack", no_argument, nullptr, 1003},
       {0, 0, 0, 0}};
   long taus_kat = 0;
   P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
@@ -447,6 +489,7 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
         break;
       case 1001: P.device = atoi(optarg); break;
       case 1002: taus_kat = atol(optarg); break;
+      case 1003: P.no_pack = true; break;
       default: exit(-1);
     }
   if (taus_kat > 0) {  // known-answer check of the generator: the N-th raw output for --seed
@@ -516,20 +559,25 @@ int main(int argc, char** argv) {
     printf("> Sites coordinates\n");
   }
   read_dist(P);
-  if (P.verbose >= 1) printf("> GENO data\n");
-  read_geno(P);
-
   // The reference dies inside iter_EM for these (EM.cpp:235-238 -> gen_func.cpp:1030-1031);
   // same message, same exit code, before any GPU work.
   if (P.freq_est == 2 || P.e_prob_calc == 2) fatal("haplo_freq", "invalid allele frequencies");
 
+  if (P.verbose >= 1) printf("> GENO data\n");
+  // Called genotypes (a called-genotype file, or --call_geno) are four values per cell and are
+  // kept as 2-bit codes; results are those of the 24-byte likelihoods (bit for bit in exact
+  // mode).  An input the codes cannot express (an empty text line) falls back to likelihoods.
   nghmm_t* h = nullptr;
-  check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode), "nghmm_create");
-  // conversion to log space, normalisation, --call_geno: on the device (read_geno, main)
-  check(nghmm_load_gl_raw(h, P.gl.data(), P.gl_space, P.call_geno ? 1 : 0, P.gl_check_nan ? 1 : 0,
-                          P.pos_dist.data()),
-        "read_geno");
-  std::vector<double>().swap(P.gl);  // the host does not need the likelihoods again
+  bool packed = (P.call_geno || !P.in_lkl) && !P.no_pack;
+  check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode | (packed ? NGHMM_GENO_PACKED : 0)),
+        "nghmm_create");
+  if (load_geno(P, h, packed) == NGHMM_ERR_NOT_PACKABLE) {
+    nghmm_destroy(h);
+    h = nullptr;
+    packed = false;
+    check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode), "nghmm_create");
+    check(load_geno(P, h, false), "read_geno");
+  }
   const bool estimate_freq = init_values(P, h);
   if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
     check(nghmm_mstep_freq(h, 1), "init_output");
@@ -555,21 +603,21 @@ int main(int argc, char** argv) {
     if (P.verbose >= 1) printf("\nIteration %lu:\n", (unsigned long)iter);
     if (P.verbose >= 1)
       printf("==> Forward Recursion\n==> Backward Recursion\n==> Marginal probabilities\n");
-    nghmm_mstep_stats stats;
-    check(nghmm_estep(h, P.ind_lkl.data()), "iter_EM");
-    if (P.indF_fixed && P.alpha_fixed) {
-      if (P.verbose >= 1) printf("==> Inbreeding and transition parameter not estimated!\n");
-    } else {
-      if (P.verbose >= 1) printf("==> Update inbreeding and transition parameter\n");
-      check(nghmm_mstep_indf(h, P.indF_fixed, P.alpha_fixed, &stats), "iter_EM");
-    }
-    if (P.freq_est == 0) {
-      if (P.verbose >= 1) printf("==> Alelle frequencies not estimated!\n");
-    } else {
-      if (P.verbose >= 1)
+    // one call per iteration: in fast mode the E-step and the M-step share their first pass
+    // over the data (nghmm_iter_em); the phase lines of EM.cpp:147-272 are printed up front
+    if (P.verbose >= 1) {
+      if (P.indF_fixed && P.alpha_fixed)
+        printf("==> Inbreeding and transition parameter not estimated!\n");
+      else
+        printf("==> Update inbreeding and transition parameter\n");
+      if (P.freq_est == 0)
+        printf("==> Alelle frequencies not estimated!\n");
+      else
         printf("==> Estimating allele frequencies and calculating emission probabilities\n");
-      check(nghmm_mstep_freq(h, P.freq_est), "iter_EM");
     }
+    nghmm_mstep_stats stats;
+    check(nghmm_iter_em(h, P.freq_est, P.indF_fixed, P.alpha_fixed, P.ind_lkl.data(), &stats),
+          "iter_EM");
     P.prev_tot_lkl = P.tot_lkl;
     P.tot_lkl = 0;
     for (uint64_t i = 0; i < I; i++) {

@@ -371,6 +371,7 @@ const char* nghmm_strerror(int code) {
     case NGHMM_ERR_ARG: return "invalid argument";
     case NGHMM_ERR_HIP: return "HIP runtime error";
     case NGHMM_ERR_NOMEM: return "out of device memory";
+    case NGHMM_ERR_NOT_PACKABLE: return "not a called genotype (packed handle)";
     default: return "unknown error";
   }
 }
@@ -538,7 +539,7 @@ static int check_load_flags(nghmm_t* h, bool check_nan) {
   if (f[FLAG_NOT_PACKABLE]) {
     set_error("a cell is not a called genotype (one-hot or uniform likelihoods): a packed handle "
               "(NGHMM_GENO_PACKED) needs --call_geno or called-genotype input");
-    return NGHMM_ERR_ARG;
+    return NGHMM_ERR_NOT_PACKABLE;
   }
   return NGHMM_OK;
 }

@@ -88,6 +88,31 @@ class GpuBackend:
     def load_device(self, gl, pos):
         self.hmm.load_device(gl.data_ptr(), pos.data_ptr())
 
+    def load_chunks_device(self, pos, chunks, space=0, call_geno=False):
+        """chunks: iterable of (site_begin, tensor [n][I][3]) on this device."""
+        def feed():
+            for s0, c in chunks:
+                self.sync()                 # the library reads on its own stream
+                yield s0, c.shape[0], c.data_ptr()
+        self.hmm.load_chunks_device(pos.data_ptr(), feed(), space=space, call_geno=call_geno)
+
+    @property
+    def packed(self):
+        return bool(self.hmm.mode & self.pkg.GENO_PACKED)
+
+    def geno_codes(self):
+        """[S][I] uint8 genotype codes of a packed handle (device tensor)."""
+        out = self.torch.empty((self.n_sites, self.n_ind), device=self.device,
+                               dtype=self.torch.uint8)
+        self.hmm._check(self.hmm.lib.nghmm_get_geno_codes_dev(self.hmm.handle, 0, self.n_sites,
+                                                             C.c_void_p(out.data_ptr())))
+        return out
+
+    def load_geno_site_shard_device(self, codes):
+        """codes: device tensor [S_own][I_tot] uint8."""
+        self.hmm._check(self.hmm.lib.nghmm_load_geno_site_shard_dev(
+            self.hmm.handle, C.c_void_p(codes.data_ptr())))
+
     def set_params(self, indF, alpha, freq):
         self.hmm.set_params(indF, alpha, freq)
 
@@ -159,6 +184,29 @@ class ShardedEM:
         self.backend.load_device(gl, pos)
         if self.world > 1:
             self._exchange_site_shard(gl)
+
+    def load_chunks_device(self, pos, chunks, space=0, call_geno=False):
+        """Chunked loading from device tensors (site_begin, [n][I_local][3]); with several
+        ranks the handle must be packed: the site shards are then built from the genotype
+        codes (a dense handle's shard needs the whole matrix: use load_device)."""
+        self.backend.load_chunks_device(pos, chunks, space=space, call_geno=call_geno)
+        if self.world > 1:
+            if not getattr(self.backend, "packed", False):
+                raise ValueError("chunked loading on several ranks needs a packed handle")
+            self._exchange_code_shard()
+
+    def _exchange_code_shard(self):
+        """One-off, packed handles: every rank's [S][I_loc] code bytes -> [S_own][I_tot]."""
+        world, I = self.world, self.n_ind
+        codes = self.backend.geno_codes()                          # [S][I] uint8
+        send = codes.reshape(world, self.S_own, I).contiguous()
+        recv = send.new_empty((world, self.S_own, I))
+        self._sync()
+        all_to_all(recv, send)
+        shard = recv.permute(1, 0, 2).contiguous().view(self.S_own, world * I)
+        self._sync()
+        self.backend.load_geno_site_shard_device(shard)
+        del codes, send, recv, shard
 
     def _exchange_site_shard(self, gl):
         """One-off: build [S_own][I_tot][3] from every rank's [S][I_loc][3]."""

@@ -239,3 +239,51 @@ def test_examples_test_sh_matrix(pkg, orc_det, orc_libm, testsh_data, cfg, typ):
     assert open(out + ".indF", "rb").read() == f_indF
     assert open(out + ".ibd", "rb").read() == f_ibd
     assert open(out + ".geno", "rb").read() == f_geno
+
+
+def test_cli_packed_default_equals_no_pack(pkg, data):
+    """The host keeps called genotypes (a called-genotype file, --call_geno) as 2-bit codes
+    unless --no_pack: the files of the two runs must be identical byte for byte (exact mode)
+    -- and in fast mode too, where the packed emission is a select among the same values."""
+    d, paths, tmp = data
+    for name, key, flags in (("tg", "geno_gz", []), ("cg", "glf_bin", ["--loglkl", "--call_geno"])):
+        for mode in ("exact", "fast"):
+            outs = []
+            for extra in ([], ["--no_pack"]):
+                out = os.path.join(tmp, f"pk_{name}_{mode}_{len(extra)}")
+                cli_util.run_cli(["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I,
+                                  "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
+                                  "--min_iters", 2, "--max_iters", 3, "--mode", mode, "--verbose", 0,
+                                  *extra])
+                outs.append(out)
+            for ext in (".indF", ".ibd", ".geno"):
+                a, b = open(outs[0] + ext, "rb").read(), open(outs[1] + ext, "rb").read()
+                if mode == "exact" or ext != ".indF":
+                    assert a == b, (name, mode, ext)
+                else:       # fast mode: packed / unpacked emissions may differ in the last bit
+                    assert len(a) == len(b)
+
+
+def test_cli_empty_line_in_called_genotype_file(pkg, orc_det, orc_libm, data):
+    """An empty line in a text input still consumes a site (read_data.cpp:60-61): its cells
+    keep the reader's initial -1e15 and see only the second normalisation.  2-bit codes
+    cannot express that, so the host falls back to likelihoods; the files must be what the
+    oracle gives for those cells."""
+    import gzip
+    d, paths, tmp = data
+    lines = gzip.open(paths["geno_gz"], "rt").read().split("\n")[:S]
+    lines[41] = ""
+    path = os.path.join(tmp, "hole.geno.gz")
+    with gzip.open(path, "wt") as fh:
+        fh.write("\n".join(lines) + "\n")
+    raw = cli_util.raw_called_genotypes(d.geno)
+    raw[41, :, 0] = np.frombuffer(np.uint64(0x7ff8dead00000001).tobytes(), dtype=np.float64)[0]
+    gl = orc_det.prepare_gl(raw, 0, call_geno=False)
+    out = os.path.join(tmp, "hole")
+    cli_util.run_cli(["--geno", path, "--pos", paths["pos_gz"], "--n_ind", I, "--n_sites", S,
+                      "--freq", 0.1, "--indF", "0.1,0.2", "--out", out, "--min_iters", 2,
+                      "--max_iters", 3, "--mode", "exact", "--verbose", 0])
+    n, (f_indF, f_ibd, f_geno) = _oracle_outputs(orc_det, orc_libm, gl, d, 0.1, 0.1, 0.2, 2, 3)
+    assert open(out + ".indF", "rb").read() == f_indF
+    assert open(out + ".ibd", "rb").read() == f_ibd
+    assert open(out + ".geno", "rb").read() == f_geno

@@ -87,9 +87,9 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
 
-    def run(*extra):
+    def run(*extra, workload="tiny"):
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
-               "--workload", "tiny", "--no_cpu_baseline", *extra]
+               "--workload", workload, "--no_cpu_baseline", *extra]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -102,6 +102,10 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert "gloo" in two["collectives"] and two["value"] > 0
     weak = run("--gpus", "2", "--scaling", "weak")
     assert weak["config"]["n_ind_total"] == 128 and weak["scaling"] == "weak"
+    # BASELINE configs[4]'s path at smoke size: --call_geno, 2-bit packed handles, the site
+    # shards built from exchanged genotype codes
+    cg = run("--gpus", "2", workload="tinycg")
+    assert cg["n_gpus"] == 2 and cg["value"] > 0 and "packed" in cg["config"]["workload"]
     # a rank count that does not match --gpus is an error, not a silent N = 1 run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
                           "--workload", "tiny", "--no_cpu_baseline"],
