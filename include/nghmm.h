@@ -84,6 +84,15 @@ int nghmm_has_hip(void);
 int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, int mode);
 int nghmm_destroy(nghmm_t* h);
 
+/* Multi-start (ngsF-HMM.sh:77-101 runs 20 replicates from different random starts and keeps
+ * the one with the best likelihood): a REPLICA shares its parent's genotype likelihoods and
+ * distances on the device (read-only, loaded once) and owns everything an EM run writes --
+ * parameters, emissions, posteriors, optimizer state -- and its own HIP stream, so R replicas
+ * driven from R host threads run R independent EM analyses concurrently on one GPU.  Every
+ * call behaves exactly as on an independent handle loaded with the same data.  The parent must
+ * be loaded, must not be reloaded while replicas exist and must be destroyed last. */
+int nghmm_create_replica(nghmm_t** out, nghmm_t* parent);
+
 /* Upload genotype likelihoods: natural-log, normalised, site-major [S][I][3]
  * (= the reference's binary --geno file order, shared/read_data.cpp:28-31, after
  * its normalisation) and per-site distances in Mb, +inf at chromosome starts

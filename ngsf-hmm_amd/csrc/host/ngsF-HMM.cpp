@@ -23,6 +23,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/nghmm.h"
@@ -52,6 +53,10 @@ struct Params {  // ngsF-HMM.hpp:13-52
   int mode = NGHMM_MODE_FAST, device = 0;
 
   bool no_pack = false;          // --no_pack: never keep called genotypes as 2-bit codes
+  unsigned n_starts = 1;         // --n_starts R: R replicates from seeds seed, seed+1, ... (ngsF-HMM.sh)
+  bool keep_starts = false;      // --keep_starts: write every replicate's files, PREFIX.REP_rr.*
+  FILE* out = stdout;            // where this run's progress lines go (replicates: a buffer)
+  std::string prefix;            // output prefix of this run
   std::vector<double> pos_dist;  // [S] Mb
   std::vector<double> freq, indF, alpha, ind_lkl;
   std::vector<uint8_t> path;
@@ -291,14 +296,14 @@ bool init_values(Params& P, nghmm_t* h) {
   std::vector<char> buf(kBuffLen);
   gzFile fh;
   if (P.in_indF == "r") {
-    if (P.verbose >= 1) printf("==> Using random initial inbreeding values.\n");
+    if (P.verbose >= 1) fprintf(P.out, "==> Using random initial inbreeding values.\n");
     for (uint64_t i = 0; i < I; i++) {
       P.indF[i] = f_min + rng.uniform() * (f_max - f_min);
       P.alpha[i] = f_min + rng.uniform() * (f_max - f_min);
     }
   } else if ((fh = gzopen(P.in_indF.c_str(), "r")) != nullptr) {
     if (P.verbose >= 1)
-      printf("==> Reading initial inbreeding values from file \"%s\".\n", P.in_indF.c_str());
+      fprintf(P.out, "==> Reading initial inbreeding values from file \"%s\".\n", P.in_indF.c_str());
     uint64_t i = 0;
     while (gzgets(fh, buf.data(), (int)kBuffLen) != nullptr) {
       chomp(buf.data());
@@ -312,7 +317,7 @@ bool init_values(Params& P, nghmm_t* h) {
     gzclose(fh);
   } else {
     if (P.verbose >= 1)
-      printf("==> Setting initial inbreeding values to: %s\n", P.in_indF.c_str());
+      fprintf(P.out, "==> Setting initial inbreeding values to: %s\n", P.in_indF.c_str());
     std::string tmp = P.in_indF;
     if (split_doubles(&tmp[0], ",-", t) != 2) fatal(__FUNCTION__, "wrong INDF parameters format!");
     for (uint64_t i = 0; i < I; i++) {
@@ -325,21 +330,21 @@ bool init_values(Params& P, nghmm_t* h) {
   P.freq.assign(S, q_min);
   bool estimate = false;
   if (P.in_freq == "r") {
-    if (P.verbose >= 1) printf("==> Using random initial frequency values.\n");
+    if (P.verbose >= 1) fprintf(P.out, "==> Using random initial frequency values.\n");
     for (uint64_t s = 0; s < S; s++) P.freq[s] = q_min + rng.uniform() * (q_max - q_min);
   } else if (P.in_freq == "e") {
-    if (P.verbose >= 1) printf("==> Estimating initial frequency values assuming HWE.\n");
+    if (P.verbose >= 1) fprintf(P.out, "==> Estimating initial frequency values assuming HWE.\n");
     estimate = true;
   } else if ((fh = gzopen(P.in_freq.c_str(), "r")) != nullptr) {
     if (P.verbose >= 1)
-      printf("==> Reading initial frequency values from file \"%s\".\n", P.in_freq.c_str());
+      fprintf(P.out, "==> Reading initial frequency values from file \"%s\".\n", P.in_freq.c_str());
     uint64_t s = 0;
     while (gzgets(fh, buf.data(), (int)kBuffLen) != nullptr) {
       chomp(buf.data());
       if (buf[0] == '\0') continue;
       const size_t n = split_doubles(buf.data(), " ,-\t", t);
       if (!n) {
-        printf("> Header found! Skipping line...\n");
+        fprintf(P.out, "> Header found! Skipping line...\n");
         continue;
       }
       if (s >= S || n != 1) fatal(__FUNCTION__, "wrong FREQ file format!");
@@ -347,7 +352,7 @@ bool init_values(Params& P, nghmm_t* h) {
     }
     gzclose(fh);
   } else {
-    if (P.verbose >= 1) printf("==> Setting initial frequency values to: %s\n", P.in_freq.c_str());
+    if (P.verbose >= 1) fprintf(P.out, "==> Setting initial frequency values to: %s\n", P.in_freq.c_str());
     for (uint64_t s = 0; s < S; s++) P.freq[s] = clampd(atof(P.in_freq.c_str()), q_min, q_max);
   }
   check(nghmm_set_params(h, P.indF.data(), P.alpha.data(), P.freq.data()), "init_output");
@@ -365,7 +370,7 @@ inline char* put_fixed(char* p, double v, int prec) {
 // EM.cpp:293-380
 void print_iter(const Params& P, nghmm_t* h) {
   const uint64_t I = P.n_ind, S = P.n_sites;
-  std::string name = std::string(P.out_prefix) + ".indF";
+  std::string name = P.prefix + ".indF";
   FILE* fh = fopen(name.c_str(), "w");
   if (!fh) fatal(__FUNCTION__, "cannot open INDF output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
@@ -388,7 +393,7 @@ void print_iter(const Params& P, nghmm_t* h) {
   }
   fclose(fh);
 
-  name = std::string(P.out_prefix) + ".ibd";
+  name = P.prefix + ".ibd";
   fh = fopen(name.c_str(), "w");
   if (!fh) fatal(__FUNCTION__, "cannot open IBD output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
@@ -416,7 +421,7 @@ void print_iter(const Params& P, nghmm_t* h) {
   }
   fclose(fh);
 
-  name = std::string(P.out_prefix) + ".geno";
+  name = P.prefix + ".geno";
   fh = fopen(name.c_str(), "wb");
   if (!fh) fatal(__FUNCTION__, "cannot open GENO output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
@@ -452,7 +457,8 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       {"n_threads", required_argument, nullptr, 'x'}, {"verbose", required_argument, nullptr, 'V'},
       {"seed", required_argument, nullptr, 'S'},      {"mode", required_argument, nullptr, 1000},
       {"device", required_argument, nullptr, 1001},   {"taus_kat", required_argument, nullptr, 1002},
-      {"no_pack", no_argument, nullptr, 1003},
+      {"no_pack", no_argument, nullptr, 1003},        {"n_starts", required_argument, nullptr, 1004},
+      {"keep_starts", no_argument, nullptr, 1005},
       {0, 0, 0, 0}};
   long taus_kat = 0;
   P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
@@ -490,6 +496,8 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       case 1001: P.device = atoi(optarg); break;
       case 1002: taus_kat = atol(optarg); break;
       case 1003: P.no_pack = true; break;
+      case 1004: P.n_starts = (unsigned)atoi(optarg); break;
+      case 1005: P.keep_starts = true; break;
       default: exit(-1);
     }
   if (taus_kat > 0) {  // known-answer check of the generator: the N-th raw output for --seed
@@ -529,6 +537,88 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
   if (P.min_iters < 1 || P.max_iters < 1 || P.min_iters >= P.max_iters)
     fatal(__FUNCTION__, "invalid number of iterations!");
   if (P.n_threads < 1) fatal(__FUNCTION__, "invalid number of threads!");
+  if (P.n_starts < 1) fatal(__FUNCTION__, "invalid number of starts (--n_starts)!");
+  P.prefix = P.out_prefix;
+}
+
+// One EM analysis on a loaded handle: initial values, the loop of EM.cpp:27-103.
+void run_em(Params& P, nghmm_t* h) {
+  const bool estimate_freq = init_values(P, h);
+  if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
+    check(nghmm_mstep_freq(h, 1), "init_output");
+  if (P.verbose >= 1) fprintf(P.out, "==> Calculating initial emission probabilities\n");
+  check(nghmm_emission(h), "calc_emission");
+
+  // ---- EM.cpp:27-103 ----
+  const uint64_t I = P.n_ind;
+  P.ind_lkl.assign(I, -INFINITY);
+  std::vector<double> prev_ind_lkl(I, -INFINITY), eps(I, -INFINITY);
+  double max_lkl_epsilon = -INFINITY;
+  uint64_t iter = 0;
+  while ((P.prev_tot_lkl - P.tot_lkl > P.min_epsilon || max_lkl_epsilon > P.min_epsilon ||
+          iter < P.min_iters) &&
+         iter < P.max_iters) {
+    if (P.log && (iter == 1 || iter % P.log == 0)) {
+      if (P.verbose >= 1) fprintf(P.out, "==> Printing current iteration parameters\n");
+      sync_outputs(P, h, false);
+      print_iter(P, h);
+    }
+    const time_t iter_start = time(nullptr);
+    iter++;
+    if (P.verbose >= 1) fprintf(P.out, "\nIteration %lu:\n", (unsigned long)iter);
+    if (P.verbose >= 1)
+      fprintf(P.out, "==> Forward Recursion\n==> Backward Recursion\n==> Marginal probabilities\n");
+    // one call per iteration: in fast mode the E-step and the M-step share their first pass
+    // over the data (nghmm_iter_em); the phase lines of EM.cpp:147-272 are printed up front
+    if (P.verbose >= 1) {
+      if (P.indF_fixed && P.alpha_fixed)
+        fprintf(P.out, "==> Inbreeding and transition parameter not estimated!\n");
+      else
+        fprintf(P.out, "==> Update inbreeding and transition parameter\n");
+      if (P.freq_est == 0)
+        fprintf(P.out, "==> Alelle frequencies not estimated!\n");
+      else
+        fprintf(P.out, "==> Estimating allele frequencies and calculating emission probabilities\n");
+    }
+    nghmm_mstep_stats stats;
+    check(nghmm_iter_em(h, P.freq_est, P.indF_fixed, P.alpha_fixed, P.ind_lkl.data(), &stats),
+          "iter_EM");
+    P.prev_tot_lkl = P.tot_lkl;
+    P.tot_lkl = 0;
+    for (uint64_t i = 0; i < I; i++) {
+      P.tot_lkl += P.ind_lkl[i];
+      eps[i] = (P.ind_lkl[i] - prev_ind_lkl[i]) / fabs(prev_ind_lkl[i]);
+    }
+    uint64_t best = 0;  // array_max_pos, gen_func.cpp:73-84
+    double mx = -INFINITY;
+    for (uint64_t i = 0; i < I; i++)
+      if (eps[i] > mx) { best = i; mx = eps[i]; }
+    max_lkl_epsilon = eps[best];
+    prev_ind_lkl = P.ind_lkl;
+    const time_t iter_end = time(nullptr);
+    if (P.verbose >= 1)
+      fprintf(P.out, "\tLogLkl: %.15f\t max lkl epsilon: %.15f\ttime: %.0f (s)\n", P.tot_lkl,
+             max_lkl_epsilon, difftime(iter_end, iter_start));
+    if (P.verbose >= 3)
+      for (uint64_t i = 0; i < I; i++)
+        fprintf(P.out, "\tInd %lu: %.15f\t lkl epsilon: %.15f%s\n", (unsigned long)(i + 1), P.ind_lkl[i],
+               eps[i], i == best ? " (max)" : "");
+    fflush(P.out);
+  }
+  if (iter >= P.max_iters)
+    fprintf(P.out, "WARN: Maximum number of iterations reached! Check if analysis converged... \n");
+
+}
+
+// EM.cpp:105-127: decoding and the three output files
+void finish_run(Params& P, nghmm_t* h) {
+  if (P.verbose >= 1) fprintf(P.out, "\n==> Decoding most probable path (Viterbi)\n");
+  sync_outputs(P, h, true);
+  if (P.verbose >= 1) {
+    fprintf(P.out, "Final logLkl: %f\n", P.tot_lkl);
+    fprintf(P.out, "Printing final results\n");
+  }
+  print_iter(P, h);
 }
 
 }  // namespace
@@ -578,79 +668,62 @@ int main(int argc, char** argv) {
     check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode), "nghmm_create");
     check(load_geno(P, h, false), "read_geno");
   }
-  const bool estimate_freq = init_values(P, h);
-  if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
-    check(nghmm_mstep_freq(h, 1), "init_output");
-  if (P.verbose >= 1) printf("==> Calculating initial emission probabilities\n");
-  check(nghmm_emission(h), "calc_emission");
-
-  // ---- EM.cpp:27-103 ----
-  const uint64_t I = P.n_ind;
-  P.ind_lkl.assign(I, -INFINITY);
-  std::vector<double> prev_ind_lkl(I, -INFINITY), eps(I, -INFINITY);
-  double max_lkl_epsilon = -INFINITY;
-  uint64_t iter = 0;
-  while ((P.prev_tot_lkl - P.tot_lkl > P.min_epsilon || max_lkl_epsilon > P.min_epsilon ||
-          iter < P.min_iters) &&
-         iter < P.max_iters) {
-    if (P.log && (iter == 1 || iter % P.log == 0)) {
-      if (P.verbose >= 1) printf("==> Printing current iteration parameters\n");
-      sync_outputs(P, h, false);
-      print_iter(P, h);
+  if (P.n_starts == 1) {
+    run_em(P, h);
+    finish_run(P, h);
+  } else {
+    // Multi-start (ngsF-HMM.sh:77-101: N_REP replicates, each from its own seed, the one with
+    // the largest final log-likelihood is kept).  The replicates share the likelihoods on the
+    // device (nghmm_create_replica) and run concurrently, one host thread and one HIP stream
+    // each; replicate r uses seed + r (the script draws its seeds from bash's $RANDOM).  Only
+    // the best replicate is decoded and written, unless --keep_starts.
+    const unsigned R = P.n_starts;
+    std::vector<Params> runs(R, P);
+    std::vector<nghmm_t*> hs(R, nullptr);
+    std::vector<char*> bufs(R, nullptr);
+    std::vector<size_t> lens(R, 0);
+    hs[0] = h;
+    for (unsigned r = 0; r < R; r++) {
+      if (r) check(nghmm_create_replica(&hs[r], h), "nghmm_create_replica");
+      runs[r].seed = P.seed + r;
+      char tag[32];
+      snprintf(tag, sizeof tag, ".REP_%02u", r + 1);
+      runs[r].prefix = std::string(P.out_prefix) + tag;
+      runs[r].out = open_memstream(&bufs[r], &lens[r]);
     }
-    const time_t iter_start = time(nullptr);
-    iter++;
-    if (P.verbose >= 1) printf("\nIteration %lu:\n", (unsigned long)iter);
-    if (P.verbose >= 1)
-      printf("==> Forward Recursion\n==> Backward Recursion\n==> Marginal probabilities\n");
-    // one call per iteration: in fast mode the E-step and the M-step share their first pass
-    // over the data (nghmm_iter_em); the phase lines of EM.cpp:147-272 are printed up front
-    if (P.verbose >= 1) {
-      if (P.indF_fixed && P.alpha_fixed)
-        printf("==> Inbreeding and transition parameter not estimated!\n");
-      else
-        printf("==> Update inbreeding and transition parameter\n");
-      if (P.freq_est == 0)
-        printf("==> Alelle frequencies not estimated!\n");
-      else
-        printf("==> Estimating allele frequencies and calculating emission probabilities\n");
+    std::vector<std::thread> th;
+    for (unsigned r = 0; r < R; r++) th.emplace_back([&, r] { run_em(runs[r], hs[r]); });
+    for (auto& t : th) t.join();
+    unsigned best = 0;
+    for (unsigned r = 1; r < R; r++)
+      if (runs[r].tot_lkl > runs[best].tot_lkl) best = r;   // ties: the first, like sort's order
+    for (unsigned r = 0; r < R; r++) {
+      if (r == best || P.keep_starts) {
+        if (r == best && !P.keep_starts) runs[r].prefix = P.out_prefix;
+        finish_run(runs[r], hs[r]);
+      }
+      fclose(runs[r].out);
+      if (P.verbose >= 1) printf("\n========== Replicate %u (seed %u) ==========\n", r + 1, runs[r].seed);
+      fwrite(bufs[r], 1, lens[r], stdout);
+      free(bufs[r]);
     }
-    nghmm_mstep_stats stats;
-    check(nghmm_iter_em(h, P.freq_est, P.indF_fixed, P.alpha_fixed, P.ind_lkl.data(), &stats),
-          "iter_EM");
-    P.prev_tot_lkl = P.tot_lkl;
-    P.tot_lkl = 0;
-    for (uint64_t i = 0; i < I; i++) {
-      P.tot_lkl += P.ind_lkl[i];
-      eps[i] = (P.ind_lkl[i] - prev_ind_lkl[i]) / fabs(prev_ind_lkl[i]);
+    if (P.keep_starts) {  // the script moves the best replicate's files to the output prefix
+      for (const char* ext : {".indF", ".ibd", ".geno"}) {
+        const std::string from = runs[best].prefix + ext, to = std::string(P.out_prefix) + ext;
+        FILE* a = fopen(from.c_str(), "rb");
+        FILE* b = fopen(to.c_str(), "wb");
+        if (!a || !b) fatal(__FUNCTION__, "cannot copy the best replicate's files!");
+        std::vector<char> blk(1 << 22);
+        size_t n;
+        while ((n = fread(blk.data(), 1, blk.size(), a)) > 0) fwrite(blk.data(), 1, n, b);
+        fclose(a);
+        fclose(b);
+      }
     }
-    uint64_t best = 0;  // array_max_pos, gen_func.cpp:73-84
-    double mx = -INFINITY;
-    for (uint64_t i = 0; i < I; i++)
-      if (eps[i] > mx) { best = i; mx = eps[i]; }
-    max_lkl_epsilon = eps[best];
-    prev_ind_lkl = P.ind_lkl;
-    const time_t iter_end = time(nullptr);
-    if (P.verbose >= 1)
-      printf("\tLogLkl: %.15f\t max lkl epsilon: %.15f\ttime: %.0f (s)\n", P.tot_lkl,
-             max_lkl_epsilon, difftime(iter_end, iter_start));
-    if (P.verbose >= 3)
-      for (uint64_t i = 0; i < I; i++)
-        printf("\tInd %lu: %.15f\t lkl epsilon: %.15f%s\n", (unsigned long)(i + 1), P.ind_lkl[i],
-               eps[i], i == best ? " (max)" : "");
-    fflush(stdout);
+    printf("Best replicate: %u (seed %u), logLkl %.10f\n", best + 1, runs[best].seed,
+           runs[best].tot_lkl);
+    for (unsigned r = R; r-- > 1;) nghmm_destroy(hs[r]);
   }
-  if (iter >= P.max_iters)
-    printf("WARN: Maximum number of iterations reached! Check if analysis converged... \n");
-
-  // ---- EM.cpp:105-127 ----
-  if (P.verbose >= 1) printf("\n==> Decoding most probable path (Viterbi)\n");
-  sync_outputs(P, h, true);
-  if (P.verbose >= 1) {
-    printf("Final logLkl: %f\n", P.tot_lkl);
-    printf("Printing final results\n");
-  }
-  print_iter(P, h);
   if (P.verbose >= 1) printf("Freeing memory...\n");
   nghmm_destroy(h);
   if (P.verbose >= 1) printf("Done!\n");

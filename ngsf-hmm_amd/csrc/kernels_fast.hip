@@ -1240,7 +1240,10 @@ constexpr double EST_MULT = NGHMM_EST_MULT;  // ... and about this many current 
 #endif
 constexpr double EST_FIT = NGHMM_EST_FIT;    // build once k * step <= EST_FIT * EST_DMAX * r ...
 constexpr int EST_KMAX = NGHMM_EST_KMAX;     // ... or after this many passes at the latest
-constexpr double EST_TOL = 1e-13;       // interpolant vs exact pass, relative
+#ifndef NGHMM_EST_TOL
+#define NGHMM_EST_TOL 1e-13
+#endif
+constexpr double EST_TOL = NGHMM_EST_TOL;  // interpolant vs exact pass, relative
 constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back to exact
 // cos((2j+1) pi/(2 EN)) and (-1)^j sin((2j+1) pi/(2 EN)): first-kind Chebyshev nodes and
 // their barycentric weights
@@ -1734,10 +1737,32 @@ bool dalloc(T** p, size_t n) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// the arrays an EM run writes (everything but the data): emissions, frequency table,
+// posteriors, checkpoints, boundary operators
+static bool fast_alloc_run_state(FastState& fs) {
+  const size_t cells = (size_t)fs.I * fs.Spad;
+  const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
+  if (!dalloc(&fs.e_il, (cells + slack) * 2)) return false;
+  if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.freq_il, (size_t)fs.Spad + slack)) return false;
+  if (hipMemset(fs.freq_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.post, cells)) return false;
+  // the reference starts from marg_prob = 0 (parse_args.cpp:403-405): `--freq e` and a
+  // `--log` print before the first E-step read the posteriors
+  if (hipMemset(fs.post, 0, cells * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.ckpt, cells / CK * 4 + 4 * 64)) return false;  // T is a multiple of CK; slack:
+                                                                 // see lkl_run_fd
+  if (!dalloc(&fs.lane_ops, (size_t)fs.I * fs.J * 5)) return false;
+  if (!dalloc(&fs.bound, (size_t)fs.I * fs.J * 4)) return false;
+  fs.e_stale = true;
+  return true;
+}
+
 bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   fs.I = I;
   fs.S = S;
   fs.packed = packed;
+  fs.owns_data = true;
   // Waves per individual.  The objective rounds run 4 waves per SIMD = 4096 at a time and
   // all their waves take equally long, so a launch of n waves wastes the unfilled part of
   // its last batch: ~32k waves per 1000 individuals keep that below 2 % (measured at
@@ -1759,9 +1784,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   fs.Spad = fs.J * fs.T;
   const size_t cells = (size_t)I * fs.Spad;
   const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
-  if (!dalloc(&fs.e_il, (cells + slack) * 2)) return false;
   if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
-  if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (packed) {
     const size_t words = cells / 16 + slack;
@@ -1773,26 +1796,44 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
     if (!dalloc(&fs.gl1_il, cells + slack)) return false;
     if (hipMemset(fs.gl02_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
     if (hipMemset(fs.gl1_il + cells, 0, slack * sizeof(double)) != hipSuccess) return false;
+    if (!dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
   }
-  if (!dalloc(&fs.freq_il, (size_t)fs.Spad + slack)) return false;
-  if (hipMemset(fs.freq_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
-  if (!dalloc(&fs.post, cells)) return false;
-  // the reference starts from marg_prob = 0 (parse_args.cpp:403-405): `--freq e` and a
-  // `--log` print before the first E-step read the posteriors
-  if (hipMemset(fs.post, 0, cells * sizeof(double)) != hipSuccess) return false;
-  if (!dalloc(&fs.ckpt, cells / CK * 4 + 4 * 64)) return false;  // T is a multiple of CK; slack:
-                                                                 // see lkl_run_fd
-  if (!packed && !dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
-  if (!dalloc(&fs.lane_ops, (size_t)I * fs.J * 5)) return false;
-  if (!dalloc(&fs.bound, (size_t)I * fs.J * 4)) return false;
-  return true;
+  return fast_alloc_run_state(fs);
+}
+
+bool fast_create_replica(FastState& fs, const FastState& parent) {
+  fs = FastState();
+  fs.I = parent.I;
+  fs.S = parent.S;
+  fs.T = parent.T;
+  fs.C = parent.C;
+  fs.J = parent.J;
+  fs.Spad = parent.Spad;
+  fs.packed = parent.packed;
+  fs.owns_data = false;
+  fs.gl_log = parent.gl_log;
+  fs.d_pos = parent.d_pos;
+  fs.geno_il = parent.geno_il;
+  fs.cls_lin = parent.cls_lin;
+  fs.u_lin = parent.u_lin;
+  fs.gl_lin = parent.gl_lin;
+  fs.pos_il = parent.pos_il;
+  fs.gl02_il = parent.gl02_il;
+  fs.gl1_il = parent.gl1_il;
+  fs.dmax_finite = parent.dmax_finite;
+  return fast_alloc_run_state(fs);
 }
 
 void fast_destroy(FastState& fs) {
-  void* ptrs[] = {fs.e_il, fs.pos_il, fs.gl02_il, fs.gl1_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.part,
-                  fs.grp_dev, fs.redo, fs.est_status, fs.est_state, fs.gl_lin, fs.geno_il, fs.cls_lin};
-  for (void* p : ptrs)
+  void* run[] = {fs.e_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.part,
+                 fs.grp_dev, fs.redo, fs.est_status, fs.est_state};
+  for (void* p : run)
     if (p) (void)hipFree(p);
+  if (fs.owns_data) {
+    void* data[] = {fs.pos_il, fs.gl02_il, fs.gl1_il, fs.gl_lin, fs.geno_il, fs.cls_lin};
+    for (void* p : data)
+      if (p) (void)hipFree(p);
+  }
   fs = FastState();
 }
 

@@ -22,6 +22,7 @@ struct FastState {
   // packed handle (called genotypes as 2-bit codes, glview.hpp): no dense copy of the
   // likelihoods exists; the fresh forward walk reads geno_il, est_maf the site-major codes
   bool packed = false;
+  bool owns_data = true;          // false: a replica, whose data arrays belong to its parent
   uint32_t* geno_il = nullptr;    // codes interleaved [I][C][T/16][64]: 16 sites of a lane per word
   double* cls_lin = nullptr;      // [4][3] linear likelihoods of the four classes (device)
   double u_lin = 0;               // linear likelihood of a uniform (missing) cell, host copy
@@ -53,6 +54,9 @@ struct FastState {
 };
 
 bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed = false);
+// a replica of `parent` (after its fast_load): shares the read-only data arrays (likelihoods in
+// every layout, distances), owns everything an EM run writes
+bool fast_create_replica(FastState& fs, const FastState& parent);
 void fast_destroy(FastState& fs);
 // (re)build the interleaved distance table; remembers the GL / distance pointers
 bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double* d_pos);

@@ -11,6 +11,7 @@
 // log-likelihoods (8 B each) come back.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -94,6 +95,10 @@ struct nghmm_handle {
   unsigned long long* d_uniform = nullptr;  // the one value every uniform cell carries (~0: none yet)
   // chunked loading (nghmm_load_begin .. nghmm_load_end)
   uint64_t lkl_redone = 0;            // objective points re-evaluated by the general kernel
+  // replicas (nghmm_create_replica): share the parent's data arrays (d_gl / d_codes /
+  // d_cls_log / d_pos and the fast-mode layouts of the likelihoods)
+  nghmm_handle* parent = nullptr;
+  std::atomic<int> n_replicas{0};
   bool loading = false;
   double* d_stage = nullptr;          // staging buffer of one chunk of raw likelihoods
   size_t stage_cap = 0;
@@ -459,20 +464,89 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
 
 int nghmm_destroy(nghmm_t* h) {
   if (!h) return NGHMM_OK;
+  if (h->n_replicas.load() > 0) {
+    set_error("nghmm_destroy: %d replica(s) of this handle are still alive", h->n_replicas.load());
+    return NGHMM_ERR_ARG;
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_gl, h->d_pos, h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
-                  h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
-                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
-                  h->d_gl_shard, h->d_geno, h->d_text, h->d_codes, h->d_codes_shard, h->d_cls_log,
-                  h->d_uniform, h->d_stage, h->d_stage8};
-  for (void* p : ptrs)
+  void* own[] = {h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
+                 h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
+                 h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
+                 h->d_gl_shard, h->d_geno, h->d_text, h->d_codes_shard, h->d_uniform, h->d_stage,
+                 h->d_stage8};
+  for (void* p : own)
     if (p) (void)hipFree(p);
+  if (!h->parent) {
+    void* data[] = {h->d_gl, h->d_pos, h->d_codes, h->d_cls_log};
+    for (void* p : data)
+      if (p) (void)hipFree(p);
+  } else {
+    h->parent->n_replicas.fetch_sub(1);
+  }
   fast_destroy(h->fast);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+  return NGHMM_OK;
+}
+
+int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
+  g_last_error.clear();
+  if (!out || !parent || !parent->loaded || parent->parent) {
+    set_error("nghmm_create_replica: the parent must be a loaded handle that is not itself a replica");
+    return NGHMM_ERR_ARG;
+  }
+  if (parent->I_tot != parent->I) {
+    set_error("nghmm_create_replica: sharded handles have no replicas");
+    return NGHMM_ERR_ARG;
+  }
+  int rc;
+  if ((rc = use_device(parent))) return rc;
+  nghmm_t* h = new (std::nothrow) nghmm_handle;
+  if (!h) return NGHMM_ERR_NOMEM;
+  h->I = parent->I;
+  h->S = parent->S;
+  h->device = parent->device;
+  h->mode = parent->mode;
+  h->packed = parent->packed;
+  h->I_tot = h->I;
+  h->S_own = h->S;
+  h->parent = parent;
+  parent->n_replicas.fetch_add(1);
+  h->d_gl = parent->d_gl;
+  h->d_pos = parent->d_pos;
+  h->d_codes = parent->d_codes;
+  h->d_cls_log = parent->d_cls_log;
+  const uint64_t n_ind = h->I, n_sites = h->S;
+  do {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    const size_t cells = (size_t)n_ind * n_sites;
+    if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
+    if ((rc = dev_alloc(&h->d_freq, n_sites))) break;
+    if ((rc = dev_alloc(&h->d_indF, n_ind))) break;
+    if ((rc = dev_alloc(&h->d_alpha, n_ind))) break;
+    if ((rc = dev_alloc(&h->d_ind_lkl, n_ind))) break;
+    if (h->mode == NGHMM_MODE_EXACT) {
+      if ((rc = dev_alloc(&h->d_eprob, cells * 2))) break;
+      if ((rc = dev_alloc(&h->d_fw, (cells + n_ind) * 2))) break;
+      if ((rc = dev_alloc(&h->d_marg, cells))) break;
+      if (hipMemset(h->d_marg, 0, cells * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    }
+    if (hipMemset(h->d_freq, 0, n_sites * sizeof(double)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    h->h_indF.assign(n_ind, 0.0);
+    h->h_alpha.assign(n_ind, 0.0);
+    if (h->mode == NGHMM_MODE_FAST && !fast_create_replica(h->fast, parent->fast)) { rc = NGHMM_ERR_NOMEM; break; }
+    h->loaded = true;
+  } while (0);
+  if (rc != NGHMM_OK) {
+    if (g_last_error.empty()) set_error("nghmm_create_replica failed (%d)", rc);
+    nghmm_destroy(h);
+    return rc;
+  }
+  *out = h;
   return NGHMM_OK;
 }
 
@@ -587,6 +661,10 @@ static uint64_t stage_sites(const nghmm_t* h) {
 int nghmm_load_begin(nghmm_t* h, const double* pos) {
   g_last_error.clear();
   if (!h || !pos) return NGHMM_ERR_ARG;
+  if (h->parent || h->n_replicas.load() > 0) {
+    set_error("a replica shares its parent's data: load into the parent, before creating replicas");
+    return NGHMM_ERR_ARG;
+  }
   int rc;
   if ((rc = use_device(h))) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -601,6 +679,10 @@ int nghmm_load_begin(nghmm_t* h, const double* pos) {
 }
 
 static int load_begin_dev(nghmm_t* h, const double* d_pos) {
+  if (h->parent || h->n_replicas.load() > 0) {
+    set_error("a replica shares its parent's data: load into the parent, before creating replicas");
+    return NGHMM_ERR_ARG;
+  }
   HIP_TRY(hipMemcpyAsync(h->d_pos, d_pos, h->S * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (h->packed) {
     HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));

@@ -74,6 +74,7 @@ def load_library():
         "nghmm_has_hip": (i32, []),
         "nghmm_create": (i32, [C.POINTER(vp), u64, u64, i32, i32]),
         "nghmm_destroy": (i32, [vp]),
+        "nghmm_create_replica": (i32, [C.POINTER(vp), vp]),
         "nghmm_load_gl": (i32, [vp, dp, dp]),
         "nghmm_load_gl_raw": (i32, [vp, dp, i32, i32, i32, dp]),
         "nghmm_get_gl": (i32, [vp, dp]),
@@ -127,6 +128,7 @@ def _dp(a):
 
 EXPORTED_SYMBOLS = [
     "nghmm_last_error", "nghmm_strerror", "nghmm_has_hip", "nghmm_create", "nghmm_destroy",
+    "nghmm_create_replica",
     "nghmm_load_gl", "nghmm_load_gl_raw", "nghmm_get_gl", "nghmm_geno_posteriors",
     "nghmm_format_posteriors", "nghmm_format_fixed6",
     "nghmm_load_gl_device", "nghmm_load_begin", "nghmm_load_begin_dev", "nghmm_load_gl_raw_sites",
@@ -169,12 +171,17 @@ KERNEL_SLOTS = {"emission": 0, "forward": 1, "backward": 2, "lkl_batch": 3, "est
 class NgsFHMM:
     """Device-resident EM state of one GPU (the reference's ``params`` + ``EM``)."""
 
-    def __init__(self, n_ind, n_sites, device=0, mode=MODE_EXACT):
+    def __init__(self, n_ind, n_sites, device=0, mode=MODE_EXACT, _replica_of=None):
         self.lib = load_library()
         self.n_ind, self.n_sites = int(n_ind), int(n_sites)
         self.mode = mode
         self._h = C.c_void_p()
-        self._check(self.lib.nghmm_create(C.byref(self._h), self.n_ind, self.n_sites, device, mode))
+        self._parent = _replica_of          # keeps the parent alive
+        if _replica_of is not None:
+            self._check(self.lib.nghmm_create_replica(C.byref(self._h), _replica_of._h))
+        else:
+            self._check(self.lib.nghmm_create(C.byref(self._h), self.n_ind, self.n_sites, device,
+                                              mode))
         self.tot_lkl = 0.0        # parse_args.cpp:31-32
         self.prev_tot_lkl = 0.0
         self.ind_lkl = np.full(self.n_ind, -math.inf)  # parse_args.cpp:412
@@ -187,9 +194,14 @@ class NgsFHMM:
             msg = self.lib.nghmm_last_error().decode() or self.lib.nghmm_strerror(rc).decode()
             raise NgsFHMMError(rc, msg)
 
+    def replica(self):
+        """A handle that shares this one's (loaded) data and owns its own EM state and stream
+        (nghmm_create_replica): multi-start runs, ngsF-HMM.sh:77-101."""
+        return NgsFHMM(self.n_ind, self.n_sites, mode=self.mode, _replica_of=self)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self.lib.nghmm_destroy(self._h)
+            self._check(self.lib.nghmm_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -294,3 +294,37 @@ def run_findmax(fn, objective, x0, lb, ub, data=None):
     nbd = (C.c_int * len(x))(*([2] * len(x)))
     r = fn(len(x), _dp(x), data, objective, None, _dp(lb), _dp(ub), nbd, -1)
     return x, r
+
+
+class HpAnchor:
+    """oracle/hp_anchor.c: the model of forward / backward / posteriors / est_maf evaluated in
+    binary128, independent of the oracle's restatement (no shared code, another formulation)."""
+
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "liboracle_hp.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = self.lib = C.CDLL(path)
+        L.hp_forward_backward.restype = C.c_double
+        L.hp_forward_backward.argtypes = [c_double_p, c_double_p, c_double_p, C.c_uint64,
+                                          C.c_double, C.c_double, c_double_p]
+        L.hp_est_maf.restype = C.c_double
+        L.hp_est_maf.argtypes = [C.c_uint64, c_double_p, c_double_p, C.POINTER(C.c_int)]
+
+    def forward_backward(self, gl_ind, freq, pos_dist, indF, alpha, want_post=True):
+        """gl_ind [S][3] log GLs of one individual -> (log-likelihood, posteriors [S] or None)."""
+        gl_ind = np.ascontiguousarray(gl_ind, dtype=np.float64)
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+        pos_dist = np.ascontiguousarray(pos_dist, dtype=np.float64)
+        S = len(pos_dist)
+        post = np.empty(S) if want_post else None
+        lk = self.lib.hp_forward_backward(_dp(gl_ind), _dp(freq), _dp(pos_dist), S, float(indF),
+                                          float(alpha), _dp(post) if want_post else None)
+        return lk, post
+
+    def est_maf(self, gl_site, indF):
+        gl_site = np.ascontiguousarray(gl_site, dtype=np.float64)
+        indF = np.ascontiguousarray(indF, dtype=np.float64)
+        n = C.c_int(0)
+        f = self.lib.hp_est_maf(len(indF), _dp(gl_site), _dp(indF), C.byref(n))
+        return f, n.value

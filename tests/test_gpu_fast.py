@@ -52,7 +52,7 @@ def test_fast_estep(pkg, orc_libm, mid_sim):
     assert em.estep() == 0
     lk = hmm.estep()
     np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-12)
-    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
     hmm.close()
 
 
@@ -140,7 +140,7 @@ def test_fast_teacher_forced_iterations(pkg, orc_libm, mid_sim):
         assert em.estep() == 0
         lk = hmm.estep()
         np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-12)
-        np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
         assert em.mstep_indf() == 0
         assert em.mstep_freq(1) == 0
         hmm.mstep_freq(1)
@@ -158,7 +158,7 @@ def test_fast_ragged_shapes(pkg, orc_libm, shape):
     assert em.estep() == 0
     lk = hmm.estep()
     np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-11)
-    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
     em.mstep_freq(1); hmm.mstep_freq(1)
     np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
     st = hmm.mstep_indf()
@@ -177,7 +177,7 @@ def test_fast_called_genotypes(pkg, orc_libm):
     assert em.estep() == 0
     lk = hmm.estep()
     np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-11)
-    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
     em.mstep_freq(1); hmm.mstep_freq(1)
     np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
     hmm.close()
@@ -228,7 +228,7 @@ def test_fast_estep_mstep_shares_the_forward_walk(pkg, orc_libm, mid_sim, fixed)
     st = a.estep_mstep(*fixed, after_estep=lambda: seen.append(a.marg_prob.copy()))
     assert len(seen) == 1
     np.testing.assert_allclose(a.ind_lkl, em.ind_lkl, rtol=1e-12)
-    np.testing.assert_allclose(seen[0], em.marg, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(seen[0], em.marg, rtol=RTOL, atol=1e-12)
     np.testing.assert_array_equal(a.marg_prob, seen[0])      # later rounds leave them alone
     b.estep()
     st_b = b.mstep_indf(*fixed)
@@ -312,7 +312,7 @@ def test_fast_fused_walk_through_the_general_kernel(pkg, orc_libm):
         st = a.estep_mstep()
         # (5e-12: the log-space oracle's own rounding over 3000 sites is ~1e-12 here)
         np.testing.assert_allclose(a.ind_lkl, em.ind_lkl, rtol=5e-12)
-        np.testing.assert_allclose(a.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(a.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
         # continue the oracle from the GPU's parameters (teacher forcing), then both update
         # the frequencies and, lazily on the GPU, the emissions
         em.set_params(a.indF, a.alpha, None)
@@ -340,8 +340,103 @@ def test_fast_ragged_shapes_fused_iteration(pkg, orc_libm, shape):
         assert em.estep() == 0
         hmm.iter_EM()
         np.testing.assert_allclose(hmm.ind_lkl, em.ind_lkl, rtol=1e-11)
-        np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
         em.set_params(hmm.indF, hmm.alpha, None)
         assert em.mstep_freq(1) == 0
         np.testing.assert_allclose(hmm.freq, em.freq, rtol=RTOL)
     hmm.close()
+
+
+
+def test_fast_mode_end_to_end_against_exact_mode(pkg):
+    """A whole EM run in both arithmetic modes (200 individuals x 50 000 sites, 4
+    chromosomes, random indF and site frequencies, 2 % missing cells, 25 iterations +
+    decoding): the END-TO-END spread of fast mode, as tested numbers.
+
+    Exact mode is bit-identical to the oracle (tests/test_gpu_parity.py), so it stands for
+    the reference here.  Per call the two modes agree to ~1e-13; the finite-difference
+    L-BFGS-B then amplifies that last-bit noise (SURVEY.md finding 4: the reference itself,
+    rebuilt with FMA contraction, moves its final indF by 1e-5 on 10 x 10 000 sites), so the
+    trajectory check is: total log-likelihood within 1e-9 relative at EVERY iteration,
+    frequencies within 1e-6, indF within 1e-4 (median within 1e-5), alpha within 1e-3
+    relative for 99 % of the individuals, and -- the criterion BASELINE.json states without
+    tolerance -- identical Viterbi paths in all 10^7 cells.  Measured: tot_lkl 6e-14 after the
+    first iteration, at most 6.4e-10 on the way, 1.3e-11 at the end; indF max 3.5e-5, 99 %
+    2.4e-5, median 3.5e-7; alpha 99 % 7.9e-5, median 1.1e-6 relative; freq max 1.1e-7; no
+    path cell differs."""
+    I, S, iters = 200, 50_000, 25
+    d = pkg.simulate.simulate(I, S, seed=4242, n_chrom=4, missing_rate=0.02, indF="r", freq="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    res = {}
+    for mode, name in ((pkg.MODE_FAST, "fast"), (pkg.MODE_EXACT, "exact")):
+        with pkg.NgsFHMM(I, S, mode=mode) as hmm:
+            hmm.load(gl, d.pos_dist_mb)
+            hmm.set_params(0.1, 0.2, 0.1)
+            hmm.init_emission()
+            lk = []
+            for _ in range(iters):
+                hmm.iter_EM()
+                lk.append(float(np.sum(hmm.ind_lkl)))
+            res[name] = dict(lk=np.array(lk), indF=hmm.indF.copy(), alpha=hmm.alpha.copy(),
+                             freq=hmm.freq.copy(), path=hmm.viterbi())
+    a, b = res["fast"], res["exact"]
+    rel = np.abs(a["lk"] - b["lk"]) / np.abs(b["lk"])
+    dF = np.abs(a["indF"] - b["indF"])
+    dA = np.abs(a["alpha"] - b["alpha"]) / np.abs(b["alpha"])
+    dfreq = np.abs(a["freq"] - b["freq"])
+    print("fast vs exact, %d iterations at %d x %d: tot_lkl rel first %.1e max %.1e last %.1e; indF "
+          "max %.1e p99 %.1e median %.1e; alpha rel p99 %.1e median %.1e; freq max %.1e; paths "
+          "differing %d" % (iters, I, S, rel[0], rel.max(), rel[-1], dF.max(), np.quantile(dF, 0.99),
+                            np.median(dF), np.quantile(dA, 0.99), np.median(dA), dfreq.max(),
+                            int((a["path"] != b["path"]).sum())))
+    assert rel[0] < 1e-12 and rel.max() < 1e-9
+    assert dF.max() < 1e-4 and np.median(dF) < 1e-5
+    assert np.quantile(dA, 0.99) < 1e-3 and np.median(dA) < 1e-5
+    assert dfreq.max() < 1e-6
+    assert np.array_equal(a["path"], b["path"])
+
+
+def test_fast_mode_against_the_binary128_anchor(pkg, orc_libm):
+    """Fast mode (linear space, per-block rescaling) and the oracle (the reference's log
+    space) both measured against oracle/hp_anchor.c, the model in binary128 (no code shared
+    with either; tests/test_hp_anchor.py): the linear-space kernels must be no further from
+    the truth than the reference's own double-precision formulation -- DESIGN.md section 5's
+    claim that fast mode's differences from the oracle are the ORACLE's rounding noise."""
+    hp = orclib.HpAnchor()
+    d = pkg.simulate.simulate(12, 10_000, seed=31, n_chrom=3, missing_rate=0.03, indF="r",
+                              freq="r", alpha=0.3)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    indF = np.linspace(0.02, 0.9, d.n_ind)
+    alpha = np.linspace(0.01, 5.0, d.n_ind)
+    freq = np.clip(d.freq, 0.02, 0.98)
+    em = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
+    em.set_params(indF, alpha, freq)
+    assert em.init_emission() == 0 and em.estep() == 0
+    with pkg.NgsFHMM(d.n_ind, d.n_sites, mode=pkg.MODE_FAST) as hmm:
+        hmm.load(gl, d.pos_dist_mb)
+        hmm.set_params(indF, alpha, freq)
+        hmm.init_emission()
+        lk = hmm.estep().copy()
+        marg = hmm.marg_prob
+        hmm.mstep_freq(1)
+        f_gpu = hmm.freq
+    e_l = {"fast": 0.0, "oracle": 0.0}
+    e_p = {"fast": 0.0, "oracle": 0.0}
+    for i in range(d.n_ind):
+        t_lk, post = hp.forward_backward(gl[:, i], freq, d.pos_dist_mb, indF[i], alpha[i])
+        snapped = np.where(post < 1e-5, 0.0, np.where(post > 1 - 1e-5, 1.0, post))
+        near = (np.abs(post - 1e-5) < 1e-9) | (np.abs(post - (1 - 1e-5)) < 1e-9)
+        for name, l, m in (("fast", lk[i], marg[i]), ("oracle", em.ind_lkl[i], em.marg[i])):
+            e_l[name] = max(e_l[name], abs(l - t_lk) / abs(t_lk))
+            e_p[name] = max(e_p[name], (np.abs(m - snapped)[~near] / np.maximum(snapped[~near], 1e-5)).max())
+    # est_maf on the GPU's own posteriors, a sample of sites
+    e_f = 0.0
+    for s in range(0, d.n_sites, 53):
+        f_h, _ = hp.est_maf(gl[s], marg[:, s])
+        e_f = max(e_f, abs(f_gpu[s] - f_h) / f_h)
+    print("vs binary128 -- log-likelihood rel: fast %.1e, oracle %.1e; posteriors rel: fast %.1e, "
+          "oracle %.1e; est_maf rel: fast %.1e" % (e_l["fast"], e_l["oracle"], e_p["fast"],
+                                                   e_p["oracle"], e_f))
+    assert e_l["fast"] < 1e-12 and e_p["fast"] < 1e-10 and e_f < 1e-12
+    assert e_l["fast"] <= max(2 * e_l["oracle"], 2e-15)
+    assert e_p["fast"] <= max(2 * e_p["oracle"], 1e-13)
