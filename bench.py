@@ -209,6 +209,10 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_full_c2", action="store_true",
                     help="cpu_baseline also times BASELINE configs[1] (100 x 100k) in full")
+    ap.add_argument("--replicas", type=int, default=1,
+                    help="N = 1 only: R concurrent EM runs over the same data (multi-start, "
+                         "ngsF-HMM.sh: 20 replicates), one host thread and HIP stream each; "
+                         "value counts all R runs")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: shard the workload's individuals over the ranks (strong, "
                          "BASELINE configs[3]) or give every rank the full number (weak)")
@@ -289,6 +293,33 @@ def main():
     em.set_params(0.1, 0.2, 0.1)
     em.init_emission()
 
+    # multi-start: R - 1 replicas sharing the likelihoods on the device, each with its own
+    # (perturbed) starting values, run next to the main handle from R host threads
+    replicas = []
+    if args.replicas > 1:
+        if world > 1:
+            raise SystemExit("--replicas needs --gpus 1")
+        import numpy as np
+        import threading
+        rng = np.random.default_rng(1)
+        for r in range(args.replicas - 1):
+            h = em.hmm.replica()
+            h.set_params(rng.uniform(0.05, 0.3, I), rng.uniform(0.05, 0.5, I), rng.uniform(0.05, 0.3, S))
+            h.init_emission()
+            replicas.append(h)
+
+    def iterate_all():
+        """One EM iteration of the main run (returned stats) and of every replica."""
+        if not replicas:
+            return em.iter_EM()
+        th = [threading.Thread(target=h.iter_EM) for h in replicas]
+        for t in th:
+            t.start()
+        st = em.iter_EM()
+        for t in th:
+            t.join()
+        return st
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -296,14 +327,14 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        em.iter_EM()
+        iterate_all()
     fam = {k: 0.0 for k in ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first")}
     launches = dict.fromkeys(fam, 0)
     rounds = points = ind_rounds = ref_calls = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = em.iter_EM()
+        st = iterate_all()
         rounds += st.rounds
         points += st.points
         ind_rounds += st.ind_rounds
@@ -322,7 +353,7 @@ def main():
 
     if rank == 0:
         K = max(args.steps, 1)
-        units = float(I_tot) * S * K
+        units = float(I_tot) * S * K * args.replicas
         # dominant kernel family by measured time, and its algorithmic traffic per launch
         # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
         # fast mode: the first objective round of an iteration (all I individuals) reads the
@@ -398,7 +429,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "n_ind_total": I_tot, "n_ind_per_gpu": I,
+            "replicas": args.replicas,
+            "config": {"workload": wl["name"] + (f", {args.replicas} concurrent multi-start "
+                                                 f"replicas" if args.replicas > 1 else ""),
+                       "n_ind_total": I_tot, "n_ind_per_gpu": I,
                        "n_sites": S, "mode": args.mode, "freq_est": 1,
                        "sharding": (None if world == 1 else
                                     f"{I} of {I_tot} individuals per GPU for all sites; allele-"
@@ -421,6 +455,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg, full_c2=args.cpu_full_c2)
         print(json.dumps(out))
+    for h in replicas:
+        h.close()
     em.close()
     if world > 1:
         dist.destroy_process_group()

@@ -120,6 +120,10 @@ __device__ __forceinline__ Op op_mul(const Op& L, const Op& R) {
   return o;
 }
 
+__device__ __forceinline__ Op op_load(const double* __restrict__ m) {
+  return Op{m[0], m[1], m[2], m[3], (int)m[4]};
+}
+
 __device__ __forceinline__ Op op_shfl_down(const Op& m, int off) {
   Op o;
   o.a00 = __shfl_down(m.a00, off);
@@ -532,32 +536,32 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
     if (p < (int)np) lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
 }
 
-// lkl = log( q . prod_c R_c . 1 )
+// lkl = log( q . prod_c R_c . 1 ): one wave per group; lane c holds the operator of chunk c of
+// the point at hand (C <= 64) and an ordered shuffle tree multiplies them
 __global__ void __launch_bounds__(64)
 k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint32_t C,
                   const double* __restrict__ part, double* __restrict__ lkl_out,
                   int* __restrict__ flags) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_groups * MAXP) return;
-  const uint32_t g = idx / MAXP, p = idx % MAXP;
+  const uint32_t g = blockIdx.x;
+  const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
-  if (p >= G.np) return;
-  double v0 = 1 - G.F[p], v1 = G.F[p];
-  int ex = 0;
-  for (uint32_t c = 0; c < C; ++c) {
-    const double* m = part + (((uint64_t)g * C + c) * MAXP + p) * 5;
-    const double n0 = fma(v0, m[0], v1 * m[2]);
-    const double n1 = fma(v0, m[1], v1 * m[3]);
-    v0 = n0;
-    v1 = n1;
-    ex += (int)m[4];
-    renorm2(v0, v1, ex);
+  for (uint32_t p = 0; p < G.np; ++p) {
+    Op m{1.0, 0.0, 0.0, 1.0, 0};
+    if ((uint32_t)lane < C) m = op_load(part + (((uint64_t)g * C + lane) * MAXP + p) * 5);
+    for (int off = 1; off < 64; off <<= 1) {
+      const Op o = op_shfl_down(m, off);
+      if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
+    }
+    if (lane == 0) {
+      const double q0 = 1 - G.F[p], q1 = G.F[p];
+      const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
+      const double l = log(v0 + v1) + (double)m.ex * 0.6931471805599453094;
+      lkl_out[G.out_idx[p]] = l;
+      // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
+      // in linear space; the host re-evaluates such points with the general kernel
+      if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
+    }
   }
-  const double l = log(v0 + v1) + (double)ex * 0.6931471805599453094;
-  lkl_out[G.out_idx[p]] = l;
-  // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left in
-  // linear space; the host re-evaluates such points with the general kernel
-  if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
 }
 
 // ---- E-step ---------------------------------------------------------------
@@ -636,10 +640,6 @@ __device__ __forceinline__ Op op_shfl_up(const Op& m, int off) {
   o.a11 = __shfl_up(m.a11, off);
   o.ex = __shfl_up(m.ex, off);
   return o;
-}
-
-__device__ __forceinline__ Op op_load(const double* __restrict__ m) {
-  return Op{m[0], m[1], m[2], m[3], (int)m[4]};
 }
 
 __global__ void __launch_bounds__(64)
@@ -1304,8 +1304,11 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   // W == 1: per-lane partial sums of the interval's nodes (see the build below); the pad
   // makes lane j's reads of row j conflict-free
-  __shared__ double2 nodebuf[W == 1 ? EN : 1][W == 1 ? 65 : 1];
-  __shared__ double2 xnode[W > 1 ? EN : 1][W > 1 ? W : 1];  // W > 1: per-wave node sums
+  // (few individuals per lane, NI < 8: the 16 KB would cap the waves per CU for nothing --
+  // those kernels reduce every node in registers like the multi-wave ones)
+  constexpr bool PARK = (W == 1 && NI >= 8);
+  __shared__ double2 nodebuf[PARK ? EN : 1][PARK ? 65 : 1];
+  __shared__ double2 xnode[PARK ? 1 : EN][PARK ? 1 : W];  // !PARK: per-wave node sums
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const uint32_t tix = threadIdx.x;  // index among the site's threads
@@ -1533,7 +1536,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
         half = 0.5 * (hi - lo);
         // a degenerate interval (rn not finite or not positive) keeps the site exact
         if (half > 0 && lo > 0 && hi < 1e300) {
-          if constexpr (W == 1) {
+          if constexpr (PARK) {
             // One wave holds the site: the node evaluations do not depend on each other,
             // so every lane parks its partial sums in LDS and the 16 x 64 partials are
             // added up once at the end -- no reduction tree (and its latency) per node.
@@ -1776,6 +1779,17 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   if (C > 64) C = 64;
   while (C > 1 && (S + 64 * C - 1) / (64 * C) < 16) --C;
   if (C < 1) C = 1;
+  if (!std::getenv("NGHMM_FAST_C")) {
+    // sites per lane are rounded up to whole groups of 8 (16: packed), which at a few dozen
+    // sites per lane pads a lot (100 x 100k: 24.4 -> 32 sites per lane, 31 %): take the count
+    // within a quarter below the target that pads least
+    const uint64_t q = packed ? 16 : 8;
+    auto padded = [&](uint64_t c) { return 64 * c * ((((S + 64 * c - 1) / (64 * c)) + q - 1) / q * q); };
+    uint64_t best = C;
+    for (uint64_t c = C; c >= 1 && 4 * c >= 3 * C; --c)
+      if (padded(c) < padded(best)) best = c;
+    C = best;
+  }
   fs.C = (uint32_t)C;
   fs.J = 64 * C;
   fs.T = (S + fs.J - 1) / fs.J;
@@ -2068,8 +2082,8 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     }
   }
   if (fresh) fs.e_stale = false;
-  hipLaunchKernelGGL(k_fast_lkl_finish, dim3((ng * MAXP + 63) / 64), dim3(64), 0, st, dg, ng, fs.C,
-                     fs.part, d_lkl, d_flags);
+  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64), 0, st, dg, ng, fs.C, fs.part, d_lkl,
+                     d_flags);
   return hipGetLastError() == hipSuccess;
 }
 

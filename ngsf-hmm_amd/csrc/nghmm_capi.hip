@@ -61,7 +61,8 @@ struct nghmm_handle {
   uint64_t I = 0, S = 0;
   int device = 0, mode = NGHMM_MODE_EXACT;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
+  bool blocking_sync = false;
   bool loaded = false;
 
   double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
@@ -118,6 +119,15 @@ struct nghmm_handle {
 
 namespace {
 
+// Wait for the handle's stream.  Handles that run next to others from their own host threads
+// (replicas) wait on a blocking event instead of spinning, so that more waiting threads than
+// cores do not starve the threads that have work.
+hipError_t sync_stream(nghmm_t* h) {
+  if (!h->blocking_sync) return hipStreamSynchronize(h->stream);
+  hipError_t e = hipEventRecord(h->ev_sync, h->stream);
+  return e != hipSuccess ? e : hipEventSynchronize(h->ev_sync);
+}
+
 int use_device(nghmm_t* h) {
   HIP_TRY(hipSetDevice(h->device));
   return NGHMM_OK;
@@ -161,7 +171,7 @@ int clear_flags(nghmm_t* h) {
 int check_flags(nghmm_t* h) {
   int f[NFLAGS];
   HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   if (f[FLAG_INVALID_LKL]) {
     set_error("invalid Lkl found!");
     return NGHMM_ERR_INVALID_LKL;
@@ -432,7 +442,7 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
       if (hipMemcpy(h->d_cls_log, proto, sizeof proto, hipMemcpyHostToDevice) != hipSuccess ||
           hipMemset(h->d_flags, 0, NFLAGS * sizeof(int)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
       launch_prepare_gl(h->stream, h->d_cls_log, 4, NGHMM_GL_LOG, 0, h->d_flags);
-      if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+      if (sync_stream(h) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     } else {
       if ((rc = dev_alloc(&h->d_gl, cells * 3))) break;
       if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
@@ -487,6 +497,7 @@ int nghmm_destroy(nghmm_t* h) {
   fast_destroy(h->fast);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NGHMM_OK;
@@ -522,7 +533,12 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   const uint64_t n_ind = h->I, n_sites = h->S;
   do {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
-    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+    // replicas are driven from one host thread each: wait without spinning
+    h->blocking_sync = !std::getenv("NGHMM_SPIN_SYNC");
+    const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
+    if (hipEventCreateWithFlags(&h->ev0, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev1, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_sync, evf | hipEventDisableTiming) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     const size_t cells = (size_t)n_ind * n_sites;
     if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
     if ((rc = dev_alloc(&h->d_freq, n_sites))) break;
@@ -559,18 +575,18 @@ static int after_gl_load(nghmm_t* h) {
     // the value the data's uniform cells carry becomes row 3 of the class table
     unsigned long long bits = ~0ull;
     HIP_TRY(hipMemcpyAsync(&bits, h->d_uniform, sizeof bits, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_stream(h));
     if (bits != ~0ull) {
       double u;
       std::memcpy(&u, &bits, sizeof u);
       const double row[3] = {u, u, u};
       HIP_TRY(hipMemcpyAsync(h->d_cls_log + 9, row, sizeof row, hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(sync_stream(h));
     }
   }
   if (h->mode == NGHMM_MODE_FAST) {
     if (!fast_load(h->fast, h->stream, own_gl(h), h->d_pos)) return NGHMM_ERR_HIP;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_stream(h));
   }
   return NGHMM_OK;
 }
@@ -601,7 +617,7 @@ static int ensure_stage8(nghmm_t* h, size_t bytes) {
 static int check_load_flags(nghmm_t* h, bool check_nan) {
   int f[NFLAGS];
   HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   if (check_nan && f[FLAG_NAN]) {
     set_error("NaN found! Is the file format correct?");
     return NGHMM_ERR_NAN;
@@ -672,7 +688,7 @@ int nghmm_load_begin(nghmm_t* h, const double* pos) {
     HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   h->loaded = false;
   h->loading = true;
   return NGHMM_OK;
@@ -699,7 +715,7 @@ int nghmm_load_begin_dev(nghmm_t* h, const double* d_pos) {
   int rc;
   if ((rc = use_device(h))) return rc;
   if ((rc = load_begin_dev(h, d_pos))) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -758,7 +774,7 @@ int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, con
     double u = 0;
     HIP_TRY(hipMemcpyAsync(&cur, h->d_uniform, sizeof cur, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(&u, h->d_cls_log + 9, sizeof u, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_stream(h));
     std::memcpy(&want, &u, sizeof want);
     if (cur == ~0ull)
       HIP_TRY(hipMemcpyAsync(h->d_uniform, &want, sizeof want, hipMemcpyHostToDevice, h->stream));
@@ -831,7 +847,7 @@ int nghmm_get_gl(nghmm_t* h, double* gl) {
     src = h->d_stage;
   }
   HIP_TRY(hipMemcpyAsync(gl, src, cells * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -860,7 +876,7 @@ int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const 
   }
   if (freq)
     HIP_TRY(hipMemcpyAsync(h->d_freq, freq, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -873,7 +889,7 @@ int nghmm_get_params(nghmm_t* h, double* indF, double* alpha, double* freq) {
   if (alpha) std::memcpy(alpha, h->h_alpha.data(), h->I * sizeof(double));
   if (freq) {
     HIP_TRY(hipMemcpyAsync(freq, h->d_freq, h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_stream(h));
   }
   return NGHMM_OK;
 }
@@ -996,7 +1012,7 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
                          h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_alpha, h->h_alpha.data(), h->I * sizeof(double),
                          hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   if (stats) {
     stats->rounds = batch.rounds();
     stats->points = batch.points();
@@ -1161,7 +1177,7 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   // fast mode recomputes the log emissions first: "invalid MAF!" (HMM.cpp:145-146)
   if (h->mode == NGHMM_MODE_FAST && (rc = check_flags(h))) return rc;
   HIP_TRY(hipMemcpyAsync(path, h->d_path, cells, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1185,7 +1201,7 @@ int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
   if ((rc = posteriors_ind_major(h))) return rc;
   HIP_TRY(hipMemcpyAsync(marg_ibd, h->d_tmp, (size_t)h->I * h->S * sizeof(double),
                          hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1210,7 +1226,7 @@ int nghmm_format_posteriors(nghmm_t* h, uint64_t ind_begin, uint64_t n_ind, char
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, h->d_flags, sizeof bad, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(out, h->d_text, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   if (bad) {
     set_error("nghmm_format_posteriors: a posterior outside [0, 1]");
     return NGHMM_ERR_ARG;
@@ -1241,7 +1257,7 @@ int nghmm_format_fixed6(nghmm_t* h, const double* values, uint64_t rows, uint64_
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&bad, h->d_flags, sizeof bad, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 9, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = sync_stream(h);
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   if (e != hipSuccess) {
@@ -1279,7 +1295,7 @@ int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, dou
                          h->d_geno);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, h->d_geno, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1300,7 +1316,7 @@ int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(e_prob, h->d_tmp, (size_t)h->I * h->S * 2 * sizeof(double),
                          hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1337,7 +1353,7 @@ int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
   HIP_TRY(hipMemcpyAsync(h->d_gl_shard, gl_site_shard, n * sizeof(double), hipMemcpyHostToDevice,
                          h->stream));
   if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1349,7 +1365,7 @@ int nghmm_get_geno_codes_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, uin
   if ((rc = use_device(h))) return rc;
   launch_codes_to_bytes(h->stream, h->d_codes, site_lo * h->I, (site_hi - site_lo) * h->I, d_out);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1364,7 +1380,7 @@ int nghmm_load_geno_site_shard_dev(nghmm_t* h, const uint8_t* d_codes_bytes) {
   if ((rc = dev_alloc(&h->d_codes_shard, n / 16 + 2))) return rc;
   launch_bytes_to_codes(h->stream, d_codes_bytes, n, h->d_codes_shard);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1384,7 +1400,7 @@ int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
   HIP_TRY(hipMemcpyAsync(h->d_gl_shard, d_gl_site_shard, n * sizeof(double),
                          hipMemcpyDeviceToDevice, h->stream));
   if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1398,14 +1414,14 @@ int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, do
     // ranges IS the site-major matrix, so convert the tile-major posteriors straight into it
     if (!fast_post_to_site_major(h->fast, h->stream, d_out)) return NGHMM_ERR_HIP;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_stream(h));
     return NGHMM_OK;
   }
   // marg is site-major [S][I]: the slice of a destination rank is contiguous
   if ((rc = ensure_marg(h))) return rc;
   launch_copy_f64(h->stream, h->d_marg + site_lo * h->I, d_out, (site_hi - site_lo) * h->I);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1422,7 +1438,7 @@ int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_blocks, double* 
   }
   if ((rc = estmaf_and_refresh(h, true, d_marg_blocks, h->S_own, h->I_tot, h->I, d_freq_out)))
     return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
@@ -1450,7 +1466,7 @@ int nghmm_synchronize(nghmm_t* h) {
   g_last_error.clear();
   if (!h) return NGHMM_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_stream(h));
   return NGHMM_OK;
 }
 
