@@ -249,6 +249,25 @@ int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_sites, double* d
 /* install the gathered freq[S] (device pointer) and refresh the own emissions */
 int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all);
 
+/* ---- one process, several GPUs: a GROUP of n handles ----
+ * What EM.cpp:147-272 does for all individuals at once, split over n handles (one per GPU; or
+ * several on one GPU): handle r owns the individuals [r I, (r+1) I) of n I for all sites --
+ * create and load it with those -- and, after nghmm_group_setup, the sites [r S/n, (r+1) S/n)
+ * of the allele-frequency step.  nghmm_group_iter_em = iter_EM for the whole cohort: per
+ * handle, on its own host thread, the E-step and the indF/alpha M-step; the posteriors move
+ * to their site owners by direct peer copies (every GPU pair of an MI355X node has its own
+ * xGMI link: the n (n-1) copies are the all-to-all) under the remaining objective rounds;
+ * est_maf per site range in global individual order; the frequencies go to everybody.  The
+ * result does not depend on n (tests/test_gpu_sharded.py).  Equal I and S, S divisible by n,
+ * NGHMM_MODE_FAST for n > 1; ind_lkl [n I] (host, may be NULL).  Between processes the same
+ * steps run over RCCL (ngsf-hmm_amd/distributed.py). */
+int nghmm_group_setup(nghmm_t** handles, int n);
+int nghmm_group_iter_em(nghmm_t** handles, int n, int freq_est, int indF_fixed, int alpha_fixed,
+                        double* ind_lkl, nghmm_mstep_stats* stats);
+/* the allele-frequency step alone (nghmm_mstep_freq for the cohort), from the posteriors the
+ * handles hold: all zero before the first E-step, which is `--freq e` */
+int nghmm_group_mstep_freq(nghmm_t** handles, int n, int freq_est);
+
 /* Fast-mode layout of the site axis: every individual's sites are cut into 64 * waves
  * runs of sites_per_lane sites; 0, 0 in exact mode.  Diagnostic. */
 int nghmm_fast_layout(nghmm_t* h, uint32_t* waves_per_individual, uint64_t* sites_per_lane);

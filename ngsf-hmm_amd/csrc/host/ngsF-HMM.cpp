@@ -55,12 +55,22 @@ struct Params {  // ngsF-HMM.hpp:13-52
   bool no_pack = false;          // --no_pack: never keep called genotypes as 2-bit codes
   unsigned n_starts = 1;         // --n_starts R: R replicates from seeds seed, seed+1, ... (ngsF-HMM.sh)
   bool keep_starts = false;      // --keep_starts: write every replicate's files, PREFIX.REP_rr.*
+  unsigned n_gpus = 1;           // --n_gpus N: the individuals split over N handles, one per device
+  std::vector<int> devices;      // --devices a,b,..: the device of each handle (default 0..N-1)
   FILE* out = stdout;            // where this run's progress lines go (replicates: a buffer)
   std::string prefix;            // output prefix of this run
   std::vector<double> pos_dist;  // [S] Mb
   std::vector<double> freq, indF, alpha, ind_lkl;
   std::vector<uint8_t> path;
   double tot_lkl = 0, prev_tot_lkl = 0;
+};
+
+// The cohort on the device(s): handle r holds the individuals [r I_loc, (r+1) I_loc) for all
+// sites (one handle unless --n_gpus N; include/nghmm.h "a GROUP of n handles").
+struct Cohort {
+  std::vector<nghmm_t*> hs;
+  uint64_t I_loc = 0;
+  int n() const { return (int)hs.size(); }
 };
 
 [[noreturn]] void fatal(const char* func, const char* msg) {  // gen_func.cpp:12-18
@@ -150,13 +160,47 @@ void read_dist(Params& P) {
 // called-genotype file as plain genotype values (nghmm_load_geno_sites).  Returns NGHMM_OK, or
 // NGHMM_ERR_NOT_PACKABLE when a packed handle cannot represent the input (the caller then
 // repeats the load with an unpacked handle).
-int load_geno(Params& P, nghmm_t* h, bool packed) {
+int load_geno(Params& P, Cohort& C, bool packed) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   const uint64_t n_geno = P.in_lkl ? 3 : 1;
   double unread;
   const uint64_t unread_bits = NGHMM_GL_UNREAD_BITS;
   memcpy(&unread, &unread_bits, sizeof unread);
-  check(nghmm_load_begin(h, P.pos_dist.data()), "read_geno");
+  const int N = C.n();
+  const uint64_t I_loc = C.I_loc;
+  for (nghmm_t* h : C.hs) check(nghmm_load_begin(h, P.pos_dist.data()), "read_geno");
+  // a block [ns][I][..] goes to handle r as its columns [ns][I_loc][..]
+  std::vector<double> part_d;
+  std::vector<int8_t> part_g;
+  auto send_gl = [&](uint64_t s0, uint64_t ns, const double* blockbuf, int space, int check_nan) {
+    int rc = NGHMM_OK;
+    for (int r = 0; r < N && rc == NGHMM_OK; r++) {
+      const double* src = blockbuf;
+      if (N > 1) {
+        part_d.resize((size_t)ns * I_loc * 3);
+        for (uint64_t s = 0; s < ns; s++)
+          memcpy(&part_d[s * I_loc * 3], blockbuf + (s * I + (uint64_t)r * I_loc) * 3,
+                 I_loc * 3 * sizeof(double));
+        src = part_d.data();
+      }
+      rc = nghmm_load_gl_raw_sites(C.hs[r], s0, ns, src, space, P.call_geno ? 1 : 0, check_nan);
+    }
+    return rc;
+  };
+  auto send_geno = [&](uint64_t s0, uint64_t ns, const int8_t* blockbuf) {
+    int rc = NGHMM_OK;
+    for (int r = 0; r < N && rc == NGHMM_OK; r++) {
+      const int8_t* src = blockbuf;
+      if (N > 1) {
+        part_g.resize((size_t)ns * I_loc);
+        for (uint64_t s = 0; s < ns; s++)
+          memcpy(&part_g[s * I_loc], blockbuf + s * I + (uint64_t)r * I_loc, I_loc);
+        src = part_g.data();
+      }
+      rc = nghmm_load_geno_sites(C.hs[r], s0, ns, src);
+    }
+    return rc;
+  };
   gzFile fh = gzopen(P.in_geno, P.in_bin ? "rb" : "r");
   if (!fh) fatal(__FUNCTION__, "cannot open GENO file!");
   gzbuffer(fh, 1 << 20);
@@ -177,7 +221,7 @@ int load_geno(Params& P, nghmm_t* h, bool packed) {
                                   : "cannot read binary GENO file. Check GENO file and number of sites!");
       }
       // NaN check: read_data.cpp:42-45 (binary input only)
-      rc = nghmm_load_gl_raw_sites(h, s0, ns, buf.data(), space, P.call_geno ? 1 : 0, 1);
+      rc = send_gl(s0, ns, buf.data(), space, 1);
     }
   } else {
     const bool as_codes = packed && !P.in_lkl;  // called genotypes straight to 2-bit codes
@@ -189,9 +233,7 @@ int load_geno(Params& P, nghmm_t* h, bool packed) {
     uint64_t s0 = 0, filled = 0;  // the block covers sites [s0, s0 + filled)
     auto flush = [&]() {
       if (!filled || rc != NGHMM_OK) return;
-      rc = as_codes ? nghmm_load_geno_sites(h, s0, filled, gbuf.data())
-                    : nghmm_load_gl_raw_sites(h, s0, filled, dbuf.data(), space,
-                                              P.call_geno ? 1 : 0, 0);
+      rc = as_codes ? send_geno(s0, filled, gbuf.data()) : send_gl(s0, filled, dbuf.data(), space, 0);
       s0 += filled;
       filled = 0;
     };
@@ -254,8 +296,11 @@ int load_geno(Params& P, nghmm_t* h, bool packed) {
   gzread(fh, &c, 1);
   if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
   gzclose(fh);
-  rc = nghmm_load_end(h);
-  if (rc != NGHMM_ERR_NOT_PACKABLE) check(rc, "read_geno");
+  for (nghmm_t* h : C.hs) {
+    rc = nghmm_load_end(h);
+    if (rc == NGHMM_ERR_NOT_PACKABLE) return rc;
+    check(rc, "read_geno");
+  }
   return rc;
 }
 
@@ -286,7 +331,7 @@ double clampd(double v, double lo, double hi) {
 }
 
 // parse_args.cpp:229-363 (initial indF/alpha and freq); --freq e is done on the GPU
-bool init_values(Params& P, nghmm_t* h) {
+bool init_values(Params& P, Cohort& C) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   Taus rng(P.seed);
   const double f_min = 0.000001, f_max = 1 - f_min;
@@ -355,7 +400,10 @@ bool init_values(Params& P, nghmm_t* h) {
     if (P.verbose >= 1) fprintf(P.out, "==> Setting initial frequency values to: %s\n", P.in_freq.c_str());
     for (uint64_t s = 0; s < S; s++) P.freq[s] = clampd(atof(P.in_freq.c_str()), q_min, q_max);
   }
-  check(nghmm_set_params(h, P.indF.data(), P.alpha.data(), P.freq.data()), "init_output");
+  for (int r = 0; r < C.n(); r++)
+    check(nghmm_set_params(C.hs[r], P.indF.data() + (size_t)r * C.I_loc,
+                           P.alpha.data() + (size_t)r * C.I_loc, P.freq.data()),
+          "init_output");
   return estimate;
 }
 
@@ -368,7 +416,7 @@ inline char* put_fixed(char* p, double v, int prec) {
 }
 
 // EM.cpp:293-380
-void print_iter(const Params& P, nghmm_t* h) {
+void print_iter(const Params& P, Cohort& C) {
   const uint64_t I = P.n_ind, S = P.n_sites;
   std::string name = P.prefix + ".indF";
   FILE* fh = fopen(name.c_str(), "w");
@@ -411,13 +459,14 @@ void print_iter(const Params& P, nghmm_t* h) {
   {
     uint64_t batch = (256ull << 20) / (9 * S);
     if (batch < 1) batch = 1;
-    if (batch > I) batch = I;
+    if (batch > C.I_loc) batch = C.I_loc;
     std::vector<char> text(batch * 9 * S);
-    for (uint64_t i0 = 0; i0 < I; i0 += batch) {
-      const uint64_t nb = (I - i0) < batch ? (I - i0) : batch;
-      check(nghmm_format_posteriors(h, i0, nb, text.data()), "print_iter");
-      fwrite(text.data(), 1, nb * 9 * S, fh);
-    }
+    for (nghmm_t* h : C.hs)   // individuals in order: handle by handle
+      for (uint64_t i0 = 0; i0 < C.I_loc; i0 += batch) {
+        const uint64_t nb = (C.I_loc - i0) < batch ? (C.I_loc - i0) : batch;
+        check(nghmm_format_posteriors(h, i0, nb, text.data()), "print_iter");
+        fwrite(text.data(), 1, nb * 9 * S, fh);
+      }
   }
   fclose(fh);
 
@@ -426,20 +475,34 @@ void print_iter(const Params& P, nghmm_t* h) {
   if (!fh) fatal(__FUNCTION__, "cannot open GENO output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
   const uint64_t chunk = 4096;  // sites per block
-  std::vector<double> blk(chunk * I * 3);
+  std::vector<double> blk(chunk * I * 3), part(C.n() > 1 ? chunk * C.I_loc * 3 : 0);
   for (uint64_t s0 = 0; s0 < S; s0 += chunk) {
     const uint64_t ns = (S - s0) < chunk ? (S - s0) : chunk;
     // EM.cpp:367-376 on the device, from the decoded path and the final frequencies
-    check(nghmm_geno_posteriors(h, s0, ns, blk.data()), "print_iter");
+    if (C.n() == 1) {
+      check(nghmm_geno_posteriors(C.hs[0], s0, ns, blk.data()), "print_iter");
+    } else {
+      for (int r = 0; r < C.n(); r++) {   // the file is site-major over ALL individuals
+        check(nghmm_geno_posteriors(C.hs[r], s0, ns, part.data()), "print_iter");
+        for (uint64_t s = 0; s < ns; s++)
+          memcpy(&blk[(s * I + (uint64_t)r * C.I_loc) * 3], &part[s * C.I_loc * 3],
+                 C.I_loc * 3 * sizeof(double));
+      }
+    }
     fwrite(blk.data(), sizeof(double), ns * I * 3, fh);
   }
   fclose(fh);
 }
 
-void sync_outputs(Params& P, nghmm_t* h, bool with_viterbi) {
-  check(nghmm_get_params(h, P.indF.data(), P.alpha.data(), P.freq.data()), "print_iter");
+void sync_outputs(Params& P, Cohort& C, bool with_viterbi) {
   P.path.resize((size_t)P.n_ind * P.n_sites, 0);
-  if (with_viterbi) check(nghmm_viterbi(h, P.path.data()), "viterbi");
+  for (int r = 0; r < C.n(); r++) {
+    const size_t i0 = (size_t)r * C.I_loc;
+    check(nghmm_get_params(C.hs[r], P.indF.data() + i0, P.alpha.data() + i0,
+                           r == 0 ? P.freq.data() : nullptr),
+          "print_iter");
+    if (with_viterbi) check(nghmm_viterbi(C.hs[r], P.path.data() + i0 * P.n_sites), "viterbi");
+  }
 }
 
 void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-225
@@ -458,7 +521,8 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       {"seed", required_argument, nullptr, 'S'},      {"mode", required_argument, nullptr, 1000},
       {"device", required_argument, nullptr, 1001},   {"taus_kat", required_argument, nullptr, 1002},
       {"no_pack", no_argument, nullptr, 1003},        {"n_starts", required_argument, nullptr, 1004},
-      {"keep_starts", no_argument, nullptr, 1005},
+      {"keep_starts", no_argument, nullptr, 1005},    {"n_gpus", required_argument, nullptr, 1006},
+      {"devices", required_argument, nullptr, 1007},
       {0, 0, 0, 0}};
   long taus_kat = 0;
   P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
@@ -498,6 +562,14 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       case 1003: P.no_pack = true; break;
       case 1004: P.n_starts = (unsigned)atoi(optarg); break;
       case 1005: P.keep_starts = true; break;
+      case 1006: P.n_gpus = (unsigned)atoi(optarg); break;
+      case 1007:
+        for (const char* q = optarg; *q;) {
+          P.devices.push_back(atoi(q));
+          q += strcspn(q, ",");
+          if (*q == ',') q++;
+        }
+        break;
       default: exit(-1);
     }
   if (taus_kat > 0) {  // known-answer check of the generator: the N-th raw output for --seed
@@ -538,16 +610,27 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
     fatal(__FUNCTION__, "invalid number of iterations!");
   if (P.n_threads < 1) fatal(__FUNCTION__, "invalid number of threads!");
   if (P.n_starts < 1) fatal(__FUNCTION__, "invalid number of starts (--n_starts)!");
+  if (!P.devices.empty() && P.n_gpus == 1) P.n_gpus = (unsigned)P.devices.size();
+  if (P.n_gpus < 1 || (!P.devices.empty() && P.devices.size() != P.n_gpus))
+    fatal(__FUNCTION__, "invalid --n_gpus / --devices!");
+  if (P.devices.empty())
+    for (unsigned r = 0; r < P.n_gpus; r++) P.devices.push_back(P.n_gpus == 1 ? P.device : (int)r);
+  if (P.n_gpus > 1) {
+    if (P.n_ind % P.n_gpus || P.n_sites % P.n_gpus)
+      fatal(__FUNCTION__, "--n_gpus must divide the number of individuals and of sites!");
+    if (P.mode != NGHMM_MODE_FAST) fatal(__FUNCTION__, "--n_gpus > 1 needs --mode fast!");
+    if (P.n_starts > 1) fatal(__FUNCTION__, "--n_starts and --n_gpus > 1 cannot be combined!");
+  }
   P.prefix = P.out_prefix;
 }
 
 // One EM analysis on a loaded handle: initial values, the loop of EM.cpp:27-103.
-void run_em(Params& P, nghmm_t* h) {
-  const bool estimate_freq = init_values(P, h);
+void run_em(Params& P, Cohort& C) {
+  const bool estimate_freq = init_values(P, C);
   if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
-    check(nghmm_mstep_freq(h, 1), "init_output");
+    check(nghmm_group_mstep_freq(C.hs.data(), C.n(), 1), "init_output");
   if (P.verbose >= 1) fprintf(P.out, "==> Calculating initial emission probabilities\n");
-  check(nghmm_emission(h), "calc_emission");
+  for (nghmm_t* h : C.hs) check(nghmm_emission(h), "calc_emission");
 
   // ---- EM.cpp:27-103 ----
   const uint64_t I = P.n_ind;
@@ -560,8 +643,8 @@ void run_em(Params& P, nghmm_t* h) {
          iter < P.max_iters) {
     if (P.log && (iter == 1 || iter % P.log == 0)) {
       if (P.verbose >= 1) fprintf(P.out, "==> Printing current iteration parameters\n");
-      sync_outputs(P, h, false);
-      print_iter(P, h);
+      sync_outputs(P, C, false);
+      print_iter(P, C);
     }
     const time_t iter_start = time(nullptr);
     iter++;
@@ -581,7 +664,8 @@ void run_em(Params& P, nghmm_t* h) {
         fprintf(P.out, "==> Estimating allele frequencies and calculating emission probabilities\n");
     }
     nghmm_mstep_stats stats;
-    check(nghmm_iter_em(h, P.freq_est, P.indF_fixed, P.alpha_fixed, P.ind_lkl.data(), &stats),
+    check(nghmm_group_iter_em(C.hs.data(), C.n(), P.freq_est, P.indF_fixed, P.alpha_fixed,
+                              P.ind_lkl.data(), &stats),
           "iter_EM");
     P.prev_tot_lkl = P.tot_lkl;
     P.tot_lkl = 0;
@@ -611,14 +695,14 @@ void run_em(Params& P, nghmm_t* h) {
 }
 
 // EM.cpp:105-127: decoding and the three output files
-void finish_run(Params& P, nghmm_t* h) {
+void finish_run(Params& P, Cohort& C) {
   if (P.verbose >= 1) fprintf(P.out, "\n==> Decoding most probable path (Viterbi)\n");
-  sync_outputs(P, h, true);
+  sync_outputs(P, C, true);
   if (P.verbose >= 1) {
     fprintf(P.out, "Final logLkl: %f\n", P.tot_lkl);
     fprintf(P.out, "Printing final results\n");
   }
-  print_iter(P, h);
+  print_iter(P, C);
 }
 
 }  // namespace
@@ -657,20 +741,29 @@ int main(int argc, char** argv) {
   // Called genotypes (a called-genotype file, or --call_geno) are four values per cell and are
   // kept as 2-bit codes; results are those of the 24-byte likelihoods (bit for bit in exact
   // mode).  An input the codes cannot express (an empty text line) falls back to likelihoods.
-  nghmm_t* h = nullptr;
   bool packed = (P.call_geno || !P.in_lkl) && !P.no_pack;
-  check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode | (packed ? NGHMM_GENO_PACKED : 0)),
-        "nghmm_create");
-  if (load_geno(P, h, packed) == NGHMM_ERR_NOT_PACKABLE) {
-    nghmm_destroy(h);
-    h = nullptr;
+  Cohort C;
+  C.I_loc = P.n_ind / P.n_gpus;
+  auto create_all = [&](bool pk) {
+    for (nghmm_t* h : C.hs) nghmm_destroy(h);
+    C.hs.assign(P.n_gpus, nullptr);
+    for (unsigned r = 0; r < P.n_gpus; r++)
+      check(nghmm_create(&C.hs[r], C.I_loc, P.n_sites, P.devices[r],
+                         P.mode | (pk ? NGHMM_GENO_PACKED : 0)),
+            "nghmm_create");
+  };
+  create_all(packed);
+  if (load_geno(P, C, packed) == NGHMM_ERR_NOT_PACKABLE) {
     packed = false;
-    check(nghmm_create(&h, P.n_ind, P.n_sites, P.device, P.mode), "nghmm_create");
-    check(load_geno(P, h, false), "read_geno");
+    create_all(false);
+    check(load_geno(P, C, false), "read_geno");
   }
+  // one handle: a group of one; several: shard configuration and the site-shard copies
+  check(nghmm_group_setup(C.hs.data(), C.n()), "nghmm_group_setup");
+  nghmm_t* h = C.hs[0];
   if (P.n_starts == 1) {
-    run_em(P, h);
-    finish_run(P, h);
+    run_em(P, C);
+    finish_run(P, C);
   } else {
     // Multi-start (ngsF-HMM.sh:77-101: N_REP replicates, each from its own seed, the one with
     // the largest final log-likelihood is kept).  The replicates share the likelihoods on the
@@ -691,8 +784,14 @@ int main(int argc, char** argv) {
       runs[r].prefix = std::string(P.out_prefix) + tag;
       runs[r].out = open_memstream(&bufs[r], &lens[r]);
     }
+    std::vector<Cohort> cs(R);
+    for (unsigned r = 0; r < R; r++) {
+      cs[r].hs = {hs[r]};
+      cs[r].I_loc = P.n_ind;
+      if (r) check(nghmm_group_setup(cs[r].hs.data(), 1), "nghmm_group_setup");
+    }
     std::vector<std::thread> th;
-    for (unsigned r = 0; r < R; r++) th.emplace_back([&, r] { run_em(runs[r], hs[r]); });
+    for (unsigned r = 0; r < R; r++) th.emplace_back([&, r] { run_em(runs[r], cs[r]); });
     for (auto& t : th) t.join();
     unsigned best = 0;
     for (unsigned r = 1; r < R; r++)
@@ -700,7 +799,7 @@ int main(int argc, char** argv) {
     for (unsigned r = 0; r < R; r++) {
       if (r == best || P.keep_starts) {
         if (r == best && !P.keep_starts) runs[r].prefix = P.out_prefix;
-        finish_run(runs[r], hs[r]);
+        finish_run(runs[r], cs[r]);
       }
       fclose(runs[r].out);
       if (P.verbose >= 1) printf("\n========== Replicate %u (seed %u) ==========\n", r + 1, runs[r].seed);
@@ -725,7 +824,7 @@ int main(int argc, char** argv) {
     for (unsigned r = R; r-- > 1;) nghmm_destroy(hs[r]);
   }
   if (P.verbose >= 1) printf("Freeing memory...\n");
-  nghmm_destroy(h);
+  for (nghmm_t* hh : C.hs) nghmm_destroy(hh);
   if (P.verbose >= 1) printf("Done!\n");
   return 0;
 }

@@ -19,7 +19,9 @@
 #include <chrono>
 #include <cstring>
 #include <new>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nghmm.h"
@@ -100,6 +102,11 @@ struct nghmm_handle {
   // d_cls_log / d_pos and the fast-mode layouts of the likelihoods)
   nghmm_handle* parent = nullptr;
   std::atomic<int> n_replicas{0};
+  // member of a group (nghmm_group_setup): exchange buffers on this handle's device and a
+  // second stream for the peer copies, which run under the remaining objective rounds
+  int g_n = 0, g_rank = 0;
+  double *g_send = nullptr, *g_recv = nullptr, *g_freq_own = nullptr, *g_freq_all = nullptr;
+  hipStream_t g_xstream = nullptr;
   bool loading = false;
   double* d_stage = nullptr;          // staging buffer of one chunk of raw likelihoods
   size_t stage_cap = 0;
@@ -484,7 +491,8 @@ int nghmm_destroy(nghmm_t* h) {
                  h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
                  h->d_gl_shard, h->d_geno, h->d_text, h->d_codes_shard, h->d_uniform, h->d_stage,
-                 h->d_stage8};
+                 h->d_stage8, h->g_send, h->g_recv, h->g_freq_own, h->g_freq_all};
+  if (h->g_xstream) (void)hipStreamDestroy(h->g_xstream);
   for (void* p : own)
     if (p) (void)hipFree(p);
   if (!h->parent) {
@@ -1450,6 +1458,253 @@ int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all) {
   HIP_TRY(hipMemcpyAsync(h->d_freq, d_freq_all, h->S * sizeof(double), hipMemcpyDeviceToDevice,
                          h->stream));
   return emission_impl(h);
+}
+
+
+// ---------------- one process, several GPUs ----------------
+// The group functions orchestrate what ngsf-hmm_amd/distributed.py does with RCCL between
+// processes, inside one process with direct peer copies: on an MI355X node every pair of GPUs
+// has its own xGMI link, so n*(n-1) simultaneous point-to-point copies ARE the all-to-all.
+
+namespace {
+
+struct GroupHook {
+  nghmm_t** hs;
+  int n, r;
+  int rc;
+};
+
+// after rank r's E-step: its posteriors, site-major, into the send buffer; then one slice to
+// every rank's receive buffer, on the exchange stream (the objective rounds go on meanwhile)
+void group_after_estep(void* user) {
+  GroupHook* g = static_cast<GroupHook*>(user);
+  nghmm_t* h = g->hs[g->r];
+  g->rc = nghmm_pack_posteriors_dev(h, 0, h->S, h->g_send);
+  if (g->rc != NGHMM_OK) return;
+  const size_t blk = (size_t)h->S_own * h->I;
+  for (int q = 0; q < g->n; ++q) {
+    if (hipMemcpyAsync(g->hs[q]->g_recv + (size_t)g->r * blk, h->g_send + (size_t)q * blk,
+                       blk * sizeof(double), hipMemcpyDeviceToDevice, h->g_xstream) != hipSuccess) {
+      g->rc = NGHMM_ERR_HIP;
+      return;
+    }
+  }
+}
+
+int for_each_rank(int n, const std::function<int(int)>& fn) {
+  std::vector<int> rcs(n, NGHMM_OK);
+  std::vector<std::string> msgs(n);
+  if (n == 1) {
+    rcs[0] = fn(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+      th.emplace_back([&, r] {
+        rcs[r] = fn(r);
+        if (rcs[r] != NGHMM_OK) msgs[r] = g_last_error;  // thread-local: carry it over
+      });
+    for (auto& t : th) t.join();
+  }
+  for (int r = 0; r < n; ++r)
+    if (rcs[r] != NGHMM_OK) {
+      if (!msgs[r].empty()) g_last_error = msgs[r];
+      return rcs[r];
+    }
+  return NGHMM_OK;
+}
+
+// phases 2 and 3 of a group iteration, once every rank's posteriors have arrived: est_maf on
+// the own site range over all individuals (rank blocks = the global individual order), the
+// frequencies to everybody, and their installation (emissions follow lazily)
+int group_freq_phases(nghmm_t** hs, int n) {
+  const uint64_t S_own = hs[0]->S / n;
+  int rc = for_each_rank(n, [&](int r) -> int {
+    nghmm_t* h = hs[r];
+    int rr = nghmm_mstep_freq_sites_dev(h, h->g_recv, h->g_freq_own);
+    if (rr != NGHMM_OK) return rr;
+    for (int q = 0; q < n; ++q)
+      if (hipMemcpyAsync(hs[q]->g_freq_all + (size_t)r * S_own, h->g_freq_own, S_own * sizeof(double),
+                         hipMemcpyDeviceToDevice, h->g_xstream) != hipSuccess)
+        return NGHMM_ERR_HIP;
+    return hipStreamSynchronize(h->g_xstream) == hipSuccess ? NGHMM_OK : NGHMM_ERR_HIP;
+  });
+  if (rc != NGHMM_OK) return rc;
+  return for_each_rank(n, [&](int r) -> int { return nghmm_set_freq_dev(hs[r], hs[r]->g_freq_all); });
+}
+
+}  // namespace
+
+int nghmm_group_setup(nghmm_t** hs, int n) {
+  g_last_error.clear();
+  if (!hs || n < 1) return NGHMM_ERR_ARG;
+  nghmm_t* h0 = hs[0];
+  for (int r = 0; r < n; ++r) {
+    nghmm_t* h = hs[r];
+    if (!h || !h->loaded || (n > 1 && (h->parent || h->n_replicas.load() > 0)) || h->I != h0->I ||
+        h->S != h0->S || h->mode != h0->mode ||
+        h->packed != h0->packed) {
+      set_error("nghmm_group_setup: the handles must be loaded and agree in size, mode and packing");
+      return NGHMM_ERR_ARG;
+    }
+  }
+  const uint64_t I = h0->I, S = h0->S, I_tot = I * n;
+  if (S % n != 0) {
+    set_error("nghmm_group_setup: %llu sites do not divide by %d handles", (unsigned long long)S, n);
+    return NGHMM_ERR_ARG;
+  }
+  if (n > 1 && h0->mode != NGHMM_MODE_FAST) {
+    set_error("nghmm_group_setup: several handles need NGHMM_MODE_FAST");
+    return NGHMM_ERR_ARG;
+  }
+  const uint64_t S_own = S / n;
+  int rc;
+  // peer access between the devices involved (a no-op for handles that share a device)
+  for (int r = 0; r < n; ++r)
+    for (int q = 0; q < n; ++q)
+      if (hs[r]->device != hs[q]->device) {
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, hs[r]->device, hs[q]->device));
+        if (!can) {
+          set_error("nghmm_group_setup: device %d cannot access device %d", hs[r]->device, hs[q]->device);
+          return NGHMM_ERR_HIP;
+        }
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        const hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+        (void)hipGetLastError();
+      }
+  for (int r = 0; r < n; ++r) {
+    nghmm_t* h = hs[r];
+    if ((rc = use_device(h))) return rc;
+    if ((rc = nghmm_shard_config(h, I_tot, (uint64_t)r * I, (uint64_t)r * S_own, S_own))) return rc;
+    h->g_n = n;
+    h->g_rank = r;
+    if (n == 1) continue;
+    void* old[] = {h->g_send, h->g_recv, h->g_freq_own, h->g_freq_all};
+    for (void* p : old)
+      if (p) (void)hipFree(p);
+    h->g_send = h->g_recv = h->g_freq_own = h->g_freq_all = nullptr;
+    if ((rc = dev_alloc(&h->g_send, (size_t)S * I))) return rc;
+    if ((rc = dev_alloc(&h->g_recv, (size_t)S * I))) return rc;
+    if ((rc = dev_alloc(&h->g_freq_own, (size_t)S_own))) return rc;
+    if ((rc = dev_alloc(&h->g_freq_all, (size_t)S))) return rc;
+    if (!h->g_xstream) HIP_TRY(hipStreamCreateWithFlags(&h->g_xstream, hipStreamNonBlocking));
+  }
+  if (n == 1) return NGHMM_OK;
+  // static site-shard copies: rank r gets the likelihoods of ALL individuals for its site range,
+  // pulled from every rank's own matrix with strided peer copies
+  for (int r = 0; r < n; ++r) {
+    nghmm_t* h = hs[r];
+    if ((rc = use_device(h))) return rc;
+    const uint64_t lo = (uint64_t)r * S_own;
+    if (!h->packed) {
+      if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
+      h->d_gl_shard = nullptr;
+      if ((rc = dev_alloc(&h->d_gl_shard, (size_t)S_own * I_tot * 3))) return rc;
+      for (int q = 0; q < n; ++q)
+        HIP_TRY(hipMemcpy2DAsync(h->d_gl_shard + (size_t)q * I * 3, I_tot * 3 * sizeof(double),
+                                 hs[q]->d_gl + lo * I * 3, I * 3 * sizeof(double),
+                                 I * 3 * sizeof(double), S_own, hipMemcpyDeviceToDevice, h->stream));
+      fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, (size_t)S_own * I_tot * 3);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(sync_stream(h));
+    } else {
+      uint8_t *bytes = nullptr, *part = nullptr;  // [S_own][I_tot] on r; [S_own][I] on q
+      if ((rc = dev_alloc(&bytes, (size_t)S_own * I_tot))) return rc;
+      for (int q = 0; q < n && rc == NGHMM_OK; ++q) {
+        hipError_t e = hipSetDevice(hs[q]->device);
+        if (e == hipSuccess) e = hipMalloc((void**)&part, (size_t)S_own * I);
+        if (e == hipSuccess) {
+          launch_codes_to_bytes(hs[q]->stream, hs[q]->d_codes, lo * I, S_own * I, part);
+          e = hipStreamSynchronize(hs[q]->stream);
+        }
+        if (e == hipSuccess) e = hipSetDevice(h->device);
+        if (e == hipSuccess)
+          e = hipMemcpy2DAsync(bytes + (size_t)q * I, I_tot, part, I, I, S_own,
+                               hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (part) {
+          (void)hipSetDevice(hs[q]->device);
+          (void)hipFree(part);
+          part = nullptr;
+          (void)hipSetDevice(h->device);
+        }
+        if (e != hipSuccess) {
+          set_error("nghmm_group_setup: %s", hipGetErrorString(e));
+          rc = NGHMM_ERR_HIP;
+        }
+      }
+      if (rc == NGHMM_OK) rc = nghmm_load_geno_site_shard_dev(h, bytes);
+      (void)hipFree(bytes);
+      if (rc != NGHMM_OK) return rc;
+    }
+  }
+  return NGHMM_OK;
+}
+
+int nghmm_group_iter_em(nghmm_t** hs, int n, int freq_est, int indF_fixed, int alpha_fixed,
+                        double* ind_lkl, nghmm_mstep_stats* stats) {
+  g_last_error.clear();
+  if (!hs || n < 1 || !hs[0] || hs[0]->g_n != n) {
+    set_error("nghmm_group_iter_em: call nghmm_group_setup on these handles first");
+    return NGHMM_ERR_ARG;
+  }
+  if (n == 1) return nghmm_iter_em(hs[0], freq_est, indF_fixed, alpha_fixed, ind_lkl, stats);
+  if (freq_est == 2) {
+    set_error("invalid allele frequencies");
+    return NGHMM_ERR_FREQ_EST2;
+  }
+  const uint64_t I = hs[0]->I;
+  std::vector<nghmm_mstep_stats> st(n);
+  std::vector<GroupHook> hook(n);
+  // phase 1: E-step + indF/alpha M-step per rank; posteriors leave for their site owners as
+  // soon as they are final
+  int rc = for_each_rank(n, [&](int r) -> int {
+    hook[r] = GroupHook{hs, n, r, NGHMM_OK};
+    int rr = nghmm_estep_mstep(hs[r], indF_fixed, alpha_fixed, ind_lkl ? ind_lkl + (size_t)r * I : nullptr,
+                               &st[r], freq_est ? group_after_estep : nullptr, &hook[r]);
+    if (rr == NGHMM_OK) rr = hook[r].rc;
+    if (rr == NGHMM_OK && freq_est && hipStreamSynchronize(hs[r]->g_xstream) != hipSuccess)
+      rr = NGHMM_ERR_HIP;
+    return rr;
+  });
+  if (rc != NGHMM_OK) return rc;
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    for (int r = 0; r < n; ++r) {
+      stats->rounds = st[r].rounds > stats->rounds ? st[r].rounds : stats->rounds;
+      stats->points += st[r].points;
+      stats->ref_forward_calls += st[r].ref_forward_calls;
+      stats->ind_rounds += st[r].ind_rounds;
+    }
+  }
+  if (!freq_est) return NGHMM_OK;
+  return group_freq_phases(hs, n);
+}
+
+// The allele-frequency step alone, from the posteriors the handles hold (all zero before the
+// first E-step: --freq e, parse_args.cpp:312-318).
+int nghmm_group_mstep_freq(nghmm_t** hs, int n, int freq_est) {
+  g_last_error.clear();
+  if (!hs || n < 1 || !hs[0] || hs[0]->g_n != n) {
+    set_error("nghmm_group_mstep_freq: call nghmm_group_setup on these handles first");
+    return NGHMM_ERR_ARG;
+  }
+  if (n == 1) return nghmm_mstep_freq(hs[0], freq_est);
+  if (freq_est == 0) return NGHMM_OK;
+  if (freq_est != 1) {
+    set_error(freq_est == 2 ? "invalid allele frequencies" : "wrong MAF estimation method!");
+    return freq_est == 2 ? NGHMM_ERR_FREQ_EST2 : NGHMM_ERR_ARG;
+  }
+  std::vector<GroupHook> hook(n);
+  int rc = for_each_rank(n, [&](int r) -> int {
+    hook[r] = GroupHook{hs, n, r, NGHMM_OK};
+    group_after_estep(&hook[r]);
+    if (hook[r].rc != NGHMM_OK) return hook[r].rc;
+    return hipStreamSynchronize(hs[r]->g_xstream) == hipSuccess ? NGHMM_OK : NGHMM_ERR_HIP;
+  });
+  if (rc != NGHMM_OK) return rc;
+  return group_freq_phases(hs, n);
 }
 
 int nghmm_fast_layout(nghmm_t* h, uint32_t* waves_per_individual, uint64_t* sites_per_lane) {

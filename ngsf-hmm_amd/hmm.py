@@ -109,6 +109,9 @@ def load_library():
         "nghmm_pack_posteriors_dev": (i32, [vp, u64, u64, vp]),
         "nghmm_mstep_freq_sites_dev": (i32, [vp, vp, vp]),
         "nghmm_set_freq_dev": (i32, [vp, vp]),
+        "nghmm_group_setup": (i32, [C.POINTER(vp), i32]),
+        "nghmm_group_iter_em": (i32, [C.POINTER(vp), i32, i32, i32, i32, dp, C.POINTER(MstepStats)]),
+        "nghmm_group_mstep_freq": (i32, [C.POINTER(vp), i32, i32]),
         "nghmm_fast_layout": (i32, [vp, C.POINTER(u32), C.POINTER(u64)]),
         "nghmm_stream": (vp, [vp]),
         "nghmm_synchronize": (i32, [vp]),
@@ -140,7 +143,9 @@ EXPORTED_SYMBOLS = [
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
     "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_load_gl_site_shard_dev",
     "nghmm_pack_posteriors_dev",
-    "nghmm_mstep_freq_sites_dev", "nghmm_set_freq_dev", "nghmm_fast_layout", "nghmm_stream",
+    "nghmm_mstep_freq_sites_dev", "nghmm_set_freq_dev", "nghmm_group_setup", "nghmm_group_iter_em",
+    "nghmm_group_mstep_freq",
+    "nghmm_fast_layout", "nghmm_stream",
     "nghmm_synchronize",
     "nghmm_kernel_ms",
 ]
@@ -464,3 +469,27 @@ class NgsFHMM:
 
     def synchronize(self):
         self._check(self.lib.nghmm_synchronize(self._h))
+
+
+class Group:
+    """n handles of one process as one cohort (nghmm_group_setup / nghmm_group_iter_em): handle
+    r holds the individuals [r I, (r+1) I) for all sites."""
+
+    def __init__(self, handles):
+        self.handles = list(handles)
+        self.lib = self.handles[0].lib
+        n = len(self.handles)
+        self._arr = (C.c_void_p * n)(*[h._h for h in self.handles])
+        self.handles[0]._check(self.lib.nghmm_group_setup(self._arr, n))
+        self.ind_lkl = np.full(n * self.handles[0].n_ind, -math.inf)
+
+    def mstep_freq(self, freq_est=1):
+        self.handles[0]._check(self.lib.nghmm_group_mstep_freq(self._arr, len(self.handles),
+                                                               int(freq_est)))
+
+    def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        st = MstepStats()
+        self.handles[0]._check(self.lib.nghmm_group_iter_em(
+            self._arr, len(self.handles), int(freq_est), int(indF_fixed), int(alpha_fixed),
+            _dp(self.ind_lkl), C.byref(st)))
+        return st

@@ -287,3 +287,36 @@ def test_cli_empty_line_in_called_genotype_file(pkg, orc_det, orc_libm, data):
     assert open(out + ".indF", "rb").read() == f_indF
     assert open(out + ".ibd", "rb").read() == f_ibd
     assert open(out + ".geno", "rb").read() == f_geno
+
+
+@pytest.mark.parametrize("key,flags", [("glf_bin", ["--loglkl"]), ("geno_gz", []),
+                                       ("glf_gz", ["--loglkl", "--call_geno"])])
+def test_cli_n_gpus_splits_the_cohort(pkg, data, key, flags):
+    """--n_gpus N: the individuals split over N handles (on an 8-GPU node one per GPU; here
+    --devices 0,0: two handles on the one GPU), the frequency step site-sharded with peer
+    copies (include/nghmm.h, "a GROUP of n handles").  Fixed indF/alpha: the files must equal
+    the single-handle run's except for last-bit differences of the frequencies; free
+    parameters: same paths and printed values up to the optimizer's spread."""
+    d, paths, tmp = data
+    base = ["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I, "--n_sites", S,
+            "--freq", 0.1, "--min_iters", 2, "--max_iters", 4, "--mode", "fast", "--verbose", 0]
+    for name, extra in (("fixed", ["--indF", "0.4,0.05", "--indF_fixed", "--alpha_fixed"]),
+                        ("free", ["--indF", "0.1,0.2"]), ("freq_e", ["--indF", "0.1,0.2", "--freq", "e"])):
+        one, two = os.path.join(tmp, f"g1_{key}_{name}"), os.path.join(tmp, f"g2_{key}_{name}")
+        cli_util.run_cli(base + extra + ["--out", one])
+        cli_util.run_cli(base + extra + ["--out", two, "--n_gpus", 2, "--devices", "0,0"])
+        a, b = open(one + ".indF").read().split("\n"), open(two + ".indF").read().split("\n")
+        assert abs(float(a[0]) - float(b[0])) <= 1e-9 * abs(float(a[0]))
+        fa = np.array([float(x) for x in a[1 + I:1 + I + S]])
+        fb = np.array([float(x) for x in b[1 + I:1 + I + S]])
+        assert np.abs(fa - fb).max() <= 1.1e-6
+        ia, ib = open(one + ".ibd").read().split("\n"), open(two + ".ibd").read().split("\n")
+        assert ia[1:1 + I] == ib[1:1 + I]                          # Viterbi paths
+        if name == "fixed":
+            assert a[1:1 + I] == b[1:1 + I]
+            pa = np.array([[float(x) for x in l.split("\t")] for l in ia[1 + I:1 + 2 * I]])
+            pb = np.array([[float(x) for x in l.split("\t")] for l in ib[1 + I:1 + 2 * I]])
+            assert np.abs(pa - pb).max() <= 1.1e-6
+            ga = np.fromfile(one + ".geno")
+            gb = np.fromfile(two + ".geno")
+            np.testing.assert_allclose(gb, ga, rtol=1e-9, atol=1e-300)

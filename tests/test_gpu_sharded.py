@@ -137,3 +137,47 @@ def test_est_maf_register_and_stream_variants(pkg, I):
     hmm.mstep_freq(1)
     np.testing.assert_allclose(hmm.freq, em.freq, rtol=1e-9)
     hmm.close()
+
+
+@pytest.mark.parametrize("n,packed", [(2, False), (4, False), (2, True)])
+def test_group_of_handles_equals_one_handle(pkg, n, packed):
+    """nghmm_group_setup / nghmm_group_iter_em (one process, several handles; on an 8-GPU node
+    one per GPU with peer copies over xGMI, here all on cuda:0): the cohort's EM iterations do
+    not depend on how the individuals are split."""
+    I_loc, S = 24, 2400
+    I = I_loc * n
+    d = pkg.simulate.simulate(I, S, seed=21, n_chrom=3, missing_rate=0.04, indF="r")
+    mode = pkg.MODE_FAST | (pkg.GENO_PACKED if packed else 0)
+
+    def load(h, cols):
+        h.load_raw(np.ascontiguousarray(d.gl[:, cols]), d.pos_dist_mb, space=0, call_geno=packed)
+        h.set_params(0.1, 0.2, 0.1)
+        h.init_emission()
+
+    whole = pkg.NgsFHMM(I, S, mode=mode)
+    load(whole, slice(0, I))
+    parts = [pkg.NgsFHMM(I_loc, S, mode=mode) for _ in range(n)]
+    for r, h in enumerate(parts):
+        load(h, slice(r * I_loc, (r + 1) * I_loc))
+    grp = pkg.Group(parts)
+    for it in range(3):
+        whole.iter_EM()
+        st = grp.iter_EM()
+        np.testing.assert_allclose(grp.ind_lkl, whole.ind_lkl, rtol=1e-12)
+        np.testing.assert_allclose(parts[0].freq, whole.freq, rtol=1e-12)
+        np.testing.assert_array_equal(parts[0].freq, parts[-1].freq)
+        got_F = np.concatenate([h.indF for h in parts])
+        np.testing.assert_allclose(got_F, whole.indF, atol=1e-6)
+        assert st.rounds > 0
+    post = np.concatenate([h.marg_prob for h in parts])
+    np.testing.assert_allclose(post, whole.marg_prob, rtol=1e-9, atol=1e-12)
+    # fixed parameters: nothing for the optimizer to amplify -> the split must not matter at all
+    for h in parts + [whole]:
+        h.set_params(0.3, 0.1, 0.15)
+        h.init_emission()
+    whole.iter_EM(1, True, True)
+    grp.iter_EM(1, True, True)
+    np.testing.assert_allclose(parts[1].freq, whole.freq, rtol=1e-13)
+    for h in parts:
+        h.close()
+    whole.close()
