@@ -398,12 +398,12 @@ def main():
                                "frac": winstr / (later_ms * 1e-3) / fp64_peak,
                                "instr_per_site": 91.5}}
             if "est_maf" in fam_roof:
-                # per site: 21 evaluations (4 exact passes, 16 interval nodes, the check) of
+                # per site: 17 evaluations (2 exact passes, 14 interval nodes, the check) of
                 # 8.06 instructions per individual + ~45, and ~22 per individual to set up
                 i_tot = I_tot
                 ni = min(16, -(-i_tot // 64))
                 waves = max(1, -(-i_tot // 1024))
-                per_site = waves * (21 * (8.06 * ni + 45) + 22 * ni)
+                per_site = waves * (17 * (8.06 * ni + 45) + 22 * ni)
                 sites = S / world
                 rate = per_site * sites * launches["est_maf"] / (fam["est_maf"] * 1e-3)
                 fam_roof["est_maf"]["fp64_issue"] = {"wave_instr_per_s": rate, "peak": fp64_peak,

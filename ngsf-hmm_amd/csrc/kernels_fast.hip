@@ -1212,19 +1212,19 @@ __device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
 // would be closer than 1e-9 (relative) to the threshold, or whose r leaves the
 // interval, goes back to exact evaluation (one more build is allowed per site).
 #ifndef NGHMM_EST_EN
-#define NGHMM_EST_EN 16
+#define NGHMM_EST_EN 14
 #endif
 constexpr int EN = NGHMM_EST_EN;        // Chebyshev nodes per interval
 constexpr int EST_SCALARS = 8;          // num, den, pnum, pden, iters, mid, half, tF
 constexpr int EST_FIELDS = EST_SCALARS + 2 * EN;
 enum : uint8_t { EST_DONE = 0, EST_INTERP = 1, EST_EXACT = 2 };
 #ifndef NGHMM_EST_K0
-#define NGHMM_EST_K0 4
+#define NGHMM_EST_K0 2
 #endif
 constexpr int EST_K0 = NGHMM_EST_K0;    // exact passes before the first interval
 constexpr int EST_MIN_GAIN = 24;        // build only if about this many passes remain
 #ifndef NGHMM_EST_DMAX
-#define NGHMM_EST_DMAX 0.5
+#define NGHMM_EST_DMAX 0.85
 #endif
 #ifndef NGHMM_EST_MULT
 #define NGHMM_EST_MULT 32.0
@@ -1233,7 +1233,7 @@ constexpr double EST_DMAX = NGHMM_EST_DMAX;  // interval length <= EST_DMAX * r 
 constexpr double EST_BACK = 0.1;        // ... plus this fraction of it behind
 constexpr double EST_MULT = NGHMM_EST_MULT;  // ... and about this many current steps
 #ifndef NGHMM_EST_FIT
-#define NGHMM_EST_FIT 0.6
+#define NGHMM_EST_FIT 0.72
 #endif
 #ifndef NGHMM_EST_KMAX
 #define NGHMM_EST_KMAX 32
@@ -1253,11 +1253,14 @@ __constant__ double kChebW[EN] = {0.19509032201612825, -0.5555702330196022, 0.83
 #elif NGHMM_EST_EN == 12
 __constant__ double kChebC[EN] = {0.9914448613738104, 0.9238795325112867, 0.7933533402912352, 0.6087614290087207, 0.38268343236508984, 0.1305261922200517, -0.1305261922200516, -0.3826834323650895, -0.6087614290087207, -0.793353340291235, -0.9238795325112867, -0.9914448613738104};
 __constant__ double kChebW[EN] = {0.13052619222005157, -0.3826834323650898, 0.6087614290087207, -0.7933533402912352, 0.9238795325112867, -0.9914448613738104, 0.9914448613738104, -0.9238795325112868, 0.7933533402912352, -0.6087614290087209, 0.3826834323650899, -0.130526192220052};
+#elif NGHMM_EST_EN == 14
+__constant__ double kChebC[EN] = {0.9937122098932426, 0.9438833303083676, 0.8467241992282841, 0.7071067811865476, 0.5320320765153366, 0.3302790619551673, 0.11196447610330769, -0.11196447610330758, -0.3302790619551672, -0.5320320765153365, -0.7071067811865475, -0.8467241992282841, -0.9438833303083676, -0.9937122098932426};
+__constant__ double kChebW[EN] = {0.11196447610330786, -0.3302790619551671, 0.5320320765153366, -0.7071067811865475, 0.8467241992282841, -0.9438833303083675, 0.9937122098932426, -0.9937122098932426, 0.9438833303083675, -0.8467241992282842, 0.7071067811865476, -0.5320320765153367, 0.3302790619551672, -0.11196447610330798};
 #elif NGHMM_EST_EN == 16
 __constant__ double kChebC[EN] = {0.9951847266721969, 0.9569403357322088, 0.881921264348355, 0.773010453362737, 0.6343932841636455, 0.4713967368259978, 0.29028467725446233, 0.09801714032956077, -0.09801714032956065, -0.29028467725446216, -0.4713967368259977, -0.6343932841636454, -0.773010453362737, -0.8819212643483549, -0.9569403357322088, -0.9951847266721968};
 __constant__ double kChebW[EN] = {0.0980171403295606, -0.29028467725446233, 0.47139673682599764, -0.6343932841636455, 0.773010453362737, -0.8819212643483549, 0.9569403357322089, -0.9951847266721968, 0.9951847266721969, -0.9569403357322089, 0.881921264348355, -0.7730104533627371, 0.6343932841636455, -0.47139673682599786, 0.2902846772544624, -0.09801714032956083};
 #else
-#error "NGHMM_EST_EN must be 8, 12 or 16"
+#error "NGHMM_EST_EN must be 8, 12, 14 or 16"
 #endif
 
 // W = BLOCK/64 waves per site, NI individuals per lane held in registers.  With
@@ -1335,7 +1338,10 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   // has two memory round trips here, not NI of them.
   double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
   {
-    constexpr int NB = NI < 8 ? NI : 8;  // slots per batch of loads
+#ifndef NGHMM_EST_NB
+#define NGHMM_EST_NB 8
+#endif
+    constexpr int NB = NI < NGHMM_EST_NB ? NI : NGHMM_EST_NB;  // slots per batch of loads
     const bool one_block = (I_blk == I_tot);
     const uint32_t ib = (uint32_t)I_blk;
     double tF_acc = 0;
@@ -1410,7 +1416,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   bool built = !allow_build;  // at most one interval per launch
   int n_before = n_exact;     // exact passes before deciding on it
   bool check = false, interp_ok = false;
-  double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;
+  double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;  // mid: centre a, half: h (see the build)
   // this lane's part of the two per-pass sums at odds r
   auto lane_sums = [&](double r, double& pn, double& pd) {
     pn = 0;
@@ -1471,7 +1477,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
     }
     if (check) {  // the pass after a build: exact sums in hand, compare the interpolant
       const int nj = lane < EN ? lane : 0;
-      const double t = r - fma(half, kChebC[nj], mid);
+      const double t = (r - mid) / (r + mid) - half * kChebC[nj];
       const double q = (lane < EN) ? kChebW[nj] / t : 0.0;
       const double Sq = wave_sum_uniform(q);
       const double bn = wave_sum_uniform(q * my_gn) / Sq, bd = wave_sum_uniform(q * my_gd) / Sq;
@@ -1516,24 +1522,33 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
       const double m_est = (double)iters * (sqrt(lhs / thr) - 1.0);
       const double rn = pnum * rcp_nr2(pden - pnum);
       const double step = fabs(rn - rprev);
-      const bool fits = (double)iters * step <= EST_FIT * EST_DMAX * rn;
+      // (an interval reaches EST_DMAX * r ahead when r grows, down to r / (1 + EST_DMAX) when
+      // it shrinks: the same ratio both ways)
+      const double reach = (rn >= rprev) ? EST_DMAX * rn : EST_DMAX / (1 + EST_DMAX) * rn;
+      const bool fits = (double)iters * step <= EST_FIT * reach;
       if (!fits && iters < EST_KMAX && m_est >= EST_MIN_GAIN) {
         n_before = 1;  // look again after the next exact pass
       } else {
         built = true;
       }
       if (built && m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
-        const double L = fmin(EST_DMAX * rn, fmax(EST_MULT * step, 1e-3 * rn));
+        const double g = fmin(EST_DMAX, fmax(EST_MULT * step / rn, 1e-3));  // relative length
         double lo, hi;
         if (rn >= rprev) {
-          lo = fma(-EST_BACK, L, rn);
-          hi = rn + L;
+          lo = rn * (1 - EST_BACK * g);
+          hi = rn * (1 + g);
         } else {
-          lo = rn - L;
-          hi = fma(EST_BACK, L, rn);
+          lo = rn / (1 + g);
+          hi = rn * (1 + EST_BACK * g);
         }
-        mid = 0.5 * (lo + hi);
-        half = 0.5 * (hi - lo);
+        // Interpolation variable t = (r - a) / (r + a), a = sqrt(lo hi): the half plane
+        // Re r <= 0 that holds every pole of the sums is the OUTSIDE of the unit disc in t, and
+        // [lo, hi] becomes [-h, h] around 0 -- far from everything, so the Chebyshev
+        // interpolant on EN nodes converges like rho^-EN with (rho + 1/rho) / 2 = 1/h: an
+        // interval of ratio hi / lo = 2 has rho = 11.7, where the same nodes in r itself
+        // (nearest pole at distance >= lo from an interval of length lo) would have rho = 5.8.
+        mid = sqrt(lo * hi);
+        half = (hi - mid) / (hi + mid);
         // a degenerate interval (rn not finite or not positive) keeps the site exact
         if (half > 0 && lo > 0 && hi < 1e300) {
           if constexpr (PARK) {
@@ -1545,7 +1560,8 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
 #pragma unroll 1
             for (int nd = 0; nd < EN; ++nd) {
               double pn, pd;
-              lane_sums(fma(half, kChebC[nd], mid), pn, pd);
+              const double tn = half * kChebC[nd];
+              lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), pn, pd);
               nodebuf[nd][lane] = double2{pn, pd};
             }
             __syncthreads();  // one wave: orders the LDS writes before the reads
@@ -1573,7 +1589,8 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
 #pragma unroll 1
             for (int nd = 0; nd < EN; ++nd) {
               double pn, pd;
-              lane_sums(fma(half, kChebC[nd], mid), pn, pd);
+              const double tn = half * kChebC[nd];
+              lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), pn, pd);
               const double v = wave_sum_pair(pn, pd);
               const double sn = lane_value(v, 31), sd = lane_value(v, 63);
               if (lane == 0) xnode[nd][wv] = double2{sn, sd};
@@ -1630,12 +1647,13 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
   uint8_t st = EST_EXACT;
   for (;;) {
     const double r = pnum * rcp_nr2(pden - pnum);  // the expression of k_fast_estmaf
-    if (!(fabs(r - mid) <= half)) break;           // left the interval (or not finite)
+    const double tt = (r - mid) * rcp_nr2(r + mid);  // the interpolation variable (see the build)
+    if (!(fabs(tt) <= half)) break;                // left the interval (or not finite)
     double Sq = 0, Sn = 0, Sd = 0;
     bool hit = false;
 #pragma unroll
     for (int j = 0; j < EN; ++j) {
-      const double t = r - fma(half, kChebC[j], mid);
+      const double t = fma(-half, kChebC[j], tt);
       hit |= (t == 0);
       const double q = kChebW[j] * rcp_nr2(t);  // full precision, half a division's cost
       Sq += q;
