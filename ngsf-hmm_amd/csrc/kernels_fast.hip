@@ -1341,7 +1341,9 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
 #ifndef NGHMM_EST_NB
 #define NGHMM_EST_NB 8
 #endif
-    constexpr int NB = NI < NGHMM_EST_NB ? NI : NGHMM_EST_NB;  // slots per batch of loads
+    // slots per batch of loads; NI = 12: two batches of six
+    constexpr int NB = NI < NGHMM_EST_NB ? NI : (NI % NGHMM_EST_NB ? NI / 2 : NGHMM_EST_NB);
+    static_assert(NI % NB == 0, "whole batches");
     const bool one_block = (I_blk == I_tot);
     const uint32_t ib = (uint32_t)I_blk;
     double tF_acc = 0;
@@ -2186,6 +2188,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       else if (I_tot <= 128) LAUNCH_TILE(2, 64);
       else if (I_tot <= 256) LAUNCH_TILE(4, 64);
       else if (I_tot <= 512) LAUNCH_TILE(8, 64);
+      else if (I_tot <= 768) LAUNCH_TILE(12, 64);
       else if (I_tot <= 1024) LAUNCH_TILE(16, 64);
       else if (I_tot <= 2048) LAUNCH_TILE(16, 128);
       else if (I_tot <= 4096) LAUNCH_TILE(16, 256);
@@ -2206,6 +2209,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     else if (I_tot <= 128) LAUNCH_NI(2, 64);
     else if (I_tot <= 256) LAUNCH_NI(4, 64);
     else if (I_tot <= 512) LAUNCH_NI(8, 64);
+    else if (I_tot <= 768) LAUNCH_NI(12, 64);
     else if (I_tot <= 1024) LAUNCH_NI(16, 64);
     else if (I_tot <= 2048) LAUNCH_NI(16, 128);
     else if (I_tot <= 4096) LAUNCH_NI(16, 256);
