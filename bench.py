@@ -83,7 +83,7 @@ def pmc_traffic(family, args, I, S, C, rounds, ind_rounds, K):
     + measured bytes per individual of a later round x the timed individual-rounds."""
     if args.workload != "c3" or args.mode != "fast":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if not os.path.exists(path):
         return None
     summ = json.load(open(path))
@@ -95,10 +95,12 @@ def pmc_traffic(family, args, I, S, C, rounds, ind_rounds, K):
         if not k.startswith(("k_fast_lkl_fd<", "k_fast_lkl_chunks<")) or "hbm_bytes_per_launch" not in d:
             continue
         n = d["launches_fetch_pass"]
-        if k.endswith("true>"):        # <..., EMIT, FRESH = true>: a first round, all individuals
+        targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        emit, src = targs[-2], targs[-1]      # <..., EMIT, SRC>: SRC 0 = stored emissions
+        if src != "0":                 # a fresh first round (dense or packed source), everyone
             fresh_b += d["hbm_bytes_per_launch"] * n
             fresh_n += n * (d["avg_grid_threads"] / 64.0 / C) / I
-        elif not k.endswith("true, false>"):   # later rounds
+        elif emit == "false":          # later rounds
             plain_b += d["hbm_bytes_per_launch"] * n
             plain_ind += n * d["avg_grid_threads"] / 64.0 / C
     if not fresh_n or not plain_ind or not rounds:
