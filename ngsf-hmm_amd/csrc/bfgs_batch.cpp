@@ -108,18 +108,28 @@ void BfgsBatch::plan(Problem& p) {
     p.slot_nonfinite[k] = p.slot_used[k] && (nonfinite(p.pt[k][0]) || nonfinite(p.pt[k][1]));
 }
 
+uint64_t BfgsBatch::active_in(uint64_t lo, uint64_t hi) const {
+  if (hi > probs_.size()) hi = probs_.size();
+  uint64_t n = 0;
+  for (uint64_t i = lo; i < hi; ++i) n += probs_[i].active ? 1 : 0;
+  return n;
+}
+
 size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
-                         std::vector<double>& alpha) {
+                         std::vector<double>& alpha, uint64_t lo, uint64_t hi) {
   ind.clear();
   F.clear();
   alpha.clear();
   if (n_active_ == 0) return 0;
-  const int64_t np = (int64_t)probs_.size();
-#pragma omp parallel for schedule(static) num_threads(host_threads(n_active_))
-  for (int64_t i = 0; i < np; ++i)
+  if (hi > probs_.size()) hi = probs_.size();
+  const bool whole = (lo == 0 && hi == probs_.size());
+  const uint64_t n_act = whole ? n_active_ : active_in(lo, hi);
+  if (n_act == 0) return 0;
+#pragma omp parallel for schedule(static) num_threads(host_threads(n_act))
+  for (int64_t i = (int64_t)lo; i < (int64_t)hi; ++i)
     if (probs_[i].active) plan(probs_[i]);
   for (int k = 0; k < 5; ++k) {
-    for (size_t i = 0; i < probs_.size(); ++i) {
+    for (size_t i = lo; i < hi; ++i) {
       Problem& p = probs_[i];
       if (!p.active || !p.slot_used[k] || p.slot_nonfinite[k]) continue;
       p.slot_pos[k] = (uint32_t)ind.size();
@@ -130,7 +140,7 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
   }
   ++rounds_;
   points_ += ind.size();
-  ind_rounds_ += n_active_;
+  ind_rounds_ += n_act;
   return ind.size();
 }
 
@@ -200,12 +210,12 @@ void BfgsBatch::consume(Problem& p, const double* lkl, uint64_t& ref_calls, uint
   }
 }
 
-void BfgsBatch::scatter(const double* lkl) {
-  const int64_t np = (int64_t)probs_.size();
+void BfgsBatch::scatter(const double* lkl, uint64_t lo, uint64_t hi) {
+  if (hi > probs_.size()) hi = probs_.size();
   uint64_t ref_calls = 0, finished = 0;
 #pragma omp parallel for schedule(static) reduction(+ : ref_calls, finished) \
     num_threads(host_threads(n_active_))
-  for (int64_t i = 0; i < np; ++i)
+  for (int64_t i = (int64_t)lo; i < (int64_t)hi; ++i)
     if (probs_[i].active) consume(probs_[i], lkl, ref_calls, finished);
   ref_calls_ += ref_calls;
   n_active_ -= finished;

@@ -28,12 +28,16 @@ class BfgsBatch {
 
   // Points wanted this round, ordered probe-slot-major so that lanes of a wave
   // read consecutive individuals.  Returns the count (0 when all are done).
-  size_t gather(std::vector<uint32_t>& ind, std::vector<double>& F, std::vector<double>& alpha);
+  // [lo, hi): only the individuals of that range (two halves can then be in flight at once:
+  // the host digests one half's values while the GPU evaluates the other's points).
+  size_t gather(std::vector<uint32_t>& ind, std::vector<double>& F, std::vector<double>& alpha,
+                uint64_t lo = 0, uint64_t hi = ~0ull);
 
-  // lkl[p] = forward log-likelihood of point p of the last gather().
-  void scatter(const double* lkl);
+  // lkl[p] = forward log-likelihood of point p of the last gather() over the same range.
+  void scatter(const double* lkl, uint64_t lo = 0, uint64_t hi = ~0ull);
 
   bool done() const { return n_active_ == 0; }
+  uint64_t active_in(uint64_t lo, uint64_t hi) const;
   void result(double* indF, double* alpha) const;
 
   uint32_t rounds() const { return rounds_; }

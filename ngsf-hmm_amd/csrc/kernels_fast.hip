@@ -1859,8 +1859,9 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
 }
 
 void fast_destroy(FastState& fs) {
-  void* run[] = {fs.e_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.part,
-                 fs.grp_dev, fs.redo, fs.est_status, fs.est_state};
+  void* run[] = {fs.e_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.lanes[0].part,
+                 fs.lanes[0].grp_dev, fs.lanes[1].part, fs.lanes[1].grp_dev, fs.redo, fs.est_status,
+                 fs.est_state};
   for (void* p : run)
     if (p) (void)hipFree(p);
   if (fs.owns_data) {
@@ -1971,7 +1972,8 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T) {
 
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
                       const double* h_F, const double* h_A, bool force_general) {
-  fs.n_groups = 0;
+  FastState::LklLane& L = fs.lanes[fs.cur_lane];
+  L.n_groups = 0;
   if (n_pts == 0) return true;
   // group the points by individual (<= MAXP per group): stable counting sort on the
   // individual index (the caller has checked ind < I)
@@ -2001,16 +2003,16 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
   // individual order inside a mode) and remember the ranges
   std::stable_sort(groups.begin(), groups.end(),
                    [](const GroupDesc& a, const GroupDesc& b) { return a.mode < b.mode; });
-  fs.mode_ranges.clear();
+  L.mode_ranges.clear();
   for (uint32_t k = 0; k < groups.size();) {
     uint32_t e = k;
     while (e < groups.size() && groups[e].mode == groups[k].mode) ++e;
-    fs.mode_ranges.push_back({groups[k].mode, k, e - k});
+    L.mode_ranges.push_back({groups[k].mode, k, e - k});
     k = e;
   }
   if (std::getenv("NGHMM_DEBUG_MODES")) {  // which loop-body versions this round uses
     std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
-    for (const auto& r : fs.mode_ranges) {
+    for (const auto& r : L.mode_ranges) {
       if (r.mode)
         std::fprintf(stderr, " %uF%uA%s x%u", (r.mode >> 2) & 3, r.mode & 3,
                      (r.mode & FD_SMALL) ? "s" : "", r.count);
@@ -2021,37 +2023,38 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
   }
   const uint32_t ng = (uint32_t)groups.size();
   const size_t gbytes = (size_t)ng * sizeof(GroupDesc);
-  if (gbytes > fs.grp_cap) {
-    if (fs.grp_dev) (void)hipFree(fs.grp_dev);
-    fs.grp_dev = nullptr;
-    fs.grp_cap = 0;
+  if (gbytes > L.grp_cap) {
+    if (L.grp_dev) (void)hipFree(L.grp_dev);
+    L.grp_dev = nullptr;
+    L.grp_cap = 0;
     const size_t cap = gbytes + gbytes / 4 + 4096;
-    if (hipMalloc(&fs.grp_dev, cap) != hipSuccess) return false;
-    fs.grp_cap = cap;
+    if (hipMalloc(&L.grp_dev, cap) != hipSuccess) return false;
+    L.grp_cap = cap;
   }
   const size_t pdoubles = (size_t)ng * fs.C * MAXP * 5;
-  if (pdoubles > fs.part_cap) {
-    if (fs.part) (void)hipFree(fs.part);
-    fs.part = nullptr;
-    fs.part_cap = 0;
+  if (pdoubles > L.part_cap) {
+    if (L.part) (void)hipFree(L.part);
+    L.part = nullptr;
+    L.part_cap = 0;
     const size_t cap = pdoubles + pdoubles / 4 + 1024;
-    if (!dalloc(&fs.part, cap)) return false;
-    fs.part_cap = cap;
+    if (!dalloc(&L.part, cap)) return false;
+    L.part_cap = cap;
   }
   // the descriptors must outlive the async copy
-  fs.grp_host.assign(reinterpret_cast<unsigned char*>(groups.data()),
+  L.grp_host.assign(reinterpret_cast<unsigned char*>(groups.data()),
                      reinterpret_cast<unsigned char*>(groups.data()) + gbytes);
-  if (hipMemcpyAsync(fs.grp_dev, fs.grp_host.data(), gbytes, hipMemcpyHostToDevice, st) !=
+  if (hipMemcpyAsync(L.grp_dev, L.grp_host.data(), gbytes, hipMemcpyHostToDevice, st) !=
       hipSuccess)
     return false;
-  fs.n_groups = ng;
+  L.n_groups = ng;
   return true;
 }
 
 bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags, bool emit_estep) {
-  const uint32_t ng = fs.n_groups;
+  FastState::LklLane& L = fs.lanes[fs.cur_lane];
+  const uint32_t ng = L.n_groups;
   if (ng == 0) return true;
-  const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(fs.grp_dev);
+  const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(L.grp_dev);
   const LklArrays arr{reinterpret_cast<const double2*>(fs.e_il), fs.pos_il,
                       reinterpret_cast<const double2*>(fs.gl02_il), fs.gl1_il, fs.freq_il,
                       reinterpret_cast<double2*>(fs.e_il), fs.geno_il, fs.u_lin};
@@ -2062,12 +2065,12 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
                                    : EmitPtrs{nullptr, nullptr};
   const bool fresh = emit_estep && fs.e_stale;
   if (fs.e_stale && !fresh) return false;  // the caller refreshes the emissions first
-  for (const auto& r : fs.mode_ranges) {
+  for (const auto& r : L.mode_ranges) {
     const dim3 grid(r.count * fs.C), block(64);
     switch (r.mode) {
 #define FD_LAUNCH(NF, NA, SM, EM, FR)                                                          \
   hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR>), grid, block, 0, st, arr, fs.T, fs.C, \
-                     dg, r.begin, fs.part, emit)
+                     dg, r.begin, L.part, emit)
 #define FD_CASE(NF, NA)                                                \
   case fd_mode(NF, NA, false):                                         \
     if (fresh && fs.packed) FD_LAUNCH(NF, NA, false, true, SRC_FRESH_PACKED); \
@@ -2092,25 +2095,26 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
       default:
         if (fresh && fs.packed)
           hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_FRESH_PACKED>), grid, block, 0, st, arr,
-                             fs.T, fs.C, dg, r.begin, fs.part, emit);
+                             fs.T, fs.C, dg, r.begin, L.part, emit);
         else if (fresh)
           hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_FRESH>), grid, block, 0, st, arr, fs.T,
-                             fs.C, dg, r.begin, fs.part, emit);
+                             fs.C, dg, r.begin, L.part, emit);
         else
           hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_PLAIN>), grid, block, 0, st, arr, fs.T,
-                             fs.C, dg, r.begin, fs.part, emit);
+                             fs.C, dg, r.begin, L.part, emit);
     }
   }
   if (fresh) fs.e_stale = false;
-  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64), 0, st, dg, ng, fs.C, fs.part, d_lkl,
+  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64), 0, st, dg, ng, fs.C, L.part, d_lkl,
                      d_flags);
   return hipGetLastError() == hipSuccess;
 }
 
 bool fast_lkl_covers_everyone(const FastState& fs) {
+  const FastState::LklLane& L = fs.lanes[fs.cur_lane];
   // one group per individual (points are grouped by individual, <= MAXP each; an M-step's
   // first round has <= 5 points per individual, so groups == individuals iff all are there)
-  return fs.n_groups == fs.I;
+  return L.n_groups == fs.I;
 }
 
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,

@@ -37,15 +37,21 @@ struct FastState {
   double* ckpt = nullptr;         // forward checkpoints [I][C][T/8][2][64] x double2
   double* lane_ops = nullptr;     // per-lane chunk operators [I][J][5]
   double* bound = nullptr;        // per-lane incoming forward/backward vectors [I][J][4]
-  // objective batches
-  double* part = nullptr;         // [groups][C][5 points][5]
-  size_t part_cap = 0;
-  void* grp_dev = nullptr;        // packed group descriptors
-  size_t grp_cap = 0;
-  std::vector<unsigned char> grp_host;
-  uint32_t n_groups = 0;
+  // objective batches: two independent sets of descriptor / partial-operator buffers, so that
+  // one batch can be prepared and evaluated while the host digests the other's results
+  // (fast_lkl_prepare / _launch / _covers_everyone work on lanes[cur_lane])
   struct ModeRange { uint32_t mode, begin, count; };
-  std::vector<ModeRange> mode_ranges;  // groups sorted by loop-body version
+  struct LklLane {
+    double* part = nullptr;         // [groups][C][5 points][5]
+    size_t part_cap = 0;
+    void* grp_dev = nullptr;        // packed group descriptors
+    size_t grp_cap = 0;
+    std::vector<unsigned char> grp_host;
+    uint32_t n_groups = 0;
+    std::vector<ModeRange> mode_ranges;  // groups sorted by loop-body version
+  };
+  LklLane lanes[2];
+  int cur_lane = 0;
   double dmax_finite = 0;         // largest finite distance of the loaded data
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;

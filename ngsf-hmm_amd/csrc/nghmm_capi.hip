@@ -98,6 +98,22 @@ struct nghmm_handle {
   unsigned long long* d_uniform = nullptr;  // the one value every uniform cell carries (~0: none yet)
   // chunked loading (nghmm_load_begin .. nghmm_load_end)
   uint64_t lkl_redone = 0;            // objective points re-evaluated by the general kernel
+  // fast-mode M-step after its first round: the individuals in two halves, each with its own
+  // buffers and events, so that the host advances one half's optimizers while the GPU
+  // evaluates the other half's points (mstep_indf_impl)
+  struct LklAsync {
+    double* d_lkl = nullptr;   // device results
+    size_t cap = 0;
+    double* h_lkl = nullptr;   // pinned host results
+    size_t h_cap = 0;
+    int* d_flags = nullptr;
+    int* h_flags = nullptr;    // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    std::vector<uint32_t> ind;
+    std::vector<double> F, A;
+    uint64_t lo = 0, hi = 0;
+    bool pending = false;
+  } lane[2];
   // replicas (nghmm_create_replica): share the parent's data arrays (d_gl / d_codes /
   // d_cls_log / d_pos and the fast-mode layouts of the likelihoods)
   nghmm_handle* parent = nullptr;
@@ -262,6 +278,44 @@ int fast_estep_impl(nghmm_t* h, double* ind_lkl, bool have_walk) {
   return check_flags(h);
 }
 
+// Points whose value is not finite: the pattern kernels share one scale among the points of a
+// group and can overflow when a probe's likelihood is many orders away from point 0's; the
+// general kernel carries an exponent per point.  (By-products of an emitting round come from
+// point 0 alone and stay valid.)  Synchronous; lkl[] is patched in place.
+int redo_nonfinite(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
+                   const double* alpha, double* lkl) {
+  std::vector<uint32_t> bad, bind;
+  std::vector<double> bF, bA;
+  for (uint32_t p = 0; p < n_pts; ++p)
+    if (!std::isfinite(lkl[p])) {
+      bad.push_back(p);
+      bind.push_back(ind[p]);
+      bF.push_back(F[p]);
+      bA.push_back(alpha[p]);
+    }
+  if (bad.empty()) {
+    set_error("invalid Lkl found!");
+    return NGHMM_ERR_INVALID_LKL;
+  }
+  g_last_error.clear();
+  int rc;
+  if ((rc = ensure_points(h, bad.size()))) return rc;
+  if ((rc = clear_flags(h))) return rc;
+  if (!fast_lkl_prepare(h->fast, h->stream, (uint32_t)bad.size(), bind.data(), bF.data(),
+                        bA.data(), true) ||
+      !fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags, false)) {
+    set_error("objective re-evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+    return NGHMM_ERR_HIP;
+  }
+  std::vector<double> redo(bad.size());
+  HIP_TRY(hipMemcpyAsync(redo.data(), h->d_pt_lkl, bad.size() * sizeof(double),
+                         hipMemcpyDeviceToHost, h->stream));
+  rc = check_flags(h);
+  for (size_t k = 0; k < bad.size(); ++k) lkl[bad[k]] = redo[k];
+  h->lkl_redone += bad.size();
+  return rc;
+}
+
 int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
                    const double* alpha, double* lkl, bool accumulate, bool* emit_estep = nullptr) {
   if (n_pts == 0) return NGHMM_OK;
@@ -311,37 +365,96 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
   HIP_TRY(hipMemcpyAsync(lkl, h->d_pt_lkl, n_pts * sizeof(double), hipMemcpyDeviceToHost,
                          h->stream));
   rc = check_flags(h);
-  if (rc == NGHMM_ERR_INVALID_LKL && h->mode == NGHMM_MODE_FAST) {
-    // Points whose value is not finite: the pattern kernels share one scale among the points
-    // of a group and can overflow when a probe's likelihood is many orders away from point
-    // 0's; the general kernel carries an exponent per point.  (By-products of an emitting
-    // round come from point 0 alone and stay valid.)
-    std::vector<uint32_t> bad, bind;
-    std::vector<double> bF, bA;
-    for (uint32_t p = 0; p < n_pts; ++p)
-      if (!std::isfinite(lkl[p])) {
-        bad.push_back(p);
-        bind.push_back(ind[p]);
-        bF.push_back(F[p]);
-        bA.push_back(alpha[p]);
-      }
-    if (bad.empty()) return rc;
-    g_last_error.clear();
-    if ((rc = clear_flags(h))) return rc;
-    if (!fast_lkl_prepare(h->fast, h->stream, (uint32_t)bad.size(), bind.data(), bF.data(),
-                          bA.data(), true) ||
-        !fast_lkl_launch(h->fast, h->stream, h->d_pt_lkl, h->d_flags, false)) {
-      set_error("objective re-evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc == NGHMM_ERR_INVALID_LKL && h->mode == NGHMM_MODE_FAST)
+    rc = redo_nonfinite(h, n_pts, ind, F, alpha, lkl);
+  return rc;
+}
+
+// ---- the same evaluation, asynchronous, on one of the two lanes (fast mode) ----
+int lane_setup(nghmm_t* h, int k, size_t n) {
+  auto& L = h->lane[k];
+  int rc;
+  if (!L.ev0) {
+    const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
+    HIP_TRY(hipEventCreateWithFlags(&L.ev0, evf));
+    HIP_TRY(hipEventCreateWithFlags(&L.ev1, evf));
+    HIP_TRY(hipEventCreateWithFlags(&L.ev_done, evf | hipEventDisableTiming));
+    if ((rc = dev_alloc(&L.d_flags, (size_t)NFLAGS))) return rc;
+    HIP_TRY(hipHostMalloc((void**)&L.h_flags, NFLAGS * sizeof(int), hipHostMallocDefault));
+  }
+  if (n > L.cap) {
+    if (L.d_lkl) (void)hipFree(L.d_lkl);
+    L.d_lkl = nullptr;
+    L.cap = 0;
+    const size_t cap = n + n / 4 + 1024;
+    if ((rc = dev_alloc(&L.d_lkl, cap))) return rc;
+    L.cap = cap;
+  }
+  if (n > L.h_cap) {
+    if (L.h_lkl) (void)hipHostFree(L.h_lkl);
+    L.h_lkl = nullptr;
+    L.h_cap = 0;
+    const size_t cap = n + n / 4 + 1024;
+    HIP_TRY(hipHostMalloc((void**)&L.h_lkl, cap * sizeof(double), hipHostMallocDefault));
+    L.h_cap = cap;
+  }
+  return NGHMM_OK;
+}
+
+// enqueue lane k's points (L.ind / L.F / L.A); nothing waits here
+int lkl_submit(nghmm_t* h, int k) {
+  auto& L = h->lane[k];
+  const size_t n = L.ind.size();
+  int rc;
+  if ((rc = lane_setup(h, k, n))) return rc;
+  HIP_TRY(hipMemsetAsync(L.d_flags, 0, NFLAGS * sizeof(int), h->stream));
+  h->fast.cur_lane = k;
+  const bool ok = fast_lkl_prepare(h->fast, h->stream, (uint32_t)n, L.ind.data(), L.F.data(),
+                                   L.A.data());
+  if (ok) {
+    (void)hipEventRecord(L.ev0, h->stream);
+    if (!fast_lkl_launch(h->fast, h->stream, L.d_lkl, L.d_flags, false)) {
+      h->fast.cur_lane = 0;
+      set_error("fast_lkl_launch failed: %s", hipGetErrorString(hipGetLastError()));
       return NGHMM_ERR_HIP;
     }
-    std::vector<double> redo(bad.size());
-    HIP_TRY(hipMemcpyAsync(redo.data(), h->d_pt_lkl, bad.size() * sizeof(double),
-                           hipMemcpyDeviceToHost, h->stream));
-    rc = check_flags(h);
-    for (size_t k = 0; k < bad.size(); ++k) lkl[bad[k]] = redo[k];
-    h->lkl_redone += bad.size();
+    (void)hipEventRecord(L.ev1, h->stream);
   }
-  return rc;
+  h->fast.cur_lane = 0;
+  if (!ok) {
+    set_error("fast_lkl_prepare failed: %s", hipGetErrorString(hipGetLastError()));
+    return NGHMM_ERR_HIP;
+  }
+  HIP_TRY(hipMemcpyAsync(L.h_lkl, L.d_lkl, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(L.h_flags, L.d_flags, NFLAGS * sizeof(int), hipMemcpyDeviceToHost,
+                         h->stream));
+  HIP_TRY(hipEventRecord(L.ev_done, h->stream));
+  L.pending = true;
+  return NGHMM_OK;
+}
+
+// wait for lane k; its values are in L.h_lkl afterwards
+int lkl_wait(nghmm_t* h, int k) {
+  auto& L = h->lane[k];
+  HIP_TRY(hipEventSynchronize(L.ev_done));
+  L.pending = false;
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, L.ev0, L.ev1));
+  h->ms[SLOT_LKL] += ms;
+  h->launches[SLOT_LKL] += 1;
+  const int* f = L.h_flags;
+  if (f[FLAG_INVALID_LKL]) {
+    h->fast.cur_lane = k;  // the lane is idle: its descriptor buffers serve the re-evaluation
+    const int rc = redo_nonfinite(h, (uint32_t)L.ind.size(), L.ind.data(), L.F.data(),
+                                  L.A.data(), L.h_lkl);
+    h->fast.cur_lane = 0;
+    if (rc != NGHMM_OK) return rc;
+  }
+  if (f[FLAG_NAN]) {
+    set_error("value is NaN!");
+    return NGHMM_ERR_NAN;
+  }
+  return NGHMM_OK;
 }
 
 // Emissions from the current frequencies (calc_emission, shared/HMM.cpp:144-154).  Fast
@@ -493,6 +606,14 @@ int nghmm_destroy(nghmm_t* h) {
                  h->d_gl_shard, h->d_geno, h->d_text, h->d_codes_shard, h->d_uniform, h->d_stage,
                  h->d_stage8, h->g_send, h->g_recv, h->g_freq_own, h->g_freq_all};
   if (h->g_xstream) (void)hipStreamDestroy(h->g_xstream);
+  for (auto& L : h->lane) {
+    if (L.d_lkl) (void)hipFree(L.d_lkl);
+    if (L.d_flags) (void)hipFree(L.d_flags);
+    if (L.h_lkl) (void)hipHostFree(L.h_lkl);
+    if (L.h_flags) (void)hipHostFree(L.h_flags);
+    for (hipEvent_t e : {L.ev0, L.ev1, L.ev_done})
+      if (e) (void)hipEventDestroy(e);
+  }
   for (void* p : own)
     if (p) (void)hipFree(p);
   if (!h->parent) {
@@ -983,7 +1104,60 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   std::vector<uint32_t> ind;
   std::vector<double> F, A, lkl;
   bool estep_pending = fuse_estep;
+  // Fast mode, after the first round (which covers everyone and doubles as the E-step's
+  // forward walk): the individuals in two halves on two lanes.  While the GPU evaluates one
+  // half's points the host scatters the other half's values into its L-BFGS-B machines,
+  // gathers their next points and enqueues them, so the device does not wait for the host
+  // between rounds (EM.cpp:198-201 has no such coupling either: its tasks are independent).
+  // Worth it where a round is short against the host's share of it (100 x 100k: 1.36 -> 1.25
+  // ms per iteration); at 1000 x 1M two half launches lose to their emptier last wave batches
+  // what the overlap gains (37.4-38.4 against 36.9-37.9 ms): there the rounds stay whole.
+  const char* pl = std::getenv("NGHMM_PIPELINE");  // 0 / 1 force it off / on
+  const bool pipelined = h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
+                         (pl ? std::atoi(pl) != 0 : (uint64_t)h->I * h->fast.C < 16384);
+  bool first_round = true;
   while (!batch.done()) {
+    if (pipelined && !first_round) {
+      const uint64_t half = (h->I + 1) / 2;
+      h->lane[0].lo = 0;
+      h->lane[0].hi = half;
+      h->lane[1].lo = half;
+      h->lane[1].hi = h->I;
+      if ((rc = ensure_emissions(h))) return rc;
+      auto feed = [&](int k) -> int {  // lane k's next points, enqueued; nothing waits
+        auto& L = h->lane[k];
+        for (;;) {
+          auto t1 = now();
+          const size_t n = batch.gather(L.ind, L.F, L.A, L.lo, L.hi);
+          t_gather += since(t1);
+          if (n) {
+            t1 = now();
+            const int r = lkl_submit(h, k);
+            t_lkl += since(t1);
+            return r;
+          }
+          if (batch.active_in(L.lo, L.hi) == 0) return NGHMM_OK;
+          batch.scatter(L.h_lkl, L.lo, L.hi);  // only non-finite points this round: no launch
+        }
+      };
+      for (int k = 0; k < 2; ++k)
+        if ((rc = feed(k))) return rc;
+      while (h->lane[0].pending || h->lane[1].pending) {
+        for (int k = 0; k < 2; ++k) {
+          auto& L = h->lane[k];
+          if (!L.pending) continue;
+          auto t1 = now();
+          if ((rc = lkl_wait(h, k))) return rc;
+          t_lkl += since(t1);
+          t1 = now();
+          batch.scatter(L.h_lkl, L.lo, L.hi);
+          t_scatter += since(t1);
+          if ((rc = feed(k))) return rc;
+        }
+      }
+      break;
+    }
+    first_round = false;
     t0 = now();
     const size_t n = batch.gather(ind, F, A);
     lkl.resize(n);

@@ -27,9 +27,13 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 I_loc, S = 5, 240
 d = pkg.simulate.simulate(I_loc * world, S, seed=31, n_chrom=2, missing_rate=0.05)
-gl_all = pkg.simulate.normalise_log_gl(d.gl)
-gl_loc = np.ascontiguousarray(gl_all[:, rank * I_loc:(rank + 1) * I_loc, :])
+PACKED = os.environ.get("NGHMM_TEST_PACKED") == "1"
 orc = orclib.Oracle("libm")
+gl_all = orc.prepare_gl(d.gl, 0, call_geno=True) if PACKED else pkg.simulate.normalise_log_gl(d.gl)
+gl_loc = np.ascontiguousarray(gl_all[:, rank * I_loc:(rank + 1) * I_loc, :])
+# the four classes of a called genotype as the preparation leaves them (genotype 0, 1, 2, uniform)
+PROTO = orc.prepare_gl(np.array([[0, -1e15, -1e15], [-1e15, 0, -1e15], [-1e15, -1e15, 0],
+                                 [-1.0, -1.0, -1.0]]), 0, call_geno=True)
 
 
 class OracleBackend:
@@ -38,9 +42,22 @@ class OracleBackend:
         self.em = None
     def empty(self, *shape):
         return torch.empty(shape, dtype=torch.float64)
+    packed = PACKED
     def load_device(self, gl, pos):
         self.em = orclib.OracleEM(orc, gl.numpy(), pos.numpy())
         self.pos = pos.numpy()
+    def load_chunks_device(self, pos, chunks, space=0, call_geno=False):
+        raw = np.concatenate([c.numpy() for _, c in sorted(chunks, key=lambda t: t[0])])
+        self.gl = orc.prepare_gl(raw, space, call_geno=call_geno)
+        self.load_device(torch.from_numpy(self.gl), pos)
+    def geno_codes(self):
+        codes = np.full(self.gl.shape[:2], 255, dtype=np.uint8)
+        for k in range(4):
+            codes[(self.gl == PROTO[k]).all(axis=2)] = k
+        assert (codes < 4).all()
+        return torch.from_numpy(codes)
+    def load_geno_site_shard_device(self, codes):
+        self.gl_shard = PROTO[codes.numpy()]                     # [S_own][I_tot][3]
     def set_params(self, indF, alpha, freq):
         self.em.set_params(indF, alpha, freq)
     def init_emission(self):
@@ -70,7 +87,14 @@ class OracleBackend:
 
 be = OracleBackend()
 em = dd.ShardedEM(pkg, I_loc, S, rank=rank, world=world, backend=be)
-em.load_device(torch.from_numpy(gl_loc), torch.from_numpy(d.pos_dist_mb.copy()))
+if PACKED:   # chunked loading + the one-off exchange of genotype codes
+    raw_loc = np.ascontiguousarray(d.gl[:, rank * I_loc:(rank + 1) * I_loc, :])
+    cuts = [0, 7, 100, S]
+    em.load_chunks_device(torch.from_numpy(d.pos_dist_mb.copy()),
+                          [(lo, torch.from_numpy(raw_loc[lo:hi])) for lo, hi in zip(cuts[:-1], cuts[1:])],
+                          space=0, call_geno=True)
+else:
+    em.load_device(torch.from_numpy(gl_loc), torch.from_numpy(d.pos_dist_mb.copy()))
 em.set_params(0.1, 0.2, 0.1)
 em.init_emission()
 for _ in range(3):
@@ -81,12 +105,16 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_rank_sharded_em_equals_single_process(tmp_path, pkg, orc_libm):
+@pytest.mark.parametrize("packed", [False, True])
+def test_two_rank_sharded_em_equals_single_process(tmp_path, pkg, orc_libm, packed):
+    """packed: the called-genotype path -- chunked loading, site shards built from exchanged
+    genotype codes (ShardedEM.load_chunks_device / _exchange_code_shard)."""
     import orclib
     world = 2
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\nOUT = {str(tmp_path)!r}\n" + WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29612" if packed else "29611",
+               WORLD_SIZE=str(world), NGHMM_TEST_PACKED="1" if packed else "0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)))
              for r in range(world)]
     for p in procs:
@@ -94,7 +122,7 @@ def test_two_rank_sharded_em_equals_single_process(tmp_path, pkg, orc_libm):
 
     I_loc, S = 5, 240
     d = pkg.simulate.simulate(I_loc * world, S, seed=31, n_chrom=2, missing_rate=0.05)
-    gl = pkg.simulate.normalise_log_gl(d.gl)
+    gl = orc_libm.prepare_gl(d.gl, 0, call_geno=True) if packed else pkg.simulate.normalise_log_gl(d.gl)
     ref = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
     ref.set_params(0.1, 0.2, 0.1)
     ref.init_emission()
