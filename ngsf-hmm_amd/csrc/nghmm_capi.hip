@@ -95,6 +95,8 @@ struct nghmm_handle {
   uint32_t* d_codes = nullptr;        // [S][I] cells, 16 per word
   uint32_t* d_codes_shard = nullptr;  // [S_own][I_tot] cells of the frequency step's site range
   double* d_cls_log = nullptr;        // [4][3] prepared log likelihoods of the four classes
+  double h_cls_proto[12] = {0};       // ... as nghmm_create prepared them (row 3: the reader's
+                                      // missing genotype); a load starts from these
   unsigned long long* d_uniform = nullptr;  // the one value every uniform cell carries (~0: none yet)
   // chunked loading (nghmm_load_begin .. nghmm_load_end)
   uint64_t lkl_redone = 0;            // objective points re-evaluated by the general kernel
@@ -562,7 +564,9 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
       if (hipMemcpy(h->d_cls_log, proto, sizeof proto, hipMemcpyHostToDevice) != hipSuccess ||
           hipMemset(h->d_flags, 0, NFLAGS * sizeof(int)) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
       launch_prepare_gl(h->stream, h->d_cls_log, 4, NGHMM_GL_LOG, 0, h->d_flags);
-      if (sync_stream(h) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
+      if (hipMemcpyAsync(h->h_cls_proto, h->d_cls_log, sizeof h->h_cls_proto, hipMemcpyDeviceToHost,
+                         h->stream) != hipSuccess ||
+          sync_stream(h) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     } else {
       if ((rc = dev_alloc(&h->d_gl, cells * 3))) break;
       if ((rc = dev_alloc(&h->d_flags, (size_t)NFLAGS))) break;
@@ -816,6 +820,8 @@ int nghmm_load_begin(nghmm_t* h, const double* pos) {
   if (h->packed) {
     HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_cls_log, h->h_cls_proto, sizeof h->h_cls_proto,
+                           hipMemcpyHostToDevice, h->stream));  // an earlier load's uniform value
   }
   HIP_TRY(sync_stream(h));
   h->loaded = false;
@@ -832,6 +838,8 @@ static int load_begin_dev(nghmm_t* h, const double* d_pos) {
   if (h->packed) {
     HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_cls_log, h->h_cls_proto, sizeof h->h_cls_proto,
+                           hipMemcpyHostToDevice, h->stream));
   }
   h->loaded = false;
   h->loading = true;
