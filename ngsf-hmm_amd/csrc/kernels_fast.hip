@@ -1626,6 +1626,225 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   }
 }
 
+// Small cohorts: a 64-lane wave per site leaves most lanes empty below ~128 individuals and
+// pays the per-pass bookkeeping for one site only.  Here a wave holds FOUR sites, one per
+// 16-lane DPP row (individual i of the site in lane i % 16, slot i / 16; up to 16 NI = 128
+// individuals), and every reduction is the four in-row DPP steps, which leave the row's total
+// in all of its lanes -- no cross-lane reads, no LDS.  Same recursion, same interval logic,
+// same hand-over to k_fast_estmaf_interp as k_fast_estmaf; the rows of a wave run their own
+// sites independently (a row whose site is finished idles).
+__device__ __forceinline__ double row_sum(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror: every lane holds its 16-lane row total
+  return v;
+}
+
+template <int NI, bool TILE>
+__global__ void __launch_bounds__(64)
+k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint64_t S_own,
+                   uint64_t I_tot, uint64_t I_blk, uint64_t tile_T, double* __restrict__ freq_out,
+                   uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
+                   double* __restrict__ state, uint64_t state_stride, int fresh, int n_exact,
+                   int allow_build) {
+  static_assert(EN <= 16, "a row's lanes hold the interval's node sums");
+  const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
+  uint64_t site;
+  const double* tile_col = nullptr;
+  if constexpr (TILE) {
+    // as in k_fast_estmaf, XCD x gets the sites l = 8x..8x+7 of a tile row -- here in two
+    // consecutive workgroups of four sites each
+    const uint64_t b = blockIdx.x, x = b & 7, k = b >> 3;
+    const uint64_t q = ((k >> 1) << 6) + (x << 3) + ((k & 1) << 2) + row;
+    const uint64_t tile_row = q >> 6, l = q & 63;
+    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
+    site = (c * 64 + l) * tile_T + t;
+    if (site >= S_own) return;
+    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
+  } else {
+    site = (uint64_t)blockIdx.x * 4 + row;
+    if (site >= S_own) return;
+  }
+  if (!fresh && status[site] != EST_EXACT) return;
+  const uint64_t cell_s = site * I_tot;
+
+  double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
+  double tF_acc = 0;
+  {
+    const bool one_block = (I_blk == I_tot);
+    const uint32_t ib = (uint32_t)I_blk;
+    double r0[NI], r1[NI], r2[NI], rF[NI];
+    uint64_t ic[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const uint64_t i = (uint64_t)j + 16 * k;
+      ic[k] = i < I_tot ? i : I_tot - 1;
+      gl_fetch(gl, cell_s + ic[k], r0[k], r1[k], r2[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      if constexpr (TILE) {
+        rF[k] = tile_col[ic[k] * 64];
+      } else if (one_block) {
+        rF[k] = marg_blocks[site * I_blk + ic[k]];
+      } else {
+        const uint32_t q = (uint32_t)ic[k] / ib;
+        rF[k] = marg_blocks[((uint64_t)q * S_own + site) * I_blk + ((uint32_t)ic[k] - q * ib)];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const bool valid = (uint64_t)j + 16 * k < I_tot;
+      const double p0 = r0[k], p1 = r1[k], p2 = r2[k], F = rF[k];
+      const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
+      const double n2 = (2 - F) * p2;
+      sA[k] = valid ? p0 : 1.0;
+      sb[k] = valid ? fma(F, p0 + p2, cc) : 0.0;
+      sC[k] = valid ? p2 : 0.0;
+      u0[k] = valid ? fma(n2, F, cc) : 0.0;
+      nC[k] = valid ? n2 : 0.0;
+      fc[k] = valid ? F * cc : 0.0;
+      tF_acc += valid ? 2 - F : 0.0;
+    }
+  }
+  const double tF_sum = row_sum(tF_acc);
+
+  int iters = 0;
+  double num = 0, den = 0;
+  double pnum = 0.01, pden = 1.0;  // freq = 0.01 (gen_func.cpp:976)
+  if (!fresh) {
+    num = state[0 * state_stride + site];
+    den = state[1 * state_stride + site];
+    pnum = state[2 * state_stride + site];
+    pden = state[3 * state_stride + site];
+    iters = (int)state[4 * state_stride + site];
+  }
+  bool built = !allow_build;
+  int n_before = n_exact;
+  bool check = false, interp_ok = false;
+  double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;
+  auto lane_sums = [&](double r, double& pn, double& pd) {
+    pn = 0;
+    pd = 0;
+    if constexpr (NI >= 4) {
+#pragma unroll
+      for (int k0 = 0; k0 < NI; k0 += 4) {
+        double sm[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm[k] = fma(r, fma(r, sC[k0 + k], sb[k0 + k]), sA[k0 + k]);
+        const double p01 = sm[0] * sm[1], p23 = sm[2] * sm[3];
+        const double R = rcp_nr(p01 * p23);
+        const double r01 = R * p23, r23 = R * p01;
+        const double inv0 = r01 * sm[1], inv1 = r01 * sm[0];
+        const double inv2 = r23 * sm[3], inv3 = r23 * sm[2];
+        pn = fma(fma(nC[k0], r, u0[k0]), inv0, pn);
+        pd = fma(fc[k0], inv0, pd);
+        pn = fma(fma(nC[k0 + 1], r, u0[k0 + 1]), inv1, pn);
+        pd = fma(fc[k0 + 1], inv1, pd);
+        pn = fma(fma(nC[k0 + 2], r, u0[k0 + 2]), inv2, pn);
+        pd = fma(fc[k0 + 2], inv2, pd);
+        pn = fma(fma(nC[k0 + 3], r, u0[k0 + 3]), inv3, pn);
+        pd = fma(fc[k0 + 3], inv3, pd);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const double inv = rcp_nr(fma(r, fma(r, sC[k], sb[k]), sA[k]));
+        pn = fma(fma(nC[k], r, u0[k]), inv, pn);
+        pd = fma(fc[k], inv, pd);
+      }
+    }
+  };
+  for (;;) {
+    const double r = pnum * rcp_nr2(pden - pnum);
+    double pn, pd;
+    lane_sums(r, pn, pd);
+    const double sn = row_sum(pn), sd = row_sum(pd);
+    if (check) {  // the pass after a build: exact sums in hand, compare the interpolant
+      const int nj = j < EN ? j : 0;
+      const double t = (r - mid) / (r + mid) - half * kChebC[nj];
+      const double q = (j < EN) ? kChebW[nj] / t : 0.0;
+      const double Sq = row_sum(q);
+      const double bn = row_sum(q * my_gn) / Sq, bd = row_sum(q * my_gd) / Sq;
+      interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);
+      check = false;
+    }
+    num = fma(r, sn, num);
+    den = fma(r, sd, den + tF_sum);
+    const double lhs = fabs(fma(pnum, den, -(num * pden))), thr = kEPS * (den * pden);
+    const bool again = (lhs > thr) && (iters++ < 100);
+    rprev = r;
+    pnum = num;
+    pden = den;
+    if (!again) break;
+    if (interp_ok) {  // hand the site to k_fast_estmaf_interp
+      if (j < EN) {
+        state[(EST_SCALARS + j) * state_stride + site] = my_gn;
+        state[(EST_SCALARS + EN + j) * state_stride + site] = my_gd;
+      }
+      if (j == 0) {
+        state[0 * state_stride + site] = num;
+        state[1 * state_stride + site] = den;
+        state[2 * state_stride + site] = pnum;
+        state[3 * state_stride + site] = pden;
+        state[4 * state_stride + site] = (double)iters;
+        state[5 * state_stride + site] = mid;
+        state[6 * state_stride + site] = half;
+        state[7 * state_stride + site] = tF_sum;
+        status[site] = EST_INTERP;
+      }
+      return;
+    }
+    if (!built && --n_before <= 0) {  // see k_fast_estmaf for the reasoning
+      const double m_est = (double)iters * (sqrt(lhs / thr) - 1.0);
+      const double rn = pnum * rcp_nr2(pden - pnum);
+      const double step = fabs(rn - rprev);
+      const double reach = (rn >= rprev) ? EST_DMAX * rn : EST_DMAX / (1 + EST_DMAX) * rn;
+      const bool fits = (double)iters * step <= EST_FIT * reach;
+      if (!fits && iters < EST_KMAX && m_est >= EST_MIN_GAIN) {
+        n_before = 1;
+      } else {
+        built = true;
+      }
+      if (built && m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
+        const double g = fmin(EST_DMAX, fmax(EST_MULT * step / rn, 1e-3));
+        double lo, hi;
+        if (rn >= rprev) {
+          lo = rn * (1 - EST_BACK * g);
+          hi = rn * (1 + g);
+        } else {
+          lo = rn / (1 + g);
+          hi = rn * (1 + EST_BACK * g);
+        }
+        mid = sqrt(lo * hi);
+        half = (hi - mid) / (hi + mid);
+        if (half > 0 && lo > 0 && hi < 1e300) {
+#pragma unroll 1
+          for (int nd = 0; nd < EN; ++nd) {
+            const double tn = half * kChebC[nd];
+            double qn, qd;
+            lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), qn, qd);
+            const double gn = row_sum(qn), gd = row_sum(qd);
+            if (j == nd) {  // lane nd of the row keeps node nd
+              my_gn = gn;
+              my_gd = gd;
+            }
+          }
+          check = true;
+        }
+      }
+    }
+  }
+  if (j == 0) {
+    const double freq = num / den;
+    const bool ok = freq >= 0 && freq < 1;
+    freq_out[site] = freq;
+    redo[site] = ok ? 0 : 1;
+    status[site] = EST_DONE;
+  }
+}
+
 // The passes between a checked interval and either the end of the loop or the point
 // where exact evaluation is needed again: one lane per site, sums from the barycentric
 // formula on the 16 node values.
@@ -2186,7 +2405,28 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                      allow_build)
   int cfg_ni = 0, cfg_b = 0;
   if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
+#define LAUNCH_ROWS(N, TL)                                                                      \
+  hipLaunchKernelGGL((k_fast_estmaf_rows<N, TL>),                                                \
+                     dim3((unsigned)((TL) ? fs.Spad / 4 : (S_own + 3) / 4)), dim3(64), 0, st,    \
+                     d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out, fs.redo, \
+                     fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact, allow_build)
+  // up to 128 individuals: four sites per wave (k_fast_estmaf_rows)
+  const bool rows = I_tot <= 128 && !cfg_ni && !std::getenv("NGHMM_ESTMAF_NO_ROWS");
   auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
+    if (rows) {
+      if (tile_major) {
+        if (I_tot <= 16) LAUNCH_ROWS(1, true);
+        else if (I_tot <= 32) LAUNCH_ROWS(2, true);
+        else if (I_tot <= 64) LAUNCH_ROWS(4, true);
+        else LAUNCH_ROWS(8, true);
+      } else {
+        if (I_tot <= 16) LAUNCH_ROWS(1, false);
+        else if (I_tot <= 32) LAUNCH_ROWS(2, false);
+        else if (I_tot <= 64) LAUNCH_ROWS(4, false);
+        else LAUNCH_ROWS(8, false);
+      }
+      return true;
+    }
     if (tile_major) {
       if (I_tot <= 64) LAUNCH_TILE(1, 64);
       else if (I_tot <= 128) LAUNCH_TILE(2, 64);
@@ -2239,6 +2479,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                      I_tot, I_blk, tile_T, d_freq_out, redo);
 #undef LAUNCH_NI
 #undef LAUNCH_TILE
+#undef LAUNCH_ROWS
   return hipGetLastError() == hipSuccess;
 }
 
