@@ -2163,7 +2163,7 @@ bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq,
 // Recognise the finite-difference pattern of one objective + gradient evaluation
 // (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
 // close enough for exp_small4 on every finite distance of this data set.
-static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T) {
+static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits) {
   if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
   int nf = 0, na = 0;
   for (uint32_t p = 1; p < G.np; ++p) {
@@ -2172,10 +2172,13 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T) {
       // The pattern kernel rescales all points by point 0's exponent.  A site that forces
       // the non-IBD state (a called heterozygote: e1 = 0) multiplies an F probe's operator by
       // rho0 = (1 - F_p) / (1 - F_0) relative to point 0's; with F_0 at its upper bound that
-      // is ~1e10 per such site and would overflow within a lane-chunk.  Keep rho0^T inside
-      // the double range, else the general kernel (an exponent per point) takes the group.
+      // is ~1e10 per such site and would overflow within a lane-chunk.  For called genotypes
+      // (packed handles: such sites exist by construction) keep rho0^T inside the double
+      // range, else the general kernel (an exponent per point) takes the group.  Likelihood
+      // data have no forced visits; should a probe overflow there all the same, its value
+      // comes back non-finite and the host re-evaluates it with the general kernel.
       const double rho0 = (1 - G.F[p]) / (1 - G.F[0]);
-      if (!(std::fabs(std::log(rho0)) * (double)T <= 600.0)) return 0;
+      if (forced_visits && !(std::fabs(std::log(rho0)) * (double)T <= 600.0)) return 0;
       ++nf;
     } else if (G.F[p] == G.F[0] && std::fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
       ++na;
@@ -2215,7 +2218,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T);
+    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed);
     groups.push_back(G);
   }
   // one kernel per loop-body version: sort the groups by mode (stable, so still in
