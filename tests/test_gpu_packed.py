@@ -307,3 +307,41 @@ def test_config5_shape_at_one_gpu_share(pkg):
     ms = {k: h.kernel_ms(k)[0] for k in ("lkl_batch", "forward", "est_maf")}
     print("config 5 share, one EM iteration kernels (ms):", ms)
     h.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 70), (3, 17), (5, 33), (17, 1000), (70, 515)])
+def test_packed_ragged_shapes(pkg, orc_det, orc_libm, shape):
+    """Sizes that are not multiples of anything (16 cells per code word, 16 sites per
+    interleaved word, 64 lanes, 8-site blocks): a packed handle against the oracle, exact mode
+    bit for bit and fast mode per call, one whole iteration + decoding."""
+    Ir, Sr = shape
+    d = pkg.simulate.simulate(Ir, Sr, seed=Ir * 1000 + Sr, missing_rate=0.1,
+                              n_chrom=2 if Sr > 10 else 1, freq=0.3)
+    gl = orc_det.prepare_gl(d.gl, 0, call_geno=True)
+    for mode, orc in ((pkg.MODE_EXACT, orc_det), (pkg.MODE_FAST, orc_libm)):
+        em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
+        em.set_params(0.2, 0.3, 0.25)
+        assert em.init_emission() == 0 and em.estep() == 0
+        with pkg.NgsFHMM(Ir, Sr, mode=mode | pkg.GENO_PACKED) as h:
+            h.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=True)
+            assert np.array_equal(h.gl, gl)
+            h.set_params(0.2, 0.3, 0.25)
+            h.init_emission()
+            lk = h.estep().copy()
+            if mode == pkg.MODE_EXACT:
+                assert np.array_equal(lk, em.ind_lkl) and np.array_equal(h.marg_prob, em.marg)
+                assert em.mstep_indf() == 0 and em.mstep_freq(1) == 0
+                h.mstep_indf()
+                h.mstep_freq(1)
+                assert np.array_equal(h.indF, em.indF) and np.array_equal(h.freq, em.freq)
+                assert np.array_equal(h.viterbi(), em.viterbi())
+            else:
+                np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-11)
+                np.testing.assert_allclose(h.marg_prob, em.marg, rtol=1e-9, atol=1e-12)
+                assert em.mstep_freq(1) == 0
+                h.mstep_freq(1)
+                np.testing.assert_allclose(h.freq, em.freq, rtol=1e-9)
+                st = h.mstep_indf()
+                assert st.rounds >= 1 and np.isfinite(h.indF).all()
+                h.iter_EM()                                  # the fused walk on the codes
+                assert np.isfinite(h.ind_lkl).all()
