@@ -1633,11 +1633,18 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
 // in all of its lanes -- no cross-lane reads, no LDS.  Same recursion, same interval logic,
 // same hand-over to k_fast_estmaf_interp as k_fast_estmaf; the rows of a wave run their own
 // sites independently (a row whose site is finished idles).
+// The lanes of a row take their decisions (stop, hand over, build) each for itself from these
+// totals, so the totals must be the SAME BITS in all 16 lanes: every step adds the two
+// partners' values, a + b in one lane and b + a in the other.  That only holds for plain
+// additions -- were the first one contracted with a multiplication that produced the argument
+// (fma(x, y, partner's rounded x'y') here, fma(x', y', rounded xy) there) the partners would
+// differ in the last bit, and a row's lanes would part ways at a threshold.  __dadd_rn is
+// never contracted.
 __device__ __forceinline__ double row_sum(double v) {
-  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_move<0x141>(v);  // row_half_mirror
-  v += dpp_move<0x140>(v);  // row_mirror: every lane holds its 16-lane row total
+  v = __dadd_rn(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = __dadd_rn(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = __dadd_rn(v, dpp_move<0x141>(v));  // row_half_mirror
+  v = __dadd_rn(v, dpp_move<0x140>(v));  // row_mirror: every lane holds its 16-lane row total
   return v;
 }
 
@@ -1649,6 +1656,10 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
                    double* __restrict__ state, uint64_t state_stride, int fresh, int n_exact,
                    int allow_build) {
   static_assert(EN <= 16, "a row's lanes hold the interval's node sums");
+  // Control flow is kept WAVE-UNIFORM: the rows of a wave are at different points of their
+  // recursions (one hands its site over while another still needs exact passes), but every
+  // DPP reduction runs with all 64 lanes enabled -- a finished row computes along on its stale
+  // values and ignores the results -- and the per-row decisions are applied under `!done`.
   const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
   uint64_t site;
   const double* tile_col = nullptr;
@@ -1660,13 +1671,17 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
     const uint64_t tile_row = q >> 6, l = q & 63;
     const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
     site = (c * 64 + l) * tile_T + t;
-    if (site >= S_own) return;
     tile_col = marg_blocks + tile_row * I_tot * 64 + l;
   } else {
     site = (uint64_t)blockIdx.x * 4 + row;
-    if (site >= S_own) return;
   }
-  if (!fresh && status[site] != EST_EXACT) return;
+  bool done = site >= S_own;          // padding of the layout / past the end
+  if (done) {                         // read something valid, write nothing
+    site = 0;
+    if constexpr (TILE) tile_col = marg_blocks;
+  }
+  if (!done && !fresh && status[site] != EST_EXACT) done = true;
+  if (__builtin_amdgcn_ballot_w64(!done) == 0) return;  // nothing to do in this wave
   const uint64_t cell_s = site * I_tot;
 
   double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
@@ -1713,7 +1728,7 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
   int iters = 0;
   double num = 0, den = 0;
   double pnum = 0.01, pden = 1.0;  // freq = 0.01 (gen_func.cpp:976)
-  if (!fresh) {
+  if (!fresh && !done) {
     num = state[0 * state_stride + site];
     den = state[1 * state_stride + site];
     pnum = state[2 * state_stride + site];
@@ -1722,8 +1737,8 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
   }
   bool built = !allow_build;
   int n_before = n_exact;
-  bool check = false, interp_ok = false;
-  double mid = 0, half = 0, my_gn = 0, my_gd = 0, rprev = 0;
+  bool check = false;
+  double mid = 1, half = 0.5, my_gn = 0, my_gd = 0, rprev = 0;
   auto lane_sums = [&](double r, double& pn, double& pd) {
     pn = 0;
     pd = 0;
@@ -1757,91 +1772,106 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
     }
   };
   for (;;) {
+    // ---- one exact pass of every row (all lanes) ----
     const double r = pnum * rcp_nr2(pden - pnum);
     double pn, pd;
     lane_sums(r, pn, pd);
     const double sn = row_sum(pn), sd = row_sum(pd);
-    if (check) {  // the pass after a build: exact sums in hand, compare the interpolant
+    bool interp_ok = false;
+    if (__builtin_amdgcn_ballot_w64(check && !done) != 0) {
+      // the pass after a build: exact sums in hand, compare the interpolant (rows that did
+      // not just build compute along and ignore the outcome)
       const int nj = j < EN ? j : 0;
       const double t = (r - mid) / (r + mid) - half * kChebC[nj];
       const double q = (j < EN) ? kChebW[nj] / t : 0.0;
       const double Sq = row_sum(q);
       const double bn = row_sum(q * my_gn) / Sq, bd = row_sum(q * my_gd) / Sq;
-      interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);
+      if (check && !done)
+        interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);
       check = false;
     }
-    num = fma(r, sn, num);
-    den = fma(r, sd, den + tF_sum);
-    const double lhs = fabs(fma(pnum, den, -(num * pden))), thr = kEPS * (den * pden);
-    const bool again = (lhs > thr) && (iters++ < 100);
-    rprev = r;
-    pnum = num;
-    pden = den;
-    if (!again) break;
-    if (interp_ok) {  // hand the site to k_fast_estmaf_interp
-      if (j < EN) {
-        state[(EST_SCALARS + j) * state_stride + site] = my_gn;
-        state[(EST_SCALARS + EN + j) * state_stride + site] = my_gd;
-      }
-      if (j == 0) {
-        state[0 * state_stride + site] = num;
-        state[1 * state_stride + site] = den;
-        state[2 * state_stride + site] = pnum;
-        state[3 * state_stride + site] = pden;
-        state[4 * state_stride + site] = (double)iters;
-        state[5 * state_stride + site] = mid;
-        state[6 * state_stride + site] = half;
-        state[7 * state_stride + site] = tF_sum;
-        status[site] = EST_INTERP;
-      }
-      return;
-    }
-    if (!built && --n_before <= 0) {  // see k_fast_estmaf for the reasoning
-      const double m_est = (double)iters * (sqrt(lhs / thr) - 1.0);
-      const double rn = pnum * rcp_nr2(pden - pnum);
-      const double step = fabs(rn - rprev);
-      const double reach = (rn >= rprev) ? EST_DMAX * rn : EST_DMAX / (1 + EST_DMAX) * rn;
-      const bool fits = (double)iters * step <= EST_FIT * reach;
-      if (!fits && iters < EST_KMAX && m_est >= EST_MIN_GAIN) {
-        n_before = 1;
-      } else {
-        built = true;
-      }
-      if (built && m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
-        const double g = fmin(EST_DMAX, fmax(EST_MULT * step / rn, 1e-3));
-        double lo, hi;
-        if (rn >= rprev) {
-          lo = rn * (1 - EST_BACK * g);
-          hi = rn * (1 + g);
+    // ---- the recursion and the row's decisions ----
+    bool want_build = false;
+    if (!done) {
+      num = fma(r, sn, num);
+      den = fma(r, sd, den + tF_sum);
+      const double lhs = fabs(fma(pnum, den, -(num * pden))), thr = kEPS * (den * pden);
+      const bool again = (lhs > thr) && (iters++ < 100);
+      rprev = r;
+      pnum = num;
+      pden = den;
+      if (!again) {
+        if (j == 0) {
+          const double freq = num / den;
+          const bool ok = freq >= 0 && freq < 1;
+          freq_out[site] = freq;
+          redo[site] = ok ? 0 : 1;
+          status[site] = EST_DONE;
+        }
+        done = true;
+      } else if (interp_ok) {  // hand the site to k_fast_estmaf_interp
+        if (j < EN) {
+          state[(EST_SCALARS + j) * state_stride + site] = my_gn;
+          state[(EST_SCALARS + EN + j) * state_stride + site] = my_gd;
+        }
+        if (j == 0) {
+          state[0 * state_stride + site] = num;
+          state[1 * state_stride + site] = den;
+          state[2 * state_stride + site] = pnum;
+          state[3 * state_stride + site] = pden;
+          state[4 * state_stride + site] = (double)iters;
+          state[5 * state_stride + site] = mid;
+          state[6 * state_stride + site] = half;
+          state[7 * state_stride + site] = tF_sum;
+          status[site] = EST_INTERP;
+        }
+        done = true;
+      } else if (!built && --n_before <= 0) {  // see k_fast_estmaf for the reasoning
+        const double m_est = (double)iters * (sqrt(lhs / thr) - 1.0);
+        const double rn = pnum * rcp_nr2(pden - pnum);
+        const double step = fabs(rn - rprev);
+        const double reach = (rn >= rprev) ? EST_DMAX * rn : EST_DMAX / (1 + EST_DMAX) * rn;
+        const bool fits = (double)iters * step <= EST_FIT * reach;
+        if (!fits && iters < EST_KMAX && m_est >= EST_MIN_GAIN) {
+          n_before = 1;
         } else {
-          lo = rn / (1 + g);
-          hi = rn * (1 + EST_BACK * g);
+          built = true;
         }
-        mid = sqrt(lo * hi);
-        half = (hi - mid) / (hi + mid);
-        if (half > 0 && lo > 0 && hi < 1e300) {
-#pragma unroll 1
-          for (int nd = 0; nd < EN; ++nd) {
-            const double tn = half * kChebC[nd];
-            double qn, qd;
-            lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), qn, qd);
-            const double gn = row_sum(qn), gd = row_sum(qd);
-            if (j == nd) {  // lane nd of the row keeps node nd
-              my_gn = gn;
-              my_gd = gd;
-            }
+        if (built && m_est >= EST_MIN_GAIN && 100 - iters >= EST_MIN_GAIN) {
+          const double g = fmin(EST_DMAX, fmax(EST_MULT * step / rn, 1e-3));
+          double lo, hi;
+          if (rn >= rprev) {
+            lo = rn * (1 - EST_BACK * g);
+            hi = rn * (1 + g);
+          } else {
+            lo = rn / (1 + g);
+            hi = rn * (1 + EST_BACK * g);
           }
-          check = true;
+          const double a = sqrt(lo * hi), h = (hi - a) / (hi + a);
+          if (h > 0 && lo > 0 && hi < 1e300) {
+            mid = a;
+            half = h;
+            want_build = true;
+          }
         }
       }
     }
-  }
-  if (j == 0) {
-    const double freq = num / den;
-    const bool ok = freq >= 0 && freq < 1;
-    freq_out[site] = freq;
-    redo[site] = ok ? 0 : 1;
-    status[site] = EST_DONE;
+    // ---- the interval's node sums, for the rows that build (all lanes compute) ----
+    if (__builtin_amdgcn_ballot_w64(want_build) != 0) {
+#pragma unroll 1
+      for (int nd = 0; nd < EN; ++nd) {
+        const double tn = half * kChebC[nd];
+        double qn, qd;
+        lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), qn, qd);
+        const double gn = row_sum(qn), gd = row_sum(qd);
+        if (want_build && j == nd) {  // lane nd of the row keeps node nd
+          my_gn = gn;
+          my_gd = gd;
+        }
+      }
+      if (want_build) check = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
   }
 }
 
