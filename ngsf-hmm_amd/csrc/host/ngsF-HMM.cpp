@@ -205,6 +205,7 @@ int load_geno(Params& P, Cohort& C, bool packed) {
   if (!fh) fatal(__FUNCTION__, "cannot open GENO file!");
   gzbuffer(fh, 1 << 20);
   uint64_t block = (64ull << 20) / (I * 24);  // sites per block: about 64 MB of likelihoods
+  if (const char* env = getenv("NGHMM_HOST_BLOCK_SITES")) block = strtoull(env, nullptr, 10);  // tests
   if (block < 1) block = 1;
   if (block > S) block = S;
   int rc = NGHMM_OK;

@@ -73,3 +73,51 @@ def test_taus_known_answer(binary):
         for _ in range(n):
             v = t.next()
         assert cli(seed, n) == v
+
+
+def test_host_under_address_sanitizer(pkg, tmp_path):
+    """The C++ host built with -fsanitize=address,undefined against tests/stub/nghmm_stub.cpp
+    (a stand-in that checks arguments and touches every byte it is handed, computing nothing):
+    block readers for every input type, the column split of --n_gpus, the packed fall-back on
+    an empty line, output batching, multi-start threads.  GPU AddressSanitizer is not
+    available on this pool; this covers the host side of the boundary."""
+    import gzip
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "ngsf-hmm_amd", "csrc", "host", "ngsF-HMM.cpp")
+    stub = os.path.join(root, "tests", "stub", "nghmm_stub.cpp")
+    exe = str(tmp_path / "ngsF-HMM_asan")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=undefined", host, stub, "-o", exe, "-lz", "-lpthread"],
+                   check=True)
+    I, S = 6, 522          # divisible by 2 and 3 (--n_gpus), by nothing a block size is
+    d = pkg.simulate.simulate(I, S, seed=3, n_chrom=3, missing_rate=0.1)
+    p = cli_util.write_inputs(str(tmp_path), d, d.gl)
+    lines = gzip.open(p["geno_gz"], "rt").read().split("\n")[:S]
+    lines[100] = ""
+    hole = str(tmp_path / "hole.geno.gz")
+    with gzip.open(hole, "wt") as fh:
+        fh.write("\n".join(lines) + "\n")
+    # 37 sites per block: 14 full blocks and a last one of 4 sites
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", OMP_NUM_THREADS="2",
+               NGHMM_HOST_BLOCK_SITES="37")
+    base = ["--pos", p["pos_gz"], "--n_ind", I, "--n_sites", S, "--min_iters", 2, "--max_iters", 4,
+            "--verbose", 2]
+    runs = [
+        ["--geno", p["glf_gz"], "--loglkl", "--freq", 0.1, "--indF", "0.1,0.2"],
+        ["--geno", p["glf_bin"], "--loglkl", "--call_geno", "--freq", "r", "--indF", "r", "--log", 1],
+        ["--geno", p["beagle_gz"], "--lkl", "--freq", 0.1],
+        ["--geno", p["geno_gz"], "--freq", 0.1, "--n_gpus", 2, "--devices", "0,0", "--mode", "fast"],
+        ["--geno", p["glf_bin"], "--loglkl", "--freq", "e", "--n_gpus", 3, "--devices", "0,0,0"],
+        ["--geno", hole, "--freq", 0.1],                                  # falls back to likelihoods
+        ["--geno", p["glf_gz"], "--loglkl", "--freq", "r", "--indF", "r", "--n_starts", 3,
+         "--keep_starts", "--seed", 4],
+        ["--geno", p["geno_gz"], "--no_pack", "--freq", 0.2, "--indF", "0.5,0.01", "--indF_fixed"],
+    ]
+    for k, extra in enumerate(runs):
+        out = str(tmp_path / f"asan_{k}")
+        r = subprocess.run([exe] + [str(a) for a in base + extra + ["--out", out]], env=env,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (extra, r.stderr[-3000:])
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        assert os.path.getsize(out + ".ibd") > 0 and os.path.getsize(out + ".geno") == S * I * 24
