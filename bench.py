@@ -44,7 +44,7 @@ WORKLOADS = {
                name="100 ind x 100k sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
                     "--freq 0.1 --indF 0.1,0.2"),
     "tiny": dict(n_ind=64, n_sites=20_000, name="64 ind x 20k sites (smoke)"),
-    # BASELINE.json configs[4]: needs 8 GPUs (625 individuals x 5M sites each, 29 B per cell
+    # BASELINE.json configs[4]: needs 8 GPUs (625 individuals x 5M sites each, 21 B per cell
     # packed); c5share is exactly one GPU's share of it, without the exchange
     "c5": dict(n_ind=5000, n_sites=5_000_000, n_chrom=25, call_geno=True,
                name="5000 ind x 5M sites, 25 chromosomes, --call_geno (2-bit packed), "
@@ -64,12 +64,12 @@ LIMITER_NOTES = {
                "per site; ~21 of them are evaluated over in-register data, the rest on a checked "
                "Chebyshev interpolant of the per-pass sums (DESIGN.md section 4)",
     "lkl_batch": "objective rounds of the L-BFGS-B M-step.  Round 1 of an iteration is also the "
-                 "E-step's forward walk and the emission refresh (24 B GL read, 16 B emissions + "
-                 "4 B checkpoints written per site and individual: HBM-bound, ~5.5 TB/s); later "
-                 "rounds read 16 B per site and still-active individual and are FP64-VALU-issue "
-                 "bound (~92 instructions per site for 5 probe points)",
+                 "E-step's forward walk and the emission refresh (24 B GL read, 8 B emission ratio "
+                 "+ 4 B checkpoints written per site and individual: HBM-bound, ~5.4 TB/s); later "
+                 "rounds read 8 B per site and still-active individual and are FP64-VALU-issue "
+                 "bound (~90 instructions per site for 5 probe points)",
     "forward": "E-step after the shared forward walk: boundary vectors + backward sweep with "
-               "block-wise forward recomputation (16 B emissions + 4 B checkpoints read, 8 B "
+               "block-wise forward recomputation (8 B emission ratio + 4 B checkpoints read, 8 B "
                "posteriors written)",
 }
 
@@ -359,18 +359,18 @@ def main():
         # dominant kernel family by measured time, and its algorithmic traffic per launch
         # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
         # fast mode: the first objective round of an iteration (all I individuals) reads the
-        # 24 B GL and writes 16 B emissions + 4 B checkpoints; later rounds read 16 B per
-        # still-active individual; the E-step then reads 16 + 4 B and writes 8 B
+        # 24 B GL and writes the 8 B emission ratio + 4 B checkpoints; later rounds read 8 B per
+        # still-active individual; the E-step then reads 8 + 4 B and writes 8 B
         fast = args.mode == "fast"
         glb = 0.25 if call_geno else 24.0     # bytes of genotype likelihoods per cell
         algo = {
-            "lkl_batch": (((glb + 20.0) * S * I * K + 16.0 * S * max(ind_rounds - I * K, 0)) if fast
+            "lkl_batch": (((glb + 12.0) * S * I * K + 8.0 * S * max(ind_rounds - I * K, 0)) if fast
                           else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
             "est_maf": (glb + 8.0) * (S / world) * I_tot,   # S/N own sites x all individuals per rank
-            "forward": (28.0 if fast else 40.0) * S * I,
+            "forward": (20.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
             "emission": (8.0 * S if fast else (glb + 16.0) * S * I),
-            "lkl_first": (glb + 20.0) * S * I,
+            "lkl_first": (glb + 12.0) * S * I,
         }
         dom = max((k for k in fam if k != "lkl_first"), key=lambda k: fam[k])
         avg_ms = fam[dom] / max(launches[dom], 1)
@@ -391,14 +391,14 @@ def main():
         if fast and launches["lkl_first"] and fam["lkl_batch"] > fam["lkl_first"] > 0:
             later_ms = fam["lkl_batch"] - fam["lkl_first"]
             later_ind_rounds = max(ind_rounds - I * launches["lkl_first"], 0)
-            winstr = 91.5 * S * later_ind_rounds / 64.0       # per site
+            winstr = 89.5 * S * later_ind_rounds / 64.0       # per site
             fam_roof["lkl_later_rounds"] = {
-                "achieved_GBps": 16.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9,
-                "frac": 16.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "achieved_GBps": 8.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9,
+                "frac": 8.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "ms_per_em_iteration": later_ms / K,
                 "fp64_issue": {"wave_instr_per_s": winstr / (later_ms * 1e-3), "peak": fp64_peak,
                                "frac": winstr / (later_ms * 1e-3) / fp64_peak,
-                               "instr_per_site": 91.5}}
+                               "instr_per_site": 89.5}}
             if "est_maf" in fam_roof:
                 # per site: 17 evaluations (2 exact passes, 14 interval nodes, the check) of
                 # 8.06 instructions per individual + ~45, and ~22 per individual to set up

@@ -21,9 +21,14 @@
 //    (c*64 + lane)*T + t.  Every load of the main loops is one contiguous
 //    1 KiB (double2 emissions) or 512 B segment per wave-instruction.
 //
-//  * MATERIALISED emissions (16 B per site-individual) rather than recomputing them
-//    from the 24 B genotype likelihoods in every pass of an iteration; they are
-//    refreshed by the first forward walk after a frequency update, on its way.
+//  * MATERIALISED emission RATIOS (8 B per site-individual) rather than recomputing the
+//    emissions from the 24 B genotype likelihoods in every pass of an iteration.  Scaling both
+//    emissions of a site by a common factor changes neither posteriors nor paths and adds
+//    the factor's log to the likelihood, whatever (indF, alpha) are: with
+//      rho_s = e1_s / e0_s,   base = sum_s log e0_s
+//    every walk runs on the emissions (1, rho_s) and the likelihood is base + the walk's
+//    result.  rho and base are refreshed by the first forward walk after a frequency
+//    update, on its way; base is one number per wave (individual, chunk).
 //
 //  * the <= 5 probe points of one individual's finite-difference gradient
 //    (shared/bfgs.cpp:22-43) share ONE pass over that individual's emissions, in a
@@ -145,6 +150,13 @@ __device__ __forceinline__ void op_step(Op& m, double ce0, double ce1, double g0
   m.a11 = fma(g1, s1, ce1 * m.a11);
 }
 
+// sum over the wave in a fixed (butterfly) order: the same bits in every lane and every run
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 __device__ __forceinline__ double coanc(double alpha, double d) {
   // exp(-alpha d): 0 at chromosome starts (d = +inf), 1 on padding sites (d = 0)
   return exp_nonpos(-alpha * d);
@@ -215,40 +227,66 @@ __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small) {
   return FD_FLAG | (small ? FD_SMALL : 0u) | ((uint32_t)nf << 2) | (uint32_t)na;
 }
 
-// Where a forward walk gets its per-site inputs from.  Plain: the materialised linear
-// emissions e_il.  Fresh: the first walk after an allele-frequency update computes the
+// Where a forward walk gets its per-site inputs from.  Plain: the materialised emission
+// ratios e_il.  Fresh: the first walk after an allele-frequency update computes the
 // emissions itself from the interleaved linear genotype likelihoods and the new
 // frequencies (calc_emission, shared/HMM.cpp:144-154, in linear space: e_k = sum_g p_g
-// HWE_g(f, F = k)) and WRITES e_il for every later pass -- the separate refresh pass
-// (24 B read + 16 B written per site and individual) disappears into a kernel that is
+// HWE_g(f, F = k)) and WRITES their ratio to e_il for every later pass (and the sum of
+// log e0 to base_c) -- the separate refresh pass
+// (24 B read + 8 B written per site and individual) disappears into a kernel that is
 // FP64-bound anyway.
 struct LklArrays {
-  const double2* __restrict__ e_il;
+  const double* __restrict__ e_il;      // emission ratios rho = e1 / e0
   const double* __restrict__ pos_il;
   const double2* __restrict__ gl02_il;  // (p0, p2)
   const double* __restrict__ gl1_il;    // p1
   const double* __restrict__ freq_il;
-  double2* __restrict__ e_out;          // == e_il, written by the fresh walk
+  double* __restrict__ e_out;           // == e_il, written by the fresh walk
   const uint32_t* __restrict__ geno_il; // packed handle: 2-bit codes, 16 sites of a lane per word
   double u_lin;                         // packed handle: linear likelihood of a uniform cell
+  double* __restrict__ base_c;          // [I][C]: sum of log e0 over the wave's sites (see top)
 };
 
+// Running product of the e0 of a lane's sites (fresh walks): one multiply per site, the
+// exponent taken out every RENORM sites -- e0 >= freq^2 or (1 - freq)^2 times the largest
+// likelihood of the cell, so eight factors stay far inside the double range.
+struct BaseAcc {
+  double P = 1.0;
+  int ex = 0;
+  __device__ __forceinline__ void mul(double e0) { P *= e0; }
+  __device__ __forceinline__ void rescale() {
+    const int e = exp_of(P);
+    P = __builtin_ldexp(P, -e);
+    ex += e;
+  }
+  // log of the product; -inf when a site has no probability mass (e0 = 0), NaN for NaN
+  __device__ __forceinline__ double log_value() const {
+    return log(P) + (double)ex * 0.6931471805599453094;
+  }
+};
+
+// emissions of one cell -> the ratio the walks run on; e0 = 0 (no mass) gives inf or NaN,
+// which ends as a non-finite likelihood like the zero emissions themselves would
+__device__ __forceinline__ double emission_ratio(double e0, double e1) {
+  return e1 * rcp_nr2(e0);
+}
+
+// Every source hands a site to the walk as (rho, d): the emissions are (1, rho).
 struct SrcPlain {
-  const double2* __restrict__ ep;
+  const double* __restrict__ ep;
   const double* __restrict__ dp;
   struct Buf {
-    double2 e;
+    double r;
     double d;
   };
   __device__ __forceinline__ SrcPlain(const LklArrays& A, uint64_t wave_base, uint64_t pos_base)
       : ep(A.e_il + wave_base), dp(A.pos_il + pos_base) {}
   __device__ __forceinline__ Buf load(uint64_t t) const { return Buf{ep[t * 64], dp[t * 64]}; }
-  __device__ __forceinline__ void get(const Buf& b, uint64_t, double& e0, double& e1,
-                                      double& d) const {
-    e0 = b.e.x;
-    e1 = b.e.y;
+  __device__ __forceinline__ void get(const Buf& b, uint64_t, double& rho, double& d) {
+    rho = b.r;
     d = b.d;
   }
+  __device__ __forceinline__ void rescale() {}
 };
 
 struct SrcFresh {
@@ -256,7 +294,8 @@ struct SrcFresh {
   const double* __restrict__ g1;
   const double* __restrict__ fp;
   const double* __restrict__ dp;
-  double2* __restrict__ eo;
+  double* __restrict__ eo;
+  BaseAcc base;
   struct Buf {
     double2 p02;
     double p1, f, d;
@@ -267,17 +306,20 @@ struct SrcFresh {
   __device__ __forceinline__ Buf load(uint64_t t) const {
     return Buf{g02[t * 64], g1[t * 64], fp[t * 64], dp[t * 64]};
   }
-  __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& e0, double& e1,
-                                      double& d) const {
-    // calc_HWE (gen_func.cpp:938-957) for F = 0 and F = 1, as in k_fast_emission
+  __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& rho, double& d) {
+    // calc_HWE (gen_func.cpp:938-957) for F = 0 and F = 1; with F = 1 the heterozygote
+    // weight is exp(-1e15) = 0
     const double maf = b.f, om = 1 - maf;
     const double bb = om * maf;
     const double h00 = om * om, h02 = maf * maf;
-    e0 = fma(b.p02.x, h00, fma(b.p1, 2 * bb, b.p02.y * h02));
-    e1 = fma(b.p02.x, h00 + bb, b.p02.y * (h02 + bb));
+    const double e0 = fma(b.p02.x, h00, fma(b.p1, 2 * bb, b.p02.y * h02));
+    const double e1 = fma(b.p02.x, h00 + bb, b.p02.y * (h02 + bb));
+    base.mul(e0);
+    rho = emission_ratio(e0, e1);
     d = b.d;
-    eo[t * 64] = double2{e0, e1};  // sites past T never get here
+    eo[t * 64] = rho;  // sites past T never get here
   }
+  __device__ __forceinline__ void rescale() { base.rescale(); }
 };
 
 // Fresh walk of a PACKED handle (called genotypes, glview.hpp): the cell is a 2-bit code, 16
@@ -288,8 +330,9 @@ struct SrcFreshPacked {
   const uint32_t* __restrict__ gw;
   const double* __restrict__ fp;
   const double* __restrict__ dp;
-  double2* __restrict__ eo;
+  double* __restrict__ eo;
   double u;
+  BaseAcc base;
   struct Buf {
     uint32_t w;
     double f, d;
@@ -301,8 +344,7 @@ struct SrcFreshPacked {
   __device__ __forceinline__ Buf load(uint64_t t) const {
     return Buf{gw[(t >> 4) * 64], fp[t * 64], dp[t * 64]};
   }
-  __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& e0, double& e1,
-                                      double& d) const {
+  __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& rho, double& d) {
     const uint32_t code = (b.w >> ((uint32_t)(t & 15) * 2)) & 3u;
     const double maf = b.f, om = 1 - maf;
     const double bb = om * maf;
@@ -310,11 +352,14 @@ struct SrcFreshPacked {
     // the four classes through SrcFresh's formula with p in {0, 1} (exact) or p = (u, u, u)
     const double u0 = fma(u, h00, fma(u, 2 * bb, u * h02));
     const double u1 = fma(u, h00 + bb, u * (h02 + bb));
-    e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
-    e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
+    const double e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
+    const double e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
+    base.mul(e0);
+    rho = emission_ratio(e0, e1);
     d = b.d;
-    eo[t * 64] = double2{e0, e1};
+    eo[t * 64] = rho;
   }
+  __device__ __forceinline__ void rescale() { base.rescale(); }
 };
 
 // which per-site source a forward walk reads: the materialised emissions, or (first walk
@@ -329,7 +374,7 @@ using SrcOf = std::conditional_t<SRC == SRC_PLAIN, SrcPlain,
 // by all points, 12 instructions per F-probe and 20 per alpha-probe; one exponent (point
 // 0's) rescales all points, which are perturbations of each other.
 template <int NF, int NA, bool SMALL, bool EMIT, typename Src>
-__device__ __forceinline__ void lkl_run_fd(const Src& src, uint64_t T, const GroupDesc& G,
+__device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc& G,
                                            Op (&R)[MAXP], EmitPtrs emit, uint64_t wave,
                                            int lane) {
   static_assert(NB * UG == CK && RENORM == CK, "checkpoints are stored right after a rescale");
@@ -363,8 +408,8 @@ __device__ __forceinline__ void lkl_run_fd(const Src& src, uint64_t T, const Gro
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int u = 0; u < UG; ++u) {
-        double e0, e1, d;
-        src.get(buf[b][u], t0 + (uint64_t)b * UG + u, e0, e1, d);
+        double rho, d;
+        src.get(buf[b][u], t0 + (uint64_t)b * UG + u, rho, d);
         double c0;
         if constexpr (SMALL) {
           // chromosome starts are stored as d = 1e30: c = 0 there (the polynomial of the
@@ -375,8 +420,8 @@ __device__ __forceinline__ void lkl_run_fd(const Src& src, uint64_t T, const Gro
           c0 = coanc(al0, d);
         }
         const double a0 = 1 - c0;
-        const double ce0 = c0 * e0, ce1 = c0 * e1;
-        const double eq0 = e0 * q0, eq1 = e1 * q1;
+        const double ce0 = c0, ce1 = c0 * rho;  // emissions (1, rho)
+        const double eq0 = q0, eq1 = rho * q1;
         const double g0 = a0 * eq0, g1 = a0 * eq1;
         op_step(R[0], ce0, ce1, g0, g1);
 #pragma unroll
@@ -405,6 +450,7 @@ __device__ __forceinline__ void lkl_run_fd(const Src& src, uint64_t T, const Gro
         R[p].a10 *= sc;
         R[p].a11 *= sc;
       }
+      src.rescale();
     }
     if constexpr (EMIT) {  // first round of an M-step: point 0 is the E-step's forward walk
       // (no bound check, to keep the loop one basic block: the store after the last block
@@ -455,7 +501,12 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
   const uint64_t wave_base = ((i * C + c) * T) * 64 + lane;
   const uint64_t pos_base = ((uint64_t)c * T) * 64 + lane;
   using Src = SrcOf<SRC>;
-  lkl_run_fd<NF, NA, SMALL, EMIT>(Src(arr, wave_base, pos_base), T, G, R, emit, i * C + c, lane);
+  Src src(arr, wave_base, pos_base);
+  lkl_run_fd<NF, NA, SMALL, EMIT>(src, T, G, R, emit, i * C + c, lane);
+  if constexpr (SRC != SRC_PLAIN) {  // fresh walk: the wave's part of sum log e0
+    const double bl = wave_sum(src.base.log_value());
+    if (lane == 0) arr.base_c[i * C + c] = bl;
+  }
   if constexpr (EMIT) {
     Op r0 = R[0];
     renorm(r0);
@@ -492,7 +543,7 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
   }
 
   using Src = SrcOf<SRC>;
-  const Src src(arr, ((i * C + c) * T) * 64 + lane, ((uint64_t)c * T) * 64 + lane);
+  Src src(arr, ((i * C + c) * T) * 64 + lane, ((uint64_t)c * T) * 64 + lane);
   typename Src::Buf buf[NB][UG];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -504,14 +555,14 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int u = 0; u < UG; ++u) {
-        double e0, e1, d;
-        src.get(buf[b][u], t0 + (uint64_t)b * UG + u, e0, e1, d);
+        double rho, d;
+        src.get(buf[b][u], t0 + (uint64_t)b * UG + u, rho, d);
 #pragma unroll
         for (int p = 0; p < NP_MAX; ++p) {
           if (p < (int)np) {
             const double cc = coanc(al[p], d);
             const double a = 1 - cc;
-            op_step(R[p], cc * e0, cc * e1, a * e0 * q0[p], a * e1 * q1[p]);
+            op_step(R[p], cc, cc * rho, a * q0[p], a * rho * q1[p]);
           }
         }
       }
@@ -521,10 +572,15 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
 #pragma unroll
     for (int p = 0; p < NP_MAX; ++p)
       if (p < (int)np) renorm(R[p]);
+    src.rescale();
     if (emit.ckpt) {
       const uint64_t b = t0 / CK + 1;
       if (b < T / CK) emit_checkpoint(emit.ckpt, i * C + c, T / CK, b, lane, R[0]);
     }
+  }
+  if constexpr (SRC != SRC_PLAIN) {
+    const double bl = wave_sum(src.base.log_value());
+    if (lane == 0) arr.base_c[i * C + c] = bl;
   }
   if (emit.lane_ops) {
     Op r0 = R[0];
@@ -540,11 +596,13 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
 // the point at hand (C <= 64) and an ordered shuffle tree multiplies them
 __global__ void __launch_bounds__(64)
 k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint32_t C,
-                  const double* __restrict__ part, double* __restrict__ lkl_out,
-                  int* __restrict__ flags) {
+                  const double* __restrict__ part, const double* __restrict__ base_c,
+                  double* __restrict__ lkl_out, int* __restrict__ flags) {
   const uint32_t g = blockIdx.x;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
+  // sum of log e0 over the individual's sites: the same for every point
+  const double base = wave_sum((uint32_t)lane < C ? base_c[(uint64_t)G.ind * C + lane] : 0.0);
   for (uint32_t p = 0; p < G.np; ++p) {
     Op m{1.0, 0.0, 0.0, 1.0, 0};
     if ((uint32_t)lane < C) m = op_load(part + (((uint64_t)g * C + lane) * MAXP + p) * 5);
@@ -555,7 +613,7 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
     if (lane == 0) {
       const double q0 = 1 - G.F[p], q1 = G.F[p];
       const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
-      const double l = log(v0 + v1) + (double)m.ex * 0.6931471805599453094;
+      const double l = base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
       lkl_out[G.out_idx[p]] = l;
       // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
       // in linear space; the host re-evaluates such points with the general kernel
@@ -580,7 +638,7 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
 // operator of sites [0, b*CK) of lane-chunk (c, lane); b = 0 (identity) is not stored.
 // phase A: the operator of every lane-chunk and its checkpoints, one point per individual
 __global__ void __launch_bounds__(64)
-k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
+k_fast_chunk_ops(const double* __restrict__ e_il, const double* __restrict__ pos_il, uint64_t T,
                  uint32_t C, const double* __restrict__ indF, const double* __restrict__ alpha,
                  EmitPtrs out) {
   const uint64_t i = blockIdx.x / C;
@@ -589,10 +647,10 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
   const double f = indF[i], al = alpha[i];
   const double q0 = 1 - f, q1 = f;
   Op R{1.0, 0.0, 0.0, 1.0, 0};
-  const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
+  const double* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
   const uint64_t nblk = T / CK;
-  double2 ecur[UF], enxt[UF];
+  double ecur[UF], enxt[UF];  // emission ratios: the emissions are (1, rho)
   double dcur[UF], dnxt[UF];
 #pragma unroll
   for (int u = 0; u < UF; ++u) {
@@ -610,7 +668,7 @@ k_fast_chunk_ops(const double2* __restrict__ e_il, const double* __restrict__ po
     for (int u = 0; u < UF; ++u) {
       const double cc = coanc(al, dcur[u]);
       const double a = 1 - cc;
-      op_step(R, cc * ecur[u].x, cc * ecur[u].y, a * ecur[u].x * q0, a * ecur[u].y * q1);
+      op_step(R, cc, cc * ecur[u], a * q0, a * ecur[u] * q1);
     }
     if (((t0 / UF) % (RENORM / UF)) == (RENORM / UF - 1)) {
       renorm(R);
@@ -644,8 +702,8 @@ __device__ __forceinline__ Op op_shfl_up(const Op& m, int off) {
 
 __global__ void __launch_bounds__(64)
 k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
-              const double* __restrict__ indF, double* __restrict__ bound,
-              double* __restrict__ ind_lkl, int* __restrict__ flags) {
+              const double* __restrict__ indF, const double* __restrict__ base_c,
+              double* __restrict__ bound, double* __restrict__ ind_lkl, int* __restrict__ flags) {
   const uint64_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const double f = indF[i];
@@ -705,9 +763,11 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
     renorm2(w0, w1, exb);
   }
   const double lb = __shfl(log(fma(q0, w0, q1 * w1)) + (double)exb * LN2, 0);
+  // the walks ran on the emissions (1, rho): add sum log e0 (as k_fast_lkl_finish does)
+  const double base = wave_sum((uint32_t)lane < C ? base_c[i * C + lane] : 0.0);
   if (lane == 0) {
-    ind_lkl[i] = lf;
-    if (lf != lf || lb != lb) flags[FLAG_INVALID_LKL] = 1;
+    ind_lkl[i] = base + lf;
+    if (lf != lf || lb != lb || base != base) flags[FLAG_INVALID_LKL] = 1;
     if (fabs(lf - lb) > 0.001) flags[FLAG_FW_BW] = 1;  // EM.cpp:167
   }
 }
@@ -718,7 +778,7 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
 // i.e. every wave-store is one contiguous 512 B segment and no transposition pass is
 // needed: est_maf reads this layout directly (k_fast_estmaf<.., TILE>).
 __global__ void __launch_bounds__(64)
-k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict__ pos_il,
+k_fast_bwd_recompute(const double* __restrict__ e_il, const double* __restrict__ pos_il,
                      uint64_t T, uint32_t C, uint64_t S, uint64_t I,
                      const double* __restrict__ indF, const double* __restrict__ alpha,
                      const double* __restrict__ bound, const double2* __restrict__ ckpt,
@@ -733,7 +793,7 @@ k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict_
   const double* bd = bound + (i * J + j) * 4;
   const double vin0 = bd[0], vin1 = bd[1];
   double w0 = bd[2], w1 = bd[3];
-  const double2* ep = e_il + ((i * C + c) * T) * 64 + lane;
+  const double* ep = e_il + ((i * C + c) * T) * 64 + lane;
   const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
   double* pp = post + ((uint64_t)c * T * I + i) * 64 + lane;  // site step t at pp[t * I * 64]
   const uint64_t nblk = T / CK;
@@ -742,7 +802,7 @@ k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict_
   bool nanflag = false;
   int exd = 0;
 
-  double2 ecur[CK], enxt[CK];
+  double ecur[CK], enxt[CK];  // emission ratios: the emissions are (1, rho)
   double dcur[CK], dnxt[CK];
   double2 r0c, r1c, r0n, r1n;  // rows of the prefix operator in front of the block
   {
@@ -776,8 +836,8 @@ k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict_
       cc[u] = coanc(al, dcur[u]);
       const double a = 1 - cc[u];
       const double sm = v0 + v1;
-      v0 = fma(a * q0, sm, cc[u] * v0) * ecur[u].x;
-      v1 = fma(a * q1, sm, cc[u] * v1) * ecur[u].y;
+      v0 = fma(a * q0, sm, cc[u] * v0);
+      v1 = fma(a * q1, sm, cc[u] * v1) * ecur[u];
       if (u == CK / 2 - 1) {  // the scale of (v0, v1) does not matter: keep it in range
         int dummy = 0;
         renorm2(v0, v1, dummy);
@@ -800,7 +860,7 @@ k_fast_bwd_recompute(const double2* __restrict__ e_il, const double* __restrict_
       }
       // beta step: w'_k = c u_k + a (q . u),  u = e * w
       const double a = 1 - cc[u];
-      const double u0 = ecur[u].x * w0, u1 = ecur[u].y * w1;
+      const double u0 = w0, u1 = ecur[u] * w1;
       const double sq = a * fma(q0, u0, q1 * u1);
       w0 = fma(cc[u], u0, sq);
       w1 = fma(cc[u], u1, sq);
@@ -866,76 +926,32 @@ k_fast_post_to_site_major(const double* __restrict__ post, uint64_t I, uint64_t 
 }
 
 // ---- emissions --------------------------------------------------------------
-// site-major log GL -> linear emissions in the interleaved layout.
-// tile = (c, t) x 64 lanes (sites T apart) x 32 individuals
-__global__ void __launch_bounds__(256)
-k_fast_emission(const double* __restrict__ gl_lin, const double* __restrict__ freq, uint64_t I,
-                uint64_t S, uint64_t T, uint32_t C, double2* __restrict__ e_il,
-                int* __restrict__ flags) {
-  __shared__ double2 tile[32][65];
-  const uint64_t n_it = (I + 31) / 32;
-  const uint64_t ct = blockIdx.x / n_it;
-  const uint64_t i0 = (blockIdx.x % n_it) * 32;
-  const uint64_t c = ct / T, t = ct % T;
-  {
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 individuals x 8
-    const uint64_t i = i0 + tx;
-    for (int ll = ty; ll < 64; ll += 8) {
-      const uint64_t s = (c * 64 + ll) * T + t;
-      double2 e{1.0, 1.0};  // padding sites: identity
-      if (s < S && i < I) {
-        const double maf = freq[s];
-        if (maf < 0 || maf > 1) {
-          flags[FLAG_INVALID_MAF] = 1;
-          e = double2{__builtin_nan(""), __builtin_nan("")};
-        } else {
-          const double* g = gl_lin + (s * I + i) * 3;
-          const double p0 = g[0], p1 = g[1], p2 = g[2];
-          // calc_HWE (gen_func.cpp:938-957) for F = 0 and F = 1; with F = 1 the
-          // heterozygote weight is exp(-1e15) = 0
-          const double om = 1 - maf;
-          const double b = om * maf;
-          const double h00 = om * om, h01 = 2 * om * maf, h02 = maf * maf;
-          const double h10 = om * om + b, h12 = maf * maf + b;
-          e.x = fma(p0, h00, fma(p1, h01, p2 * h02));
-          e.y = fma(p0, h10, p2 * h12);
-        }
-      }
-      tile[tx][ll] = e;
+// Stand-alone refresh of the emission ratios and of sum log e0 (an E-step or an objective
+// call that no fresh forward walk precedes): one wave per (individual, chunk) runs the fresh
+// walk's source over its sites -- the interleaved likelihoods (or codes) and frequencies in,
+// the ratios out, every access one contiguous segment per wave-instruction.
+template <int SRC>
+__global__ void __launch_bounds__(64)
+k_fast_refresh(LklArrays arr, uint64_t T, uint32_t C) {
+  static_assert(SRC != SRC_PLAIN, "a refresh computes the emissions");
+  const uint64_t w = blockIdx.x;  // i * C + c
+  const uint32_t c = (uint32_t)(w % C);
+  const int lane = threadIdx.x;
+  using Src = SrcOf<SRC>;
+  Src src(arr, (w * T) * 64 + lane, ((uint64_t)c * T) * 64 + lane);
+  for (uint64_t t0 = 0; t0 < T; t0 += RENORM) {  // T is a multiple of RENORM
+    typename Src::Buf buf[RENORM];
+#pragma unroll
+    for (int u = 0; u < RENORM; ++u) buf[u] = src.load(t0 + u);
+#pragma unroll
+    for (int u = 0; u < RENORM; ++u) {
+      double rho, d;
+      src.get(buf[u], t0 + u, rho, d);
     }
+    src.rescale();
   }
-  __syncthreads();
-  {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 lanes x 4
-    for (int ii = ty; ii < 32; ii += 4) {
-      const uint64_t i = i0 + ii;
-      if (i < I) e_il[((i * C + c) * T + t) * 64 + tx] = tile[ii][tx];
-    }
-  }
-}
-
-// packed handle: codes and frequencies are both interleaved already, so the refresh is a
-// straight elementwise pass (no transposition); same expressions as SrcFreshPacked::get
-__global__ void __launch_bounds__(256)
-k_fast_emission_packed(const uint32_t* __restrict__ geno_il, const double* __restrict__ freq_il,
-                       uint64_t I, uint64_t T, uint32_t C, double u, double2* __restrict__ e_il) {
-  const uint64_t n = I * C * T * 64;
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
-       k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t lane = k & 63, wt = k >> 6;  // wt = (i*C + c)*T + t
-    const uint64_t t = wt % T, wv = wt / T;
-    const uint64_t c = wv % C;
-    const uint32_t w = geno_il[(wv * (T >> 4) + (t >> 4)) * 64 + lane];
-    const uint32_t code = (w >> ((uint32_t)(t & 15) * 2)) & 3u;
-    const double maf = freq_il[(c * T + t) * 64 + lane], om = 1 - maf;
-    const double bb = om * maf;
-    const double h00 = om * om, h02 = maf * maf;
-    const double u0 = fma(u, h00, fma(u, 2 * bb, u * h02));
-    const double u1 = fma(u, h00 + bb, u * (h02 + bb));
-    const double e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
-    const double e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
-    e_il[k] = double2{e0, e1};
-  }
+  const double bl = wave_sum(src.base.log_value());
+  if (lane == 0) arr.base_c[w] = bl;
 }
 
 // site-major codes [S][I] (2 bits per cell) -> interleaved words [I][C][T/16][64]: word
@@ -1071,9 +1087,11 @@ k_fast_gl_interleave(const double* __restrict__ gl_lin, uint64_t I, uint64_t S, 
   }
 }
 
-// out[i][s][k] = log(e_il) (test/debug read-back)
+// out[i][s][k] = log emission of state k (test/debug read-back): recomputed from the
+// interleaved likelihoods (or codes) and frequencies with the fresh walk's expressions --
+// only the ratio of the two is kept between walks
 __global__ void __launch_bounds__(256)
-k_fast_export_e(const double2* __restrict__ e_il, uint64_t I, uint64_t S, uint64_t T, uint32_t C,
+k_fast_export_e(LklArrays arr, bool packed, uint64_t I, uint64_t S, uint64_t T, uint32_t C,
                 double* __restrict__ out) {
   const uint64_t n = I * S;
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
@@ -1081,18 +1099,32 @@ k_fast_export_e(const double2* __restrict__ e_il, uint64_t I, uint64_t S, uint64
     const uint64_t i = k / S, s = k % S;
     const uint64_t j = s / T, t = s % T;
     const uint64_t c = j >> 6, lane = j & 63;
-    const double2 e = e_il[((i * C + c) * T + t) * 64 + lane];
-    out[k * 2] = log(e.x);
-    out[k * 2 + 1] = log(e.y);
+    const uint64_t wv = i * C + c;
+    const uint64_t idx = (wv * T + t) * 64 + lane;
+    const double maf = arr.freq_il[(c * T + t) * 64 + lane], om = 1 - maf;
+    const double bb = om * maf;
+    const double h00 = om * om, h02 = maf * maf;
+    double e0, e1;
+    if (packed) {
+      const uint32_t w = arr.geno_il[(wv * (T >> 4) + (t >> 4)) * 64 + lane];
+      const uint32_t code = (w >> ((uint32_t)(t & 15) * 2)) & 3u;
+      const double u = arr.u_lin;
+      const double u0 = fma(u, h00, fma(u, 2 * bb, u * h02));
+      const double u1 = fma(u, h00 + bb, u * (h02 + bb));
+      e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
+      e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
+    } else {
+      const double2 p02 = arr.gl02_il[idx];
+      const double p1 = arr.gl1_il[idx];
+      e0 = fma(p02.x, h00, fma(p1, 2 * bb, p02.y * h02));
+      e1 = fma(p02.x, h00 + bb, p02.y * (h02 + bb));
+    }
+    out[k * 2] = log(e0);
+    out[k * 2 + 1] = log(e1);
   }
 }
 
 // ---- est_maf ----------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
 
 // reference-order log-space term for a cell whose linear weights all vanish
 // (e.g. a called heterozygote with posterior IBD = 1): gen_func.cpp:984-1000
@@ -2014,8 +2046,9 @@ bool dalloc(T** p, size_t n) {
 static bool fast_alloc_run_state(FastState& fs) {
   const size_t cells = (size_t)fs.I * fs.Spad;
   const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
-  if (!dalloc(&fs.e_il, (cells + slack) * 2)) return false;
-  if (hipMemset(fs.e_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.e_il, cells + slack)) return false;
+  if (hipMemset(fs.e_il + cells, 0, slack * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.base_c, (size_t)fs.I * fs.C)) return false;
   if (!dalloc(&fs.freq_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.freq_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.post, cells)) return false;
@@ -2108,7 +2141,7 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
 }
 
 void fast_destroy(FastState& fs) {
-  void* run[] = {fs.e_il, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.lanes[0].part,
+  void* run[] = {fs.e_il, fs.base_c, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.lanes[0].part,
                  fs.lanes[0].grp_dev, fs.lanes[1].part, fs.lanes[1].grp_dev, fs.redo, fs.est_status,
                  fs.est_state};
   for (void* p : run)
@@ -2175,17 +2208,20 @@ bool fast_refresh_freq_table(FastState& fs, hipStream_t st, const double* d_freq
   return hipGetLastError() == hipSuccess;
 }
 
+static LklArrays lkl_arrays(const FastState& fs) {
+  return LklArrays{fs.e_il, fs.pos_il, reinterpret_cast<const double2*>(fs.gl02_il), fs.gl1_il,
+                   fs.freq_il, fs.e_il, fs.geno_il, fs.u_lin, fs.base_c};
+}
+
 bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
-  if (fs.packed) {  // the interleaved frequency table is current (fast_refresh_freq_table)
-    hipLaunchKernelGGL(k_fast_emission_packed, dim3(16384), dim3(256), 0, st, fs.geno_il, fs.freq_il,
-                       fs.I, fs.T, fs.C, fs.u_lin, reinterpret_cast<double2*>(fs.e_il));
-    fs.e_stale = false;
-    return hipGetLastError() == hipSuccess;
-  }
-  const uint64_t n_it = (fs.I + 31) / 32;
-  const uint64_t blocks = (uint64_t)fs.C * fs.T * n_it;
-  hipLaunchKernelGGL(k_fast_emission, dim3((unsigned)blocks), dim3(256), 0, st, fs.gl_lin, d_freq,
-                     fs.I, fs.S, fs.T, fs.C, reinterpret_cast<double2*>(fs.e_il), d_flags);
+  // from the frequencies as they are now (the table may predate a parameter upload)
+  if (!fast_refresh_freq_table(fs, st, d_freq, d_flags)) return false;
+  const dim3 grid((unsigned)(fs.I * fs.C)), block(64);
+  if (fs.packed)
+    hipLaunchKernelGGL((k_fast_refresh<SRC_FRESH_PACKED>), grid, block, 0, st, lkl_arrays(fs), fs.T,
+                       fs.C);
+  else
+    hipLaunchKernelGGL((k_fast_refresh<SRC_FRESH>), grid, block, 0, st, lkl_arrays(fs), fs.T, fs.C);
   fs.e_stale = false;
   return hipGetLastError() == hipSuccess;
 }
@@ -2307,9 +2343,7 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
   const uint32_t ng = L.n_groups;
   if (ng == 0) return true;
   const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(L.grp_dev);
-  const LklArrays arr{reinterpret_cast<const double2*>(fs.e_il), fs.pos_il,
-                      reinterpret_cast<const double2*>(fs.gl02_il), fs.gl1_il, fs.freq_il,
-                      reinterpret_cast<double2*>(fs.e_il), fs.geno_il, fs.u_lin};
+  const LklArrays arr = lkl_arrays(fs);
   // first round of an M-step inside nghmm_estep_mstep: point 0 of every individual is the
   // E-step's forward walk, whose lane operators and checkpoints it leaves behind; if the
   // emissions are stale (frequencies just updated) the same walk recomputes and stores them
@@ -2357,8 +2391,8 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     }
   }
   if (fresh) fs.e_stale = false;
-  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64), 0, st, dg, ng, fs.C, L.part, d_lkl,
-                     d_flags);
+  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64), 0, st, dg, ng, fs.C, L.part, fs.base_c,
+                     d_lkl, d_flags);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -2371,14 +2405,14 @@ bool fast_lkl_covers_everyone(const FastState& fs) {
 
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
                 double* d_ind_lkl, int* d_flags, bool have_forward_walk) {
-  const double2* e2 = reinterpret_cast<const double2*>(fs.e_il);
+  const double* e2 = fs.e_il;
   double2* ck = reinterpret_cast<double2*>(fs.ckpt);
   const unsigned waves = (unsigned)(fs.I * fs.C);
   if (!have_forward_walk)
     hipLaunchKernelGGL(k_fast_chunk_ops, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
                        d_indF, d_alpha, EmitPtrs{fs.lane_ops, ck});
   hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J, fs.C,
-                     d_indF, fs.bound, d_ind_lkl, d_flags);
+                     d_indF, fs.base_c, fs.bound, d_ind_lkl, d_flags);
   hipLaunchKernelGGL(k_fast_bwd_recompute, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
                      fs.S, fs.I, d_indF, d_alpha, fs.bound, ck, fs.post, d_flags);
   return hipGetLastError() == hipSuccess;
@@ -2522,19 +2556,21 @@ bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const dou
                   double* d_scratch, uint64_t chunk_sites) {
   // Decoding runs once per analysis and must give the reference's path, ties and
   // its in-place update included: use the exact-mode kernels on log emissions.  The
-  // site-major log emissions [S][I][2] take the place of the interleaved linear ones in
-  // e_il (never smaller: I * Spad * 2 doubles), which the next reader recomputes.
-  double* eprob_log = fs.e_il;
-  fs.e_stale = true;
+  // site-major log emissions [S][I][2] (16 B per site and individual; the fast path keeps
+  // only the 8 B ratio) live in a buffer of their own for the duration of the call.
+  double* eprob_log = nullptr;
+  if (!dalloc(&eprob_log, (size_t)fs.I * fs.S * 2)) return false;
   launch_emission_exact(st, fs.gl_log, d_freq, eprob_log, fs.S, fs.I, d_flags);
   launch_viterbi_exact(st, eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites,
                        d_scratch, chunk_sites);
-  return hipGetLastError() == hipSuccess;
+  const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  (void)hipFree(eprob_log);
+  return ok;
 }
 
 bool fast_export_emissions(FastState& fs, hipStream_t st, double* d_out) {
-  hipLaunchKernelGGL(k_fast_export_e, dim3(2048), dim3(256), 0, st,
-                     reinterpret_cast<const double2*>(fs.e_il), fs.I, fs.S, fs.T, fs.C, d_out);
+  hipLaunchKernelGGL(k_fast_export_e, dim3(2048), dim3(256), 0, st, lkl_arrays(fs), fs.packed, fs.I,
+                     fs.S, fs.T, fs.C, d_out);
   return hipGetLastError() == hipSuccess;
 }
 

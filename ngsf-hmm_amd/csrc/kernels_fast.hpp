@@ -27,7 +27,8 @@ struct FastState {
   double* cls_lin = nullptr;      // [4][3] linear likelihoods of the four classes (device)
   double u_lin = 0;               // linear likelihood of a uniform (missing) cell, host copy
   double* gl_lin = nullptr;       // exp(GL), site-major [S][I][3] (emission refresh, est_maf)
-  double* e_il = nullptr;         // linear emissions, interleaved [I][C][T][64] x double2
+  double* e_il = nullptr;         // emission ratios e1/e0, interleaved [I][C][T][64]
+  double* base_c = nullptr;       // [I][C]: sum of log e0 over the wave's sites
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
   double* gl02_il = nullptr;      // linear GL (p0, p2), interleaved like e_il
   double* gl1_il = nullptr;       // linear GL p1, interleaved [I][C][T][64]

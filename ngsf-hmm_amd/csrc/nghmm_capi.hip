@@ -461,7 +461,7 @@ int lkl_wait(nghmm_t* h, int k) {
 
 // Emissions from the current frequencies (calc_emission, shared/HMM.cpp:144-154).  Fast
 // mode checks the frequencies and rebuilds its interleaved frequency table now, but leaves
-// the 16 B per site and individual of e_il to whoever reads them next: the first forward
+// the 8 B per site and individual of e_il to whoever reads them next: the first forward
 // walk of the next EM iteration recomputes them on its way (fast_lkl_launch), anything
 // else calls ensure_emissions.
 int emission_impl(nghmm_t* h) {
