@@ -64,7 +64,7 @@ LIMITER_NOTES = {
                "per site; ~21 of them are evaluated over in-register data, the rest on a checked "
                "Chebyshev interpolant of the per-pass sums (DESIGN.md section 4)",
     "lkl_batch": "objective rounds of the L-BFGS-B M-step.  Round 1 of an iteration is also the "
-                 "E-step's forward walk and the emission refresh (24 B GL read, 8 B emission ratio "
+                 "E-step's forward walk and the emission refresh (16 B GL read, 8 B emission ratio "
                  "+ 4 B checkpoints written per site and individual: HBM-bound, ~5.4 TB/s); later "
                  "rounds read 8 B per site and still-active individual and are FP64-VALU-issue "
                  "bound (~90 instructions per site for 5 probe points)",
@@ -359,18 +359,19 @@ def main():
         # dominant kernel family by measured time, and its algorithmic traffic per launch
         # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
         # fast mode: the first objective round of an iteration (all I individuals) reads the
-        # 24 B GL and writes the 8 B emission ratio + 4 B checkpoints; later rounds read 8 B per
+        # 16 B GL and writes the 8 B emission ratio + 4 B checkpoints; later rounds read 8 B per
         # still-active individual; the E-step then reads 8 + 4 B and writes 8 B
         fast = args.mode == "fast"
-        glb = 0.25 if call_geno else 24.0     # bytes of genotype likelihoods per cell
+        glb = 0.25 if call_geno else 24.0     # bytes of genotype likelihoods per cell (est_maf)
+        glq = 0.25 if call_geno else 16.0     # ... in the interleaved copy the forward walk reads
         algo = {
-            "lkl_batch": (((glb + 12.0) * S * I * K + 8.0 * S * max(ind_rounds - I * K, 0)) if fast
+            "lkl_batch": (((glq + 12.0) * S * I * K + 8.0 * S * max(ind_rounds - I * K, 0)) if fast
                           else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
             "est_maf": (glb + 8.0) * (S / world) * I_tot,   # S/N own sites x all individuals per rank
             "forward": (20.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
             "emission": (8.0 * S if fast else (glb + 16.0) * S * I),
-            "lkl_first": (glb + 12.0) * S * I,
+            "lkl_first": (glq + 12.0) * S * I,
         }
         dom = max((k for k in fam if k != "lkl_first"), key=lambda k: fam[k])
         avg_ms = fam[dom] / max(launches[dom], 1)

@@ -238,14 +238,34 @@ __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small) {
 struct LklArrays {
   const double* __restrict__ e_il;      // emission ratios rho = e1 / e0
   const double* __restrict__ pos_il;
-  const double2* __restrict__ gl02_il;  // (p0, p2)
-  const double* __restrict__ gl1_il;    // p1
+  const double2* __restrict__ glq_il;   // likelihoods relative to the cell's largest (glq_decode)
   const double* __restrict__ freq_il;
   double* __restrict__ e_out;           // == e_il, written by the fresh walk
   const uint32_t* __restrict__ geno_il; // packed handle: 2-bit codes, 16 sites of a lane per word
   double u_lin;                         // packed handle: linear likelihood of a uniform cell
   double* __restrict__ base_c;          // [I][C]: sum of log e0 over the wave's sites (see top)
+  const double* __restrict__ gl_scale_c; // [I][C]: sum of the cells' largest log likelihoods, or null
 };
+
+// The interleaved copy of the likelihoods holds each cell RELATIVE TO ITS LARGEST value: a
+// common factor of (p0, p1, p2) scales both emissions alike, so it moves from the ratio
+// into `base` -- as the cell's largest LOG likelihood, summed per wave at load
+// (gl_scale_c).  One of the three is then exactly 1 and need not be stored: 16 B per cell
+// instead of 24, the other two in index order with the position of the 1 in their sign bits
+// (likelihoods are non-negative).
+__device__ __forceinline__ double2 glq_encode(double l0, double l1, double l2) {
+  const int tag = (l0 >= l1 && l0 >= l2) ? 0 : (l1 >= l2 ? 1 : 2);
+  const double m = tag == 0 ? l0 : tag == 1 ? l1 : l2;
+  const double a = exp((tag == 0 ? l1 : l0) - m), b = exp((tag == 2 ? l1 : l2) - m);
+  return double2{(tag & 1) ? -a : a, (tag & 2) ? -b : b};
+}
+__device__ __forceinline__ void glq_decode(double2 q, double& p0, double& p1, double& p2) {
+  const int tag = (int)(ngh_bits(q.x) >> 63) | ((int)(ngh_bits(q.y) >> 63) << 1);
+  const double a = fabs(q.x), b = fabs(q.y);
+  p0 = tag == 0 ? 1.0 : a;
+  p1 = tag == 0 ? a : tag == 1 ? 1.0 : b;
+  p2 = tag == 2 ? 1.0 : b;
+}
 
 // Running product of the e0 of a lane's sites (fresh walks): one multiply per site, the
 // exponent taken out every RENORM sites -- e0 >= freq^2 or (1 - freq)^2 times the largest
@@ -290,21 +310,20 @@ struct SrcPlain {
 };
 
 struct SrcFresh {
-  const double2* __restrict__ g02;
-  const double* __restrict__ g1;
+  const double2* __restrict__ gq;
   const double* __restrict__ fp;
   const double* __restrict__ dp;
   double* __restrict__ eo;
   BaseAcc base;
   struct Buf {
-    double2 p02;
-    double p1, f, d;
+    double2 q;
+    double f, d;
   };
   __device__ __forceinline__ SrcFresh(const LklArrays& A, uint64_t wave_base, uint64_t pos_base)
-      : g02(A.gl02_il + wave_base), g1(A.gl1_il + wave_base), fp(A.freq_il + pos_base),
-        dp(A.pos_il + pos_base), eo(A.e_out + wave_base) {}
+      : gq(A.glq_il + wave_base), fp(A.freq_il + pos_base), dp(A.pos_il + pos_base),
+        eo(A.e_out + wave_base) {}
   __device__ __forceinline__ Buf load(uint64_t t) const {
-    return Buf{g02[t * 64], g1[t * 64], fp[t * 64], dp[t * 64]};
+    return Buf{gq[t * 64], fp[t * 64], dp[t * 64]};
   }
   __device__ __forceinline__ void get(const Buf& b, uint64_t t, double& rho, double& d) {
     // calc_HWE (gen_func.cpp:938-957) for F = 0 and F = 1; with F = 1 the heterozygote
@@ -312,8 +331,10 @@ struct SrcFresh {
     const double maf = b.f, om = 1 - maf;
     const double bb = om * maf;
     const double h00 = om * om, h02 = maf * maf;
-    const double e0 = fma(b.p02.x, h00, fma(b.p1, 2 * bb, b.p02.y * h02));
-    const double e1 = fma(b.p02.x, h00 + bb, b.p02.y * (h02 + bb));
+    double p0, p1, p2;
+    glq_decode(b.q, p0, p1, p2);
+    const double e0 = fma(p0, h00, fma(p1, 2 * bb, p2 * h02));
+    const double e1 = fma(p0, h00 + bb, p2 * (h02 + bb));
     base.mul(e0);
     rho = emission_ratio(e0, e1);
     d = b.d;
@@ -505,7 +526,7 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
   lkl_run_fd<NF, NA, SMALL, EMIT>(src, T, G, R, emit, i * C + c, lane);
   if constexpr (SRC != SRC_PLAIN) {  // fresh walk: the wave's part of sum log e0
     const double bl = wave_sum(src.base.log_value());
-    if (lane == 0) arr.base_c[i * C + c] = bl;
+    if (lane == 0) arr.base_c[i * C + c] = bl + (arr.gl_scale_c ? arr.gl_scale_c[i * C + c] : 0.0);
   }
   if constexpr (EMIT) {
     Op r0 = R[0];
@@ -580,7 +601,7 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
   }
   if constexpr (SRC != SRC_PLAIN) {
     const double bl = wave_sum(src.base.log_value());
-    if (lane == 0) arr.base_c[i * C + c] = bl;
+    if (lane == 0) arr.base_c[i * C + c] = bl + (arr.gl_scale_c ? arr.gl_scale_c[i * C + c] : 0.0);
   }
   if (emit.lane_ops) {
     Op r0 = R[0];
@@ -951,7 +972,7 @@ k_fast_refresh(LklArrays arr, uint64_t T, uint32_t C) {
     src.rescale();
   }
   const double bl = wave_sum(src.base.log_value());
-  if (lane == 0) arr.base_c[w] = bl;
+  if (lane == 0) arr.base_c[w] = bl + (arr.gl_scale_c ? arr.gl_scale_c[w] : 0.0);
 }
 
 // site-major codes [S][I] (2 bits per cell) -> interleaved words [I][C][T/16][64]: word
@@ -1045,14 +1066,14 @@ k_fast_freq_interleave(const double* __restrict__ freq, uint64_t S, uint64_t T, 
   }
 }
 
-// site-major linear GL [S][I][3] -> interleaved planes (p0, p2) and p1, layout of e_il;
-// padding sites get (1, 1, 1), which any frequency turns into the identity emission (1, 1).
+// site-major LOG GL [S][I][3] -> interleaved, each cell relative to its largest likelihood
+// (glq_encode), layout of e_il; padding sites get (1, 1, 1), which any frequency turns into
+// the identity emission (1, 1).
 // tile = (c, t) x 64 lanes (sites T apart) x 32 individuals
 __global__ void __launch_bounds__(256)
-k_fast_gl_interleave(const double* __restrict__ gl_lin, uint64_t I, uint64_t S, uint64_t T,
-                     uint32_t C, double2* __restrict__ gl02_il, double* __restrict__ gl1_il) {
-  __shared__ double2 t02[32][65];
-  __shared__ double t1[32][65];
+k_fast_gl_interleave(const double* __restrict__ gl_log, uint64_t I, uint64_t S, uint64_t T,
+                     uint32_t C, double2* __restrict__ glq_il) {
+  __shared__ double2 tq[32][65];
   const uint64_t n_it = (I + 31) / 32;
   const uint64_t ct = blockIdx.x / n_it;
   const uint64_t i0 = (blockIdx.x % n_it) * 32;
@@ -1062,15 +1083,12 @@ k_fast_gl_interleave(const double* __restrict__ gl_lin, uint64_t I, uint64_t S, 
     const uint64_t i = i0 + tx;
     for (int ll = ty; ll < 64; ll += 8) {
       const uint64_t s = (c * 64 + ll) * T + t;
-      double p0 = 1, p1 = 1, p2 = 1;
+      double2 q{1.0, 1.0};
       if (s < S && i < I) {
-        const double* g = gl_lin + (s * I + i) * 3;
-        p0 = g[0];
-        p1 = g[1];
-        p2 = g[2];
+        const double* g = gl_log + (s * I + i) * 3;
+        q = glq_encode(g[0], g[1], g[2]);
       }
-      t02[tx][ll] = double2{p0, p2};
-      t1[tx][ll] = p1;
+      tq[tx][ll] = q;
     }
   }
   __syncthreads();
@@ -1078,21 +1096,49 @@ k_fast_gl_interleave(const double* __restrict__ gl_lin, uint64_t I, uint64_t S, 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 lanes x 4
     for (int ii = ty; ii < 32; ii += 4) {
       const uint64_t i = i0 + ii;
-      if (i < I) {
-        const uint64_t o = ((i * C + c) * T + t) * 64 + tx;
-        gl02_il[o] = t02[ii][tx];
-        gl1_il[o] = t1[ii][tx];
-      }
+      if (i < I) glq_il[((i * C + c) * T + t) * 64 + tx] = tq[ii][tx];
     }
   }
 }
 
+// scale_c[i][c] = sum over the sites of wave (i, c) of the cell's largest log likelihood (what
+// glq_encode divides out).  Block = chunk c x 32 individuals; a thread adds its sites in
+// order, the eight partial sums of an individual are added in order: the same bits every run.
+__global__ void __launch_bounds__(256)
+k_fast_gl_scale(const double* __restrict__ gl_log, uint64_t I, uint64_t S, uint64_t T, uint32_t C,
+                double* __restrict__ scale_c) {
+  __shared__ double part[8][33];
+  const uint64_t n_it = (I + 31) / 32;
+  const uint64_t c = blockIdx.x / n_it;
+  const uint64_t i0 = (blockIdx.x % n_it) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const uint64_t i = i0 + tx;
+  double acc = 0;
+  if (i < I) {
+    for (uint64_t j = c * 64 + ty; j < c * 64 + 64; j += 8) {
+      for (uint64_t t = 0; t < T; ++t) {
+        const uint64_t s = j * T + t;
+        if (s >= S) break;
+        const double* g = gl_log + (s * I + i) * 3;
+        acc += fmax(g[0], fmax(g[1], g[2]));
+      }
+    }
+  }
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < I) {
+    double sum = 0;
+    for (int k = 0; k < 8; ++k) sum += part[k][tx];
+    scale_c[i * C + c] = sum;
+  }
+}
+
 // out[i][s][k] = log emission of state k (test/debug read-back): recomputed from the
-// interleaved likelihoods (or codes) and frequencies with the fresh walk's expressions --
+// likelihoods (or interleaved codes) and frequencies with the fresh walk's expressions --
 // only the ratio of the two is kept between walks
 __global__ void __launch_bounds__(256)
-k_fast_export_e(LklArrays arr, bool packed, uint64_t I, uint64_t S, uint64_t T, uint32_t C,
-                double* __restrict__ out) {
+k_fast_export_e(LklArrays arr, bool packed, const double* __restrict__ gl_lin, uint64_t I,
+                uint64_t S, uint64_t T, uint32_t C, double* __restrict__ out) {
   const uint64_t n = I * S;
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
        k += (uint64_t)gridDim.x * blockDim.x) {
@@ -1100,7 +1146,6 @@ k_fast_export_e(LklArrays arr, bool packed, uint64_t I, uint64_t S, uint64_t T, 
     const uint64_t j = s / T, t = s % T;
     const uint64_t c = j >> 6, lane = j & 63;
     const uint64_t wv = i * C + c;
-    const uint64_t idx = (wv * T + t) * 64 + lane;
     const double maf = arr.freq_il[(c * T + t) * 64 + lane], om = 1 - maf;
     const double bb = om * maf;
     const double h00 = om * om, h02 = maf * maf;
@@ -1114,10 +1159,9 @@ k_fast_export_e(LklArrays arr, bool packed, uint64_t I, uint64_t S, uint64_t T, 
       e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
       e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
     } else {
-      const double2 p02 = arr.gl02_il[idx];
-      const double p1 = arr.gl1_il[idx];
-      e0 = fma(p02.x, h00, fma(p1, 2 * bb, p02.y * h02));
-      e1 = fma(p02.x, h00 + bb, p02.y * (h02 + bb));
+      const double* g = gl_lin + (s * I + i) * 3;  // the site-major linear copy est_maf reads
+      e0 = fma(g[0], h00, fma(g[1], 2 * bb, g[2] * h02));
+      e1 = fma(g[0], h00 + bb, g[2] * (h02 + bb));
     }
     out[k * 2] = log(e0);
     out[k * 2 + 1] = log(e1);
@@ -2108,10 +2152,9 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
     if (hipMemset(fs.geno_il, 0, words * sizeof(uint32_t)) != hipSuccess) return false;
     if (!dalloc(&fs.cls_lin, (size_t)12)) return false;
   } else {
-    if (!dalloc(&fs.gl02_il, (cells + slack) * 2)) return false;
-    if (!dalloc(&fs.gl1_il, cells + slack)) return false;
-    if (hipMemset(fs.gl02_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
-    if (hipMemset(fs.gl1_il + cells, 0, slack * sizeof(double)) != hipSuccess) return false;
+    if (!dalloc(&fs.glq_il, (cells + slack) * 2)) return false;
+    if (hipMemset(fs.glq_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
+    if (!dalloc(&fs.gl_scale_c, (size_t)I * C)) return false;
     if (!dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
   }
   return fast_alloc_run_state(fs);
@@ -2134,8 +2177,8 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
   fs.u_lin = parent.u_lin;
   fs.gl_lin = parent.gl_lin;
   fs.pos_il = parent.pos_il;
-  fs.gl02_il = parent.gl02_il;
-  fs.gl1_il = parent.gl1_il;
+  fs.glq_il = parent.glq_il;
+  fs.gl_scale_c = parent.gl_scale_c;
   fs.dmax_finite = parent.dmax_finite;
   return fast_alloc_run_state(fs);
 }
@@ -2147,7 +2190,7 @@ void fast_destroy(FastState& fs) {
   for (void* p : run)
     if (p) (void)hipFree(p);
   if (fs.owns_data) {
-    void* data[] = {fs.pos_il, fs.gl02_il, fs.gl1_il, fs.gl_lin, fs.geno_il, fs.cls_lin};
+    void* data[] = {fs.pos_il, fs.glq_il, fs.gl_scale_c, fs.gl_lin, fs.geno_il, fs.cls_lin};
     for (void* p : data)
       if (p) (void)hipFree(p);
   }
@@ -2178,11 +2221,14 @@ bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double
                        gl_log.cell0, fs.I, fs.S, fs.T, fs.C, fs.geno_il);
   } else {
     if (!gl_log.dense) return false;
-    fast_exp(st, gl_log.dense + gl_log.cell0 * 3, fs.gl_lin, fs.I * fs.S * 3);
+    const double* lg = gl_log.dense + gl_log.cell0 * 3;
+    fast_exp(st, lg, fs.gl_lin, fs.I * fs.S * 3);
     const uint64_t n_it = (fs.I + 31) / 32;
     hipLaunchKernelGGL(k_fast_gl_interleave, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)),
-                       dim3(256), 0, st, fs.gl_lin, fs.I, fs.S, fs.T, fs.C,
-                       reinterpret_cast<double2*>(fs.gl02_il), fs.gl1_il);
+                       dim3(256), 0, st, lg, fs.I, fs.S, fs.T, fs.C,
+                       reinterpret_cast<double2*>(fs.glq_il));
+    hipLaunchKernelGGL(k_fast_gl_scale, dim3((unsigned)((uint64_t)fs.C * n_it)), dim3(256), 0, st, lg,
+                       fs.I, fs.S, fs.T, fs.C, fs.gl_scale_c);
   }
   hipLaunchKernelGGL(k_fast_pos_interleave, dim3(1024), dim3(256), 0, st, d_pos, fs.S, fs.T, fs.C,
                      fs.pos_il);
@@ -2209,8 +2255,8 @@ bool fast_refresh_freq_table(FastState& fs, hipStream_t st, const double* d_freq
 }
 
 static LklArrays lkl_arrays(const FastState& fs) {
-  return LklArrays{fs.e_il, fs.pos_il, reinterpret_cast<const double2*>(fs.gl02_il), fs.gl1_il,
-                   fs.freq_il, fs.e_il, fs.geno_il, fs.u_lin, fs.base_c};
+  return LklArrays{fs.e_il, fs.pos_il, reinterpret_cast<const double2*>(fs.glq_il), fs.freq_il,
+                   fs.e_il,  fs.geno_il, fs.u_lin, fs.base_c, fs.gl_scale_c};
 }
 
 bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq, int* d_flags) {
@@ -2569,8 +2615,8 @@ bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const dou
 }
 
 bool fast_export_emissions(FastState& fs, hipStream_t st, double* d_out) {
-  hipLaunchKernelGGL(k_fast_export_e, dim3(2048), dim3(256), 0, st, lkl_arrays(fs), fs.packed, fs.I,
-                     fs.S, fs.T, fs.C, d_out);
+  hipLaunchKernelGGL(k_fast_export_e, dim3(2048), dim3(256), 0, st, lkl_arrays(fs), fs.packed,
+                     fs.gl_lin, fs.I, fs.S, fs.T, fs.C, d_out);
   return hipGetLastError() == hipSuccess;
 }
 

@@ -30,8 +30,9 @@ struct FastState {
   double* e_il = nullptr;         // emission ratios e1/e0, interleaved [I][C][T][64]
   double* base_c = nullptr;       // [I][C]: sum of log e0 over the wave's sites
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
-  double* gl02_il = nullptr;      // linear GL (p0, p2), interleaved like e_il
-  double* gl1_il = nullptr;       // linear GL p1, interleaved [I][C][T][64]
+  double* glq_il = nullptr;       // linear GL relative to the cell's largest, interleaved like
+                                  // e_il, 16 B per cell (kernels_fast.hip: glq_encode)
+  double* gl_scale_c = nullptr;   // [I][C]: sum of the cells' largest log GL over the wave's sites
   double* freq_il = nullptr;      // allele frequencies, interleaved [C][T][64]
   bool e_stale = true;            // e_il older than freq_il (refreshed lazily)
   double* post = nullptr;         // posteriors, tile-major [C][T][I][64] (site (c*64+l)*T + t)
