@@ -346,13 +346,12 @@ struct SrcFresh {
 // Fresh walk of a PACKED handle (called genotypes, glview.hpp): the cell is a 2-bit code, 16
 // consecutive sites of a lane share one 32-bit word, and the linear likelihoods are exactly
 // (1,0,0), (0,1,0), (0,0,1) or (u,u,u): the emission of SrcFresh::get collapses to a select
-// among four per-site values.  0.25 B read instead of 24 B per site and individual.
+// among four per-site values.  0.25 B read instead of 16 B per site and individual.
 struct SrcFreshPacked {
   const uint32_t* __restrict__ gw;
   const double* __restrict__ fp;
   const double* __restrict__ dp;
   double* __restrict__ eo;
-  double u;
   BaseAcc base;
   struct Buf {
     uint32_t w;
@@ -361,7 +360,7 @@ struct SrcFreshPacked {
   __device__ __forceinline__ SrcFreshPacked(const LklArrays& A, uint64_t wave_base,
                                             uint64_t pos_base)
       : gw(A.geno_il + (((wave_base & ~63ull) >> 4) + (wave_base & 63))), fp(A.freq_il + pos_base),
-        dp(A.pos_il + pos_base), eo(A.e_out + wave_base), u(A.u_lin) {}
+        dp(A.pos_il + pos_base), eo(A.e_out + wave_base) {}
   __device__ __forceinline__ Buf load(uint64_t t) const {
     return Buf{gw[(t >> 4) * 64], fp[t * 64], dp[t * 64]};
   }
@@ -370,9 +369,11 @@ struct SrcFreshPacked {
     const double maf = b.f, om = 1 - maf;
     const double bb = om * maf;
     const double h00 = om * om, h02 = maf * maf;
-    // the four classes through SrcFresh's formula with p in {0, 1} (exact) or p = (u, u, u)
-    const double u0 = fma(u, h00, fma(u, 2 * bb, u * h02));
-    const double u1 = fma(u, h00 + bb, u * (h02 + bb));
+    // the four classes through SrcFresh's formula on what glq_encode makes of them: p in
+    // {0, 1} (exact), and (1, 1, 1) for a uniform cell, whose common factor u is part of
+    // gl_scale_c like any cell's largest likelihood -- the same bits as the dense handle
+    const double u0 = fma(1.0, h00, fma(1.0, 2 * bb, h02));
+    const double u1 = fma(1.0, h00 + bb, h02 + bb);
     const double e0 = code == 0 ? h00 : code == 1 ? 2 * bb : code == 2 ? h02 : u0;
     const double e1 = code == 0 ? h00 + bb : code == 1 ? 0.0 : code == 2 ? h02 + bb : u1;
     base.mul(e0);
@@ -1105,7 +1106,7 @@ k_fast_gl_interleave(const double* __restrict__ gl_log, uint64_t I, uint64_t S, 
 // glq_encode divides out).  Block = chunk c x 32 individuals; a thread adds its sites in
 // order, the eight partial sums of an individual are added in order: the same bits every run.
 __global__ void __launch_bounds__(256)
-k_fast_gl_scale(const double* __restrict__ gl_log, uint64_t I, uint64_t S, uint64_t T, uint32_t C,
+k_fast_gl_scale(const GlView gl_log, uint64_t I, uint64_t S, uint64_t T, uint32_t C,
                 double* __restrict__ scale_c) {
   __shared__ double part[8][33];
   const uint64_t n_it = (I + 31) / 32;
@@ -1119,8 +1120,9 @@ k_fast_gl_scale(const double* __restrict__ gl_log, uint64_t I, uint64_t S, uint6
       for (uint64_t t = 0; t < T; ++t) {
         const uint64_t s = j * T + t;
         if (s >= S) break;
-        const double* g = gl_log + (s * I + i) * 3;
-        acc += fmax(g[0], fmax(g[1], g[2]));
+        double g0, g1, g2;
+        gl_fetch(gl_log, s * I + i, g0, g1, g2);
+        acc += fmax(g0, fmax(g1, g2));
       }
     }
   }
@@ -2146,6 +2148,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
   if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.gl_scale_c, (size_t)I * C)) return false;
   if (packed) {
     const size_t words = cells / 16 + slack;
     if (!dalloc(&fs.geno_il, words)) return false;
@@ -2154,7 +2157,6 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   } else {
     if (!dalloc(&fs.glq_il, (cells + slack) * 2)) return false;
     if (hipMemset(fs.glq_il + cells * 2, 0, slack * 2 * sizeof(double)) != hipSuccess) return false;
-    if (!dalloc(&fs.gl_scale_c, (size_t)I * C)) return false;
     if (!dalloc(&fs.gl_lin, (size_t)I * S * 3)) return false;
   }
   return fast_alloc_run_state(fs);
@@ -2227,9 +2229,9 @@ bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double
     hipLaunchKernelGGL(k_fast_gl_interleave, dim3((unsigned)((uint64_t)fs.C * fs.T * n_it)),
                        dim3(256), 0, st, lg, fs.I, fs.S, fs.T, fs.C,
                        reinterpret_cast<double2*>(fs.glq_il));
-    hipLaunchKernelGGL(k_fast_gl_scale, dim3((unsigned)((uint64_t)fs.C * n_it)), dim3(256), 0, st, lg,
-                       fs.I, fs.S, fs.T, fs.C, fs.gl_scale_c);
   }
+  hipLaunchKernelGGL(k_fast_gl_scale, dim3((unsigned)((uint64_t)fs.C * ((fs.I + 31) / 32))), dim3(256),
+                     0, st, gl_log, fs.I, fs.S, fs.T, fs.C, fs.gl_scale_c);
   hipLaunchKernelGGL(k_fast_pos_interleave, dim3(1024), dim3(256), 0, st, d_pos, fs.S, fs.T, fs.C,
                      fs.pos_il);
   // the largest finite distance decides when the objective kernel may use its

@@ -251,7 +251,7 @@ def test_config5_shape_at_one_gpu_share(pkg):
     checks what does not need an oracle at that size: finite, increasing log-likelihoods,
     frequencies in (0, 1), posteriors in [0, 1], additivity of the log-likelihood over the
     25 chromosomes against 25 separate small handles for a few individuals, and the device
-    memory the handle takes (the DESIGN.md section 3 table: <= 30 B per cell packed)."""
+    memory the handle takes (the DESIGN.md section 3 table: <= 22 B per cell packed)."""
     import torch
     Ib, Sb, nchr = 625, 5_000_000, 25
     dev = torch.device("cuda", 0)
@@ -279,7 +279,7 @@ def test_config5_shape_at_one_gpu_share(pkg):
     used = free0 - torch.cuda.mem_get_info(dev)[0]
     per_cell = used / (Ib * Sb)
     print(f"packed handle: {used / 2**30:.1f} GiB = {per_cell:.2f} B per site and individual")
-    assert per_cell <= 30.0
+    assert per_cell <= 22.0
     lk0 = h.estep().copy()
     assert np.isfinite(lk0).all()
     # additivity over chromosomes: the E-step's per-individual log-likelihood is the sum of
