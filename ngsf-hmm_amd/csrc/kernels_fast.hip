@@ -1367,6 +1367,16 @@ __constant__ double kChebW[EN] = {0.0980171403295606, -0.29028467725446233, 0.47
 // resume from `state`.  n_exact passes are evaluated exactly, then (allow_build) the
 // interval is built and checked; a site that ends here writes freq_out/redo.
 constexpr int ESTMAF_MAXW = 16;
+
+// is site (c*64 + l)*T + t in the tile rows c*T + t of [row0, row1)?  (tile_T == 0: no tiles,
+// every site is)
+__device__ __forceinline__ bool in_tile_rows(uint64_t site, uint64_t tile_T, uint64_t row0,
+                                             uint64_t row1) {
+  if (tile_T == 0) return true;
+  const uint64_t j = site / tile_T, t = site - j * tile_T;
+  const uint64_t row = (j >> 6) * tile_T + t;
+  return row >= row0 && row < row1;
+}
 // TILE: the posteriors are read from the E-step's tile-major layout post[(c*T + t)*I + i][l]
 // (site (c*64 + l)*T + t), one wave per site.  A lane's 8-byte loads are then 512 B apart,
 // and the 64 B sector around each holds the posteriors of the eight sites l0..l0+7 of the
@@ -1380,7 +1390,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
               double* __restrict__ freq_out, uint8_t* __restrict__ redo,
               uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
-              int fresh, int n_exact, int allow_build) {
+              int fresh, int n_exact, int allow_build, uint64_t blk0) {
   constexpr int W = BLOCK / 64;
   __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
   // W == 1: per-lane partial sums of the interval's nodes (see the build below); the pad
@@ -1397,7 +1407,8 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   uint64_t site;
   const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[i * 64]
   if constexpr (TILE) {
-    const uint64_t b = blockIdx.x, x = b & 7, k = b >> 3;
+    // blk0: first block of the launch's part of the grid (whole tile rows: blk0 % 64 == 0)
+    const uint64_t b = blockIdx.x + blk0, x = b & 7, k = b >> 3;
     const uint64_t q = ((k >> 3) << 6) + (x << 3) + (k & 7);
     const uint64_t tile_row = q >> 6, l = q & 63;  // tile_row = c * T + t
     const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
@@ -1954,14 +1965,16 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
 }
 
 // The passes between a checked interval and either the end of the loop or the point
+// (a launch may cover only the tile rows [row0, row1) of the E-step's layout: see fast_estmaf)
 // where exact evaluation is needed again: one lane per site, sums from the barycentric
 // formula on the 16 node values.
 __global__ void __launch_bounds__(256)
 k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
                      uint8_t* __restrict__ status, double* __restrict__ state,
-                     uint64_t state_stride) {
+                     uint64_t state_stride, uint64_t tile_T, uint64_t row0, uint64_t row1) {
   const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (site >= S_own || status[site] != EST_INTERP) return;
+  if (site >= S_own || !in_tile_rows(site, tile_T, row0, row1) || status[site] != EST_INTERP)
+    return;
   double num = state[0 * state_stride + site], den = state[1 * state_stride + site];
   double pnum = state[2 * state_stride + site], pden = state[3 * state_stride + site];
   int iters = (int)state[4 * state_stride + site];
@@ -2023,10 +2036,11 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
 __global__ void __launch_bounds__(256)
 k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
                      uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
-                     double* __restrict__ freq_out, const uint8_t* __restrict__ redo) {
+                     double* __restrict__ freq_out, const uint8_t* __restrict__ redo,
+                     uint64_t row0, uint64_t row1) {
   const int lane = threadIdx.x & 63;
   const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (site >= S_own) return;
+  if (site >= S_own || !in_tile_rows(site, tile_T, row0, row1)) return;
   if (redo && !redo[site]) return;
   const uint64_t cell_s = site * I_tot;
   // tile_T != 0: posteriors in the tile-major layout (see k_fast_estmaf<.., TILE>)
@@ -2480,10 +2494,24 @@ bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg) {
   return hipGetLastError() == hipSuccess;
 }
 
+bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major) {
+  // the wave-per-site kernels on the E-step's tile-major posteriors: a part is a range of
+  // tile rows, i.e. of workgroups
+  return tile_major && I_tot > 128 && I_tot <= 8192 && !std::getenv("NGHMM_ESTMAF_CFG");
+}
+
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
-                 double* d_freq_out, bool tile_major) {
+                 double* d_freq_out, bool tile_major, uint32_t part, uint32_t n_parts) {
   if (S_own == 0) return true;
+  if (n_parts == 0 || part >= n_parts) return false;
+  if (n_parts > 1 && !fast_estmaf_splittable(fs, I_tot, tile_major)) return false;
+  // tile rows [row0, row1) of this call (everything when n_parts == 1)
+  const uint64_t n_rows = (uint64_t)fs.C * fs.T;
+  const uint64_t row0 = n_parts > 1 ? n_rows * part / n_parts : 0;
+  const uint64_t row1 = n_parts > 1 ? n_rows * (part + 1) / n_parts : n_rows;
+  const uint64_t blk0 = row0 * 64, nblk = (row1 - row0) * 64;
+  if (nblk == 0) return true;
   // tile-major posteriors (the E-step's own layout) only for the handle's whole site range
   // and individuals that fit the registers of one workgroup
   if (tile_major && !(I_tot <= 8192 && I_blk == I_tot && S_own == fs.S)) return false;
@@ -2512,12 +2540,12 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B), 0, st,        \
                      d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0, d_freq_out,   \
                      fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
-                     allow_build)
+                     allow_build, (uint64_t)0)
 #define LAUNCH_TILE(N, B)                                                                       \
-  hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)fs.Spad), dim3(B), 0, st,      \
+  hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)nblk), dim3(B), 0, st,         \
                      d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,        \
                      fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
-                     allow_build)
+                     allow_build, blk0)
   int cfg_ni = 0, cfg_b = 0;
   if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
 #define LAUNCH_ROWS(N, TL)                                                                      \
@@ -2584,14 +2612,14 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     const dim3 igrid((unsigned)((S_own + 255) / 256));
     if (!launch(1, EST_K0, 1)) return false;
     hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
-                       fs.est_status, fs.est_state, fs.redo_cap);
+                       fs.est_status, fs.est_state, fs.redo_cap, tile_T, row0, row1);
     if (!launch(0, 1, 1)) return false;  // sites that left their interval: one more
     hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
-                       fs.est_status, fs.est_state, fs.redo_cap);
+                       fs.est_status, fs.est_state, fs.redo_cap, tile_T, row0, row1);
     if (!launch(0, 0, 0)) return false;  // whatever is left finishes on exact passes
   }
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
-                     I_tot, I_blk, tile_T, d_freq_out, redo);
+                     I_tot, I_blk, tile_T, d_freq_out, redo, row0, row1);
 #undef LAUNCH_NI
 #undef LAUNCH_TILE
 #undef LAUNCH_ROWS

@@ -95,9 +95,14 @@ void fast_exp(hipStream_t st, const double* d_in, double* d_out, uint64_t n);
 // site shard passed through fast_exp; packed: codes + fs.cls_lin), posteriors in rank blocks
 // [I_tot / I_blk][S_own][I_blk] or (tile_major) fs.post itself
 GlView fast_gl_lin(const FastState& fs);
+// part / n_parts: only the sites of tile rows [R part / n_parts, R (part + 1) / n_parts) of
+// the E-step's layout (R = C T) -- the caller spreads the parts between other work on the
+// stream; needs fast_estmaf_splittable().  Every site's result is the one the whole call gives.
+bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major);
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_lin_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
-                 double* d_freq_out, bool tile_major = false);
+                 double* d_freq_out, bool tile_major = false, uint32_t part = 0,
+                 uint32_t n_parts = 1);
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
                   const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags,
                   double* d_scratch, uint64_t chunk_sites);

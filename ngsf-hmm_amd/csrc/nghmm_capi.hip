@@ -116,6 +116,18 @@ struct nghmm_handle {
     uint64_t lo = 0, hi = 0;
     bool pending = false;
   } lane[2];
+  // Background work of a fused EM iteration (mstep_indf_impl): the E-step's backward sweep and
+  // the allele-frequency step do not depend on the objective rounds after the first, so they
+  // go onto the stream in pieces right behind each round's kernels and run while the host
+  // digests that round's values.  Error flags of their own (the rounds clear theirs), a pool
+  // of timing events (one pair per piece, read when the iteration ends).
+  struct BgSpan {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int slot = 0;
+  };
+  int* d_flags_bg = nullptr;
+  std::vector<BgSpan> bg_spans;
+  size_t bg_used = 0;
   // replicas (nghmm_create_replica): share the parent's data arrays (d_gl / d_codes /
   // d_cls_log / d_pos and the fast-mode layouts of the likelihoods)
   nghmm_handle* parent = nullptr;
@@ -193,9 +205,10 @@ int clear_flags(nghmm_t* h) {
 }
 
 // Reads the kernel error flags and maps them to the reference's fatal errors.
-int check_flags(nghmm_t* h) {
+int check_flags(nghmm_t* h, const int* d_flags = nullptr) {
   int f[NFLAGS];
-  HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(f, d_flags ? d_flags : h->d_flags, sizeof f, hipMemcpyDeviceToHost,
+                         h->stream));
   HIP_TRY(sync_stream(h));
   if (f[FLAG_INVALID_LKL]) {
     set_error("invalid Lkl found!");
@@ -481,6 +494,54 @@ int emission_impl(nghmm_t* h) {
   return check_flags(h);
 }
 
+// ---- background pieces of a fused iteration (see nghmm_handle::BgSpan) ----
+int bg_begin(nghmm_t* h) {
+  int rc;
+  if (!h->d_flags_bg && (rc = dev_alloc(&h->d_flags_bg, (size_t)NFLAGS))) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_flags_bg, 0, NFLAGS * sizeof(int), h->stream));
+  h->bg_used = 0;
+  return NGHMM_OK;
+}
+
+// start / stop the timer of one piece (nothing waits)
+int bg_open(nghmm_t* h, int slot) {
+  if (h->bg_used == h->bg_spans.size()) {
+    nghmm_handle::BgSpan sp;
+    const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
+    HIP_TRY(hipEventCreateWithFlags(&sp.ev0, evf));
+    HIP_TRY(hipEventCreateWithFlags(&sp.ev1, evf));
+    h->bg_spans.push_back(sp);
+  }
+  h->bg_spans[h->bg_used].slot = slot;
+  HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev0, h->stream));
+  return NGHMM_OK;
+}
+
+int bg_close(nghmm_t* h) {
+  HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev1, h->stream));
+  ++h->bg_used;
+  return NGHMM_OK;
+}
+
+// end of the iteration: wait for everything, book the pieces' times, map their flags
+int bg_finish(nghmm_t* h) {
+  const int rc = check_flags(h, h->d_flags_bg);  // synchronises the stream
+  bool seen[NSLOTS] = {};
+  for (size_t k = 0; k < h->bg_used; ++k) {
+    const auto& sp = h->bg_spans[k];
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sp.ev0, sp.ev1));
+    if (!seen[sp.slot]) {
+      seen[sp.slot] = true;
+      h->ms[sp.slot] = 0;
+      h->launches[sp.slot] = 1;
+    }
+    h->ms[sp.slot] += ms;
+  }
+  h->bg_used = 0;
+  return rc;
+}
+
 int ensure_emissions(nghmm_t* h) {
   if (h->mode != NGHMM_MODE_FAST || !h->fast.e_stale) return NGHMM_OK;
   int rc;
@@ -610,6 +671,10 @@ int nghmm_destroy(nghmm_t* h) {
                  h->d_gl_shard, h->d_geno, h->d_text, h->d_codes_shard, h->d_uniform, h->d_stage,
                  h->d_stage8, h->g_send, h->g_recv, h->g_freq_own, h->g_freq_all};
   if (h->g_xstream) (void)hipStreamDestroy(h->g_xstream);
+  if (h->d_flags_bg) (void)hipFree(h->d_flags_bg);
+  for (auto& sp : h->bg_spans)
+    for (hipEvent_t e : {sp.ev0, sp.ev1})
+      if (e) (void)hipEventDestroy(e);
   for (auto& L : h->lane) {
     if (L.d_lkl) (void)hipFree(L.d_lkl);
     if (L.d_flags) (void)hipFree(L.d_flags);
@@ -1079,10 +1144,21 @@ int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const doubl
 // start values), and neither step writes anything the other reads.  So the first round
 // runs first and leaves the forward walk of every individual behind (lane operators and
 // checkpoints); the E-step then needs no forward pass over the emissions of its own.
+//
+// fuse_freq (nghmm_iter_em with --freq_est 1 on an unsharded handle): the allele-frequency
+// step (EM.cpp:209-257) reads the E-step's posteriors and the likelihoods only, so it does not
+// have to wait for the objective rounds either.  The backward sweep and est_maf, cut into
+// parts, go onto the stream right behind each round's kernels: the GPU works on them while the
+// host digests the round's values and prepares the next -- otherwise ~0.25 ms of idle device
+// per round.  Same kernels on the same data in a different order; every result is unchanged.
+// *freq_done tells the caller that the frequency step (and the frequency-table refresh of
+// nghmm_init_emission) has been done here.
 static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats,
                            bool fuse_estep, double* ind_lkl, nghmm_hook_fn after_estep = nullptr,
-                           void* user = nullptr) {
+                           void* user = nullptr, bool fuse_freq = false,
+                           bool* freq_done = nullptr) {
   int rc;
+  if (freq_done) *freq_done = false;
   // the E-step inside the loop below, then the caller's hook (multi-GPU: start moving the
   // posteriors while the remaining objective rounds run)
   auto estep_then_hook = [&](bool have_walk) -> int {
@@ -1123,8 +1199,73 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   const char* pl = std::getenv("NGHMM_PIPELINE");  // 0 / 1 force it off / on
   const bool pipelined = h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
                          (pl ? std::atoi(pl) != 0 : (uint64_t)h->I * h->fast.C < 16384);
+  // background pieces (see above): closures that enqueue one piece each, in order
+  const bool want_bg = fuse_freq && fuse_estep && !after_estep && !pipelined &&
+                       h->mode == NGHMM_MODE_FAST && h->I_tot == h->I &&
+                       !std::getenv("NGHMM_EAGER_EMISSION") && !std::getenv("NGHMM_NO_BG");
+  bool bg_active = false;
+  std::vector<std::function<int()>> bg_queue;
+  size_t bg_next = 0;
+  auto bg_push_next = [&]() -> int {
+    return bg_next < bg_queue.size() ? bg_queue[bg_next++]() : NGHMM_OK;
+  };
+  auto bg_start = [&](bool have_walk) -> int {  // the E-step now, est_maf queued in parts
+    int r;
+    if (!have_walk && (r = ensure_emissions(h))) return r;
+    if ((r = bg_begin(h))) return r;
+    if ((r = bg_open(h, SLOT_FORWARD))) return r;
+    if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_flags_bg,
+                    have_walk))
+      return NGHMM_ERR_HIP;
+    if ((r = bg_close(h))) return r;
+    h->ms[SLOT_BACKWARD] = 0;
+    h->launches[SLOT_BACKWARD] = 0;
+    h->marg_valid = false;
+    h->tmp_is_posteriors = false;
+    const bool tile_major = h->I <= 4096 && !std::getenv("NGHMM_ESTMAF_SITEMAJOR");
+    uint32_t n_parts = 1;
+    if (fast_estmaf_splittable(h->fast, h->I, tile_major)) {
+      // measured at 1000 x 1M (ms per iteration): 1 part 32.4, 2 parts 32.27, 3 parts 32.35,
+      // 6 parts 32.5 (every part ends in a tail of partly filled CUs); without any of this 32.9
+      n_parts = 2;
+      if (const char* env = std::getenv("NGHMM_BG_PARTS")) n_parts = (uint32_t)std::atoi(env);
+      if (n_parts < 1) n_parts = 1;
+    }
+    for (uint32_t part = 0; part < n_parts; ++part)
+      bg_queue.push_back([h, part, n_parts, tile_major]() -> int {
+        int q;
+        if ((q = bg_open(h, SLOT_ESTMAF))) return q;
+        if (!tile_major && (q = ensure_marg(h))) return q;
+        if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast),
+                         tile_major ? h->fast.post : h->d_marg, h->S, h->I, h->I, h->d_freq,
+                         tile_major, part, n_parts))
+          return NGHMM_ERR_HIP;
+        return bg_close(h);
+      });
+    bg_active = true;
+    return NGHMM_OK;
+  };
   bool first_round = true;
   while (!batch.done()) {
+    if (bg_active) {
+      // whole rounds on lane 0's pinned buffers: submit, put the next background piece behind
+      // the round's kernels, and only then wait for the round's values
+      auto& L = h->lane[0];
+      t0 = now();
+      const size_t n = batch.gather(L.ind, L.F, L.A, 0, h->I);
+      t_gather += since(t0);
+      if (n) {
+        t0 = now();
+        if ((rc = lkl_submit(h, 0))) return rc;
+        if ((rc = bg_push_next())) return rc;
+        if ((rc = lkl_wait(h, 0))) return rc;
+        t_lkl += since(t0);
+      }
+      t0 = now();
+      batch.scatter(L.h_lkl, 0, h->I);
+      t_scatter += since(t0);
+      continue;
+    }
     if (pipelined && !first_round) {
       const uint64_t half = (h->I + 1) / 2;
       h->lane[0].lo = 0;
@@ -1182,7 +1323,7 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
     t_lkl += since(t0);
     if (estep_pending) {
       t0 = now();
-      if ((rc = estep_then_hook(emit))) return rc;
+      if ((rc = want_bg ? bg_start(emit) : estep_then_hook(emit))) return rc;
       estep_pending = false;
       t_estep += since(t0);
     }
@@ -1197,12 +1338,27 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
                  t_gather, t_lkl, h->ms[SLOT_LKL], t_estep, h->ms[SLOT_FORWARD], t_scatter,
                  batch.rounds());
   if (estep_pending && (rc = estep_then_hook(false))) return rc;
+  if (bg_active) {  // what is left of the background work, then the frequency table
+    while (bg_next < bg_queue.size())
+      if ((rc = bg_push_next())) return rc;
+    if ((rc = bg_open(h, SLOT_EMISSION))) return rc;
+    if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
+    if ((rc = bg_close(h))) return rc;
+  }
   batch.result(h->h_indF.data(), h->h_alpha.data());
   HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
                          h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_alpha, h->h_alpha.data(), h->I * sizeof(double),
                          hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(sync_stream(h));
+  if (bg_active) {
+    if (ind_lkl)
+      HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                             h->stream));
+    if ((rc = bg_finish(h))) return rc;
+    if (freq_done) *freq_done = true;
+  } else {
+    HIP_TRY(sync_stream(h));
+  }
   if (stats) {
     stats->rounds = batch.rounds();
     stats->points = batch.points();
@@ -1333,7 +1489,15 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  // fast mode: E-step and indF/alpha M-step share their first forward walk (mstep_indf_impl)
+  // fast mode: E-step and indF/alpha M-step share their first forward walk, and the frequency
+  // step runs in the shadow of the objective rounds (mstep_indf_impl)
+  if (h->mode == NGHMM_MODE_FAST && !std::getenv("NGHMM_NO_FUSE")) {
+    bool freq_done = false;
+    if ((rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl, nullptr, nullptr,
+                              freq_est == 1, &freq_done)))
+      return rc;
+    return freq_done ? NGHMM_OK : nghmm_mstep_freq(h, freq_est);
+  }
   if ((rc = nghmm_estep_mstep(h, indF_fixed, alpha_fixed, ind_lkl, stats, nullptr, nullptr)))
     return rc;
   return nghmm_mstep_freq(h, freq_est);
