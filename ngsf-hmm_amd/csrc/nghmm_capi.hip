@@ -1200,9 +1200,9 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   const bool pipelined = h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
                          (pl ? std::atoi(pl) != 0 : (uint64_t)h->I * h->fast.C < 16384);
   // background pieces (see above): closures that enqueue one piece each, in order
-  const bool want_bg = fuse_freq && fuse_estep && !after_estep && !pipelined &&
-                       h->mode == NGHMM_MODE_FAST && h->I_tot == h->I &&
-                       !std::getenv("NGHMM_EAGER_EMISSION") && !std::getenv("NGHMM_NO_BG");
+  const bool want_bg = fuse_freq && fuse_estep && !after_estep && h->mode == NGHMM_MODE_FAST &&
+                       h->I_tot == h->I && !std::getenv("NGHMM_EAGER_EMISSION") &&
+                       !std::getenv("NGHMM_NO_BG");
   bool bg_active = false;
   std::vector<std::function<int()>> bg_queue;
   size_t bg_next = 0;
@@ -1247,7 +1247,7 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
   };
   bool first_round = true;
   while (!batch.done()) {
-    if (bg_active) {
+    if (bg_active && !pipelined) {
       // whole rounds on lane 0's pinned buffers: submit, put the next background piece behind
       // the round's kernels, and only then wait for the round's values
       auto& L = h->lane[0];
@@ -1291,6 +1291,8 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
       };
       for (int k = 0; k < 2; ++k)
         if ((rc = feed(k))) return rc;
+      while (bg_next < bg_queue.size())  // (fused iteration) est_maf behind the two halves
+        if ((rc = bg_push_next())) return rc;
       while (h->lane[0].pending || h->lane[1].pending) {
         for (int k = 0; k < 2; ++k) {
           auto& L = h->lane[k];
