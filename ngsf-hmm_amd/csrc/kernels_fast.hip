@@ -1966,8 +1966,11 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
 
 // The passes between a checked interval and either the end of the loop or the point
 // (a launch may cover only the tile rows [row0, row1) of the E-step's layout: see fast_estmaf)
-// where exact evaluation is needed again: one lane per site, sums from the barycentric
-// formula on the 16 node values.
+// where exact evaluation is needed again: one lane per site.  The EN node values of each sum
+// become Chebyshev coefficients once (c_k = 2/EN sum_j f_j T_k(x_j), the T_k by their
+// recurrence: 3 EN^2 instructions), and a pass is then two Clenshaw recurrences of EN steps
+// -- no divisions, where the barycentric formula spends one per node and pass (the ~80 passes
+// of a site cost 3x less; the checked interpolant is the same polynomial).
 __global__ void __launch_bounds__(256)
 k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
                      uint8_t* __restrict__ status, double* __restrict__ state,
@@ -1986,24 +1989,44 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
     gn[j] = state[(EST_SCALARS + j) * state_stride + site];
     gd[j] = state[(EST_SCALARS + EN + j) * state_stride + site];
   }
+  // node values -> Chebyshev coefficients (in place would need a second array anyway)
+  double cn[EN], cd[EN];
+#pragma unroll
+  for (int k = 0; k < EN; ++k) cn[k] = cd[k] = 0;
+#pragma unroll
+  for (int j = 0; j < EN; ++j) {
+    const double x = kChebC[j], fn = gn[j] * (2.0 / EN), fd = gd[j] * (2.0 / EN);
+    double t0 = 1.0, t1 = x;
+    cn[0] += fn;
+    cd[0] += fd;
+#pragma unroll
+    for (int k = 1; k < EN; ++k) {
+      cn[k] = fma(fn, t1, cn[k]);
+      cd[k] = fma(fd, t1, cd[k]);
+      const double t2 = fma(2 * x, t1, -t0);
+      t0 = t1;
+      t1 = t2;
+    }
+  }
+  const double inv_half = 1.0 / half;
   uint8_t st = EST_EXACT;
   for (;;) {
     const double r = pnum * rcp_nr2(pden - pnum);  // the expression of k_fast_estmaf
     const double tt = (r - mid) * rcp_nr2(r + mid);  // the interpolation variable (see the build)
     if (!(fabs(tt) <= half)) break;                // left the interval (or not finite)
-    double Sq = 0, Sn = 0, Sd = 0;
-    bool hit = false;
+    // Clenshaw: p(x) = c_0 / 2 + sum_{k >= 1} c_k T_k(x),  x = tt / half in [-1, 1]
+    const double x2 = 2 * (tt * inv_half);
+    double bn1 = 0, bn2 = 0, bd1 = 0, bd2 = 0;
 #pragma unroll
-    for (int j = 0; j < EN; ++j) {
-      const double t = fma(-half, kChebC[j], tt);
-      hit |= (t == 0);
-      const double q = kChebW[j] * rcp_nr2(t);  // full precision, half a division's cost
-      Sq += q;
-      Sn = fma(q, gn[j], Sn);
-      Sd = fma(q, gd[j], Sd);
+    for (int k = EN - 1; k >= 1; --k) {
+      const double bn0 = fma(x2, bn1, cn[k] - bn2), bd0 = fma(x2, bd1, cd[k] - bd2);
+      bn2 = bn1;
+      bn1 = bn0;
+      bd2 = bd1;
+      bd1 = bd0;
     }
-    if (hit) break;  // exactly on a node: let the exact kernel evaluate this pass
-    const double sn = Sn / Sq, sd = Sd / Sq;
+    const double sn = fma(0.5 * x2, bn1, 0.5 * cn[0] - bn2);
+    const double sd = fma(0.5 * x2, bd1, 0.5 * cd[0] - bd2);
     const double num2 = fma(r, sn, num), den2 = fma(r, sd, den + tF_sum);
     const double lhs = fabs(fma(pnum, den2, -(num2 * pden))), thr = kEPS * (den2 * pden);
     if (!(fabs(lhs - thr) >= EST_GUARD * thr)) break;  // too close to call (or not finite)
