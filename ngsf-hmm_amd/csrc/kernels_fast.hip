@@ -1384,41 +1384,23 @@ __device__ __forceinline__ bool in_tile_rows(uint64_t site, uint64_t tile_T, uin
 // blockIdx -> site map gives XCD x the sites l = 8x..8x+7 of every tile row, in eight
 // consecutive workgroups of that XCD: the sector is fetched from HBM once and hit in that
 // L2 seven times.
+// one site on the W = BLOCK / 64 waves of a workgroup (see above); the shared arrays are the
+// calling kernel's
 template <int NI, int BLOCK, bool TILE>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
-k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
-              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
-              double* __restrict__ freq_out, uint8_t* __restrict__ redo,
-              uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
-              int fresh, int n_exact, int allow_build, uint64_t blk0) {
+__device__ __forceinline__ void estmaf_site(
+    const GlView& gl, const double* __restrict__ marg_blocks, uint64_t S_own, uint64_t I_tot,
+    uint64_t I_blk, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+    uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride, int fresh,
+    int n_exact, int allow_build, uint64_t site, const double* __restrict__ tile_col,
+    double (&xch)[2][ESTMAF_MAXW][2],
+    double2 (&nodebuf)[(BLOCK == 64 && NI >= 8) ? EN : 1][(BLOCK == 64 && NI >= 8) ? 65 : 1],
+    double2 (&xnode)[(BLOCK == 64 && NI >= 8) ? 1 : EN][(BLOCK == 64 && NI >= 8) ? 1 : BLOCK / 64]) {
   constexpr int W = BLOCK / 64;
-  __shared__ double xch[2][ESTMAF_MAXW][2];  // [buffer][wave][num, den]
-  // W == 1: per-lane partial sums of the interval's nodes (see the build below); the pad
-  // makes lane j's reads of row j conflict-free
-  // (few individuals per lane, NI < 8: the 16 KB would cap the waves per CU for nothing --
-  // those kernels reduce every node in registers like the multi-wave ones)
   constexpr bool PARK = (W == 1 && NI >= 8);
-  __shared__ double2 nodebuf[PARK ? EN : 1][PARK ? 65 : 1];
-  __shared__ double2 xnode[PARK ? 1 : EN][PARK ? 1 : W];  // !PARK: per-wave node sums
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const uint32_t tix = threadIdx.x;  // index among the site's threads
   constexpr uint64_t stride = BLOCK;
-  uint64_t site;
-  const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[i * 64]
-  if constexpr (TILE) {
-    // blk0: first block of the launch's part of the grid (whole tile rows: blk0 % 64 == 0)
-    const uint64_t b = blockIdx.x + blk0, x = b & 7, k = b >> 3;
-    const uint64_t q = ((k >> 3) << 6) + (x << 3) + (k & 7);
-    const uint64_t tile_row = q >> 6, l = q & 63;  // tile_row = c * T + t
-    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
-    site = (c * 64 + l) * tile_T + t;
-    if (site >= S_own) return;  // padding of the interleaved layout
-    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
-  } else {
-    site = blockIdx.x;
-  }
-  if (!fresh && status[site] != EST_EXACT) return;
   const uint64_t cell_s = site * I_tot;  // first cell of the site's row
 
   double tF_lane_out;
@@ -1715,6 +1697,82 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   }
 }
 
+// tile-major posteriors: where site (c*64 + l)*T + t finds individual i at col[i * 64]
+__device__ __forceinline__ const double* estmaf_tile_col(const double* marg_blocks, uint64_t site,
+                                                         uint64_t tile_T, uint64_t I_tot) {
+  const uint64_t j = site / tile_T, t = site - j * tile_T;
+  return marg_blocks + (((j >> 6) * tile_T + t) * I_tot) * 64 + (j & 63);
+}
+
+#define ESTMAF_SHARED(NI, BLOCK)                                                              \
+  constexpr bool PARK_ = ((BLOCK) == 64 && (NI) >= 8);                                         \
+  __shared__ double xch[2][ESTMAF_MAXW][2];                      /* [buffer][wave][num, den] */ \
+  __shared__ double2 nodebuf[PARK_ ? EN : 1][PARK_ ? 65 : 1];                                  \
+  __shared__ double2 xnode[PARK_ ? 1 : EN][PARK_ ? 1 : (BLOCK) / 64] /* !PARK: per-wave node sums */
+
+// every site from the start (freq = 0.01): one workgroup per site
+template <int NI, int BLOCK, bool TILE>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
+k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
+              uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+              double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+              uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
+              int n_exact, int allow_build, uint64_t blk0) {
+  // W == 1: per-lane partial sums of the interval's nodes (see the build); the pad makes lane
+  // j's reads of row j conflict-free (few individuals per lane, NI < 8: the 16 KB would cap
+  // the waves per CU for nothing -- those kernels reduce every node in registers like the
+  // multi-wave ones)
+  ESTMAF_SHARED(NI, BLOCK);
+  uint64_t site;
+  const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[i * 64]
+  if constexpr (TILE) {
+    // blk0: first block of the launch's part of the grid (whole tile rows: blk0 % 64 == 0)
+    const uint64_t b = blockIdx.x + blk0, x = b & 7, k = b >> 3;
+    const uint64_t q = ((k >> 3) << 6) + (x << 3) + (k & 7);
+    const uint64_t tile_row = q >> 6, l = q & 63;  // tile_row = c * T + t
+    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
+    site = (c * 64 + l) * tile_T + t;
+    if (site >= S_own) return;  // padding of the interleaved layout
+    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
+  } else {
+    site = blockIdx.x;
+  }
+  estmaf_site<NI, BLOCK, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status, state,
+                               state_stride, 1, n_exact, allow_build, site, tile_col, xch, nodebuf,
+                               xnode);
+}
+
+// The sites k_fast_estmaf_interp handed back (status EST_EXACT) resume from `state`.  They are
+// few: instead of a workgroup per site that finds nothing to do, a workgroup reads the status
+// of 64 sites at a time and takes the flagged ones in turn (tile rows [row0, row1) only).
+template <int NI, int BLOCK, bool TILE>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
+k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
+                     uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+                     double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+                     uint8_t* __restrict__ status, double* __restrict__ state,
+                     uint64_t state_stride, int n_exact, int allow_build, uint64_t row0,
+                     uint64_t row1) {
+  ESTMAF_SHARED(NI, BLOCK);
+  const int lane = threadIdx.x & 63;
+  for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
+    const uint64_t s = base + lane;
+    const bool need = s < S_own && in_tile_rows(s, TILE ? tile_T : 0, row0, row1) &&
+                      status[s] == EST_EXACT;
+    uint64_t mask = __ballot(need);  // the same in every wave of the workgroup
+    if constexpr (BLOCK > 64) __syncthreads();  // ... all have read before anyone writes a status
+    while (mask) {
+      const uint64_t site = base + (uint64_t)__builtin_ctzll(mask);
+      mask &= mask - 1;
+      const double* tile_col = TILE ? estmaf_tile_col(marg_blocks, site, tile_T, I_tot) : nullptr;
+      estmaf_site<NI, BLOCK, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status,
+                                   state, state_stride, 0, n_exact, allow_build, site, tile_col, xch,
+                                   nodebuf, xnode);
+      if constexpr (BLOCK > 64) __syncthreads();  // the shared buffers serve the next site
+    }
+  }
+}
+
 // Small cohorts: a 64-lane wave per site leaves most lanes empty below ~128 individuals and
 // pays the per-pass bookkeeping for one site only.  Here a wave holds FOUR sites, one per
 // 16-lane DPP row (individual i of the site in lane i % 16, slot i / 16; up to 16 NI = 128
@@ -1737,40 +1795,20 @@ __device__ __forceinline__ double row_sum(double v) {
   return v;
 }
 
+// four sites on the four 16-lane rows of a wave; a row with done = true idles (site and
+// tile_col must still be readable)
 template <int NI, bool TILE>
-__global__ void __launch_bounds__(64)
-k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint64_t S_own,
-                   uint64_t I_tot, uint64_t I_blk, uint64_t tile_T, double* __restrict__ freq_out,
-                   uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
-                   double* __restrict__ state, uint64_t state_stride, int fresh, int n_exact,
-                   int allow_build) {
+__device__ __forceinline__ void estmaf_rows_sites(
+    const GlView& gl, const double* __restrict__ marg_blocks, uint64_t S_own, uint64_t I_tot,
+    uint64_t I_blk, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+    uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride, int fresh,
+    int n_exact, int allow_build, uint64_t site, const double* __restrict__ tile_col, bool done) {
   static_assert(EN <= 16, "a row's lanes hold the interval's node sums");
   // Control flow is kept WAVE-UNIFORM: the rows of a wave are at different points of their
   // recursions (one hands its site over while another still needs exact passes), but every
   // DPP reduction runs with all 64 lanes enabled -- a finished row computes along on its stale
   // values and ignores the results -- and the per-row decisions are applied under `!done`.
-  const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
-  uint64_t site;
-  const double* tile_col = nullptr;
-  if constexpr (TILE) {
-    // as in k_fast_estmaf, XCD x gets the sites l = 8x..8x+7 of a tile row -- here in two
-    // consecutive workgroups of four sites each
-    const uint64_t b = blockIdx.x, x = b & 7, k = b >> 3;
-    const uint64_t q = ((k >> 1) << 6) + (x << 3) + ((k & 1) << 2) + row;
-    const uint64_t tile_row = q >> 6, l = q & 63;
-    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
-    site = (c * 64 + l) * tile_T + t;
-    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
-  } else {
-    site = (uint64_t)blockIdx.x * 4 + row;
-  }
-  bool done = site >= S_own;          // padding of the layout / past the end
-  if (done) {                         // read something valid, write nothing
-    site = 0;
-    if constexpr (TILE) tile_col = marg_blocks;
-  }
-  if (!done && !fresh && status[site] != EST_EXACT) done = true;
-  if (__builtin_amdgcn_ballot_w64(!done) == 0) return;  // nothing to do in this wave
+  const int lane = threadIdx.x, j = lane & 15;
   const uint64_t cell_s = site * I_tot;
 
   double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
@@ -1964,6 +2002,73 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
   }
 }
 
+template <int NI, bool TILE>
+__global__ void __launch_bounds__(64)
+k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint64_t S_own,
+                   uint64_t I_tot, uint64_t I_blk, uint64_t tile_T, double* __restrict__ freq_out,
+                   uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
+                   double* __restrict__ state, uint64_t state_stride, int n_exact,
+                   int allow_build) {
+  const int lane = threadIdx.x, row = lane >> 4;
+  uint64_t site;
+  const double* tile_col = nullptr;
+  if constexpr (TILE) {
+    // as in k_fast_estmaf, XCD x gets the sites l = 8x..8x+7 of a tile row -- here in two
+    // consecutive workgroups of four sites each
+    const uint64_t b = blockIdx.x, x = b & 7, k = b >> 3;
+    const uint64_t q = ((k >> 1) << 6) + (x << 3) + ((k & 1) << 2) + row;
+    const uint64_t tile_row = q >> 6, l = q & 63;
+    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
+    site = (c * 64 + l) * tile_T + t;
+    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
+  } else {
+    site = (uint64_t)blockIdx.x * 4 + row;
+  }
+  bool done = site >= S_own;          // padding of the layout / past the end
+  if (done) {                         // read something valid, write nothing
+    site = 0;
+    if constexpr (TILE) tile_col = marg_blocks;
+  }
+  if (__builtin_amdgcn_ballot_w64(!done) == 0) return;  // nothing to do in this wave
+  estmaf_rows_sites<NI, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status, state,
+                              state_stride, 1, n_exact, allow_build, site, tile_col, done);
+}
+
+// resuming sites (see k_fast_estmaf_resume): the wave reads 64 statuses at a time and gives the
+// flagged sites to its rows four at a time
+template <int NI, bool TILE>
+__global__ void __launch_bounds__(64)
+k_fast_estmaf_rows_resume(const GlView gl, const double* __restrict__ marg_blocks, uint64_t S_own,
+                          uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+                          double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+                          uint8_t* __restrict__ status, double* __restrict__ state,
+                          uint64_t state_stride, int n_exact, int allow_build) {
+  const int lane = threadIdx.x, row = lane >> 4;
+  for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
+    const uint64_t s = base + lane;
+    uint64_t mask = __ballot(s < S_own && status[s] == EST_EXACT);
+    while (mask) {
+      uint64_t site = 0;
+      bool done = true;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (mask) {
+          const uint64_t cand = base + (uint64_t)__builtin_ctzll(mask);
+          mask &= mask - 1;
+          if (r == row) {
+            site = cand;
+            done = false;
+          }
+        }
+      }
+      const double* tile_col =
+          TILE ? (done ? marg_blocks : estmaf_tile_col(marg_blocks, site, tile_T, I_tot)) : nullptr;
+      estmaf_rows_sites<NI, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status,
+                                  state, state_stride, 0, n_exact, allow_build, site, tile_col, done);
+    }
+  }
+}
+
 // The passes between a checked interval and either the end of the loop or the point
 // (a launch may cover only the tile rows [row0, row1) of the E-step's layout: see fast_estmaf)
 // where exact evaluation is needed again: one lane per site.  The EN node values of each sum
@@ -2055,16 +2160,13 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
   status[site] = st;
 }
 
-// any number of individuals: re-reads the (L2-resident) site row every pass
-__global__ void __launch_bounds__(256)
-k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
-                     uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
-                     double* __restrict__ freq_out, const uint8_t* __restrict__ redo,
-                     uint64_t row0, uint64_t row1) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (site >= S_own || !in_tile_rows(site, tile_T, row0, row1)) return;
-  if (redo && !redo[site]) return;
+// any number of individuals: re-reads the (L2-resident) site row every pass.  One wave per
+// site; a wave looks at the flags of 64 sites at a time (normally none is set: the launch is
+// then a few thousand waves reading a cache line each, whatever the number of sites) and
+// takes the flagged ones in turn.
+__device__ void estmaf_stream_site(const GlView& gl, const double* __restrict__ marg_blocks,
+                                   uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+                                   double* __restrict__ freq_out, uint64_t site, int lane) {
   const uint64_t cell_s = site * I_tot;
   // tile_T != 0: posteriors in the tile-major layout (see k_fast_estmaf<.., TILE>)
   const uint64_t tj = tile_T ? site / tile_T : 0;  // lane-chunk c*64 + l; t = site - tj*T
@@ -2113,6 +2215,32 @@ k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
     again = (fabs(prev - freq) > kEPS) && (iters++ < 100);
   } while (again);
   if (lane == 0) freq_out[site] = freq;
+}
+
+__global__ void __launch_bounds__(256)
+k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
+                     uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+                     double* __restrict__ freq_out, const uint8_t* __restrict__ redo,
+                     uint64_t row0, uint64_t row1) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  if (!redo) {  // every site (more individuals than the register kernels hold): a wave each
+    for (uint64_t site = wave; site < S_own; site += n_waves)
+      if (in_tile_rows(site, tile_T, row0, row1))
+        estmaf_stream_site(gl, marg_blocks, S_own, I_tot, I_blk, tile_T, freq_out, site, lane);
+    return;
+  }
+  for (uint64_t base = wave * 64; base < S_own; base += n_waves * 64) {
+    const uint64_t s = base + lane;
+    const bool need = s < S_own && in_tile_rows(s, tile_T, row0, row1) && redo[s];
+    uint64_t mask = __ballot(need);
+    while (mask) {
+      const int b = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      estmaf_stream_site(gl, marg_blocks, S_own, I_tot, I_blk, tile_T, freq_out, base + b, lane);
+    }
+  }
 }
 
 template <typename T>
@@ -2539,7 +2667,11 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   // and individuals that fit the registers of one workgroup
   if (tile_major && !(I_tot <= 8192 && I_blk == I_tot && S_own == fs.S)) return false;
   const uint64_t tile_T = tile_major ? fs.T : 0;
-  const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
+  // k_fast_estmaf_stream, 4 waves per workgroup: a wave per site when it streams every site,
+  // else 64 flags per wave and turn
+  const bool stream_all = I_tot > 8192 && !tile_major && !std::getenv("NGHMM_ESTMAF_CFG");
+  const uint64_t stream_wgs = stream_all ? (S_own + 3) / 4 : (S_own + 255) / 256;
+  const dim3 grid((unsigned)(stream_wgs < 65536 ? stream_wgs : 65536)), block(256);
   if (S_own > fs.redo_cap) {
     if (fs.redo) (void)hipFree(fs.redo);
     if (fs.est_status) (void)hipFree(fs.est_status);
@@ -2559,23 +2691,51 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   if (const char* env = std::getenv("NGHMM_ESTMAF_INTERP")) interp = std::atoi(env) != 0;
   // waves per site (W) and individuals per lane (NI): 16 per lane at two waves per SIMD;
   // a workgroup must fit one CU
+  // resuming launches: 64 statuses per workgroup and turn
+  const uint64_t scan_wgs_all = (S_own + 63) / 64;
+  const unsigned scan_wgs = (unsigned)(scan_wgs_all < 16384 ? scan_wgs_all : 16384);
 #define LAUNCH_NI(N, B)                                                                         \
-  hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B), 0, st,        \
-                     d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0, d_freq_out,   \
-                     fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
-                     allow_build, (uint64_t)0)
+  do {                                                                                          \
+    if (fresh)                                                                                  \
+      hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B), 0, st,    \
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
+                         d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
+                         n_exact, allow_build, (uint64_t)0);                                    \
+    else                                                                                        \
+      hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, false>), dim3(scan_wgs), dim3(B), 0, st,   \
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
+                         d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
+                         n_exact, allow_build, row0, row1);                                     \
+  } while (0)
 #define LAUNCH_TILE(N, B)                                                                       \
-  hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)nblk), dim3(B), 0, st,         \
-                     d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,        \
-                     fs.redo, fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact,         \
-                     allow_build, blk0)
+  do {                                                                                          \
+    if (fresh)                                                                                  \
+      hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)nblk), dim3(B), 0, st,     \
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
+                         fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
+                         allow_build, blk0);                                                    \
+    else                                                                                        \
+      hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, true>), dim3(scan_wgs), dim3(B), 0, st,    \
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
+                         fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
+                         allow_build, row0, row1);                                              \
+  } while (0)
   int cfg_ni = 0, cfg_b = 0;
   if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
 #define LAUNCH_ROWS(N, TL)                                                                      \
-  hipLaunchKernelGGL((k_fast_estmaf_rows<N, TL>),                                                \
-                     dim3((unsigned)((TL) ? fs.Spad / 4 : (S_own + 3) / 4)), dim3(64), 0, st,    \
-                     d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out, fs.redo, \
-                     fs.est_status, fs.est_state, fs.redo_cap, fresh, n_exact, allow_build)
+  do {                                                                                          \
+    if (fresh)                                                                                  \
+      hipLaunchKernelGGL((k_fast_estmaf_rows<N, TL>),                                            \
+                         dim3((unsigned)((TL) ? fs.Spad / 4 : (S_own + 3) / 4)), dim3(64), 0,   \
+                         st, d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out, \
+                         fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
+                         allow_build);                                                          \
+    else                                                                                        \
+      hipLaunchKernelGGL((k_fast_estmaf_rows_resume<N, TL>), dim3(scan_wgs), dim3(64), 0, st,    \
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
+                         fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
+                         allow_build);                                                          \
+  } while (0)
   // up to 128 individuals: four sites per wave (k_fast_estmaf_rows)
   const bool rows = I_tot <= 128 && !cfg_ni && !std::getenv("NGHMM_ESTMAF_NO_ROWS");
   auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
