@@ -734,8 +734,20 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   const double* ops = lane_ops + (i * J + (uint64_t)lane * C) * 5;
   double* bd = bound + (i * J + (uint64_t)lane * C) * 4;
 
+  // A lane's C operators are read three times below, each time as a chain of dependent
+  // multiplications: the loads of PF operators are issued together ahead of their chain link,
+  // or every link would wait a memory round trip (100 us per call at C = 51, whatever I is).
+  constexpr uint32_t PF = 8;
   Op L{1.0, 0.0, 0.0, 1.0, 0};
-  for (uint32_t k = 0; k < C; ++k) L = op_mul(L, op_load(ops + (uint64_t)k * 5));
+  for (uint32_t k0 = 0; k0 < C; k0 += PF) {
+    Op o[PF];
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u)
+      o[u] = op_load(ops + (uint64_t)(k0 + u < C ? k0 + u : C - 1) * 5);
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u)
+      if (k0 + u < C) L = op_mul(L, o[u]);
+  }
 
   // forward: product of the lanes to the left
   Op P = L;
@@ -748,16 +760,25 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   double v0 = fma(q0, E.a00, q1 * E.a10), v1 = fma(q0, E.a01, q1 * E.a11);
   int ex = E.ex;
   renorm2(v0, v1, ex);
-  for (uint32_t k = 0; k < C; ++k) {
-    bd[(uint64_t)k * 4 + 0] = v0;
-    bd[(uint64_t)k * 4 + 1] = v1;
-    const double* m = ops + (uint64_t)k * 5;
-    const double n0 = fma(v0, m[0], v1 * m[2]);
-    const double n1 = fma(v0, m[1], v1 * m[3]);
-    v0 = n0;
-    v1 = n1;
-    ex += (int)m[4];
-    renorm2(v0, v1, ex);
+  for (uint32_t k0 = 0; k0 < C; k0 += PF) {
+    Op o[PF];
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u)
+      o[u] = op_load(ops + (uint64_t)(k0 + u < C ? k0 + u : C - 1) * 5);
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u) {
+      const uint32_t k = k0 + u;
+      if (k < C) {
+        bd[(uint64_t)k * 4 + 0] = v0;
+        bd[(uint64_t)k * 4 + 1] = v1;
+        const double n0 = fma(v0, o[u].a00, v1 * o[u].a10);
+        const double n1 = fma(v0, o[u].a01, v1 * o[u].a11);
+        v0 = n0;
+        v1 = n1;
+        ex += o[u].ex;
+        renorm2(v0, v1, ex);
+      }
+    }
   }
   const double lf = __shfl(log(v0 + v1) + (double)ex * LN2, 63);  // lane 63 has walked it all
 
@@ -772,17 +793,25 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   double w0 = X.a00 + X.a01, w1 = X.a10 + X.a11;
   int exb = X.ex;
   renorm2(w0, w1, exb);
-  for (uint32_t kk = C; kk > 0; --kk) {
-    const uint32_t k = kk - 1;
-    bd[(uint64_t)k * 4 + 2] = w0;
-    bd[(uint64_t)k * 4 + 3] = w1;
-    const double* m = ops + (uint64_t)k * 5;
-    const double n0 = fma(m[0], w0, m[1] * w1);
-    const double n1 = fma(m[2], w0, m[3] * w1);
-    w0 = n0;
-    w1 = n1;
-    exb += (int)m[4];
-    renorm2(w0, w1, exb);
+  for (uint32_t kk0 = C; kk0 > 0; kk0 = kk0 > PF ? kk0 - PF : 0) {
+    Op o[PF];  // operators kk0-1, kk0-2, ...
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u)
+      o[u] = op_load(ops + (uint64_t)(kk0 > u ? kk0 - 1 - u : 0) * 5);
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u) {
+      if (kk0 > u) {
+        const uint32_t k = kk0 - 1 - u;
+        bd[(uint64_t)k * 4 + 2] = w0;
+        bd[(uint64_t)k * 4 + 3] = w1;
+        const double n0 = fma(o[u].a00, w0, o[u].a01 * w1);
+        const double n1 = fma(o[u].a10, w0, o[u].a11 * w1);
+        w0 = n0;
+        w1 = n1;
+        exb += o[u].ex;
+        renorm2(w0, w1, exb);
+      }
+    }
   }
   const double lb = __shfl(log(fma(q0, w0, q1 * w1)) + (double)exb * LN2, 0);
   // the walks ran on the emissions (1, rho): add sum log e0 (as k_fast_lkl_finish does)
