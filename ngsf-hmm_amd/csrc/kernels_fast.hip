@@ -74,6 +74,29 @@ constexpr int UF = 4;     // prefetch depth (sites) of the E-step sweeps
 constexpr int NB = 4;     // objective kernel: load buffers in flight ...
 constexpr int UG = 2;     // ... of this many sites each (NB * UG == RENORM)
 
+// The E-step's posteriors, "tile" layout: one tile per tile row c*T + t (the 64 sites
+// (c*64 + l)*T + t, l = 0..63) -- [tile row][i / 8][l][i % 8]: the eight individuals of a group
+// are adjacent, so the 64 B sector around a posterior holds ONE site (est_maf fetches nothing
+// it does not use), and a group's 64 x 8 block of a tile row is 4 KB contiguous (the backward
+// sweep writes it with full wave-stores from eight waves through LDS).
+// NGHMM_POST8=0: the earlier [tile row][i][l] (a sector = 8 sites of one individual, which
+// est_maf shares between neighbouring workgroups through L2 as far as L2 keeps it).
+#ifndef NGHMM_POST8
+#define NGHMM_POST8 1
+#endif
+constexpr bool kPost8 = NGHMM_POST8 != 0;
+__host__ __device__ constexpr uint64_t post_tile_doubles(uint64_t I) {
+  return kPost8 ? ((I + 7) / 8) * 512 : I * 64;
+}
+// offset of individual i inside a tile, relative to (i = 0, lane l)
+__device__ __forceinline__ uint64_t post_ind_off(uint64_t i) {
+  return kPost8 ? (i >> 3) * 512 + (i & 7) : i * 64;
+}
+// posterior of (tile row, individual 0, lane l)
+__device__ __forceinline__ uint64_t post_lane_off(uint64_t tile_row, uint64_t l, uint64_t I) {
+  return tile_row * post_tile_doubles(I) + (kPost8 ? l * 8 : l);
+}
+
 struct GroupDesc {
   uint32_t ind;
   uint32_t np;
@@ -929,6 +952,127 @@ k_fast_bwd_recompute(const double* __restrict__ e_il, const double* __restrict__
   if (nanflag) flags[FLAG_NAN] = 1;
 }
 
+// The same sweep for the [tile row][i / 8][l][i % 8] layout (kPost8).  A workgroup of four waves
+// is the eight individuals of a group x one half (32) of the lane-chunks of chunk c: a wave
+// walks 32 lane-chunks of two individuals (every load two 256 B segments), the posteriors of a
+// block of CK sites are staged in LDS and leave as contiguous 2 KB stores.  Four waves, because
+// three such workgroups fit a CU at this kernel's three waves per SIMD (eight-wave workgroups
+// -- a whole tile row block per store -- fit once: 4.5 instead of 4.1 ms).
+__global__ void __launch_bounds__(256)
+k_fast_bwd_recompute8(const double* __restrict__ e_il, const double* __restrict__ pos_il,
+                     uint64_t T, uint32_t C, uint64_t S, uint64_t I,
+                     const double* __restrict__ indF, const double* __restrict__ alpha,
+                     const double* __restrict__ bound, const double2* __restrict__ ckpt,
+                     double* __restrict__ post, int* __restrict__ flags) {
+  // (a partial last group repeats its last individual: the copies land in the layout's padding)
+  __shared__ double stage[2][CK][8][40];  // [buffer][site of the block][individual][chunk, padded]
+  const uint64_t grp = blockIdx.x / ((uint64_t)C * 2);
+  const uint32_t c = (uint32_t)((blockIdx.x >> 1) % C);
+  const int half = blockIdx.x & 1;
+  const int lp = threadIdx.x & 31;                                    // chunk within the half
+  const int m8 = (threadIdx.x >> 6) * 2 + ((threadIdx.x >> 5) & 1);  // individual within the group
+  const int lane = half * 32 + lp;                                    // the lane-chunk, 0..63
+  const uint64_t i = (grp * 8 + m8 < I) ? grp * 8 + m8 : I - 1;
+  const double f = indF[i], al = alpha[i];
+  const double q0 = 1 - f, q1 = f;
+  const uint64_t J = (uint64_t)C * 64;
+  const uint64_t j = (uint64_t)c * 64 + lane;
+  const double* bd = bound + (i * J + j) * 4;
+  const double vin0 = bd[0], vin1 = bd[1];
+  double w0 = bd[2], w1 = bd[3];
+  const double* ep = e_il + ((i * C + c) * T) * 64 + lane;
+  const double* dp = pos_il + ((uint64_t)c * T) * 64 + lane;
+  // the half's 32 x 8 block of tile row c*T + t: 256 contiguous doubles, thread k's at [k]
+  double* pp = post + (uint64_t)c * T * post_tile_doubles(I) + grp * 512 + half * 256 + threadIdx.x;
+  const uint64_t nblk = T / CK;
+  const double2* ck = ckpt + ((i * C + c) * nblk * 2) * 64 + lane;
+  const uint64_t tstride = post_tile_doubles(I);
+  bool nanflag = false;
+  int exd = 0;
+
+  double ecur[CK], enxt[CK];  // emission ratios: the emissions are (1, rho)
+  double dcur[CK], dnxt[CK];
+  double2 r0c, r1c, r0n, r1n;  // rows of the prefix operator in front of the block
+  {
+    const uint64_t b = nblk - 1;
+#pragma unroll
+    for (int u = 0; u < CK; ++u) {
+      ecur[u] = ep[(b * CK + u) * 64];
+      dcur[u] = dp[(b * CK + u) * 64];
+    }
+    r0c = b ? ck[(b * 2) * 64] : double2{1.0, 0.0};
+    r1c = b ? ck[(b * 2 + 1) * 64] : double2{0.0, 1.0};
+  }
+  for (uint64_t b = nblk;;) {
+    --b;
+    if (b > 0) {  // the block in front: in flight while this one is computed
+      const uint64_t bn = b - 1;
+#pragma unroll
+      for (int u = 0; u < CK; ++u) {
+        enxt[u] = ep[(bn * CK + u) * 64];
+        dnxt[u] = dp[(bn * CK + u) * 64];
+      }
+      r0n = bn ? ck[(bn * 2) * 64] : double2{1.0, 0.0};
+      r1n = bn ? ck[(bn * 2 + 1) * 64] : double2{0.0, 1.0};
+    }
+    // forward vectors of the block's sites, from the checkpoint
+    double v0 = fma(vin0, r0c.x, vin1 * r1c.x);
+    double v1 = fma(vin0, r0c.y, vin1 * r1c.y);
+    double f0[CK], f1[CK], cc[CK];
+#pragma unroll
+    for (int u = 0; u < CK; ++u) {
+      cc[u] = coanc(al, dcur[u]);
+      const double a = 1 - cc[u];
+      const double sm = v0 + v1;
+      v0 = fma(a * q0, sm, cc[u] * v0);
+      v1 = fma(a * q1, sm, cc[u] * v1) * ecur[u];
+      if (u == CK / 2 - 1) {  // the scale of (v0, v1) does not matter: keep it in range
+        int dummy = 0;
+        renorm2(v0, v1, dummy);
+      }
+      f0[u] = v0;
+      f1[u] = v1;
+    }
+    // backward through the block: posterior, then the beta step
+#pragma unroll
+    for (int u = CK - 1; u >= 0; --u) {
+      const uint64_t t = b * CK + u;
+      const double x0 = f0[u] * w0, x1 = f1[u] * w1;
+      double g1 = x1 * rcp_nr2(x0 + x1);  // 0/0 (no probability mass) stays NaN
+      if (j * T + t < S && g1 != g1) nanflag = true;
+      // check_interv (gen_func.cpp:55-70)
+      if (g1 < kEPS) g1 = 0;
+      else if (g1 > 1 - kEPS) g1 = 1;
+      stage[b & 1][u][m8][lp] = g1;
+      // beta step: w'_k = c u_k + a (q . u),  u = e * w
+      const double a = 1 - cc[u];
+      const double u0 = w0, u1 = ecur[u] * w1;
+      const double sq = a * fma(q0, u0, q1 * u1);
+      w0 = fma(cc[u], u0, sq);
+      w1 = fma(cc[u], u1, sq);
+    }
+    renorm2(w0, w1, exd);
+    // the block's 8 x 32 x 8 posteriors leave through LDS: thread k writes chunk k / 8 of
+    // individual k % 8, i.e. the 256 threads store 2 KB contiguous per site (the buffers
+    // alternate: the barrier of block b orders its reads before the writes of block b - 2)
+    __syncthreads();
+    {
+      const int rl = threadIdx.x >> 3, rm = threadIdx.x & 7;
+#pragma unroll
+      for (int u = 0; u < CK; ++u) pp[(b * CK + u) * tstride] = stage[b & 1][u][rm][rl];
+    }
+    if (b == 0) break;
+#pragma unroll
+    for (int u = 0; u < CK; ++u) {
+      ecur[u] = enxt[u];
+      dcur[u] = dnxt[u];
+    }
+    r0c = r0n;
+    r1c = r1n;
+  }
+  if (nanflag) flags[FLAG_NAN] = 1;
+}
+
 // tile-major posteriors -> site-major [S][I] (multi-GPU packing, host read-back, est_maf
 // with more individuals than one wave holds); tile = (c, t) x 64 lanes x 64 individuals,
 // 16-byte accesses on both sides: a thread reads two lanes of one individual and writes
@@ -948,9 +1092,14 @@ k_fast_post_to_site_major(const double* __restrict__ post, uint64_t I, uint64_t 
     for (int ii = ty; ii < TI; ii += 8) {
       const uint64_t i = i0 + ii;
       if (i < I) {
-        const double2 v = *reinterpret_cast<const double2*>(post + (ct * I + i) * 64 + 2 * lp);
-        tile[2 * lp][ii] = v.x;
-        tile[2 * lp + 1][ii] = v.y;
+        if constexpr (kPost8) {  // lanes are 8 doubles apart: two 8-byte reads
+          tile[2 * lp][ii] = post[post_lane_off(ct, 2 * lp, I) + post_ind_off(i)];
+          tile[2 * lp + 1][ii] = post[post_lane_off(ct, 2 * lp + 1, I) + post_ind_off(i)];
+        } else {
+          const double2 v = *reinterpret_cast<const double2*>(post + (ct * I + i) * 64 + 2 * lp);
+          tile[2 * lp][ii] = v.x;
+          tile[2 * lp + 1][ii] = v.y;
+        }
       }
     }
     __syncthreads();
@@ -965,7 +1114,7 @@ k_fast_post_to_site_major(const double* __restrict__ post, uint64_t I, uint64_t 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int ii = ty; ii < TI; ii += 4) {
       const uint64_t i = i0 + ii;
-      if (i < I) tile[tx][ii] = post[(ct * I + i) * 64 + tx];
+      if (i < I) tile[tx][ii] = post[post_lane_off(ct, tx, I) + post_ind_off(i)];
     }
     __syncthreads();
     for (int ll = ty; ll < 64; ll += 4) {
@@ -1459,7 +1608,7 @@ __device__ __forceinline__ void estmaf_site(
       }
       if constexpr (TILE) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) rF[j] = tile_col[ic[j] * 64];
+        for (int j = 0; j < NB; ++j) rF[j] = tile_col[post_ind_off(ic[j])];
       } else if (one_block) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) rF[j] = marg_blocks[site * I_blk + ic[j]];
@@ -1730,7 +1879,7 @@ __device__ __forceinline__ void estmaf_site(
 __device__ __forceinline__ const double* estmaf_tile_col(const double* marg_blocks, uint64_t site,
                                                          uint64_t tile_T, uint64_t I_tot) {
   const uint64_t j = site / tile_T, t = site - j * tile_T;
-  return marg_blocks + (((j >> 6) * tile_T + t) * I_tot) * 64 + (j & 63);
+  return marg_blocks + post_lane_off((j >> 6) * tile_T + t, j & 63, I_tot);
 }
 
 #define ESTMAF_SHARED(NI, BLOCK)                                                              \
@@ -1762,7 +1911,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
     const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
     site = (c * 64 + l) * tile_T + t;
     if (site >= S_own) return;  // padding of the interleaved layout
-    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
+    tile_col = marg_blocks + post_lane_off(tile_row, l, I_tot);
   } else {
     site = blockIdx.x;
   }
@@ -1856,7 +2005,7 @@ __device__ __forceinline__ void estmaf_rows_sites(
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       if constexpr (TILE) {
-        rF[k] = tile_col[ic[k] * 64];
+        rF[k] = tile_col[post_ind_off(ic[k])];
       } else if (one_block) {
         rF[k] = marg_blocks[site * I_blk + ic[k]];
       } else {
@@ -2049,7 +2198,7 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
     const uint64_t tile_row = q >> 6, l = q & 63;
     const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
     site = (c * 64 + l) * tile_T + t;
-    tile_col = marg_blocks + tile_row * I_tot * 64 + l;
+    tile_col = marg_blocks + post_lane_off(tile_row, l, I_tot);
   } else {
     site = (uint64_t)blockIdx.x * 4 + row;
   }
@@ -2200,7 +2349,7 @@ __device__ void estmaf_stream_site(const GlView& gl, const double* __restrict__ 
   // tile_T != 0: posteriors in the tile-major layout (see k_fast_estmaf<.., TILE>)
   const uint64_t tj = tile_T ? site / tile_T : 0;  // lane-chunk c*64 + l; t = site - tj*T
   const double* trow =
-      tile_T ? marg_blocks + (((tj >> 6) * tile_T + (site - tj * tile_T)) * I_tot) * 64 + (tj & 63)
+      tile_T ? marg_blocks + post_lane_off((tj >> 6) * tile_T + (site - tj * tile_T), tj & 63, I_tot)
              : nullptr;
   int iters = 0;
   double num = 0, den = 0, freq = 0.01, prev;
@@ -2212,7 +2361,7 @@ __device__ void estmaf_stream_site(const GlView& gl, const double* __restrict__ 
     const double A = om * om, Cq = freq * freq;
     double pn = 0, pd = 0;
     for (uint64_t i = lane; i < I_tot; i += 64) {
-      const double F = trow ? trow[i * 64]
+      const double F = trow ? trow[post_ind_off(i)]
                             : marg_blocks[((i / I_blk) * S_own + site) * I_blk + (i % I_blk)];
       const double bF = b * F;
       const double h0 = A + bF, h2 = Cq + bF;
@@ -2291,10 +2440,11 @@ static bool fast_alloc_run_state(FastState& fs) {
   if (!dalloc(&fs.base_c, (size_t)fs.I * fs.C)) return false;
   if (!dalloc(&fs.freq_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.freq_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
-  if (!dalloc(&fs.post, cells)) return false;
+  const size_t post_cells = (size_t)fs.C * fs.T * post_tile_doubles(fs.I);
+  if (!dalloc(&fs.post, post_cells)) return false;
   // the reference starts from marg_prob = 0 (parse_args.cpp:403-405): `--freq e` and a
   // `--log` print before the first E-step read the posteriors
-  if (hipMemset(fs.post, 0, cells * sizeof(double)) != hipSuccess) return false;
+  if (hipMemset(fs.post, 0, post_cells * sizeof(double)) != hipSuccess) return false;
   if (!dalloc(&fs.ckpt, cells / CK * 4 + 4 * 64)) return false;  // T is a multiple of CK; slack:
                                                                  // see lkl_run_fd
   if (!dalloc(&fs.lane_ops, (size_t)fs.I * fs.J * 5)) return false;
@@ -2655,8 +2805,13 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
                        d_indF, d_alpha, EmitPtrs{fs.lane_ops, ck});
   hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J, fs.C,
                      d_indF, fs.base_c, fs.bound, d_ind_lkl, d_flags);
-  hipLaunchKernelGGL(k_fast_bwd_recompute, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
-                     fs.S, fs.I, d_indF, d_alpha, fs.bound, ck, fs.post, d_flags);
+  if (kPost8)
+    hipLaunchKernelGGL(k_fast_bwd_recompute8, dim3((unsigned)(((fs.I + 7) / 8) * fs.C * 2)), dim3(256),
+                       0, st, e2, fs.pos_il, fs.T, fs.C, fs.S, fs.I, d_indF, d_alpha, fs.bound, ck,
+                       fs.post, d_flags);
+  else
+    hipLaunchKernelGGL(k_fast_bwd_recompute, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
+                       fs.S, fs.I, d_indF, d_alpha, fs.bound, ck, fs.post, d_flags);
   return hipGetLastError() == hipSuccess;
 }
 
