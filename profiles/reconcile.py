@@ -5,8 +5,8 @@ with --warmup 0, so the trace holds exactly the timed kernels).
 
 bench.py times kernel FAMILIES (nghmm_kernel_ms): `lkl_batch` = one objective round = the
 k_fast_lkl_fd<...> / k_fast_lkl_chunks<...> launches of that round + k_fast_lkl_finish;
-`forward` = k_fast_bounds + k_fast_bwd_recompute (+ k_fast_chunk_ops outside
-nghmm_estep_mstep); `est_maf` = k_fast_estmaf<...> x 3 + k_fast_estmaf_interp x 2 +
+`forward` = k_fast_bounds + k_fast_bwd_recompute8 (+ k_fast_chunk_ops outside
+nghmm_estep_mstep); `est_maf` = k_fast_estmaf<...> (+ _resume x 2) + k_fast_estmaf_interp x 2 +
 k_fast_estmaf_stream + k_fast_freq_interleave's neighbour kernels.  The family's average per
 launch is therefore  sum(TotalDurationNs of its kernels) / (rounds or EM iterations).
 
@@ -19,8 +19,10 @@ import sys
 
 FAMILIES = {
     "lkl_batch": ("k_fast_lkl_fd", "k_fast_lkl_chunks", "k_fast_lkl_finish"),
-    "forward": ("k_fast_chunk_ops", "k_fast_bounds", "k_fast_bwd_recompute"),
-    "est_maf": ("k_fast_estmaf", "k_fast_estmaf_interp", "k_fast_estmaf_stream",
+    "forward": ("k_fast_chunk_ops", "k_fast_bounds", "k_fast_bwd_recompute",
+                "k_fast_bwd_recompute8"),
+    "est_maf": ("k_fast_estmaf", "k_fast_estmaf_resume", "k_fast_estmaf_rows",
+                "k_fast_estmaf_rows_resume", "k_fast_estmaf_interp", "k_fast_estmaf_stream",
                 "k_fast_post_to_site_major"),
 }
 
@@ -40,7 +42,7 @@ def main():
         tot[k] = tot.get(k, 0.0) + float(r["TotalDurationNs"]) / 1e6
         calls[k] = calls.get(k, 0) + int(r["Calls"])
     b = json.load(open(bench))
-    iters = calls.get("k_fast_bwd_recompute", 0)
+    iters = calls.get("k_fast_bwd_recompute8", 0) or calls.get("k_fast_bwd_recompute", 0)
     rounds = calls.get("k_fast_lkl_finish", 0)
     out = {"em_iterations_in_trace": iters, "objective_rounds_in_trace": rounds,
            "bench_steps": b["steps"], "families": {}}

@@ -23,8 +23,10 @@ import sys
 
 FAMILIES = {
     "lkl_batch": ("k_fast_lkl_fd", "k_fast_lkl_chunks", "k_fast_lkl_finish"),
-    "forward": ("k_fast_chunk_ops", "k_fast_bounds", "k_fast_bwd_recompute"),
-    "est_maf": ("k_fast_estmaf",),
+    "forward": ("k_fast_chunk_ops", "k_fast_bounds", "k_fast_bwd_recompute",
+                "k_fast_bwd_recompute8"),
+    "est_maf": ("k_fast_estmaf", "k_fast_estmaf_resume", "k_fast_estmaf_rows",
+                "k_fast_estmaf_rows_resume", "k_fast_estmaf_interp", "k_fast_estmaf_stream"),
     "emission": ("k_fast_emission", "k_fast_freq_interleave"),
 }
 
@@ -81,7 +83,8 @@ def main():
                 "write_bytes_per_launch", 0.0)
         res[k] = d
     # the backward sweep runs exactly once per EM iteration of the pass
-    iters = res.get("k_fast_bwd_recompute", {}).get("launches_fetch_pass", 0)
+    iters = (res.get("k_fast_bwd_recompute8") or res.get("k_fast_bwd_recompute", {})).get(
+        "launches_fetch_pass", 0)
     rounds = res.get("k_fast_lkl_finish", {}).get("launches_fetch_pass", 0)
     fam = {}
     for name, prefixes in FAMILIES.items():

@@ -18,7 +18,9 @@ KERNELS = {
         "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb1ELi1EEE",
     "est_maf: k_fast_estmaf<16, 64, true> (1000 individuals per site: 16 per lane)":
         "_ZN5nghmm12_GLOBAL__N_113k_fast_estmafILi16ELi64ELb1EEE",
-    "backward sweep: k_fast_bwd_recompute": "_ZN5nghmm12_GLOBAL__N_120k_fast_bwd_recompute",
+    "backward sweep: k_fast_bwd_recompute8 (4 waves = 8 individuals x 32 lane-chunks, LDS staging)":
+        "_ZN5nghmm12_GLOBAL__N_121k_fast_bwd_recompute8",
+    "est_maf interpolated passes: k_fast_estmaf_interp": "_ZN5nghmm12_GLOBAL__N_120k_fast_estmaf_interp",
 }
 
 
