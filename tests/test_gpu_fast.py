@@ -348,6 +348,41 @@ def test_fast_ragged_shapes_fused_iteration(pkg, orc_libm, shape):
 
 
 
+@pytest.mark.parametrize("shape", [(600, 6000), (90, 9000)])
+def test_fast_background_pieces_change_nothing(pkg, monkeypatch, shape):
+    """nghmm_iter_em puts the backward sweep and est_maf (in parts) onto the stream behind the
+    objective rounds' kernels (nghmm_capi.hip: bg_*).  Same kernels on the same data in a
+    different order: with the pieces after the rounds (NGHMM_NO_BG) or est_maf cut differently
+    (NGHMM_BG_PARTS) every array of three iterations must come out bit for bit the same --
+    600 individuals: whole rounds, est_maf in tile-row parts; 90: the two-lane rounds."""
+    I, S = shape
+    d = pkg.simulate.simulate(I, S, seed=4242, n_chrom=3, missing_rate=0.05, indF="r", freq="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+
+    def run():
+        with pkg.NgsFHMM(I, S, device=0, mode=pkg.MODE_FAST) as h:
+            h.load(gl, d.pos_dist_mb)
+            h.set_params(0.1, 0.2, 0.1)
+            h.init_emission()
+            out = []
+            for _ in range(3):
+                h.iter_EM()
+                out.append((h.ind_lkl.copy(), h.indF.copy(), h.alpha.copy(), h.freq.copy(),
+                            h.marg_prob.copy()))
+            return out
+
+    ref = run()
+    for env in ({"NGHMM_NO_BG": "1"}, {"NGHMM_BG_PARTS": "1"}, {"NGHMM_BG_PARTS": "5"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        for a, b in zip(ref, got):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), env
+
+
 def test_fast_mode_end_to_end_against_exact_mode(pkg):
     """A whole EM run in both arithmetic modes (200 individuals x 50 000 sites, 4
     chromosomes, random indF and site frequencies, 2 % missing cells, 25 iterations +
