@@ -637,18 +637,20 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
     if (p < (int)np) lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
 }
 
-// lkl = log( q . prod_c R_c . 1 ): one wave per group; lane c holds the operator of chunk c of
-// the point at hand (C <= 64) and an ordered shuffle tree multiplies them
-__global__ void __launch_bounds__(64)
+// lkl = log( q . prod_c R_c . 1 ): one workgroup per group, one wave per point; lane c holds the
+// operator of chunk c of the wave's point (C <= 64) and an ordered shuffle tree multiplies them
+__global__ void __launch_bounds__(64 * MAXP)
 k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint32_t C,
                   const double* __restrict__ part, const double* __restrict__ base_c,
                   double* __restrict__ lkl_out, int* __restrict__ flags) {
   const uint32_t g = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const GroupDesc& G = groups[g];
+  const uint32_t p = threadIdx.x >> 6;
+  if (p >= G.np) return;
   // sum of log e0 over the individual's sites: the same for every point
   const double base = wave_sum((uint32_t)lane < C ? base_c[(uint64_t)G.ind * C + lane] : 0.0);
-  for (uint32_t p = 0; p < G.np; ++p) {
+  {
     Op m{1.0, 0.0, 0.0, 1.0, 0};
     if ((uint32_t)lane < C) m = op_load(part + (((uint64_t)g * C + lane) * MAXP + p) * 5);
     for (int off = 1; off < 64; off <<= 1) {
@@ -2783,7 +2785,7 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     }
   }
   if (fresh) fs.e_stale = false;
-  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64), 0, st, dg, ng, fs.C, L.part, fs.base_c,
+  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part, fs.base_c,
                      d_lkl, d_flags);
   return hipGetLastError() == hipSuccess;
 }
