@@ -637,8 +637,21 @@ k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __rest
     if (p < (int)np) lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
 }
 
-// lkl = log( q . prod_c R_c . 1 ): one workgroup per group, one wave per point; lane c holds the
-// operator of chunk c of the wave's point (C <= 64) and an ordered shuffle tree multiplies them
+// sum of base_c[0..C) over a wave: lane l adds the K = ceil(C / 64) entries l*K .. l*K + K - 1,
+// then the fixed butterfly (C <= 64: one entry per lane)
+__device__ __forceinline__ double base_sum(const double* __restrict__ base_c, uint32_t C, int lane) {
+  const uint32_t K = (C + 63) / 64;
+  double acc = 0.0;
+  for (uint32_t u = 0; u < K; ++u) {
+    const uint32_t k = (uint32_t)lane * K + u;
+    if (k < C) acc += base_c[k];
+  }
+  return wave_sum(acc);
+}
+
+// lkl = log( q . prod_c R_c . 1 ): one workgroup per group, one wave per point; lane l holds the
+// ordered product of the operators of chunks l*K .. l*K + K - 1 of the wave's point (K =
+// ceil(C / 64): one chunk per lane up to 64 chunks) and an ordered shuffle tree multiplies them
 __global__ void __launch_bounds__(64 * MAXP)
 k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint32_t C,
                   const double* __restrict__ part, const double* __restrict__ base_c,
@@ -649,10 +662,15 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
   const uint32_t p = threadIdx.x >> 6;
   if (p >= G.np) return;
   // sum of log e0 over the individual's sites: the same for every point
-  const double base = wave_sum((uint32_t)lane < C ? base_c[(uint64_t)G.ind * C + lane] : 0.0);
+  const double base = base_sum(base_c + (uint64_t)G.ind * C, C, lane);
   {
+    const uint32_t K = (C + 63) / 64;
     Op m{1.0, 0.0, 0.0, 1.0, 0};
-    if ((uint32_t)lane < C) m = op_load(part + (((uint64_t)g * C + lane) * MAXP + p) * 5);
+    if ((uint32_t)lane * K < C) m = op_load(part + (((uint64_t)g * C + (uint32_t)lane * K) * MAXP + p) * 5);
+    for (uint32_t u = 1; u < K; ++u) {
+      const uint32_t k = (uint32_t)lane * K + u;
+      if (k < C) m = op_mul(m, op_load(part + (((uint64_t)g * C + k) * MAXP + p) * 5));
+    }
     for (int off = 1; off < 64; off <<= 1) {
       const Op o = op_shfl_down(m, off);
       if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
@@ -840,7 +858,7 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   }
   const double lb = __shfl(log(fma(q0, w0, q1 * w1)) + (double)exb * LN2, 0);
   // the walks ran on the emissions (1, rho): add sum log e0 (as k_fast_lkl_finish does)
-  const double base = wave_sum((uint32_t)lane < C ? base_c[i * C + lane] : 0.0);
+  const double base = base_sum(base_c + i * C, C, lane);
   if (lane == 0) {
     ind_lkl[i] = base + lf;
     if (lf != lf || lb != lb || base != base) flags[FLAG_INVALID_LKL] = 1;
@@ -2470,8 +2488,10 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
     const long v = std::atol(env);
     if (v >= 1) C = (uint64_t)v;
   }
-  if (C > 64) C = 64;
-  while (C > 1 && (S + 64 * C - 1) / (64 * C) < 16) --C;
+  if (C > 256) C = 256;  // (measured at 125 x 1M: 5.50 ms per iteration with 64, 5.30 with 256)
+  // at least 32 sites per lane above 64 waves per individual (16 below): a wave's fixed cost
+  // -- the 64-lane operator tree of every point -- is that of about a dozen sites
+  while (C > 1 && (S + 64 * C - 1) / (64 * C) < (C > 64 ? 32u : 16u)) --C;
   if (C < 1) C = 1;
   if (!std::getenv("NGHMM_FAST_C")) {
     // sites per lane are rounded up to whole groups of 8 (16: packed), which at a few dozen
