@@ -38,8 +38,8 @@
 //    E-step (it leaves lane operators and a checkpoint every 8 sites; the backward
 //    sweep recomputes forward vectors block-wise) and the emission refresh.
 //
-//  * posteriors in the TILE-MAJOR layout [C][T][I][64] the backward sweep writes with
-//    contiguous stores; est_maf reads it in place.
+//  * posteriors in a TILE-MAJOR layout ([tile row c*T + t][i / 8][l][i % 8]: kPost8 below) the
+//    backward sweep writes with contiguous stores; est_maf reads it in place.
 //
 // The streaming kernels are HBM-bound, the objective rounds and est_maf FP64-issue
 // bound (no MFMA: there is no contraction longer than 2).  DESIGN.md section 4.
@@ -867,10 +867,12 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
 }
 
 // phase C: backward sweep with block-wise forward recomputation.  Posterior of the IBD
-// state, snapped like check_interv (gen_func.cpp:55-70), in the TILE-MAJOR layout
+// state, snapped like check_interv (gen_func.cpp:55-70).  This version (kPost8 == false)
+// writes the TILE-MAJOR layout
 //   post[(c*T + t)*I + i][lane]      (site (c*64 + lane)*T + t)
 // i.e. every wave-store is one contiguous 512 B segment and no transposition pass is
-// needed: est_maf reads this layout directly (k_fast_estmaf<.., TILE>).
+// needed: est_maf reads the layout directly (k_fast_estmaf<.., TILE>); the version in use,
+// k_fast_bwd_recompute8, follows.
 __global__ void __launch_bounds__(64)
 k_fast_bwd_recompute(const double* __restrict__ e_il, const double* __restrict__ pos_il,
                      uint64_t T, uint32_t C, uint64_t S, uint64_t I,
@@ -1575,13 +1577,13 @@ __device__ __forceinline__ bool in_tile_rows(uint64_t site, uint64_t tile_T, uin
   const uint64_t row = (j >> 6) * tile_T + t;
   return row >= row0 && row < row1;
 }
-// TILE: the posteriors are read from the E-step's tile-major layout post[(c*T + t)*I + i][l]
-// (site (c*64 + l)*T + t), one wave per site.  A lane's 8-byte loads are then 512 B apart,
-// and the 64 B sector around each holds the posteriors of the eight sites l0..l0+7 of the
-// same individual.  Workgroups go round-robin to the 8 XCDs (each with its own L2), so the
-// blockIdx -> site map gives XCD x the sites l = 8x..8x+7 of every tile row, in eight
-// consecutive workgroups of that XCD: the sector is fetched from HBM once and hit in that
-// L2 seven times.
+// TILE: the posteriors are read from the E-step's tile-major layout (post_lane_off /
+// post_ind_off; site (c*64 + l)*T + t), one wave per site.  With kPost8 a wave-load of 64
+// consecutive individuals is eight fully used 64 B sectors.  (Without: a lane's 8-byte loads
+// are 512 B apart and the sector around each holds the eight sites l0..l0+7 of one individual;
+// workgroups go round-robin to the 8 XCDs, each with its own L2, so the blockIdx -> site map
+// gives XCD x the sites l = 8x..8x+7 of every tile row in eight consecutive workgroups, for
+// the sector to be fetched once and hit in that L2 seven times.  The map is kept.)
 // one site on the W = BLOCK / 64 waves of a workgroup (see above); the shared arrays are the
 // calling kernel's
 template <int NI, int BLOCK, bool TILE>
@@ -1922,7 +1924,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   // multi-wave ones)
   ESTMAF_SHARED(NI, BLOCK);
   uint64_t site;
-  const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[i * 64]
+  const double* tile_col = nullptr;  // TILE: posterior of individual i at tile_col[post_ind_off(i)]
   if constexpr (TILE) {
     // blk0: first block of the launch's part of the grid (whole tile rows: blk0 % 64 == 0)
     const uint64_t b = blockIdx.x + blk0, x = b & 7, k = b >> 3;

@@ -35,7 +35,8 @@ struct FastState {
   double* gl_scale_c = nullptr;   // [I][C]: sum of the cells' largest log GL over the wave's sites
   double* freq_il = nullptr;      // allele frequencies, interleaved [C][T][64]
   bool e_stale = true;            // e_il older than freq_il (refreshed lazily)
-  double* post = nullptr;         // posteriors, tile-major [C][T][I][64] (site (c*64+l)*T + t)
+  double* post = nullptr;         // posteriors, tile-major [c*T + t][i / 8][l][i % 8] (site
+                                  // (c*64+l)*T + t; kernels_fast.hip: kPost8)
   double* ckpt = nullptr;         // forward checkpoints [I][C][T/8][2][64] x double2
   double* lane_ops = nullptr;     // per-lane chunk operators [I][J][5]
   double* bound = nullptr;        // per-lane incoming forward/backward vectors [I][J][4]
