@@ -1645,16 +1645,20 @@ __device__ __forceinline__ void estmaf_site(
       for (int j = 0; j < NB; ++j) {
         const int k = k0 + j;
         const bool valid = (uint64_t)tix + stride * k < I_tot;
-        const double p0 = r0[j], p1 = r1[j], p2 = r2[j], F = rF[j];  // linear GL
-        const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
+        // empty slot: likelihoods (1, 0, 0) at posterior 0 give sum' = 1 and numerators 0 --
+        // it contributes nothing (four selects on the inputs instead of six on the results)
+        const double p0 = valid ? r0[j] : 1.0, p1 = valid ? r1[j] : 0.0;  // linear GL
+        const double p2 = valid ? r2[j] : 0.0, F = valid ? rF[j] : 0.0;
+        // (at F = 1 the heterozygote's weight is the reference's exp(-1e15) = 0: so is the
+        // product, p1 being finite)
+        const double cc = 2 * p1 * (1 - F);
         const double n2 = (2 - F) * p2;
-        // empty slot: sum' = 1, numerators 0: contributes nothing
-        sA[k] = valid ? p0 : 1.0;
-        sb[k] = valid ? fma(F, p0 + p2, cc) : 0.0;
-        sC[k] = valid ? p2 : 0.0;
-        u0[k] = valid ? fma(n2, F, cc) : 0.0;
-        nC[k] = valid ? n2 : 0.0;
-        fc[k] = valid ? F * cc : 0.0;
+        sA[k] = p0;
+        sb[k] = fma(F, p0 + p2, cc);
+        sC[k] = p2;
+        u0[k] = fma(n2, F, cc);
+        nC[k] = n2;
+        fc[k] = F * cc;
         tF_acc += valid ? 2 - F : 0.0;
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the next batch's loads out of this one
@@ -2038,15 +2042,16 @@ __device__ __forceinline__ void estmaf_rows_sites(
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const bool valid = (uint64_t)j + 16 * k < I_tot;
-      const double p0 = r0[k], p1 = r1[k], p2 = r2[k], F = rF[k];
-      const double cc = (F == 1) ? 0.0 : 2 * p1 * (1 - F);
+      const double p0 = valid ? r0[k] : 1.0, p1 = valid ? r1[k] : 0.0;  // (see estmaf_site)
+      const double p2 = valid ? r2[k] : 0.0, F = valid ? rF[k] : 0.0;
+      const double cc = 2 * p1 * (1 - F);  // 0 at F = 1, as the reference's exp(-1e15)
       const double n2 = (2 - F) * p2;
-      sA[k] = valid ? p0 : 1.0;
-      sb[k] = valid ? fma(F, p0 + p2, cc) : 0.0;
-      sC[k] = valid ? p2 : 0.0;
-      u0[k] = valid ? fma(n2, F, cc) : 0.0;
-      nC[k] = valid ? n2 : 0.0;
-      fc[k] = valid ? F * cc : 0.0;
+      sA[k] = p0;
+      sb[k] = fma(F, p0 + p2, cc);
+      sC[k] = p2;
+      u0[k] = fma(n2, F, cc);
+      nC[k] = n2;
+      fc[k] = F * cc;
       tF_acc += valid ? 2 - F : 0.0;
     }
   }
