@@ -1834,11 +1834,14 @@ __device__ __forceinline__ void estmaf_site(
             // added up once at the end -- no reduction tree (and its latency) per node.
             // Lane q*16 + j adds quarter q of node j's partials; two shuffles join the
             // quarters.
+            // the nodes' odds: lane nd forms node nd's once, the loop reads them lane by lane
+            // (a reciprocal and its Newton steps per node otherwise)
+            const double tnl = half * kChebC[lane < EN ? lane : 0];
+            const double r_nodes = mid * (1 + tnl) * rcp_nr2(1 - tnl);
 #pragma unroll 1
             for (int nd = 0; nd < EN; ++nd) {
               double pn, pd;
-              const double tn = half * kChebC[nd];
-              lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), pn, pd);
+              lane_sums(lane_value(r_nodes, nd), pn, pd);
               nodebuf[nd][lane] = double2{pn, pd};
             }
             __syncthreads();  // one wave: orders the LDS writes before the reads
@@ -1863,11 +1866,12 @@ __device__ __forceinline__ void estmaf_site(
             // several waves per site: every wave reduces its own part of each node and the
             // waves' parts meet in LDS once for the whole interval (one barrier instead of
             // one per node), added in wave order
+            const double tnl = half * kChebC[lane < EN ? lane : 0];
+            const double r_nodes = mid * (1 + tnl) * rcp_nr2(1 - tnl);
 #pragma unroll 1
             for (int nd = 0; nd < EN; ++nd) {
               double pn, pd;
-              const double tn = half * kChebC[nd];
-              lane_sums(mid * (1 + tn) * rcp_nr2(1 - tn), pn, pd);
+              lane_sums(lane_value(r_nodes, nd), pn, pd);
               const double v = wave_sum_pair(pn, pd);
               const double sn = lane_value(v, 31), sd = lane_value(v, 63);
               if (lane == 0) xnode[nd][wv] = double2{sn, sd};
