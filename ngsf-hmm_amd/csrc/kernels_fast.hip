@@ -1586,6 +1586,13 @@ __device__ __forceinline__ bool in_tile_rows(uint64_t site, uint64_t tile_T, uin
 // the sector to be fetched once and hit in that L2 seven times.  The map is kept.)
 // one site on the W = BLOCK / 64 waves of a workgroup (see above); the shared arrays are the
 // calling kernel's
+// The size dispatch of fast_estmaf gives the variant (NI, BLOCK) only to cohorts larger than
+// the previous variant holds, so its first slots are full for every thread: no masking there.
+__host__ __device__ constexpr int estmaf_full_slots(int NI, int BLOCK) {
+  return BLOCK == 64 ? (NI == 16 ? 12 : NI == 12 ? 8 : NI == 8 ? 4 : NI == 4 ? 2 : NI == 2 ? 1 : 0)
+                     : (NI == 16 ? 8 : 0);  // 128: > 1024 = 8 x 128; 256: > 2048; 512: > 4096
+}
+
 template <int NI, int BLOCK, bool TILE>
 __device__ __forceinline__ void estmaf_site(
     const GlView& gl, const double* __restrict__ marg_blocks, uint64_t S_own, uint64_t I_tot,
@@ -1644,7 +1651,7 @@ __device__ __forceinline__ void estmaf_site(
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int k = k0 + j;
-        const bool valid = (uint64_t)tix + stride * k < I_tot;
+        const bool valid = k < estmaf_full_slots(NI, BLOCK) || (uint64_t)tix + stride * k < I_tot;
         // empty slot: likelihoods (1, 0, 0) at posterior 0 give sum' = 1 and numerators 0 --
         // it contributes nothing (four selects on the inputs instead of six on the results)
         const double p0 = valid ? r0[j] : 1.0, p1 = valid ? r1[j] : 0.0;  // linear GL
@@ -2865,7 +2872,7 @@ bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg) {
 bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major) {
   // the wave-per-site kernels on the E-step's tile-major posteriors: a part is a range of
   // tile rows, i.e. of workgroups
-  return tile_major && I_tot > 128 && I_tot <= 8192 && !std::getenv("NGHMM_ESTMAF_CFG");
+  return tile_major && I_tot > 128 && I_tot <= 8192;
 }
 
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
@@ -2886,7 +2893,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   const uint64_t tile_T = tile_major ? fs.T : 0;
   // k_fast_estmaf_stream, 4 waves per workgroup: a wave per site when it streams every site,
   // else 64 flags per wave and turn
-  const bool stream_all = I_tot > 8192 && !tile_major && !std::getenv("NGHMM_ESTMAF_CFG");
+  const bool stream_all = I_tot > 8192 && !tile_major;
   const uint64_t stream_wgs = stream_all ? (S_own + 3) / 4 : (S_own + 255) / 256;
   const dim3 grid((unsigned)(stream_wgs < 65536 ? stream_wgs : 65536)), block(256);
   if (S_own > fs.redo_cap) {
@@ -2937,8 +2944,6 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
                          allow_build, row0, row1);                                              \
   } while (0)
-  int cfg_ni = 0, cfg_b = 0;
-  if (const char* env = std::getenv("NGHMM_ESTMAF_CFG")) std::sscanf(env, "%d,%d", &cfg_ni, &cfg_b);
 #define LAUNCH_ROWS(N, TL)                                                                      \
   do {                                                                                          \
     if (fresh)                                                                                  \
@@ -2954,7 +2959,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                          allow_build);                                                          \
   } while (0)
   // up to 128 individuals: four sites per wave (k_fast_estmaf_rows)
-  const bool rows = I_tot <= 128 && !cfg_ni && !std::getenv("NGHMM_ESTMAF_NO_ROWS");
+  const bool rows = I_tot <= 128 && !std::getenv("NGHMM_ESTMAF_NO_ROWS");
   auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
     if (rows) {
       if (tile_major) {
@@ -2980,18 +2985,6 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       else if (I_tot <= 2048) LAUNCH_TILE(16, 128);
       else if (I_tot <= 4096) LAUNCH_TILE(16, 256);
       else LAUNCH_TILE(16, 512);
-    } else if (cfg_ni && (uint64_t)cfg_ni * cfg_b >= I_tot) {  // tuning knob: NI,BLOCK
-      if (cfg_ni == 16 && cfg_b == 64) LAUNCH_NI(16, 64);
-      else if (cfg_ni == 16 && cfg_b == 128) LAUNCH_NI(16, 128);
-      else if (cfg_ni == 16 && cfg_b == 256) LAUNCH_NI(16, 256);
-      else if (cfg_ni == 16 && cfg_b == 512) LAUNCH_NI(16, 512);
-      else if (cfg_ni == 8 && cfg_b == 64) LAUNCH_NI(8, 64);
-      else if (cfg_ni == 8 && cfg_b == 128) LAUNCH_NI(8, 128);
-      else if (cfg_ni == 8 && cfg_b == 256) LAUNCH_NI(8, 256);
-      else if (cfg_ni == 8 && cfg_b == 512) LAUNCH_NI(8, 512);
-      else if (cfg_ni == 4 && cfg_b == 256) LAUNCH_NI(4, 256);
-      else if (cfg_ni == 4 && cfg_b == 512) LAUNCH_NI(4, 512);
-      else return false;
     } else if (I_tot <= 64) LAUNCH_NI(1, 64);
     else if (I_tot <= 128) LAUNCH_NI(2, 64);
     else if (I_tot <= 256) LAUNCH_NI(4, 64);
@@ -3004,7 +2997,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     return true;
   };
   const uint8_t* redo = fs.redo;
-  if (I_tot > 8192 && !cfg_ni && !tile_major) {
+  if (I_tot > 8192 && !tile_major) {
     redo = nullptr;  // more individuals than registers hold: stream every site
   } else if (!interp) {
     if (!launch(1, 0, 0)) return false;
