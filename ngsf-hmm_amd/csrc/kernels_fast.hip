@@ -1632,12 +1632,17 @@ __device__ __forceinline__ void estmaf_site(
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const uint64_t i = (uint64_t)tix + stride * (k0 + j);
-        ic[j] = i < I_tot ? i : I_tot - 1;
+        // (a slot that is full for every thread needs no clamp: its addresses are the lane's
+        // plus a constant)
+        ic[j] = (k0 + j < estmaf_full_slots(NI, BLOCK) || i < I_tot) ? i : I_tot - 1;
         gl_fetch(gl, cell_s + ic[j], r0[j], r1[j], r2[j]);
       }
       if constexpr (TILE) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) rF[j] = tile_col[post_ind_off(ic[j])];
+        for (int j = 0; j < NB; ++j)  // (post_ind_off is additive over multiples of 8)
+          rF[j] = tile_col[k0 + j < estmaf_full_slots(NI, BLOCK)
+                               ? post_ind_off(tix) + (uint64_t)(k0 + j) * post_ind_off(stride)
+                               : post_ind_off(ic[j])];
       } else if (one_block) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) rF[j] = marg_blocks[site * I_blk + ic[j]];
