@@ -283,11 +283,13 @@ __device__ __forceinline__ double2 glq_encode(double l0, double l1, double l2) {
   return double2{(tag & 1) ? -a : a, (tag & 2) ? -b : b};
 }
 __device__ __forceinline__ void glq_decode(double2 q, double& p0, double& p1, double& p2) {
-  const int tag = (int)(ngh_bits(q.x) >> 63) | ((int)(ngh_bits(q.y) >> 63) << 1);
+  // sign of x: the 1 is p1; sign of y: the 1 is p2; neither: p0 (tests on the high words: the
+  // stored value may be -0.0)
+  const bool sx = (int)(ngh_bits(q.x) >> 32) < 0, sy = (int)(ngh_bits(q.y) >> 32) < 0;
   const double a = fabs(q.x), b = fabs(q.y);
-  p0 = tag == 0 ? 1.0 : a;
-  p1 = tag == 0 ? a : tag == 1 ? 1.0 : b;
-  p2 = tag == 2 ? 1.0 : b;
+  p0 = (sx || sy) ? a : 1.0;
+  p1 = sx ? 1.0 : (sy ? b : a);
+  p2 = sy ? 1.0 : b;
 }
 
 // Running product of the e0 of a lane's sites (fresh walks): one multiply per site, the
