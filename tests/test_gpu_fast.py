@@ -348,6 +348,43 @@ def test_fast_ragged_shapes_fused_iteration(pkg, orc_libm, shape):
 
 
 
+def test_fast_more_than_64_waves_per_individual(pkg, orc_libm):
+    """A small cohort over many sites gets more than 64 lane-chunk waves per individual (a rank's
+    share of a strong-scaling run): the objective's finish kernel and the boundary scan then
+    combine K > 1 chunk operators per lane.  3 x 300 000 (> 100 waves each), against the
+    binary128 anchor (oracle/hp_anchor.c) -- over 300 000 sites the log-space double recursion
+    of the reference, as the oracle restates it, is itself 3e-7 off in the posteriors and 6e-13
+    (relative) in the log-likelihood; fast mode stays within 1e-14 of the anchor."""
+    I, S = 3, 300_000
+    d = pkg.simulate.simulate(I, S, seed=77, n_chrom=2, missing_rate=0.05, indF="r", freq="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    hmm, em = _pair(pkg, orc_libm, gl, d.pos_dist_mb)
+    assert hmm.layout()[0] > 64
+    em.init_emission(); hmm.init_emission()
+    hp = orclib.HpAnchor()
+    lk = hmm.estep().copy()
+    mp = hmm.marg_prob
+    assert em.estep() == 0
+    for i in range(I):
+        lk_hp, post = hp.forward_backward(gl[:, i, :].copy(), em.freq.copy(), d.pos_dist_mb, 0.1, 0.2)
+        post[post < 1e-5] = 0
+        post[post > 1 - 1e-5] = 1
+        assert abs(lk[i] - lk_hp) <= 1e-13 * abs(lk_hp)
+        assert abs(em.ind_lkl[i] - lk_hp) <= 1e-11 * abs(lk_hp)      # the oracle's own distance
+        snapped_differently = (mp[i] != post) & ((mp[i] == 0) | (mp[i] == 1) | (post == 0) | (post == 1))
+        assert snapped_differently.sum() <= 2                        # a value next to 1e-5
+        ok = ~snapped_differently
+        np.testing.assert_allclose(mp[i][ok], post[ok], rtol=0, atol=1e-13)
+    # objective values of arbitrary points (general kernel) and two fused iterations: finite,
+    # consistent with the E-step's walk
+    ind = np.arange(I, dtype=np.uint32)
+    np.testing.assert_allclose(hmm.lkl(ind, np.full(I, 0.1), np.full(I, 0.2)), lk, rtol=1e-13)
+    for _ in range(2):
+        hmm.iter_EM()
+        assert np.isfinite(hmm.ind_lkl).all() and np.isfinite(hmm.freq).all()
+    hmm.close()
+
+
 @pytest.mark.parametrize("shape", [(600, 6000), (90, 9000)])
 def test_fast_background_pieces_change_nothing(pkg, monkeypatch, shape):
     """nghmm_iter_em puts the backward sweep and est_maf (in parts) onto the stream behind the
