@@ -2505,10 +2505,12 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   fs.owns_data = true;
   // Waves per individual.  The objective rounds run 4 waves per SIMD = 4096 at a time and
   // all their waves take equally long, so a launch of n waves wastes the unfilled part of
-  // its last batch: ~32k waves per 1000 individuals keep that below 2 % (measured at
-  // 1000 x 1M: FP64 issue 51 % -> 57 % of peak from C = 9 to C = 32).  At least 16 sites
-  // per lane.
-  uint64_t C = (32768 + I - 1) / I;
+  // its last batch, and the later rounds launch only the still-active individuals: ~49k waves
+  // per 1000 individuals (measured at 1000 x 1M, ms per EM iteration: C = 9: 45, 33: 28.85,
+  // 40: 28.3, 48: 28.1-28.3, 56: 28.2, 64: 28.9, 96: 29.0, 128: 29.8 -- beyond ~56 a wave's
+  // fixed cost, the operator tree of every point, outweighs the fuller batches).  At least 16
+  // sites per lane.
+  uint64_t C = (49152 + I - 1) / I;
   if (const char* env = std::getenv("NGHMM_FAST_C")) {  // tuning knob: waves per individual
     const long v = std::atol(env);
     if (v >= 1) C = (uint64_t)v;
