@@ -62,6 +62,18 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
                            uint64_t S, uint64_t I, const double* indF, const double* alpha,
                            const double* ind_lkl, double* marg, int* flags);
 
+// The same two recursions as producer-consumer workgroups (kernels_exact_pc.hip): the
+// state-independent transition logs of a block of sites computed in parallel by producer
+// waves, the sequential chain reduced to its two logsums per site, two lanes per chain.
+// Bit-identical to the serial kernels above; what the C ABI launches.
+void launch_forward_exact_pc(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                             uint64_t I, uint32_t n_pts, const uint32_t* ind, const double* F,
+                             const double* alpha, double* lkl_out, double* fw, int* flags);
+void launch_backward_exact_pc(hipStream_t st, const double* eprob, const double* pos,
+                              const double* fw, uint64_t S, uint64_t I, const double* indF,
+                              const double* alpha, const double* ind_lkl, double* marg,
+                              int* flags);
+
 // est_maf per site (shared/gen_func.cpp:974-1009): gl_sites [S_own][I_tot][3],
 // marg_sites [S_own][I_tot] -> freq_out[S_own]; passes_out (nullable) counts passes.
 void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,

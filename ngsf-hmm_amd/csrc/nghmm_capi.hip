@@ -64,8 +64,14 @@ struct nghmm_handle {
   int device = 0, mode = NGHMM_MODE_EXACT;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
+  // exact mode, fused iteration: est_maf on a second stream underneath the objective rounds
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr;
   bool blocking_sync = false;
   bool loaded = false;
+  // exact mode: the recursions as one lane per chain (kernels_exact.hip) instead of the
+  // producer-consumer workgroups (kernels_exact_pc.hip); same bits, NGHMM_EXACT_SERIAL=1
+  bool exact_serial = false;
 
   double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
          *d_marg = nullptr, *d_indF = nullptr, *d_alpha = nullptr, *d_ind_lkl = nullptr;
@@ -367,8 +373,9 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     HIP_TRY(hipMemcpyAsync(h->d_pt_A, alpha, n_pts * sizeof(double), hipMemcpyHostToDevice,
                            h->stream));
     tic(h);
-    launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind,
-                         h->d_pt_F, h->d_pt_A, h->d_pt_lkl, nullptr, h->d_flags);
+    (h->exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
+        h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
+        h->d_pt_lkl, nullptr, h->d_flags);
   }
   const double ms_before = accumulate ? h->ms[SLOT_LKL] : 0.0;
   if ((rc = toc(h, SLOT_LKL, accumulate))) return rc;
@@ -605,6 +612,7 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
   h->packed = packed;
   h->I_tot = n_ind;
   h->S_own = n_sites;
+  h->exact_serial = std::getenv("NGHMM_EXACT_SERIAL") != nullptr;
   int rc = NGHMM_OK;
   do {
     if (hipSetDevice(device) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
@@ -693,6 +701,9 @@ int nghmm_destroy(nghmm_t* h) {
     h->parent->n_replicas.fetch_sub(1);
   }
   fast_destroy(h->fast);
+  for (hipEvent_t e : {h->aux_ev0, h->aux_ev1, h->aux_go})
+    if (e) (void)hipEventDestroy(e);
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
@@ -720,6 +731,7 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   h->device = parent->device;
   h->mode = parent->mode;
   h->packed = parent->packed;
+  h->exact_serial = parent->exact_serial;
   h->I_tot = h->I;
   h->S_own = h->S;
   h->parent = parent;
@@ -1113,13 +1125,15 @@ int nghmm_estep(nghmm_t* h, double* ind_lkl) {
   if ((rc = clear_flags(h))) return rc;
   {
     tic(h);
-    launch_forward_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr,
-                         h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_fw, h->d_flags);
+    (h->exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
+        h->stream, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr, h->d_indF,
+        h->d_alpha, h->d_ind_lkl, h->d_fw, h->d_flags);
     if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
     tic(h);
     h->tmp_is_posteriors = false;
-    launch_backward_exact(h->stream, h->d_eprob, h->d_pos, h->d_fw, h->S, h->I, h->d_indF,
-                          h->d_alpha, h->d_ind_lkl, h->d_marg, h->d_flags);
+    (h->exact_serial ? launch_backward_exact : launch_backward_exact_pc)(
+        h->stream, h->d_eprob, h->d_pos, h->d_fw, h->S, h->I, h->d_indF, h->d_alpha,
+        h->d_ind_lkl, h->d_marg, h->d_flags);
     if ((rc = toc(h, SLOT_BACKWARD, false))) return rc;
   }
   HIP_TRY(hipGetLastError());
@@ -1499,6 +1513,35 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
                               freq_est == 1, &freq_done)))
       return rc;
     return freq_done ? NGHMM_OK : nghmm_mstep_freq(h, freq_est);
+  }
+  if (h->mode == NGHMM_MODE_EXACT && freq_est == 1 && h->I_tot == h->I) {
+    // Exact mode: est_maf (EM.cpp:209-257) reads the E-step's posteriors and the likelihoods
+    // and writes the frequencies; the objective rounds (EM.cpp:198-201) read the emissions of
+    // the OLD frequencies.  Neither touches what the other uses, and a round is a few hundred
+    // latency-bound waves on a chip of 1024 SIMDs: est_maf goes onto a second stream right
+    // after the E-step and runs underneath the rounds (whose chain waves raise their issue
+    // priority); the emissions are refreshed when both are done.  Same kernels, same data.
+    if ((rc = nghmm_estep(h, ind_lkl))) return rc;
+    if (!h->aux_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreate(&h->aux_ev0));
+      HIP_TRY(hipEventCreate(&h->aux_ev1));
+      HIP_TRY(hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(h->aux_go, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
+    HIP_TRY(hipEventRecord(h->aux_ev0, h->aux_stream));
+    launch_estmaf_exact(h->aux_stream, own_gl(h), h->d_marg, h->S, h->I, h->d_freq, nullptr);
+    HIP_TRY(hipEventRecord(h->aux_ev1, h->aux_stream));
+    HIP_TRY(hipGetLastError());
+    rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats);
+    HIP_TRY(hipEventSynchronize(h->aux_ev1));  // also when the M-step failed: nothing left running
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->aux_ev0, h->aux_ev1));
+    h->ms[SLOT_ESTMAF] = ms;
+    h->launches[SLOT_ESTMAF] = 1;
+    if (rc != NGHMM_OK) return rc;
+    return emission_impl(h);
   }
   if ((rc = nghmm_estep_mstep(h, indF_fixed, alpha_fixed, ind_lkl, stats, nullptr, nullptr)))
     return rc;

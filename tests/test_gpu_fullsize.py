@@ -56,7 +56,7 @@ def test_fast_equals_exact_at_full_size(pkg, big):
     F = rng.uniform(0.01, 0.99, 300)
     A = rng.uniform(1e-3, 5, 300)
     obj_fast = fast.lkl(ind, F, A)
-    sub = slice(0, 40)
+    sub = slice(0, 250)   # 2.5 x 10^8 posteriors
     post_fast = fast.marg_prob[sub].copy()
     fast.mstep_freq(1)
     freq_fast = fast.freq
