@@ -254,6 +254,19 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    preflight = None
+    if world > 1:
+        # known-answer all-to-all + all-gather on float64 device tensors through the very
+        # calls the iteration makes, BEFORE any data is loaded: a backend that moves wrong
+        # bytes (or none: the nccl path had never run before the driver's 8-GPU node) must
+        # end the run with a message, not a plausible number
+        ddp = importlib.import_module("ngsf-hmm_amd.distributed")
+        try:
+            preflight = ddp.preflight(device)
+        except Exception as e:   # noqa: BLE001 - any failure of the collectives ends the run
+            sys.stderr.write(f"bench.py: rank {rank}: {type(e).__name__}: {e}\n")
+            sys.stderr.flush()
+            os._exit(3)
 
     wl = dict(WORKLOADS[args.workload])
     if args.n_ind:
@@ -330,6 +343,7 @@ def main():
 
     for _ in range(args.warmup):
         iterate_all()
+    em.reset_timing()
     fam = {k: 0.0 for k in ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first")}
     launches = dict.fromkeys(fam, 0)
     rounds = points = ind_rounds = ref_calls = 0
@@ -347,11 +361,26 @@ def main():
             launches[k] += n
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64,
                          device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank's own clocks, so that the scaling line can be read: kernel families
+        # (HIP events on the library's stream), the exchange (duration and the part of it the
+        # host actually waited for), the frequency step on the own site range
+        K_ = max(args.steps, 1)
+        mine = {"rank": rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
+                "exchange_ms_per_iter": {
+                    "all_to_all": em.timing["a2a_ms"] / K_,
+                    "all_to_all_exposed": em.timing["a2a_exposed_ms"] / K_,
+                    "all_to_all_hidden": max(em.timing["a2a_ms"] - em.timing["a2a_exposed_ms"], 0.0) / K_,
+                    "all_gather": em.timing["allgather_ms"] / K_,
+                    "freq_step_call": em.timing["freq_step_ms"] / K_},
+                "rounds_per_iter": rounds / K_}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         K = max(args.steps, 1)
@@ -451,6 +480,16 @@ def main():
                          "note": LIMITER_NOTES.get(dom, "")},
             "roofline_all_kernels": fam_roof,
             "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
+            "preflight": preflight,
+            "collective_bytes_per_iter": (None if world == 1 else dict(
+                em.collective_bytes_per_iter(),
+                note="bytes leaving each GPU per EM iteration: posterior slices to the other "
+                     "ranks' site ranges (all-to-all, issued right after the E-step, under the "
+                     "remaining objective rounds) and the own frequencies (all-gather)")),
+            "exchange_ms": (None if world == 1 else {
+                k: max(r["exchange_ms_per_iter"][k] for r in per_rank)
+                for k in per_rank[0]["exchange_ms_per_iter"]}),
+            "per_rank": per_rank,
             "bfgs": {"rounds_per_iter": rounds / K, "points_per_iter": points / K,
                      "ind_rounds_per_iter": ind_rounds / K,
                      "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},

@@ -59,14 +59,18 @@ enum {
    * shared/gen_func.cpp:886-914), of which every cell is one of four -- genotype 0, 1, 2
    * or missing -- and is kept as a 2-bit code (0.25 B instead of 24 B per site and
    * individual).  Results equal those of an unpacked handle given the same cells: bit for bit
-   * in exact mode.  A loader that meets a cell which is not a called genotype returns
-   * NGHMM_ERR_ARG. */
+   * in exact mode.  A loader that meets a cell which is not a called genotype (one-hot or
+   * uniform likelihoods) returns NGHMM_ERR_NOT_PACKABLE -- the host then falls back to an
+   * unpacked handle; NGHMM_ERR_ARG is for input that is wrong either way: a reader genotype
+   * > 2, or uniform cells carrying different values within one data set. */
   NGHMM_GENO_PACKED = 0x10
 };
 
 /* Statistics of one indF/alpha M-step (shared/bfgs.cpp rounds). */
 typedef struct {
-  uint32_t rounds;          /* lock-step objective rounds (GPU launches)            */
+  uint32_t rounds;          /* objective rounds: the longest sequence of evaluations any
+                               individual needed (= lock-step launches when every round
+                               covers all individuals; the two-lane M-step launches more) */
   uint64_t points;          /* objective evaluations sent to the GPU                */
   uint64_t ref_forward_calls; /* forward passes the reference would have spent      */
   uint64_t ind_rounds;      /* sum over rounds of the individuals still being optimised:
@@ -124,6 +128,11 @@ int nghmm_load_gl_device(nghmm_t* h, const double* d_gl_site_major, const double
  * goes to the device a block of sites at a time; read_geno, shared/read_data.cpp:13-116,
  * holds the whole matrix): nghmm_load_begin with the distances, then every site exactly once
  * in chunks [site_begin, site_begin + n_sites) of any size and order, then nghmm_load_end.
+ * "Exactly once" is checked: a chunk that overlaps sites this load has already received is
+ * NGHMM_ERR_ARG (nothing of it is taken), and so is nghmm_load_end before all n_sites have
+ * arrived.  A chunk that fails for another reason (NGHMM_ERR_NAN, NGHMM_ERR_NOT_PACKABLE, a
+ * genotype > 2) may have left cells behind: it ends the load, which starts again with
+ * nghmm_load_begin.
  *   nghmm_load_gl_raw_sites      raw likelihoods [n_sites][I][3] as nghmm_load_gl_raw takes them
  *   nghmm_load_gl_raw_sites_dev  the same from a device buffer (left unmodified)
  *   nghmm_load_geno_sites        called genotypes [n_sites][I] as the reader sees them, -1
@@ -267,6 +276,28 @@ int nghmm_group_iter_em(nghmm_t** handles, int n, int freq_est, int indF_fixed, 
 /* the allele-frequency step alone (nghmm_mstep_freq for the cohort), from the posteriors the
  * handles hold: all zero before the first E-step, which is `--freq e` */
 int nghmm_group_mstep_freq(nghmm_t** handles, int n, int freq_est);
+
+/* Measurement and debugging switches of a handle.  None changes a result beyond rounding (the
+ * kernels, their order on the stream or what is printed; DESIGN.md section 7 says what each is
+ * for).  A handle reads them from the environment ONCE, in nghmm_create -- NGHMM_<NAME> with
+ * the name in capitals; a variable that is set without a number counts as 1 -- and a replica
+ * inherits its parent's; later only this call changes them:
+ *   pipeline          two-lane objective rounds: -1 by cohort size (default), 0 off, 1 on
+ *   no_bg             1: backward sweep and est_maf after the objective rounds, not behind them
+ *   bg_parts          est_maf goes behind the rounds in this many parts (default 2)
+ *   no_fuse           1: E-step and M-step each make a forward walk of their own
+ *   eager_emission    1: stored emissions refreshed right after every frequency update
+ *   estmaf_interp     0: every est_maf pass evaluated over all individuals (default 1)
+ *   estmaf_sitemajor  1: est_maf on a site-major copy of the posteriors
+ *   estmaf_no_rows    1: small cohorts take a wave per site instead of four sites per wave
+ *   exact_serial      1: exact-mode recursions as one lane per chain (kernels_exact.hip)
+ *                     instead of producer-consumer workgroups (kernels_exact_pc.hip): same bits
+ *   timing            1: host-side phase times of every M-step on stderr
+ *   debug_modes       1: kernel versions of every objective round on stderr
+ * Fixed at creation (environment only): fast_c (waves per individual), spin_sync (replicas
+ * wait spinning).  Unknown names return NGHMM_ERR_ARG.  Outside the handle: NGHMM_HOST_THREADS
+ * (host threads of the L-BFGS-B state machines, read once per process). */
+int nghmm_set_switch(nghmm_t* h, const char* name, long value);
 
 /* Fast-mode layout of the site axis: every individual's sites are cut into 64 * waves
  * runs of sites_per_lane sites; 0, 0 in exact mode.  Diagnostic. */

@@ -57,6 +57,7 @@ void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, b
     if (F_fixed) p.lb[0] = p.ub[0] = indF[i];
     if (alpha_fixed) p.lb[1] = p.ub[1] = alpha[i];
     p.like = 0;
+    p.n_rounds = 0;
     p.grad[0] = p.grad[1] = 0;
     p.have_eval = false;
     p.started = false;
@@ -138,7 +139,14 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
       alpha.push_back(p.pt[k][1]);
     }
   }
-  ++rounds_;
+  // rounds = the longest sequence of evaluations any individual has needed: the number of
+  // lock-step rounds when every gather covers everybody, and the same figure when the
+  // individuals are gathered in parts (two-lane M-step), whatever the number of launches
+  for (size_t i = lo; i < hi; ++i) {
+    Problem& p = probs_[i];
+    if (!p.active) continue;
+    if (++p.n_rounds > rounds_) rounds_ = p.n_rounds;
+  }
   points_ += ind.size();
   ind_rounds_ += n_act;
   return ind.size();

@@ -54,6 +54,7 @@ class BfgsBatch {
     bool have_eval = false;
     bool started = false;
     bool active = true;
+    uint32_t n_rounds = 0;  // rounds this problem has had points in
     // plan of the current round
     int probe_kind[2];  // 0 central, 1 forward (x + 2eh), 2 backward (x - 2eh), 3 fixed (skipped)
     double eh[2];

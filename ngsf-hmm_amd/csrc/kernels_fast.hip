@@ -50,7 +50,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -2466,6 +2468,19 @@ k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
   }
 }
 
+struct SwitchName {
+  const char* name;
+  int Switches::*field;
+};
+const SwitchName kSwitches[] = {
+    {"pipeline", &Switches::pipeline}, {"no_bg", &Switches::no_bg},
+    {"bg_parts", &Switches::bg_parts}, {"no_fuse", &Switches::no_fuse},
+    {"eager_emission", &Switches::eager_emission}, {"estmaf_interp", &Switches::estmaf_interp},
+    {"estmaf_sitemajor", &Switches::estmaf_sitemajor}, {"estmaf_no_rows", &Switches::estmaf_no_rows},
+    {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
+    {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
+    {"debug_modes", &Switches::debug_modes}};
+
 template <typename T>
 bool dalloc(T** p, size_t n) {
   if (n == 0) n = 1;
@@ -2475,6 +2490,29 @@ bool dalloc(T** p, size_t n) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
+Switches Switches::from_env() {
+  Switches sw;
+  for (const auto& k : kSwitches) {
+    std::string env = "NGHMM_";
+    for (const char* c = k.name; *c; ++c) env += (char)std::toupper((unsigned char)*c);
+    if (const char* v = std::getenv(env.c_str())) {
+      char* end = nullptr;
+      const long n = std::strtol(v, &end, 10);
+      sw.*(k.field) = (end != v) ? (int)n : 1;  // set without a number: on
+    }
+  }
+  return sw;
+}
+
+bool Switches::set(const char* name, long value) {
+  for (const auto& k : kSwitches)
+    if (std::strcmp(k.name, name) == 0) {
+      this->*(k.field) = (int)value;
+      return true;
+    }
+  return false;
+}
+
 // the arrays an EM run writes (everything but the data): emissions, frequency table,
 // posteriors, checkpoints, boundary operators
 static bool fast_alloc_run_state(FastState& fs) {
@@ -2511,16 +2549,13 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   // fixed cost, the operator tree of every point, outweighs the fuller batches).  At least 16
   // sites per lane.
   uint64_t C = (49152 + I - 1) / I;
-  if (const char* env = std::getenv("NGHMM_FAST_C")) {  // tuning knob: waves per individual
-    const long v = std::atol(env);
-    if (v >= 1) C = (uint64_t)v;
-  }
+  if (fs.sw.fast_c >= 1) C = (uint64_t)fs.sw.fast_c;  // tuning knob: waves per individual
   if (C > 256) C = 256;  // (measured at 125 x 1M: 5.50 ms per iteration with 64, 5.30 with 256)
   // at least 32 sites per lane above 64 waves per individual (16 below): a wave's fixed cost
   // -- the 64-lane operator tree of every point -- is that of about a dozen sites
   while (C > 1 && (S + 64 * C - 1) / (64 * C) < (C > 64 ? 32u : 16u)) --C;
   if (C < 1) C = 1;
-  if (!std::getenv("NGHMM_FAST_C")) {
+  if (fs.sw.fast_c < 1) {
     // sites per lane are rounded up to whole groups of 8 (16: packed), which at a few dozen
     // sites per lane pads a lot (100 x 100k: 24.4 -> 32 sites per lane, 31 %): take the count
     // within a quarter below the target that pads least
@@ -2557,6 +2592,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
 
 bool fast_create_replica(FastState& fs, const FastState& parent) {
   fs = FastState();
+  fs.sw = parent.sw;
   fs.I = parent.I;
   fs.S = parent.S;
   fs.T = parent.T;
@@ -2739,7 +2775,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     L.mode_ranges.push_back({groups[k].mode, k, e - k});
     k = e;
   }
-  if (std::getenv("NGHMM_DEBUG_MODES")) {  // which loop-body versions this round uses
+  if (fs.sw.debug_modes) {  // which loop-body versions this round uses
     std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
     for (const auto& r : L.mode_ranges) {
       if (r.mode)
@@ -2921,7 +2957,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   // Interpolated passes (see k_fast_estmaf) unless NGHMM_ESTMAF_INTERP=0, which runs
   // every pass exactly.
   bool interp = true;
-  if (const char* env = std::getenv("NGHMM_ESTMAF_INTERP")) interp = std::atoi(env) != 0;
+  interp = fs.sw.estmaf_interp != 0;
   // waves per site (W) and individuals per lane (NI): 16 per lane at two waves per SIMD;
   // a workgroup must fit one CU
   // resuming launches: 64 statuses per workgroup and turn
@@ -2968,7 +3004,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                          allow_build);                                                          \
   } while (0)
   // up to 128 individuals: four sites per wave (k_fast_estmaf_rows)
-  const bool rows = I_tot <= 128 && !std::getenv("NGHMM_ESTMAF_NO_ROWS");
+  const bool rows = I_tot <= 128 && !fs.sw.estmaf_no_rows;
   auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
     if (rows) {
       if (tile_major) {

@@ -11,7 +11,30 @@
 
 namespace nghmm {
 
+// Measurement / debugging switches of a handle (include/nghmm.h lists them).  None changes a
+// result beyond rounding.  Read from the environment ONCE, when the handle is created
+// (NGHMM_<NAME in capitals>); afterwards only nghmm_set_switch changes them.
+struct Switches {
+  int pipeline = -1;          // two-lane objective rounds: -1 by cohort size, 0 off, 1 on
+  int no_bg = 0;              // backward sweep and est_maf after the rounds, not behind them
+  int bg_parts = 2;           // est_maf behind the rounds in this many parts
+  int no_fuse = 0;            // E-step and M-step each with a forward walk of their own
+  int eager_emission = 0;     // refresh the stored emissions right after a frequency update
+  int estmaf_interp = 1;      // 0: every est_maf pass evaluated over all individuals
+  int estmaf_sitemajor = 0;   // est_maf on a site-major copy of the posteriors
+  int estmaf_no_rows = 0;     // small cohorts: a wave per site instead of four sites per wave
+  int fast_c = 0;             // waves per individual (0: by cohort size); at creation only
+  int exact_serial = 0;       // exact mode: one lane per chain instead of producer-consumer
+  int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
+  int timing = 0;             // host-side phase times of every M-step on stderr
+  int debug_modes = 0;        // kernel versions of every objective round on stderr
+  static Switches from_env();
+  // false: no switch of that name
+  bool set(const char* name, long value);
+};
+
 struct FastState {
+  Switches sw;
   uint64_t I = 0, S = 0;
   uint64_t T = 0;     // sites walked by one lane
   uint32_t C = 0;     // waves (chunks of 64 lanes) per individual

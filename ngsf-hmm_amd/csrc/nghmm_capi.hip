@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <functional>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -69,9 +70,6 @@ struct nghmm_handle {
   hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr;
   bool blocking_sync = false;
   bool loaded = false;
-  // exact mode: the recursions as one lane per chain (kernels_exact.hip) instead of the
-  // producer-consumer workgroups (kernels_exact_pc.hip); same bits, NGHMM_EXACT_SERIAL=1
-  bool exact_serial = false;
 
   double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
          *d_marg = nullptr, *d_indF = nullptr, *d_alpha = nullptr, *d_ind_lkl = nullptr;
@@ -144,6 +142,9 @@ struct nghmm_handle {
   double *g_send = nullptr, *g_recv = nullptr, *g_freq_own = nullptr, *g_freq_all = nullptr;
   hipStream_t g_xstream = nullptr;
   bool loading = false;
+  // sites that have arrived since nghmm_load_begin, as disjoint [begin, end) runs: every site
+  // must arrive exactly once (a repeated site would OR two codes into a packed cell)
+  std::map<uint64_t, uint64_t> load_cover;
   double* d_stage = nullptr;          // staging buffer of one chunk of raw likelihoods
   size_t stage_cap = 0;
   int8_t* d_stage8 = nullptr;         // ... of one chunk of reader genotypes
@@ -373,7 +374,7 @@ int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     HIP_TRY(hipMemcpyAsync(h->d_pt_A, alpha, n_pts * sizeof(double), hipMemcpyHostToDevice,
                            h->stream));
     tic(h);
-    (h->exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
+    (h->fast.sw.exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
         h->stream, h->d_eprob, h->d_pos, h->S, h->I, n_pts, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
         h->d_pt_lkl, nullptr, h->d_flags);
   }
@@ -490,7 +491,7 @@ int emission_impl(nghmm_t* h) {
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
     if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags)) return NGHMM_ERR_HIP;
-    if (std::getenv("NGHMM_EAGER_EMISSION") &&
+    if (h->fast.sw.eager_emission &&
         !fast_refresh_emissions(h->fast, h->stream, h->d_freq, h->d_flags))
       return NGHMM_ERR_HIP;
   } else {
@@ -612,7 +613,7 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
   h->packed = packed;
   h->I_tot = n_ind;
   h->S_own = n_sites;
-  h->exact_serial = std::getenv("NGHMM_EXACT_SERIAL") != nullptr;
+  h->fast.sw = Switches::from_env();  // the only place the environment is read
   int rc = NGHMM_OK;
   do {
     if (hipSetDevice(device) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
@@ -731,7 +732,7 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   h->device = parent->device;
   h->mode = parent->mode;
   h->packed = parent->packed;
-  h->exact_serial = parent->exact_serial;
+  h->fast.sw = parent->fast.sw;
   h->I_tot = h->I;
   h->S_own = h->S;
   h->parent = parent;
@@ -744,7 +745,7 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   do {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     // replicas are driven from one host thread each: wait without spinning
-    h->blocking_sync = !std::getenv("NGHMM_SPIN_SYNC");
+    h->blocking_sync = !h->fast.sw.spin_sync;
     const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
     if (hipEventCreateWithFlags(&h->ev0, evf) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev1, evf) != hipSuccess ||
@@ -903,6 +904,7 @@ int nghmm_load_begin(nghmm_t* h, const double* pos) {
   HIP_TRY(sync_stream(h));
   h->loaded = false;
   h->loading = true;
+  h->load_cover.clear();
   return NGHMM_OK;
 }
 
@@ -920,6 +922,7 @@ static int load_begin_dev(nghmm_t* h, const double* d_pos) {
   }
   h->loaded = false;
   h->loading = true;
+  h->load_cover.clear();
   return NGHMM_OK;
 }
 
@@ -933,6 +936,51 @@ int nghmm_load_begin_dev(nghmm_t* h, const double* d_pos) {
   return NGHMM_OK;
 }
 
+// chunked loading: claim the sites [b, b + n) of the current load; overlap is an error
+static int claim_sites(nghmm_t* h, uint64_t b, uint64_t n) {
+  const uint64_t e = b + n;
+  auto it = h->load_cover.upper_bound(b);  // first run that begins after b
+  if (it != h->load_cover.begin()) {
+    auto prev = std::prev(it);
+    if (prev->second > b) {
+      set_error("chunk loader: sites [%llu, %llu) overlap [%llu, %llu), which this load has "
+                "already received: every site exactly once",
+                (unsigned long long)b, (unsigned long long)e, (unsigned long long)prev->first,
+                (unsigned long long)prev->second);
+      return NGHMM_ERR_ARG;
+    }
+  }
+  if (it != h->load_cover.end() && it->first < e) {
+    set_error("chunk loader: sites [%llu, %llu) overlap [%llu, %llu), which this load has "
+              "already received: every site exactly once",
+              (unsigned long long)b, (unsigned long long)e, (unsigned long long)it->first,
+              (unsigned long long)it->second);
+    return NGHMM_ERR_ARG;
+  }
+  // insert, merging with the neighbours it touches
+  uint64_t nb = b, ne = e;
+  if (it != h->load_cover.begin()) {
+    auto prev = std::prev(it);
+    if (prev->second == b) {
+      nb = prev->first;
+      h->load_cover.erase(prev);
+    }
+  }
+  if (it != h->load_cover.end() && it->first == e) {
+    ne = it->second;
+    h->load_cover.erase(it);
+  }
+  h->load_cover[nb] = ne;
+  return NGHMM_OK;
+}
+
+// a chunk that failed half way has left cells behind (a packed handle ORs codes in): the load
+// is over, the caller starts again with nghmm_load_begin
+static int fail_load(nghmm_t* h, int rc) {
+  if (rc != NGHMM_OK) h->loading = false;
+  return rc;
+}
+
 static int load_sites_impl(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* src,
                            bool src_on_device, bool prepare, int space, int call_geno,
                            int check_nan) {
@@ -944,16 +992,23 @@ static int load_sites_impl(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, co
   if (n_sites == 0) return NGHMM_OK;
   int rc;
   if ((rc = use_device(h))) return rc;
+  if ((rc = claim_sites(h, site_begin, n_sites))) return rc;
   const uint64_t n_cells = n_sites * h->I;
   if (src_on_device)
-    return ingest_chunk(h, site_begin, n_sites, src, false, prepare, space, call_geno, check_nan);
+    return fail_load(h, ingest_chunk(h, site_begin, n_sites, src, false, prepare, space,
+                                     call_geno, check_nan));
   double* dst = h->packed ? nullptr : h->d_gl + site_begin * h->I * 3;
   if (h->packed) {
-    if ((rc = ensure_stage(h, n_cells * 3))) return rc;
+    if ((rc = ensure_stage(h, n_cells * 3))) return fail_load(h, rc);
     dst = h->d_stage;
   }
-  HIP_TRY(hipMemcpyAsync(dst, src, n_cells * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  return ingest_chunk(h, site_begin, n_sites, dst, true, prepare, space, call_geno, check_nan);
+  if (hipMemcpyAsync(dst, src, n_cells * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream) !=
+      hipSuccess) {
+    set_error("chunk loader: copy to the device failed");
+    return fail_load(h, NGHMM_ERR_HIP);
+  }
+  return fail_load(h, ingest_chunk(h, site_begin, n_sites, dst, true, prepare, space, call_geno,
+                                   check_nan));
 }
 
 int nghmm_load_gl_raw_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* gl_raw,
@@ -977,8 +1032,9 @@ int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, con
   if (n_sites == 0) return NGHMM_OK;
   int rc;
   if ((rc = use_device(h))) return rc;
+  if ((rc = claim_sites(h, site_begin, n_sites))) return rc;
   const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
-  if ((rc = ensure_stage8(h, n_cells))) return rc;
+  if ((rc = ensure_stage8(h, n_cells))) return fail_load(h, rc);
   HIP_TRY(hipMemcpyAsync(h->d_stage8, geno, n_cells, hipMemcpyHostToDevice, h->stream));
   if ((rc = clear_flags(h))) return rc;
   if (h->packed) {
@@ -1003,14 +1059,27 @@ int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, con
     launch_prepare_gl(h->stream, dst, n_cells, NGHMM_GL_LOG, 0, h->d_flags);
   }
   HIP_TRY(hipGetLastError());
-  return check_load_flags(h, false);
+  return fail_load(h, check_load_flags(h, false));
 }
 
 int nghmm_load_end(nghmm_t* h) {
   g_last_error.clear();
-  if (!h || !h->loading) return NGHMM_ERR_ARG;
+  if (!h || !h->loading) {
+    set_error("nghmm_load_end: no load in progress (nghmm_load_begin not called, or a chunk failed)");
+    return NGHMM_ERR_ARG;
+  }
   int rc;
   if ((rc = use_device(h))) return rc;
+  // every site exactly once: one run [0, S)
+  if (h->load_cover.size() != 1 || h->load_cover.begin()->first != 0 ||
+      h->load_cover.begin()->second != h->S) {
+    uint64_t got = 0;
+    for (const auto& r : h->load_cover) got += r.second - r.first;
+    set_error("nghmm_load_end: %llu of %llu sites have been loaded", (unsigned long long)got,
+              (unsigned long long)h->S);
+    h->loading = false;
+    return NGHMM_ERR_ARG;
+  }
   return after_gl_load(h);
 }
 
@@ -1125,13 +1194,13 @@ int nghmm_estep(nghmm_t* h, double* ind_lkl) {
   if ((rc = clear_flags(h))) return rc;
   {
     tic(h);
-    (h->exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
+    (h->fast.sw.exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
         h->stream, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr, h->d_indF,
         h->d_alpha, h->d_ind_lkl, h->d_fw, h->d_flags);
     if ((rc = toc(h, SLOT_FORWARD, false))) return rc;
     tic(h);
     h->tmp_is_posteriors = false;
-    (h->exact_serial ? launch_backward_exact : launch_backward_exact_pc)(
+    (h->fast.sw.exact_serial ? launch_backward_exact : launch_backward_exact_pc)(
         h->stream, h->d_eprob, h->d_pos, h->d_fw, h->S, h->I, h->d_indF, h->d_alpha,
         h->d_ind_lkl, h->d_marg, h->d_flags);
     if ((rc = toc(h, SLOT_BACKWARD, false))) return rc;
@@ -1165,65 +1234,72 @@ int nghmm_lkl_batch(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const doubl
 // parts, go onto the stream right behind each round's kernels: the GPU works on them while the
 // host digests the round's values and prepares the next -- otherwise ~0.25 ms of idle device
 // per round.  Same kernels on the same data in a different order; every result is unchanged.
-// *freq_done tells the caller that the frequency step (and the frequency-table refresh of
-// nghmm_init_emission) has been done here.
-static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats,
-                           bool fuse_estep, double* ind_lkl, nghmm_hook_fn after_estep = nullptr,
-                           void* user = nullptr, bool fuse_freq = false,
-                           bool* freq_done = nullptr) {
-  int rc;
-  if (freq_done) *freq_done = false;
-  // the E-step inside the loop below, then the caller's hook (multi-GPU: start moving the
-  // posteriors while the remaining objective rounds run)
-  auto estep_then_hook = [&](bool have_walk) -> int {
-    int r = fast_estep_impl(h, ind_lkl, have_walk);
-    if (r == NGHMM_OK && after_estep) after_estep(user);
-    return r;
-  };
-  if (stats) std::memset(stats, 0, sizeof *stats);
-  h->ms[SLOT_LKL] = 0;
-  h->launches[SLOT_LKL] = 0;
-  h->ms[SLOT_LKL_FIRST] = 0;
-  h->launches[SLOT_LKL_FIRST] = 0;
-  if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
-    return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
+//
+// The rounds themselves take one of three routes:
+//   first_or_plain_round  a whole round through lkl_batch_impl, synchronous: the first round
+//                         of every M-step (it may double as the E-step's forward walk), and
+//                         every round of a handle with neither of the two below;
+//   round_with_background a whole round on lane 0's pinned buffers with the next background
+//                         piece enqueued behind its kernels before the host waits for it;
+//   two_lane_rounds       after the first round, small cohorts: the individuals in two halves
+//                         on two lanes -- while the GPU evaluates one half's points the host
+//                         scatters the other half's values into its L-BFGS-B machines, gathers
+//                         their next points and enqueues them (EM.cpp:198-201 has no coupling
+//                         between individuals either).  Worth it where a round is short against
+//                         the host's share of it (100 x 100k: 1.36 -> 1.25 ms per iteration); at
+//                         1000 x 1M two half launches lose to their emptier last wave batches
+//                         what the overlap gains (37.4-38.4 against 36.9-37.9 ms).
+namespace {
 
-  // NGHMM_TIMING=1: host-side wall time of the phases of this call on stderr
-  const bool timing = std::getenv("NGHMM_TIMING") != nullptr;
+struct MstepRun {
+  nghmm_t* h;
+  int indF_fixed, alpha_fixed;
+  bool fuse_estep, fuse_freq;
+  double* ind_lkl;
+  nghmm_hook_fn after_estep;
+  void* user;
+
+  BfgsBatch& batch;
+  bool estep_pending = false;
+  bool bg_active = false;
+  bool tile_major = false;      // est_maf reads the tile-major posteriors in place
+  uint32_t bg_parts = 0, bg_next = 0;  // est_maf parts queued / already on the stream
+  // host-side wall time of the phases (switch `timing`)
   double t_gather = 0, t_lkl = 0, t_estep = 0, t_scatter = 0;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto since = [&](std::chrono::steady_clock::time_point t0) {
-    return std::chrono::duration<double, std::milli>(now() - t0).count();
-  };
-  BfgsBatch& batch = h->batch;
-  auto t0 = now();
-  batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
-  t_gather += since(t0);
   std::vector<uint32_t> ind;
   std::vector<double> F, A, lkl;
-  bool estep_pending = fuse_estep;
-  // Fast mode, after the first round (which covers everyone and doubles as the E-step's
-  // forward walk): the individuals in two halves on two lanes.  While the GPU evaluates one
-  // half's points the host scatters the other half's values into its L-BFGS-B machines,
-  // gathers their next points and enqueues them, so the device does not wait for the host
-  // between rounds (EM.cpp:198-201 has no such coupling either: its tasks are independent).
-  // Worth it where a round is short against the host's share of it (100 x 100k: 1.36 -> 1.25
-  // ms per iteration); at 1000 x 1M two half launches lose to their emptier last wave batches
-  // what the overlap gains (37.4-38.4 against 36.9-37.9 ms): there the rounds stay whole.
-  const char* pl = std::getenv("NGHMM_PIPELINE");  // 0 / 1 force it off / on
-  const bool pipelined = h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
-                         (pl ? std::atoi(pl) != 0 : (uint64_t)h->I * h->fast.C < 16384);
-  // background pieces (see above): closures that enqueue one piece each, in order
-  const bool want_bg = fuse_freq && fuse_estep && !after_estep && h->mode == NGHMM_MODE_FAST &&
-                       h->I_tot == h->I && !std::getenv("NGHMM_EAGER_EMISSION") &&
-                       !std::getenv("NGHMM_NO_BG");
-  bool bg_active = false;
-  std::vector<std::function<int()>> bg_queue;
-  size_t bg_next = 0;
-  auto bg_push_next = [&]() -> int {
-    return bg_next < bg_queue.size() ? bg_queue[bg_next++]() : NGHMM_OK;
-  };
-  auto bg_start = [&](bool have_walk) -> int {  // the E-step now, est_maf queued in parts
+
+  using clock = std::chrono::steady_clock;
+  static double since(clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(clock::now() - t0).count();
+  }
+
+  MstepRun(nghmm_t* h_, int f, int a, bool fe, double* il, nghmm_hook_fn hook, void* u, bool ff)
+      : h(h_), indF_fixed(f), alpha_fixed(a), fuse_estep(fe), fuse_freq(ff), ind_lkl(il),
+        after_estep(hook), user(u), batch(h_->batch) {}
+
+  // the E-step, then the caller's hook (multi-GPU: start moving the posteriors while the
+  // remaining objective rounds run)
+  int estep_then_hook(bool have_walk) {
+    const int r = fast_estep_impl(h, ind_lkl, have_walk);
+    if (r == NGHMM_OK && after_estep) after_estep(user);
+    return r;
+  }
+
+  bool wants_background() const {
+    const Switches& sw = h->fast.sw;
+    return fuse_freq && fuse_estep && !after_estep && h->mode == NGHMM_MODE_FAST &&
+           h->I_tot == h->I && !sw.eager_emission && !sw.no_bg;
+  }
+
+  bool wants_two_lanes() const {
+    const int pl = h->fast.sw.pipeline;
+    return h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
+           (pl >= 0 ? pl != 0 : (uint64_t)h->I * h->fast.C < 16384);
+  }
+
+  // the E-step's backward sweep onto the stream now, est_maf queued in parts
+  int start_background(bool have_walk) {
     int r;
     if (!have_walk && (r = ensure_emissions(h))) return r;
     if ((r = bg_begin(h))) return r;
@@ -1236,99 +1312,40 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
     h->launches[SLOT_BACKWARD] = 0;
     h->marg_valid = false;
     h->tmp_is_posteriors = false;
-    const bool tile_major = h->I <= 4096 && !std::getenv("NGHMM_ESTMAF_SITEMAJOR");
-    uint32_t n_parts = 1;
+    tile_major = h->I <= 4096 && !h->fast.sw.estmaf_sitemajor;
+    bg_parts = 1;
     if (fast_estmaf_splittable(h->fast, h->I, tile_major)) {
       // measured at 1000 x 1M (ms per iteration): 1 part 32.4, 2 parts 32.27, 3 parts 32.35,
       // 6 parts 32.5 (every part ends in a tail of partly filled CUs); without any of this 32.9
-      n_parts = 2;
-      if (const char* env = std::getenv("NGHMM_BG_PARTS")) n_parts = (uint32_t)std::atoi(env);
-      if (n_parts < 1) n_parts = 1;
+      bg_parts = h->fast.sw.bg_parts >= 1 ? (uint32_t)h->fast.sw.bg_parts : 1;
     }
-    for (uint32_t part = 0; part < n_parts; ++part)
-      bg_queue.push_back([h, part, n_parts, tile_major]() -> int {
-        int q;
-        if ((q = bg_open(h, SLOT_ESTMAF))) return q;
-        if (!tile_major && (q = ensure_marg(h))) return q;
-        if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast),
-                         tile_major ? h->fast.post : h->d_marg, h->S, h->I, h->I, h->d_freq,
-                         tile_major, part, n_parts))
-          return NGHMM_ERR_HIP;
-        return bg_close(h);
-      });
+    bg_next = 0;
     bg_active = true;
     return NGHMM_OK;
-  };
-  bool first_round = true;
-  while (!batch.done()) {
-    if (bg_active && !pipelined) {
-      // whole rounds on lane 0's pinned buffers: submit, put the next background piece behind
-      // the round's kernels, and only then wait for the round's values
-      auto& L = h->lane[0];
-      t0 = now();
-      const size_t n = batch.gather(L.ind, L.F, L.A, 0, h->I);
-      t_gather += since(t0);
-      if (n) {
-        t0 = now();
-        if ((rc = lkl_submit(h, 0))) return rc;
-        if ((rc = bg_push_next())) return rc;
-        if ((rc = lkl_wait(h, 0))) return rc;
-        t_lkl += since(t0);
-      }
-      t0 = now();
-      batch.scatter(L.h_lkl, 0, h->I);
-      t_scatter += since(t0);
-      continue;
-    }
-    if (pipelined && !first_round) {
-      const uint64_t half = (h->I + 1) / 2;
-      h->lane[0].lo = 0;
-      h->lane[0].hi = half;
-      h->lane[1].lo = half;
-      h->lane[1].hi = h->I;
-      if ((rc = ensure_emissions(h))) return rc;
-      auto feed = [&](int k) -> int {  // lane k's next points, enqueued; nothing waits
-        auto& L = h->lane[k];
-        for (;;) {
-          auto t1 = now();
-          const size_t n = batch.gather(L.ind, L.F, L.A, L.lo, L.hi);
-          t_gather += since(t1);
-          if (n) {
-            t1 = now();
-            const int r = lkl_submit(h, k);
-            t_lkl += since(t1);
-            return r;
-          }
-          if (batch.active_in(L.lo, L.hi) == 0) return NGHMM_OK;
-          batch.scatter(L.h_lkl, L.lo, L.hi);  // only non-finite points this round: no launch
-        }
-      };
-      for (int k = 0; k < 2; ++k)
-        if ((rc = feed(k))) return rc;
-      while (bg_next < bg_queue.size())  // (fused iteration) est_maf behind the two halves
-        if ((rc = bg_push_next())) return rc;
-      while (h->lane[0].pending || h->lane[1].pending) {
-        for (int k = 0; k < 2; ++k) {
-          auto& L = h->lane[k];
-          if (!L.pending) continue;
-          auto t1 = now();
-          if ((rc = lkl_wait(h, k))) return rc;
-          t_lkl += since(t1);
-          t1 = now();
-          batch.scatter(L.h_lkl, L.lo, L.hi);
-          t_scatter += since(t1);
-          if ((rc = feed(k))) return rc;
-        }
-      }
-      break;
-    }
-    first_round = false;
-    t0 = now();
+  }
+
+  // the next part of est_maf behind whatever is on the stream (nothing waits)
+  int push_background_piece() {
+    if (bg_next >= bg_parts) return NGHMM_OK;
+    const uint32_t part = bg_next++;
+    int q;
+    if ((q = bg_open(h, SLOT_ESTMAF))) return q;
+    if (!tile_major && (q = ensure_marg(h))) return q;
+    if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast),
+                     tile_major ? h->fast.post : h->d_marg, h->S, h->I, h->I, h->d_freq,
+                     tile_major, part, bg_parts))
+      return NGHMM_ERR_HIP;
+    return bg_close(h);
+  }
+
+  int first_or_plain_round() {
+    int rc;
+    auto t0 = clock::now();
     const size_t n = batch.gather(ind, F, A);
     lkl.resize(n);
     t_gather += since(t0);
     bool emit = estep_pending;
-    t0 = now();
+    t0 = clock::now();
     if (n) {
       if ((rc = lkl_batch_impl(h, (uint32_t)n, ind.data(), F.data(), A.data(), lkl.data(), true,
                                &emit)))
@@ -1338,50 +1355,157 @@ static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_ms
     }
     t_lkl += since(t0);
     if (estep_pending) {
-      t0 = now();
-      if ((rc = want_bg ? bg_start(emit) : estep_then_hook(emit))) return rc;
+      t0 = clock::now();
+      if ((rc = wants_background() ? start_background(emit) : estep_then_hook(emit))) return rc;
       estep_pending = false;
       t_estep += since(t0);
     }
-    t0 = now();
+    t0 = clock::now();
     batch.scatter(lkl.data());
     t_scatter += since(t0);
+    return NGHMM_OK;
   }
-  if (timing)
-    std::fprintf(stderr,
-                 "[nghmm timing] mstep: gather %.3f ms, lkl calls %.3f ms (kernels %.3f), "
-                 "estep call %.3f ms (kernels %.3f), scatter %.3f ms, rounds %u\n",
-                 t_gather, t_lkl, h->ms[SLOT_LKL], t_estep, h->ms[SLOT_FORWARD], t_scatter,
-                 batch.rounds());
-  if (estep_pending && (rc = estep_then_hook(false))) return rc;
-  if (bg_active) {  // what is left of the background work, then the frequency table
-    while (bg_next < bg_queue.size())
-      if ((rc = bg_push_next())) return rc;
-    if ((rc = bg_open(h, SLOT_EMISSION))) return rc;
-    if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
-    if ((rc = bg_close(h))) return rc;
+
+  int round_with_background() {
+    int rc;
+    auto& L = h->lane[0];
+    auto t0 = clock::now();
+    const size_t n = batch.gather(L.ind, L.F, L.A, 0, h->I);
+    t_gather += since(t0);
+    if (n) {
+      t0 = clock::now();
+      if ((rc = lkl_submit(h, 0))) return rc;
+      if ((rc = push_background_piece())) return rc;
+      if ((rc = lkl_wait(h, 0))) return rc;
+      t_lkl += since(t0);
+    }
+    t0 = clock::now();
+    batch.scatter(L.h_lkl, 0, h->I);
+    t_scatter += since(t0);
+    return NGHMM_OK;
   }
-  batch.result(h->h_indF.data(), h->h_alpha.data());
-  HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
-                         h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_alpha, h->h_alpha.data(), h->I * sizeof(double),
-                         hipMemcpyHostToDevice, h->stream));
-  if (bg_active) {
-    if (ind_lkl)
-      HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
-                             h->stream));
-    if ((rc = bg_finish(h))) return rc;
-    if (freq_done) *freq_done = true;
-  } else {
-    HIP_TRY(sync_stream(h));
+
+  // lane k's next points, enqueued; nothing waits
+  int feed_lane(int k) {
+    auto& L = h->lane[k];
+    for (;;) {
+      auto t1 = clock::now();
+      const size_t n = batch.gather(L.ind, L.F, L.A, L.lo, L.hi);
+      t_gather += since(t1);
+      if (n) {
+        t1 = clock::now();
+        const int r = lkl_submit(h, k);
+        t_lkl += since(t1);
+        return r;
+      }
+      if (batch.active_in(L.lo, L.hi) == 0) return NGHMM_OK;
+      batch.scatter(L.h_lkl, L.lo, L.hi);  // only non-finite points this round: no launch
+    }
   }
-  if (stats) {
-    stats->rounds = batch.rounds();
-    stats->points = batch.points();
-    stats->ref_forward_calls = batch.ref_forward_calls();
-    stats->ind_rounds = batch.ind_rounds();
+
+  // every remaining round of the M-step
+  int two_lane_rounds() {
+    int rc;
+    const uint64_t half = (h->I + 1) / 2;
+    h->lane[0].lo = 0;
+    h->lane[0].hi = half;
+    h->lane[1].lo = half;
+    h->lane[1].hi = h->I;
+    if ((rc = ensure_emissions(h))) return rc;
+    for (int k = 0; k < 2; ++k)
+      if ((rc = feed_lane(k))) return rc;
+    while (bg_active && bg_next < bg_parts)  // (fused iteration) est_maf behind the two halves
+      if ((rc = push_background_piece())) return rc;
+    while (h->lane[0].pending || h->lane[1].pending) {
+      for (int k = 0; k < 2; ++k) {
+        auto& L = h->lane[k];
+        if (!L.pending) continue;
+        auto t1 = clock::now();
+        if ((rc = lkl_wait(h, k))) return rc;
+        t_lkl += since(t1);
+        t1 = clock::now();
+        batch.scatter(L.h_lkl, L.lo, L.hi);
+        t_scatter += since(t1);
+        if ((rc = feed_lane(k))) return rc;
+      }
+    }
+    return NGHMM_OK;
   }
-  return NGHMM_OK;
+
+  // *freq_done tells the caller that the frequency step (and the frequency-table refresh of
+  // nghmm_init_emission) has been done here.
+  int run(nghmm_mstep_stats* stats, bool* freq_done) {
+    int rc;
+    if (freq_done) *freq_done = false;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    h->ms[SLOT_LKL] = 0;
+    h->launches[SLOT_LKL] = 0;
+    h->ms[SLOT_LKL_FIRST] = 0;
+    h->launches[SLOT_LKL_FIRST] = 0;
+    if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
+      return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
+
+    auto t0 = clock::now();
+    batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
+    t_gather += since(t0);
+    estep_pending = fuse_estep;
+    const bool two_lanes = wants_two_lanes();
+    bool first_round = true;
+    while (!batch.done()) {
+      if (!first_round && two_lanes) {
+        if ((rc = two_lane_rounds())) return rc;
+        break;
+      }
+      rc = (bg_active && !first_round) ? round_with_background() : first_or_plain_round();
+      if (rc) return rc;
+      first_round = false;
+    }
+    if (h->fast.sw.timing)
+      std::fprintf(stderr,
+                   "[nghmm timing] mstep: gather %.3f ms, lkl calls %.3f ms (kernels %.3f), "
+                   "estep call %.3f ms (kernels %.3f), scatter %.3f ms, rounds %u\n",
+                   t_gather, t_lkl, h->ms[SLOT_LKL], t_estep, h->ms[SLOT_FORWARD], t_scatter,
+                   batch.rounds());
+    if (estep_pending && (rc = estep_then_hook(false))) return rc;
+    if (bg_active) {  // what is left of the background work, then the frequency table
+      while (bg_next < bg_parts)
+        if ((rc = push_background_piece())) return rc;
+      if ((rc = bg_open(h, SLOT_EMISSION))) return rc;
+      if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
+      if ((rc = bg_close(h))) return rc;
+    }
+    batch.result(h->h_indF.data(), h->h_alpha.data());
+    HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_alpha, h->h_alpha.data(), h->I * sizeof(double),
+                           hipMemcpyHostToDevice, h->stream));
+    if (bg_active) {
+      if (ind_lkl)
+        HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                               h->stream));
+      if ((rc = bg_finish(h))) return rc;
+      if (freq_done) *freq_done = true;
+    } else {
+      HIP_TRY(sync_stream(h));
+    }
+    if (stats) {
+      stats->rounds = batch.rounds();
+      stats->points = batch.points();
+      stats->ref_forward_calls = batch.ref_forward_calls();
+      stats->ind_rounds = batch.ind_rounds();
+    }
+    return NGHMM_OK;
+  }
+};
+
+}  // namespace
+
+static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats,
+                           bool fuse_estep, double* ind_lkl, nghmm_hook_fn after_estep = nullptr,
+                           void* user = nullptr, bool fuse_freq = false,
+                           bool* freq_done = nullptr) {
+  MstepRun run(h, indF_fixed, alpha_fixed, fuse_estep, ind_lkl, after_estep, user, fuse_freq);
+  return run.run(stats, freq_done);
 }
 
 int nghmm_mstep_indf(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats) {
@@ -1436,7 +1560,7 @@ static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_block
     if (!d_marg_blocks) {  // the handle's own posteriors of its whole site range
       // measured at 10^9 site-individuals: in place 13.6 vs 14.4 ms via the site-major copy
       // at 4000 individuals, 19.7 vs 16.5 ms at 8000 (a site group's sectors outgrow L2)
-      tile_major = I_tot <= 4096 && !std::getenv("NGHMM_ESTMAF_SITEMAJOR");
+      tile_major = I_tot <= 4096 && !h->fast.sw.estmaf_sitemajor;
       if (tile_major) {
         d_marg_blocks = h->fast.post;
       } else {
@@ -1492,7 +1616,7 @@ int nghmm_estep_mstep(nghmm_t* h, int indF_fixed, int alpha_fixed, double* ind_l
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  if (h->mode == NGHMM_MODE_FAST && !std::getenv("NGHMM_NO_FUSE"))
+  if (h->mode == NGHMM_MODE_FAST && !h->fast.sw.no_fuse)
     return mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl, after_estep, user);
   if ((rc = nghmm_estep(h, ind_lkl))) return rc;
   if (after_estep) after_estep(user);
@@ -1507,7 +1631,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
   if ((rc = use_device(h))) return rc;
   // fast mode: E-step and indF/alpha M-step share their first forward walk, and the frequency
   // step runs in the shadow of the objective rounds (mstep_indf_impl)
-  if (h->mode == NGHMM_MODE_FAST && !std::getenv("NGHMM_NO_FUSE")) {
+  if (h->mode == NGHMM_MODE_FAST && !h->fast.sw.no_fuse) {
     bool freq_done = false;
     if ((rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl, nullptr, nullptr,
                               freq_est == 1, &freq_done)))
@@ -2041,9 +2165,9 @@ int nghmm_group_iter_em(nghmm_t** hs, int n, int freq_est, int indF_fixed, int a
     return NGHMM_ERR_ARG;
   }
   if (n == 1) return nghmm_iter_em(hs[0], freq_est, indF_fixed, alpha_fixed, ind_lkl, stats);
-  if (freq_est == 2) {
-    set_error("invalid allele frequencies");
-    return NGHMM_ERR_FREQ_EST2;
+  if (freq_est != 0 && freq_est != 1) {  // as nghmm_mstep_freq (EM.cpp:212-239)
+    set_error(freq_est == 2 ? "invalid allele frequencies" : "wrong MAF estimation method!");
+    return freq_est == 2 ? NGHMM_ERR_FREQ_EST2 : NGHMM_ERR_ARG;
   }
   const uint64_t I = hs[0]->I;
   std::vector<nghmm_mstep_stats> st(n);
@@ -2096,6 +2220,21 @@ int nghmm_group_mstep_freq(nghmm_t** hs, int n, int freq_est) {
   });
   if (rc != NGHMM_OK) return rc;
   return group_freq_phases(hs, n);
+}
+
+int nghmm_set_switch(nghmm_t* h, const char* name, long value) {
+  g_last_error.clear();
+  if (!h || !name) return NGHMM_ERR_ARG;
+  if (std::strcmp(name, "fast_c") == 0 || std::strcmp(name, "spin_sync") == 0) {
+    set_error("nghmm_set_switch: %s is fixed when the handle is created (NGHMM_%s in the environment)",
+              name, std::strcmp(name, "fast_c") == 0 ? "FAST_C" : "SPIN_SYNC");
+    return NGHMM_ERR_ARG;
+  }
+  if (!h->fast.sw.set(name, value)) {
+    set_error("nghmm_set_switch: no switch named %s", name);
+    return NGHMM_ERR_ARG;
+  }
+  return NGHMM_OK;
 }
 
 int nghmm_fast_layout(nghmm_t* h, uint32_t* waves_per_individual, uint64_t* sites_per_lane) {

@@ -57,6 +57,47 @@ def all_gather(out, inp):
         dist.all_gather_into_tensor(out, inp)
 
 
+def preflight(device=None):
+    """Known-answer all-to-all and all-gather on float64 through the current process group,
+    with the same calls the EM iteration makes (device tensors under nccl = RCCL; staged
+    through the host under gloo).  Raises RuntimeError with the rank and the first wrong
+    element: a collective that moves the wrong bytes must stop the run before any data is
+    loaded, not bend the frequencies quietly."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    n = 257                                    # odd on purpose: not a multiple of anything
+    # element j of the slice rank r sends to rank q
+    send = torch.stack([1e6 * rank + 1e3 * q + torch.arange(n, dtype=torch.float64) / 1024.0
+                        for q in range(world)]).to(dev)
+    recv = torch.full_like(send, float("nan"))
+    all_to_all(recv, send)
+    part = (torch.arange(n, dtype=torch.float64) * (rank + 1) + 0.25 * rank).to(dev)
+    whole = torch.full((world * n,), float("nan"), dtype=torch.float64, device=dev)
+    all_gather(whole, part)
+    if recv.is_cuda:
+        torch.cuda.synchronize(recv.device)
+    # (both collectives are issued before either is judged: every rank makes the same calls)
+    want = torch.stack([1e6 * src + 1e3 * rank + torch.arange(n, dtype=torch.float64) / 1024.0
+                        for src in range(world)])
+    got = recv.cpu()
+    if not torch.equal(got, want):
+        bad = (got != want).nonzero()[0].tolist()
+        raise RuntimeError(f"collective preflight: all_to_all_single delivered {got[tuple(bad)].item()!r} "
+                           f"instead of {want[tuple(bad)].item()!r} at [source rank, element] {bad} "
+                           f"on rank {rank} of {world} ({dist.get_backend()})")
+    want = torch.cat([torch.arange(n, dtype=torch.float64) * (r + 1) + 0.25 * r for r in range(world)])
+    got = whole.cpu()
+    if not torch.equal(got, want):
+        bad = int((got != want).nonzero()[0])
+        raise RuntimeError(f"collective preflight: all_gather_into_tensor delivered {got[bad].item()!r} "
+                           f"instead of {want[bad].item()!r} at element {bad} on rank {rank} of "
+                           f"{world} ({dist.get_backend()})")
+    return {"backend": dist.get_backend(), "world": world, "elements": n,
+            "checked": ["all_to_all_single float64", "all_gather_into_tensor float64"]}
+
+
 def site_ranges(n_sites: int, world: int):
     """Contiguous, equal site ranges (the all-to-all uses equal splits)."""
     if n_sites % world != 0:
@@ -168,6 +209,14 @@ class ShardedEM:
                                              pkg.MODE_FAST if mode is None else mode)
         self.hmm = getattr(self.backend, "hmm", None)
         self.ind_lkl = None
+        # exchange accounting (milliseconds, summed over iterations; reset_timing() zeroes it):
+        #   a2a_ms          duration of the posterior all-to-all (device events around it)
+        #   a2a_exposed_ms  how long the host waited for it after the objective rounds were done
+        #   allgather_ms    the frequency all-gather (host clock, synchronous)
+        #   freq_step_ms    est_maf on the own site range (host clock)
+        self.timing = dict(a2a_ms=0.0, a2a_exposed_ms=0.0, allgather_ms=0.0, freq_step_ms=0.0,
+                           iterations=0)
+        self._ev = None
         if world > 1:
             self.ranges = site_ranges(n_sites, world)
             lo, hi = self.ranges[rank]
@@ -250,26 +299,73 @@ class ShardedEM:
             self.finish_exchange_and_update_freq(box.get("work"))
         return st
 
+    def reset_timing(self):
+        for k in self.timing:
+            self.timing[k] = 0 if k == "iterations" else 0.0
+
+    def collective_bytes_per_iter(self):
+        """Bytes that leave this rank's GPU per EM iteration: the posterior slices of the other
+        ranks' site ranges, and its own frequencies to everybody (ring all-gather: each rank
+        forwards world - 1 pieces)."""
+        if self.world == 1:
+            return {"all_to_all_out": 0, "all_gather_out": 0}
+        w = self.world
+        return {"all_to_all_out": 8 * self.S_own * self.n_ind * (w - 1),
+                "all_gather_out": 8 * self.S_own * (w - 1)}
+
+    def _events(self):
+        torch = getattr(self.backend, "torch", None)
+        if torch is None or not self._send.is_cuda:
+            return None
+        if self._ev is None:
+            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        return self._ev
+
     def start_posterior_exchange(self):
         import torch.distributed as dist
         # equal contiguous site ranges: the send buffer [rank][S_own][I] is the whole
         # site-major posterior matrix
         self.backend.pack_posteriors(0, self.n_sites, self._send)
         self._sync()
+        ev = self._events()
+        if ev:
+            ev[0].record()
         if _staged(self._send):
+            # gloo through the host: synchronous, nothing of it is hidden
+            import time
+            t0 = time.perf_counter()
             all_to_all(self._recv, self._send)
+            self.timing["a2a_exposed_ms"] += (time.perf_counter() - t0) * 1e3
+            if ev:
+                ev[1].record()
             return None
         return dist.all_to_all_single(self._recv.view(-1), self._send.view(-1), async_op=True)
 
     def finish_exchange_and_update_freq(self, work):
+        import time
+        t0 = time.perf_counter()
+        ev = self._events()
         if work is not None:
-            work.wait()
+            work.wait()            # torch's current stream now waits for the collective
+            if ev:
+                ev[1].record()
         self._sync()
+        t1 = time.perf_counter()
         # _recv is [source rank][S_own][I_loc]: the rank-blocked layout est_maf reads
         self.backend.mstep_freq_sites(self._recv, self._freq_own)
+        t2 = time.perf_counter()
         all_gather(self._freq_all, self._freq_own)
         self._sync()
+        t3 = time.perf_counter()
         self.backend.set_freq(self._freq_all)
+        tm = self.timing
+        if work is not None:
+            tm["a2a_exposed_ms"] += (t1 - t0) * 1e3
+        tm["freq_step_ms"] += (t2 - t1) * 1e3
+        tm["allgather_ms"] += (t3 - t2) * 1e3
+        if ev:
+            tm["a2a_ms"] += ev[0].elapsed_time(ev[1])
+        tm["iterations"] += 1
 
     def _sync(self):
         if hasattr(self.backend, "sync"):

@@ -12,6 +12,7 @@ computes a result itself and has no fallback.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import math
 import os
 import subprocess
@@ -116,6 +117,7 @@ def load_library():
         "nghmm_stream": (vp, [vp]),
         "nghmm_synchronize": (i32, [vp]),
         "nghmm_kernel_ms": (i32, [vp, i32, dp, C.POINTER(u32)]),
+        "nghmm_set_switch": (i32, [vp, C.c_char_p, C.c_long]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -147,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "nghmm_group_mstep_freq",
     "nghmm_fast_layout", "nghmm_stream",
     "nghmm_synchronize",
-    "nghmm_kernel_ms",
+    "nghmm_kernel_ms", "nghmm_set_switch",
 ]
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_void_p)
@@ -182,8 +184,10 @@ class NgsFHMM:
         self.mode = mode
         self._h = C.c_void_p()
         self._parent = _replica_of          # keeps the parent alive
+        self._replicas = weakref.WeakSet()  # a parent closes its live replicas before itself
         if _replica_of is not None:
             self._check(self.lib.nghmm_create_replica(C.byref(self._h), _replica_of._h))
+            _replica_of._replicas.add(self)
         else:
             self._check(self.lib.nghmm_create(C.byref(self._h), self.n_ind, self.n_sites, device,
                                               mode))
@@ -204,14 +208,31 @@ class NgsFHMM:
         (nghmm_create_replica): multi-start runs, ngsF-HMM.sh:77-101."""
         return NgsFHMM(self.n_ind, self.n_sites, mode=self.mode, _replica_of=self)
 
-    def close(self):
+    def close(self, _finalizing=False):
+        """Destroys the handle.  A parent whose replicas are still open refuses, as the library
+        does (they share its data): close them first.  Garbage collection (no order is
+        guaranteed there) closes a parent's remaining replicas before the parent."""
         if getattr(self, "_h", None) is not None and self._h:
+            live = [r for r in list(getattr(self, "_replicas", ())) if not r.closed]
+            if live and not _finalizing:
+                raise NgsFHMMError(-10, f"{len(live)} replica(s) of this handle are still open: "
+                                        "close them first")
+            for r in live:
+                r.close(_finalizing=True)
             self._check(self.lib.nghmm_destroy(self._h))
             self._h = C.c_void_p()
 
+    @property
+    def closed(self):
+        return not self._h
+
+    def set_switch(self, name, value):
+        """A measurement / debugging switch of this handle (nghmm_set_switch, include/nghmm.h)."""
+        self._check(self.lib.nghmm_set_switch(self._h, name.encode(), int(value)))
+
     def __del__(self):
         try:
-            self.close()
+            self.close(_finalizing=True)
         except Exception:
             pass
 
@@ -483,11 +504,19 @@ class Group:
         self.handles[0]._check(self.lib.nghmm_group_setup(self._arr, n))
         self.ind_lkl = np.full(n * self.handles[0].n_ind, -math.inf)
 
+    def _members_open(self):
+        # the group keeps its members alive; one that was closed by hand leaves a dangling
+        # pointer in the array the library is given
+        if any(h.closed for h in self.handles):
+            raise NgsFHMMError(-10, "a member of this group has been closed")
+
     def mstep_freq(self, freq_est=1):
+        self._members_open()
         self.handles[0]._check(self.lib.nghmm_group_mstep_freq(self._arr, len(self.handles),
                                                                int(freq_est)))
 
     def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        self._members_open()
         st = MstepStats()
         self.handles[0]._check(self.lib.nghmm_group_iter_em(
             self._arr, len(self.handles), int(freq_est), int(indF_fixed), int(alpha_fixed),

@@ -25,6 +25,25 @@ dd = importlib.import_module("ngsf-hmm_amd.distributed")
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
+pf = dd.preflight()                       # known-answer all-to-all / all-gather first
+assert pf["world"] == world and pf["backend"] == "gloo"
+if os.environ.get("NGHMM_TEST_CORRUPT"):
+    # a collective that delivers one wrong element must stop the run
+    real = dd.all_to_all if os.environ["NGHMM_TEST_CORRUPT"] == "a2a" else dd.all_gather
+    def corrupt(out, inp):
+        real(out, inp)
+        if rank == 1:
+            out.view(-1)[3] += 1e-9
+    setattr(dd, "all_to_all" if os.environ["NGHMM_TEST_CORRUPT"] == "a2a" else "all_gather", corrupt)
+    try:
+        dd.preflight()
+    except RuntimeError as e:
+        print("PREFLIGHT_CAUGHT rank", rank, str(e)[:120], flush=True)
+    else:
+        print("PREFLIGHT_PASSED rank", rank, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 I_loc, S = 5, 240
 d = pkg.simulate.simulate(I_loc * world, S, seed=31, n_chrom=2, missing_rate=0.05)
 PACKED = os.environ.get("NGHMM_TEST_PACKED") == "1"
@@ -97,8 +116,12 @@ else:
     em.load_device(torch.from_numpy(gl_loc), torch.from_numpy(d.pos_dist_mb.copy()))
 em.set_params(0.1, 0.2, 0.1)
 em.init_emission()
-for _ in range(3):
+for it in range(3):
     em.iter_EM()
+    tm = em.timing                        # exchange accounting of bench.py's N > 1 line
+    assert tm["iterations"] == it + 1 and tm["freq_step_ms"] > 0 and tm["allgather_ms"] > 0
+assert em.collective_bytes_per_iter() == {"all_to_all_out": 8 * (S // world) * I_loc * (world - 1),
+                                          "all_gather_out": 8 * (S // world) * (world - 1)}
 np.savez(os.path.join(OUT, f"rank{rank}.npz"), indF=be.em.indF, alpha=be.em.alpha,
          freq=be.em.freq, marg=be.em.marg, ind_lkl=be.em.ind_lkl)
 dist.destroy_process_group()
@@ -117,8 +140,13 @@ def test_two_rank_sharded_em_equals_single_process(tmp_path, pkg, orc_libm, pack
                WORLD_SIZE=str(world), NGHMM_TEST_PACKED="1" if packed else "0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)))
              for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
 
     I_loc, S = 5, 240
     d = pkg.simulate.simulate(I_loc * world, S, seed=31, n_chrom=2, missing_rate=0.05)
@@ -136,6 +164,30 @@ def test_two_rank_sharded_em_equals_single_process(tmp_path, pkg, orc_libm, pack
         assert np.array_equal(got["freq"], ref.freq)
         assert np.array_equal(got["marg"], ref.marg[sl])
         assert np.array_equal(got["ind_lkl"], ref.ind_lkl[sl])
+
+
+@pytest.mark.parametrize("which", ["a2a", "gather"])
+def test_collective_preflight_catches_a_wrong_element(tmp_path, which):
+    """distributed.preflight (what bench.py runs before loading any data, also under nccl =
+    RCCL): one element off by 1e-9 on one rank, in either collective, raises there."""
+    world = 2
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\nOUT = {str(tmp_path)!r}\n" + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613" if which == "a2a" else "29614",
+               WORLD_SIZE=str(world), NGHMM_TEST_CORRUPT=which)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "PREFLIGHT_CAUGHT rank 1" in outs[1], outs[1]
+    assert ("all_to_all_single" if which == "a2a" else "all_gather_into_tensor") in outs[1]
+    assert "PREFLIGHT_PASSED rank 0" in outs[0], outs[0]
 
 
 def test_site_ranges(pkg):

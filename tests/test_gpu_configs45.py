@@ -1,0 +1,218 @@
+"""BASELINE.json configs[3] and configs[4] at their SHARDED shape, on the one GPU a test box
+has: eight handles on cuda:0 play the eight GPUs of the node.
+
+* configs[3] (1000 individuals x 1 M sites sharded by individual over 8 GPUs): 8 handles of
+  125 x 1 M through nghmm_group_setup / nghmm_group_iter_em -- the posterior exchange (peer
+  copies here between buffers of one device, xGMI on a node), est_maf per site range over all
+  1000 individuals in global order, the frequency exchange -- against ONE handle that owns all
+  1000 individuals.  What is split: EM.cpp:147-272.
+* configs[4] (5000 x 5 M, 25 chromosomes, --call_geno, 100 iterations, 8 GPUs): 8 packed
+  handles of 625 individuals x 625 000 sites (config 5's individuals per GPU and chromosome
+  count, an eighth of its sites so that the cohort fits one device), against one packed handle
+  of 5000 x 625 000; and the 100 iterations the config asks for at 625 x 500 000.
+* the same job through bench.py's process-per-rank path with four ranks (gloo on one GPU).
+
+The optimizer's finite differences amplify last-bit differences of the objective (SURVEY
+finding 4), and a 125-individual handle cuts the site axis into other lane-chunks than a
+1000-individual one, so free-parameter runs are compared TEACHER-FORCED: every iteration starts
+from the single handle's parameters.  With fixed parameters nothing is forced.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _iterate_pair(whole, grp, parts, n_iter, fixed, force):
+    """n_iter EM iterations of both; returns the worst relative differences seen."""
+    I_loc = parts[0].n_ind
+    worst = dict(lkl=0.0, freq=0.0, indF=0.0)
+    for it in range(n_iter):
+        if force:
+            F, A, f = whole.indF, whole.alpha, whole.freq
+            for r, h in enumerate(parts):
+                h.set_params(F[r * I_loc:(r + 1) * I_loc], A[r * I_loc:(r + 1) * I_loc], f)
+                h.init_emission()
+        whole.iter_EM(1, fixed, fixed)
+        st = grp.iter_EM(1, fixed, fixed)
+        assert fixed or st.rounds > 0
+        lk_w, lk_g = whole.ind_lkl, grp.ind_lkl
+        assert np.isfinite(lk_w).all()
+        worst["lkl"] = max(worst["lkl"], float(np.max(np.abs(lk_g - lk_w) / np.abs(lk_w))))
+        fw, fg = whole.freq, parts[0].freq
+        assert np.array_equal(fg, parts[-1].freq)            # everybody holds the same frequencies
+        worst["freq"] = max(worst["freq"], float(np.max(np.abs(fg - fw) / fw)))
+        gF = np.concatenate([h.indF for h in parts])
+        worst["indF"] = max(worst["indF"], float(np.max(np.abs(gF - whole.indF))))
+    return worst
+
+
+def test_config4_eight_shards_of_1000_x_1M(pkg):
+    import torch
+    I, S, n = 1000, 1_000_000, 8
+    I_loc = I // n
+    dev = torch.device("cuda", 0)
+    gl, pos = pkg.simulate.simulate_torch(I, S, dev, seed=2025)
+    pos[S // 3] = float("inf")
+    pos[2 * S // 3] = float("inf")               # three chromosomes
+    torch.cuda.synchronize()
+
+    whole = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST)
+    whole.load_device(gl.data_ptr(), pos.data_ptr())
+    parts = []
+    for r in range(n):
+        h = pkg.NgsFHMM(I_loc, S, mode=pkg.MODE_FAST)
+        cols = gl[:, r * I_loc:(r + 1) * I_loc, :].contiguous()
+        torch.cuda.synchronize()
+        h.load_device(cols.data_ptr(), pos.data_ptr())
+        del cols
+        parts.append(h)
+    del gl
+    torch.cuda.empty_cache()
+    for h in parts + [whole]:
+        h.set_params(0.1, 0.2, 0.1)
+        h.init_emission()
+    grp = pkg.Group(parts)                         # builds the site-shard copies (peer copies)
+
+    free = _iterate_pair(whole, grp, parts, 3, fixed=False, force=True)
+    print("config 4 shape, free parameters (teacher-forced):", free)
+    assert free["lkl"] < 1e-12 and free["freq"] < 1e-9 and free["indF"] < 1e-4
+
+    for h in parts + [whole]:
+        h.set_params(0.3, 0.05, 0.15)
+        h.init_emission()
+    fix = _iterate_pair(whole, grp, parts, 3, fixed=True, force=False)
+    print("config 4 shape, fixed parameters:", fix)
+    assert fix["lkl"] < 1e-12 and fix["freq"] < 1e-9 and fix["indF"] == 0.0
+    # decoding with the frequencies each side arrived at on its own (they agree to 1e-9, the
+    # decoder takes the argmax of sums of their logs): identical paths
+    path_w = whole.viterbi()
+    for r, h in enumerate(parts):
+        p = h.viterbi()
+        assert np.array_equal(p, path_w[r * I_loc:(r + 1) * I_loc]), r
+        del p
+    for h in parts + [whole]:
+        h.close()
+
+
+def test_config5_eight_packed_shards(pkg):
+    import torch
+    I, S, n, nchr = 5000, 625_000, 8, 25
+    I_loc = I // n
+    dev = torch.device("cuda", 0)
+    mode = pkg.MODE_FAST | pkg.GENO_PACKED
+    whole = pkg.NgsFHMM(I, S, mode=mode)
+    parts = [pkg.NgsFHMM(I_loc, S, mode=mode) for _ in range(n)]
+    pos, chunks = pkg.simulate.simulate_torch_chunks(I, S, dev, seed=9, n_chrom=nchr,
+                                                     chunk_sites=25_000)
+    # one pass over the generated blocks feeds all nine handles (begin / sites / end by hand)
+    import ctypes as C
+    lib = whole.lib
+    for h in parts + [whole]:
+        h._check(lib.nghmm_load_begin_dev(h._h, C.c_void_p(pos.data_ptr())))
+    for s0, c in chunks:
+        torch.cuda.synchronize()
+        whole._check(lib.nghmm_load_gl_raw_sites_dev(whole._h, int(s0), c.shape[0],
+                                                     C.c_void_p(c.data_ptr()), 0, 1, 0))
+        for r, h in enumerate(parts):
+            cols = c[:, r * I_loc:(r + 1) * I_loc, :].contiguous()
+            torch.cuda.synchronize()
+            h._check(lib.nghmm_load_gl_raw_sites_dev(h._h, int(s0), c.shape[0],
+                                                     C.c_void_p(cols.data_ptr()), 0, 1, 0))
+            del cols
+        del c
+    for h in parts + [whole]:
+        h._check(lib.nghmm_load_end(h._h))
+        h.set_params(0.1, 0.2, 0.1)
+        h.init_emission()
+    torch.cuda.empty_cache()
+    grp = pkg.Group(parts)                         # site shards from exchanged genotype codes
+    free = _iterate_pair(whole, grp, parts, 2, fixed=False, force=True)
+    print("config 5 shape (an eighth of the sites), free parameters (teacher-forced):", free)
+    assert free["lkl"] < 1e-12 and free["freq"] < 1e-9 and free["indF"] < 1e-4
+    for h in parts + [whole]:
+        h.set_params(0.3, 0.05, 0.15)
+        h.init_emission()
+    fix = _iterate_pair(whole, grp, parts, 2, fixed=True, force=False)
+    print("config 5 shape, fixed parameters:", fix)
+    assert fix["lkl"] < 1e-12 and fix["freq"] < 1e-9
+    path_w = whole.viterbi()
+    for r in (0, n - 1):
+        assert np.array_equal(parts[r].viterbi(), path_w[r * I_loc:(r + 1) * I_loc]), r
+    for h in parts + [whole]:
+        h.close()
+
+
+def test_config5_hundred_iterations(pkg):
+    """--max_iters 100 --min_iters 99 of configs[4] on one GPU's number of individuals (625,
+    25 chromosomes, called genotypes, packed) at 500 000 sites: every array finite and in
+    range throughout, the total log-likelihood never drops by more than rounding once the
+    first iterations are over, and the run settles."""
+    import torch
+    I, S, nchr, n_iter = 625, 500_000, 25, 100
+    dev = torch.device("cuda", 0)
+    h = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST | pkg.GENO_PACKED)
+    pos, chunks = pkg.simulate.simulate_torch_chunks(I, S, dev, seed=11, n_chrom=nchr,
+                                                     chunk_sites=50_000)
+
+    def feed():
+        for s0, c in chunks:
+            torch.cuda.synchronize()
+            yield s0, c.shape[0], c.data_ptr()
+    h.load_chunks_device(pos.data_ptr(), feed(), space=0, call_geno=True)
+    h.set_params(0.1, 0.2, 0.1)
+    h.init_emission()
+    tot = []
+    for it in range(n_iter):
+        h.iter_EM()
+        tot.append(float(h.ind_lkl.sum()))
+        assert np.isfinite(tot[-1]), it
+    tot = np.array(tot)
+    f, F, A = h.freq, h.indF, h.alpha
+    assert np.isfinite(f).all() and (f >= 0).all() and (f < 1).all()
+    assert np.isfinite(F).all() and (F >= 1e-15).all() and (F <= 1 - 1e-15).all()
+    assert np.isfinite(A).all() and (A >= 1e-15).all() and (A <= 10).all()
+    post = h.marg_prob[:4]
+    assert ((post >= 0) & (post <= 1)).all()
+    rel_step = np.abs(np.diff(tot)) / np.abs(tot[1:])
+    print(f"100 iterations of {I} x {S}: total lkl {tot[0]:.3f} -> {tot[-1]:.3f}; relative change "
+          f"per iteration after the 20th: max {rel_step[20:].max():.2e}")
+    assert tot[-1] > tot[0]
+    assert rel_step[20:].max() < 1e-6          # settled
+    assert np.diff(tot)[10:].min() > -1e-6 * abs(tot[-1])
+    h.close()
+
+
+def test_bench_four_ranks_on_the_full_workload(pkg):
+    """`python bench.py --gpus 4 --workload c3` as the driver starts it: four rank processes,
+    250 of the 1000 individuals each for all 10^6 sites, the collectives' known-answer
+    preflight, the all-to-all / all-gather of every iteration (gloo through the host here:
+    one GPU; nccl = RCCL on a node), and the accounting the scaling line carries."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c3",
+           "--steps", "2", "--warmup", "1", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["ranks"] == 4 and out["scaling"] == "strong"
+    cfg = out["config"]
+    assert cfg["n_ind_total"] == 1000 and cfg["n_ind_per_gpu"] == 250 and cfg["n_sites"] == 1_000_000
+    assert out["preflight"]["world"] == 4 and "all_to_all_single float64" in out["preflight"]["checked"]
+    cb = out["collective_bytes_per_iter"]
+    assert cb["all_to_all_out"] == 8 * 250_000 * 250 * 3 and cb["all_gather_out"] == 8 * 250_000 * 3
+    assert len(out["per_rank"]) == 4 and sorted(p["rank"] for p in out["per_rank"]) == [0, 1, 2, 3]
+    for p in out["per_rank"]:
+        assert p["kernel_ms_per_iter"]["lkl_batch"] > 0 and p["kernel_ms_per_iter"]["est_maf"] > 0
+        assert p["exchange_ms_per_iter"]["all_to_all"] > 0
+    assert out["exchange_ms"]["all_to_all"] > 0 and out["value"] > 0
+    print(json.dumps({k: out[k] for k in ("value", "ms_per_step", "exchange_ms", "collectives")}))

@@ -129,7 +129,7 @@ def test_est_maf_properties_at_full_size(pkg, big):
 ])
 def test_est_maf_interpolated_passes_equal_exact_passes(pkg, n_ind, n_sites, kw):
     """est_maf runs most of its <= 101 passes per site on a checked Chebyshev interpolant of
-    the per-pass sums (k_fast_estmaf / k_fast_estmaf_interp); NGHMM_ESTMAF_INTERP=0 evaluates
+    the per-pass sums (k_fast_estmaf / k_fast_estmaf_interp); the switch estmaf_interp = 0 evaluates
     every pass over all individuals.  Same recursion, same stopping rule: the frequencies
     must agree far inside the 1e-9 parity tolerance, on fixed and on uniform site
     frequencies, at low and high depth, and across the kernel's individuals-per-lane
@@ -144,7 +144,7 @@ def test_est_maf_interpolated_passes_equal_exact_passes(pkg, n_ind, n_sites, kw)
     res = {}
     try:
         for interp in ("0", "1"):
-            os.environ["NGHMM_ESTMAF_INTERP"] = interp
+            hmm.set_switch("estmaf_interp", int(interp))
             hmm.set_params(np.full(n_ind, 0.1), np.full(n_ind, 0.01), np.full(n_sites, 0.1))
             hmm.init_emission()
             for _ in range(2):
@@ -152,7 +152,6 @@ def test_est_maf_interpolated_passes_equal_exact_passes(pkg, n_ind, n_sites, kw)
                 hmm.mstep_freq(1)
             res[interp] = hmm.freq.copy()
     finally:
-        del os.environ["NGHMM_ESTMAF_INTERP"]
         hmm.close()
         torch.cuda.empty_cache()
     f0, f1 = res["0"], res["1"]

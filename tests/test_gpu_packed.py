@@ -345,3 +345,53 @@ def test_packed_ragged_shapes(pkg, orc_det, orc_libm, shape):
                 assert st.rounds >= 1 and np.isfinite(h.indF).all()
                 h.iter_EM()                                  # the fused walk on the codes
                 assert np.isfinite(h.ind_lkl).all()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_chunked_loading_checks_every_site_exactly_once(pkg, packed):
+    """nghmm_load_begin / _sites / _end: a chunk that overlaps sites already received is
+    refused (a packed handle would OR two codes into one cell), nghmm_load_end before all
+    sites have arrived is refused, and a clean load after either works."""
+    I, S = 12, 300
+    d = pkg.simulate.simulate(I, S, seed=3, missing_rate=0.1)
+    mode = pkg.MODE_EXACT | (pkg.GENO_PACKED if packed else 0)
+    ref = pkg.NgsFHMM(I, S, mode=mode)
+    ref.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=packed)
+    want = ref.gl
+    ref.close()
+    h = pkg.NgsFHMM(I, S, mode=mode)
+    cut = lambda lo, hi: (lo, d.gl[lo:hi])
+    with pytest.raises(pkg.NgsFHMMError) as ei:               # [90, 120) twice
+        h.load_chunks(d.pos_dist_mb, [cut(0, 100), cut(100, 120), cut(90, 200), cut(200, S)],
+                      space=0, call_geno=packed)
+    assert ei.value.code == -10 and "overlap" in str(ei.value)
+    with pytest.raises(pkg.NgsFHMMError) as ei:               # [100, 150) never arrives
+        h.load_chunks(d.pos_dist_mb, [cut(150, S), cut(0, 100)], space=0, call_geno=packed)
+    assert ei.value.code == -10 and "250 of 300 sites" in str(ei.value)
+    with pytest.raises(pkg.NgsFHMMError):                     # the failed load is over
+        h._check(h.lib.nghmm_load_end(h._h))
+    h.load_chunks(d.pos_dist_mb, [cut(150, S), cut(100, 150), cut(0, 100)], space=0,
+                  call_geno=packed)                            # any order, every site once
+    assert np.array_equal(h.gl, want)
+    h.close()
+
+
+def test_switches_are_per_handle(pkg):
+    """Measurement switches are read from the environment once, when a handle is created, and
+    changed on a live handle by nghmm_set_switch only (include/nghmm.h)."""
+    import os
+    h = pkg.NgsFHMM(8, 200, mode=pkg.MODE_FAST)
+    h.set_switch("estmaf_interp", 0)
+    h.set_switch("bg_parts", 3)
+    with pytest.raises(pkg.NgsFHMMError):
+        h.set_switch("no_such_switch", 1)
+    with pytest.raises(pkg.NgsFHMMError):
+        h.set_switch("fast_c", 7)                              # layout: fixed at creation
+    os.environ["NGHMM_FAST_C"] = "2"
+    try:
+        g = pkg.NgsFHMM(8, 2000, mode=pkg.MODE_FAST)
+    finally:
+        del os.environ["NGHMM_FAST_C"]
+    assert g.layout()[0] == 2 and h.layout()[0] != 2
+    h.close()
+    g.close()

@@ -314,41 +314,54 @@ def test_producer_consumer_recursions_equal_the_serial_ones(pkg):
     (kernels_exact_pc.hip: transition logs of a block of sites computed in parallel, two lanes
     per chain, detmath.h's chain forms of exp / log); NGHMM_EXACT_SERIAL=1 selects the one-lane-
     per-chain kernels they replaced.  Same operations on the same operands: every array of two
-    EM iterations and the decoded paths must be the same bits, at a size the oracle does not
-    reach in test time (ragged: 333 individuals are 10.4 workgroups of 32 chains, 24 007 sites
-    are 1200.35 ring blocks of 20), over three chromosomes, with missing data and objective
-    points at the parameter bounds."""
+    EM iterations and the decoded paths must be the same bits, at a size the oracle needs
+    minutes for (ragged: 333 individuals are 10.4 workgroups of 32 chains, 24 007 sites are
+    1200.35 ring blocks of 20), over three chromosomes, with missing data and objective points
+    at the parameter bounds.  The second data set (true indF uniform in (0, 1)) drives
+    individuals onto the bounds F = 1 - 1e-15, alpha = 1e-15 and, in its second iteration, the
+    recursion into the reference's "invalid Lkl found!" (shared/HMM.cpp:18-21; the oracle
+    returns the same there): both kernel sets must fail the same way at the same point."""
     import os
     I, S = 333, 24_007
-    d = pkg.simulate.simulate(I, S, seed=77, n_chrom=3, missing_rate=0.03, indF="r", freq="r")
-    gl = pkg.simulate.normalise_log_gl(d.gl)
     rng = np.random.default_rng(5)
     ind = rng.integers(0, I, 500)
     F = np.concatenate([rng.uniform(0, 1, 490), [1e-15, 1 - 1e-15, 1e-15, 1 - 1e-15, 0.5,
                                                   0.5, 0.3, 0.7, 1e-6, 1 - 1e-6]])
     A = np.concatenate([rng.uniform(1e-3, 10, 490), [1e-15, 10, 10, 1e-15, 1e-15, 10, 1e-9,
                                                       5.0, 1e-6, 1e-6]])
-    res = {}
-    try:
-        for serial in (False, True):
-            if serial:
-                os.environ["NGHMM_EXACT_SERIAL"] = "1"
-            with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT) as hmm:
-                hmm.load(gl, d.pos_dist_mb)
-                hmm.set_params(0.1, 0.2, 0.1)
-                hmm.init_emission()
-                out = {"obj": hmm.lkl(ind, F, A)}
-                for it in range(2):
-                    hmm.iter_EM()
-                    out[f"lkl{it}"] = hmm.ind_lkl.copy()
-                    out[f"post{it}"] = hmm.marg_prob.copy()
-                    out[f"indF{it}"] = hmm.indF.copy()
-                    out[f"alpha{it}"] = hmm.alpha.copy()
-                    out[f"freq{it}"] = hmm.freq.copy()
-                out["path"] = hmm.viterbi()
-            res[serial] = out
-    finally:
-        os.environ.pop("NGHMM_EXACT_SERIAL", None)
-    assert np.all(np.isfinite(res[False]["obj"]))
-    for k in res[False]:
-        assert np.array_equal(res[False][k], res[True][k]), k
+    for kw, n_ok in ((dict(), 2), (dict(indF="r"), 1)):
+        d = pkg.simulate.simulate(I, S, seed=77, n_chrom=3, missing_rate=0.03, freq="r", **kw)
+        gl = pkg.simulate.normalise_log_gl(d.gl)
+        res = {}
+        try:
+            for serial in (False, True):
+                if serial:
+                    os.environ["NGHMM_EXACT_SERIAL"] = "1"
+                with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT) as hmm:
+                    hmm.load(gl, d.pos_dist_mb)
+                    hmm.set_params(0.1, 0.2, 0.1)
+                    hmm.init_emission()
+                    out = {"obj": hmm.lkl(ind, F, A)}
+                    for it in range(2):
+                        try:
+                            hmm.iter_EM()
+                        except pkg.NgsFHMMError as e:
+                            out[f"error{it}"] = np.array([e.code])
+                            break
+                        out[f"lkl{it}"] = hmm.ind_lkl.copy()
+                        out[f"post{it}"] = hmm.marg_prob.copy()
+                        out[f"indF{it}"] = hmm.indF.copy()
+                        out[f"alpha{it}"] = hmm.alpha.copy()
+                        out[f"freq{it}"] = hmm.freq.copy()
+                    else:
+                        out["path"] = hmm.viterbi()
+                res[serial] = out
+        finally:
+            os.environ.pop("NGHMM_EXACT_SERIAL", None)
+        assert np.all(np.isfinite(res[False]["obj"]))
+        assert sorted(res[False]) == sorted(res[True])
+        assert f"lkl{n_ok - 1}" in res[False] and (n_ok == 2) == ("path" in res[False])
+        if n_ok == 1:
+            assert res[False]["error1"][0] == -1          # NGHMM_ERR_INVALID_LKL
+        for k in res[False]:
+            assert np.array_equal(res[False][k], res[True][k]), k

@@ -186,7 +186,7 @@ def test_group_of_handles_equals_one_handle(pkg, n, packed):
 @pytest.mark.parametrize("I", [16, 40, 100, 128])
 def test_est_maf_rows_kernel_equals_wave_kernel(pkg, I):
     """Below 129 individuals est_maf runs four sites per wave, one per 16-lane DPP row
-    (k_fast_estmaf_rows); NGHMM_ESTMAF_NO_ROWS=1 forces the one-site-per-wave kernel.  Same
+    (k_fast_estmaf_rows); the switch estmaf_no_rows forces the one-site-per-wave kernel.  Same
     recursion and interval logic: the frequencies must agree to summation-order rounding on
     data whose sites travel far (uniform site frequencies: odds from 0.01 up to ~20, several
     intervals per site).  The lanes of a row decide for themselves from row totals, which
@@ -203,15 +203,13 @@ def test_est_maf_rows_kernel_equals_wave_kernel(pkg, I):
     res = {}
     try:
         for rows in ("1", "0"):
-            if rows == "0":
-                os.environ["NGHMM_ESTMAF_NO_ROWS"] = "1"
+            hmm.set_switch("estmaf_no_rows", 1 if rows == "0" else 0)
             hmm.set_params(np.full(I, 0.1), np.full(I, 0.01), np.full(S, 0.1))
             hmm.init_emission()
             hmm.estep()
             hmm.mstep_freq(1)
             res[rows] = hmm.freq.copy()
     finally:
-        os.environ.pop("NGHMM_ESTMAF_NO_ROWS", None)
         hmm.close()
     rel = np.abs(res["1"] - res["0"]) / res["0"]
     assert rel.max() < 1e-12, (rel.max(), int((rel > 1e-12).sum()))

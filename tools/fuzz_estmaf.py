@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stress run of est_maf's interpolated passes against all-exact passes (NGHMM_ESTMAF_INTERP=0)
+"""Stress run of est_maf's interpolated passes against all-exact passes (switch estmaf_interp = 0)
 over cohort sizes (every kernel variant: rows, 1..16 individuals per lane, several waves per
 site, the streaming kernel) and data regimes (depth, uniform / extreme site frequencies,
 called genotypes).  Prints the worst relative difference per case; anything above 1e-10 is
@@ -36,7 +36,7 @@ def main():
         res = {}
         try:
             for interp in ("0", "1"):
-                os.environ["NGHMM_ESTMAF_INTERP"] = interp
+                hmm.set_switch("estmaf_interp", int(interp))
                 hmm.set_params(np.full(I, 0.2), np.full(I, 0.05), np.full(S, 0.1))
                 hmm.init_emission()
                 out = []
@@ -49,8 +49,6 @@ def main():
             print(f"I={I} S={S} {kw} call_geno={call}: {e}")
             hmm.close()
             continue
-        finally:
-            os.environ.pop("NGHMM_ESTMAF_INTERP", None)
         hmm.close()
         torch.cuda.empty_cache()
         f0, f1 = res["0"][0], res["1"][0]     # first step: both start from the same posteriors
