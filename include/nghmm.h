@@ -184,7 +184,24 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
 
 /* Allele-frequency M-step + emission refresh (EM.cpp:210-272; est_maf,
  * shared/gen_func.cpp:974-1009).  freq_est 0 = keep, 1 = per-site EM,
- * 2 = NGHMM_ERR_FREQ_EST2 (the reference aborts). */
+ * 2 = NGHMM_ERR_FREQ_EST2 (the reference aborts).
+ *
+ * OPT-IN, PARITY UNPINNED -- --freq_est 2 / --e_prob 2 AS INTENDED.  The reference aborts on
+ * both at the first site (EM.cpp:235-238 -> shared/gen_func.cpp:1030-1031), so there is no
+ * reference output; what is computed is its loop (EM.cpp:224-263) as written -- sites in
+ * order, frequencies updated in place, haplotype frequencies of every adjacent site pair by
+ * the pair EM of gen_func.cpp:1027-1119 -- with its three defects repaired the smallest way
+ * (no pair step at the first site; the normal-space pair iteration, the log-space one loses a
+ * logsum at :1160; the LD emission of EM.cpp:258-260 reachable).  Asked for by OR-ing
+ * NGHMM_LD_INTENDED into freq_est:
+ *   2 | NGHMM_LD_INTENDED                    freq[s] from the pair's haplotype frequencies
+ *   2 | NGHMM_LD_INTENDED | NGHMM_EPROB_LD   ... and emissions by calc_emissionLD
+ *                                            (shared/HMM.cpp:175-236) past the first site
+ *   1 | NGHMM_LD_INTENDED | NGHMM_EPROB_LD   est_maf frequencies, LD emissions
+ * NGHMM_EPROB_LD needs NGHMM_MODE_EXACT (materialised emissions).  One unsharded handle, at
+ * most 8192 individuals; the chain through the sites is sequential by its definition.  Plain
+ * 2 keeps returning the reference's abort. */
+enum { NGHMM_LD_INTENDED = 0x20, NGHMM_EPROB_LD = 0x40 };
 int nghmm_mstep_freq(nghmm_t* h, int freq_est);
 
 /* E-step + indF/alpha M-step of one EM iteration (EM.cpp:147-201) in one call.  In fast

@@ -43,6 +43,9 @@ struct Params {  // ngsF-HMM.hpp:13-52
   bool call_geno = false;
   std::string in_freq, in_indF;
   int freq_est = 1, e_prob_calc = 1;
+  // --ld_intended: --freq_est 2 / --e_prob 2 do what EM.cpp:224-263 evidently means instead of
+  // what the reference does with them (abort).  Opt-in; parity unpinned (include/nghmm.h).
+  bool ld_intended = false;
   bool indF_fixed = false, alpha_fixed = false;
   const char* out_prefix = nullptr;
   unsigned log = 0;
@@ -523,7 +526,7 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       {"device", required_argument, nullptr, 1001},   {"taus_kat", required_argument, nullptr, 1002},
       {"no_pack", no_argument, nullptr, 1003},        {"n_starts", required_argument, nullptr, 1004},
       {"keep_starts", no_argument, nullptr, 1005},    {"n_gpus", required_argument, nullptr, 1006},
-      {"devices", required_argument, nullptr, 1007},
+      {"devices", required_argument, nullptr, 1007},  {"ld_intended", no_argument, nullptr, 1008},
       {0, 0, 0, 0}};
   long taus_kat = 0;
   P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
@@ -553,6 +556,7 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       case 'x': P.n_threads = atoi(optarg); break;
       case 'V': P.verbose = atoi(optarg); break;
       case 'S': P.seed = atoi(optarg); break;
+      case 1008: P.ld_intended = true; break;
       case 1000:
         if (!strcmp(optarg, "exact")) P.mode = NGHMM_MODE_EXACT;
         else if (!strcmp(optarg, "fast")) P.mode = NGHMM_MODE_FAST;
@@ -665,7 +669,10 @@ void run_em(Params& P, Cohort& C) {
         fprintf(P.out, "==> Estimating allele frequencies and calculating emission probabilities\n");
     }
     nghmm_mstep_stats stats;
-    check(nghmm_group_iter_em(C.hs.data(), C.n(), P.freq_est, P.indF_fixed, P.alpha_fixed,
+    int freq_step = P.freq_est;
+    if (P.ld_intended && (P.freq_est == 2 || P.e_prob_calc == 2) && P.freq_est != 0)
+      freq_step |= NGHMM_LD_INTENDED | (P.e_prob_calc == 2 ? NGHMM_EPROB_LD : 0);
+    check(nghmm_group_iter_em(C.hs.data(), C.n(), freq_step, P.indF_fixed, P.alpha_fixed,
                               P.ind_lkl.data(), &stats),
           "iter_EM");
     P.prev_tot_lkl = P.tot_lkl;
@@ -736,7 +743,12 @@ int main(int argc, char** argv) {
   read_dist(P);
   // The reference dies inside iter_EM for these (EM.cpp:235-238 -> gen_func.cpp:1030-1031);
   // same message, same exit code, before any GPU work.
-  if (P.freq_est == 2 || P.e_prob_calc == 2) fatal("haplo_freq", "invalid allele frequencies");
+  if ((P.freq_est == 2 || P.e_prob_calc == 2) && !P.ld_intended)
+    fatal("haplo_freq", "invalid allele frequencies");
+  if (P.ld_intended && (P.freq_est == 2 || P.e_prob_calc == 2))
+    warn(__FUNCTION__,
+         "--ld_intended: --freq_est 2 / --e_prob 2 as the code intends them; the reference "
+         "aborts here, so these results have no reference counterpart (parity unpinned)");
 
   if (P.verbose >= 1) printf("> GENO data\n");
   // Called genotypes (a called-genotype file, or --call_geno) are four values per cell and are

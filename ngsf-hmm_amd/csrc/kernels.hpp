@@ -12,7 +12,7 @@ namespace nghmm {
 // Error flags raised by kernels (device int[NFLAGS]); the C ABI maps them to the
 // reference's fatal messages.
 enum Flag { FLAG_INVALID_LKL = 0, FLAG_FW_BW = 1, FLAG_INVALID_MAF = 2, FLAG_NAN = 3,
-            FLAG_NOT_PACKABLE = 4, FLAG_BAD_GENO = 5, NFLAGS = 8 };
+            FLAG_NOT_PACKABLE = 4, FLAG_BAD_GENO = 5, FLAG_LD_FREQ = 6, NFLAGS = 8 };
 
 // ---------------- exact mode (kernels_exact.hip) ----------------
 // All arrays site-major: gl [S][I][3], eprob [S][I][2], fw [S+1][I][2], marg [S][I].
@@ -78,6 +78,20 @@ void launch_backward_exact_pc(hipStream_t st, const double* eprob, const double*
 // marg_sites [S_own][I_tot] -> freq_out[S_own]; passes_out (nullable) counts passes.
 void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out);
+
+// --freq_est 2 / --e_prob 2 AS INTENDED (kernels_ld.hip; opt-in, parity unpinned: the reference
+// aborts).  The chain through the sites: gl = log GL (exact) or linear GL (fast), site-major;
+// marg [S][I]; freq_old [S]; freq_new [S] holds site 0's new frequency (freq_est 2) or every
+// site's (freq_est 1) on entry and the new frequencies afterwards; hap [S][4] receives the
+// pairs' haplotype frequencies (row 0 unused).  FLAG_LD_FREQ: a frequency outside [0, 1].
+// false: more than 8192 individuals.
+bool launch_freq_ld_chain(hipStream_t st, bool exact, const GlView& gl, const double* marg,
+                          const double* freq_old, double* freq_new, double* hap, uint64_t S,
+                          uint64_t I, int freq_est, int* flags);
+// e_prob[s][i][k] = calc_emissionLD (shared/HMM.cpp:175-236) for the sites s >= 1
+void launch_emission_ld_exact(hipStream_t st, const GlView& gl, const double* freq,
+                              const double* hap, double* eprob, uint64_t S, uint64_t I,
+                              int* flags);
 
 // Viterbi (shared/HMM.cpp:98-125): bp [viterbi_blocked_bytes + I] scratch bytes, path_sites
 // [viterbi_blocked_bytes] bytes blocked [site/16][I][16] (launch_unblock_path gives [I][S]),

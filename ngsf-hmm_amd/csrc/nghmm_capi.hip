@@ -88,6 +88,7 @@ struct nghmm_handle {
   size_t text_cap = 0;
   bool tmp_is_posteriors = false;  // d_tmp holds the [I][S] posteriors of the last E-step
   uint32_t* d_passes = nullptr;
+  double *d_freq_new = nullptr, *d_hap = nullptr;  // --freq_est 2 as intended: [S], [S][4]
 
   // multi-GPU shard
   uint64_t I_tot = 0, ind_begin = 0, site_begin = 0, S_own = 0;
@@ -678,6 +679,7 @@ int nghmm_destroy(nghmm_t* h) {
                  h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
                  h->d_gl_shard, h->d_geno, h->d_text, h->d_codes_shard, h->d_uniform, h->d_stage,
+                 h->d_freq_new, h->d_hap,
                  h->d_stage8, h->g_send, h->g_recv, h->g_freq_own, h->g_freq_all};
   if (h->g_xstream) (void)hipStreamDestroy(h->g_xstream);
   if (h->d_flags_bg) (void)hipFree(h->d_flags_bg);
@@ -1586,11 +1588,78 @@ static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_block
   return NGHMM_OK;
 }
 
+// --freq_est 2 / --e_prob 2 AS INTENDED (opt-in; PARITY UNPINNED: the reference aborts on
+// both): the loop of EM.cpp:224-263 as written, sites in order with the frequencies updated in
+// place, minus its three defects -- kernels_ld.hip says which; oracle: orc_em_mstep_freq_ld.
+static int mstep_freq_ld_impl(nghmm_t* h, int freq_est, int e_prob) {
+  const bool exact = h->mode == NGHMM_MODE_EXACT;
+  if (h->I_tot != h->I) {
+    set_error("the intended --freq_est 2 walks the sites in order on ONE handle: not available "
+              "for a sharded cohort");
+    return NGHMM_ERR_ARG;
+  }
+  if (e_prob == 2 && !exact) {
+    set_error("the intended --e_prob 2 needs materialised emissions: NGHMM_MODE_EXACT only");
+    return NGHMM_ERR_ARG;
+  }
+  if (h->I > 8192) {
+    set_error("the intended --freq_est 2 holds a site pair's cohort in one workgroup: at most "
+              "8192 individuals");
+    return NGHMM_ERR_ARG;
+  }
+  int rc;
+  if (!h->d_freq_new && (rc = dev_alloc(&h->d_freq_new, (size_t)h->S))) return rc;
+  if (!h->d_hap && (rc = dev_alloc(&h->d_hap, (size_t)h->S * 4))) return rc;
+  if ((rc = clear_flags(h))) return rc;
+  if (!exact && (rc = ensure_marg(h))) return rc;  // site-major posteriors
+  // the first site, or (freq_est 1) every site, by est_maf (EM.cpp:242-244)
+  const uint64_t n_est = freq_est == 1 ? h->S : 1;
+  tic(h);
+  if (exact) {
+    launch_estmaf_exact(h->stream, own_gl(h), h->d_marg, n_est, h->I, h->d_freq_new, nullptr);
+  } else if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast), h->d_marg, n_est, h->I, h->I,
+                          h->d_freq_new, false)) {
+    return NGHMM_ERR_HIP;
+  }
+  if (!launch_freq_ld_chain(h->stream, exact, exact ? own_gl(h) : fast_gl_lin(h->fast), h->d_marg,
+                            h->d_freq, h->d_freq_new, h->d_hap, h->S, h->I, freq_est, h->d_flags))
+    return NGHMM_ERR_ARG;
+  HIP_TRY(hipMemcpyAsync(h->d_freq, h->d_freq_new, h->S * sizeof(double), hipMemcpyDeviceToDevice,
+                         h->stream));
+  if ((rc = toc(h, SLOT_ESTMAF, false))) return rc;
+  HIP_TRY(hipGetLastError());
+  int f[NFLAGS];
+  HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(sync_stream(h));
+  if (f[FLAG_LD_FREQ]) {
+    set_error("invalid allele frequencies");  // shared/gen_func.cpp:1030-1031
+    return NGHMM_ERR_FREQ_EST2;
+  }
+  if ((rc = emission_impl(h))) return rc;  // calc_emission for every site (EM.cpp:252-257)
+  if (e_prob == 2) {                       // ... and calc_emissionLD past the first (:258-260)
+    if ((rc = clear_flags(h))) return rc;
+    launch_emission_ld_exact(h->stream, own_gl(h), h->d_freq, h->d_hap, h->d_eprob, h->S, h->I,
+                             h->d_flags);
+    HIP_TRY(hipGetLastError());
+    if ((rc = check_flags(h))) return rc;
+  }
+  return NGHMM_OK;
+}
+
 int nghmm_mstep_freq(nghmm_t* h, int freq_est) {
   g_last_error.clear();
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
+  if (freq_est & NGHMM_LD_INTENDED) {
+    const int fe = freq_est & 3, ep = (freq_est & NGHMM_EPROB_LD) ? 2 : 1;
+    if ((freq_est & ~(NGHMM_LD_INTENDED | NGHMM_EPROB_LD | 3)) || (fe != 1 && fe != 2)) {
+      set_error("wrong MAF estimation method!");
+      return NGHMM_ERR_ARG;
+    }
+    if (fe == 1 && ep == 1) freq_est = 1;  // nothing of the LD route is asked for
+    else return mstep_freq_ld_impl(h, fe, ep);
+  }
   if (freq_est == 0) return NGHMM_OK;  // EM.cpp:212-214
   if (freq_est == 2) {
     set_error("invalid allele frequencies");
@@ -2165,6 +2234,11 @@ int nghmm_group_iter_em(nghmm_t** hs, int n, int freq_est, int indF_fixed, int a
     return NGHMM_ERR_ARG;
   }
   if (n == 1) return nghmm_iter_em(hs[0], freq_est, indF_fixed, alpha_fixed, ind_lkl, stats);
+  if (freq_est & NGHMM_LD_INTENDED) {
+    set_error("the intended --freq_est 2 walks the sites in order on ONE handle: not available "
+              "for a group of several");
+    return NGHMM_ERR_ARG;
+  }
   if (freq_est != 0 && freq_est != 1) {  // as nghmm_mstep_freq (EM.cpp:212-239)
     set_error(freq_est == 2 ? "invalid allele frequencies" : "wrong MAF estimation method!");
     return freq_est == 2 ? NGHMM_ERR_FREQ_EST2 : NGHMM_ERR_ARG;

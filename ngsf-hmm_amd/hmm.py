@@ -22,6 +22,10 @@ import numpy as np
 MODE_EXACT = 0
 MODE_FAST = 1
 GENO_PACKED = 0x10   # OR-ed into the mode: called genotypes kept as 2-bit codes
+# OR-ed into freq_est: --freq_est 2 / --e_prob 2 AS INTENDED (opt-in, parity unpinned: the
+# reference aborts on both; include/nghmm.h)
+LD_INTENDED = 0x20
+EPROB_LD = 0x40
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None

@@ -122,3 +122,74 @@ double hp_est_maf(uint64_t n_ind, const double* gl_site, const double* indF, int
   if (n_passes) *n_passes = passes;
   return (double)freq;
 }
+
+/* ---- --freq_est 2 as intended: the haplotype-frequency EM of a site pair in binary128 ----
+ * The model: individual i carries genotype probabilities a_i[g] at the first site and b_i[g] at
+ * the second (posteriors, given here in linear space as doubles); with haplotype frequencies f
+ * over (first allele, second allele) in {BA, Ba, bA, ba} the probability of the individual's
+ * data is sum over ordered haplotype pairs (k, h) of f_k f_h a[g1(k, h)] b[g2(k, h)], and one EM
+ * step sets f_k to the expected share of haplotype k among the 2 n haplotypes (gen_func.cpp:
+ * 1076-1119 computes the same from a different arrangement of the sum).  Iterated from the
+ * product of the marginal frequencies until no frequency moves by 1e-5, at most 100 times
+ * (gen_func.cpp:1027-1063).  Returns the number of iterations; hap_out receives f. */
+int hp_haplo_freq(double hap_out[4], const double* a, const double* b, double maf1, double maf2,
+                  uint64_t n) {
+  q128 f[4] = {(1 - (q128)maf1) * (1 - (q128)maf2), (1 - (q128)maf1) * (q128)maf2,
+               (q128)maf1 * (1 - (q128)maf2), (q128)maf1 * (q128)maf2};
+  int it;
+  for (it = 0; it < 100; ++it) {
+    q128 cnt[4] = {0, 0, 0, 0};
+    for (uint64_t i = 0; i < n; ++i) {
+      q128 w[4][4], tot = 0;
+      for (int k = 0; k < 4; ++k)
+        for (int h = 0; h < 4; ++h) {
+          const int g1 = (k >> 1) + (h >> 1), g2 = (k & 1) + (h & 1);
+          w[k][h] = f[k] * f[h] * (q128)a[3 * i + g1] * (q128)b[3 * i + g2];
+          tot += w[k][h];
+        }
+      /* expected copies of haplotype k in individual i: once as the first, once as the second
+       * member of the ordered pair */
+      for (int k = 0; k < 4; ++k) {
+        q128 c = 0;
+        for (int h = 0; h < 4; ++h) c += w[k][h] + w[h][k];
+        cnt[k] += c / tot;
+      }
+    }
+    q128 nf[4], norm = 0, eps = 0;
+    for (int k = 0; k < 4; ++k) {
+      nf[k] = cnt[k] / (2 * (q128)n);
+      norm += nf[k];
+    }
+    for (int k = 0; k < 4; ++k) {
+      nf[k] /= norm; /* (the counts already sum to 2 n: norm = 1 up to rounding) */
+      const q128 d = fabsq(nf[k] - f[k]);
+      if (d > eps) eps = d;
+      f[k] = nf[k];
+    }
+    if (eps < (q128)1e-5) break;
+  }
+  for (int k = 0; k < 4; ++k) hap_out[k] = (double)f[k];
+  return it;
+}
+
+/* calc_emissionLD's model (shared/HMM.cpp:175-236): P(data at both sites | state F) / P(data at
+ * the previous site | state F), the pair's genotypes drawn from two haplotypes (F = 0) or from
+ * one haplotype twice (F = 1); linear likelihoods exp(gl).  Returned as a log. */
+double hp_emission_ld(const double hap[4], const double gl_p[3], const double gl_c[3], double maf_p,
+                      int F) {
+  q128 sp[3], sc[3], joint = 0, hw[3];
+  for (int g = 0; g < 3; ++g) {
+    sp[g] = q_exp(gl_p[g]);
+    sc[g] = q_exp(gl_c[g]);
+  }
+  if (F == 0) {
+    for (int k = 0; k < 4; ++k)
+      for (int h = 0; h < 4; ++h)
+        joint += (q128)hap[k] * (q128)hap[h] * sp[(k >> 1) + (h >> 1)] * sc[(k & 1) + (h & 1)];
+  } else {
+    for (int k = 0; k < 4; ++k) joint += (q128)hap[k] * sp[2 * (k >> 1)] * sc[2 * (k & 1)];
+  }
+  hwe((q128)maf_p, (q128)F, hw);
+  const q128 marg = sp[0] * hw[0] + sp[1] * hw[1] + sp[2] * hw[2];
+  return (double)(logq(joint) - logq(marg));
+}

@@ -193,6 +193,101 @@ double orc_est_maf(uint64_t n_ind, const double* gl_site, const double* indF, in
   return freq;
 }
 
+/* ------------------------------------------------------------------ */
+/* --freq_est 2 / --e_prob 2 as INTENDED (opt-in; PARITY UNPINNED: the    */
+/* reference aborts on both, SURVEY.md finding 3)                          */
+/* ------------------------------------------------------------------ */
+/* shared/gen_func.cpp:1070-1071 */
+#define ORC_G1(h, k) (((h) >> 1 & 1) + ((k) >> 1 & 1))
+#define ORC_G2(h, k) (((h) & 1) + ((k) & 1))
+
+/* shared/gen_func.cpp:1076-1119, ignore_miss_data = false (EM.cpp:237): one EM iteration of
+ * the four haplotype frequencies of a pair of sites from per-individual genotype
+ * probabilities in NORMAL space, s1 / s2 = [n][3].  The in-place normalisation at the end
+ * divides f[1] by a sum that already holds the normalised f[0], and so on: kept. */
+uint64_t orc_pair_freq_iter(double f[4], const double* s1, const double* s2, uint64_t n) {
+  double ff[4] = {0, 0, 0, 0};
+  uint64_t x = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const double* p0 = s1 + 3 * i;
+    const double* p1 = s2 + 3 * i;
+    double sum, tmp;
+    x++;
+    sum = 0;
+    for (int k = 0; k < 4; ++k)
+      for (int h = 0; h < 4; ++h) sum += f[k] * f[h] * p0[ORC_G1(k, h)] * p1[ORC_G2(k, h)];
+    for (int k = 0; k < 4; ++k) {
+      tmp = 0;
+      for (int h = 0; h < 4; ++h)
+        tmp += f[k] * f[h] *
+               (p0[ORC_G1(h, k)] * p1[ORC_G2(h, k)] + p0[ORC_G1(k, h)] * p1[ORC_G2(k, h)]);
+      ff[k] += tmp / sum;
+    }
+  }
+  for (int k = 0; k < 4; ++k) f[k] = ff[k] / (2 * x);
+  for (int k = 0; k < 4; k++) f[k] /= f[0] + f[1] + f[2] + f[3];
+  return x;
+}
+
+/* shared/gen_func.cpp:1027-1063 on the normal-space iteration (the log-space one discards a
+ * logsum result at :1160 and returns NaN frequencies; the intended path is :1076-1119).
+ * Returns the number of iterations, or -5 for "invalid allele frequencies" (:1030-1031). */
+int orc_haplo_freq(double hap_freq[4], const double* gl1, const double* gl2, double maf1,
+                   double maf2, uint64_t n_ind) {
+  double last[4];
+  if (maf1 < 0 || maf1 > 1 || maf2 < 0 || maf2 > 1) return -5;
+  hap_freq[0] = (1 - maf1) * (1 - maf2);
+  hap_freq[1] = (1 - maf1) * maf2;
+  hap_freq[2] = maf1 * (1 - maf2);
+  hap_freq[3] = maf1 * maf2;
+  int n_iter;
+  for (n_iter = 0; n_iter < 100; n_iter++) { /* ITER_MAX, gen_func.hpp:18 */
+    double eps = 0;
+    memcpy(last, hap_freq, sizeof last);
+    orc_pair_freq_iter(hap_freq, gl1, gl2, n_ind);
+    for (int j = 0; j < 4; j++) {
+      double x = fabs(hap_freq[j] - last[j]);
+      if (x > eps) eps = x;
+    }
+    if (eps < ORC_EPSILON) break;
+  }
+  return n_iter;
+}
+
+/* shared/HMM.cpp:216-236 (F_p == F_c; pow(x, 2) is x * x) */
+double orc_joint_geno_prob(const double h[4], int g_p, int g_c, int F) {
+  if (g_p == 0 && g_c == 0) return F == 0 ? h[0] * h[0] : h[0];
+  if (g_p == 0 && g_c == 1) return F == 0 ? 2 * h[0] * h[1] : 0;
+  if (g_p == 0 && g_c == 2) return F == 0 ? h[1] * h[1] : h[1];
+  if (g_p == 1 && g_c == 0) return F == 0 ? 2 * h[0] * h[2] : 0;
+  if (g_p == 1 && g_c == 1) return F == 0 ? 2 * (h[0] * h[3] + h[1] * h[2]) : 0;
+  if (g_p == 1 && g_c == 2) return F == 0 ? 2 * h[1] * h[3] : 0;
+  if (g_p == 2 && g_c == 0) return F == 0 ? h[2] * h[2] : h[2];
+  if (g_p == 2 && g_c == 1) return F == 0 ? 2 * h[2] * h[3] : 0;
+  if (g_p == 2 && g_c == 2) return F == 0 ? h[3] * h[3] : h[3];
+  return -1;
+}
+
+/* shared/HMM.cpp:175-212, the live branch (:203-211): emission of the current site given the
+ * previous one through the pair's haplotype frequencies */
+double orc_calc_emission_ld(const double hap_freq[4], const double gl_p[3], const double gl_c[3],
+                            double maf_p, double maf_c, int F, int* bad) {
+  if (maf_p < 0 || maf_p > 1 || maf_c < 0 || maf_c > 1) {
+    if (bad) *bad = 1;
+    return NAN;
+  }
+  double s_p[3], s_c[3];
+  for (int g = 0; g < 3; g++) {
+    s_p[g] = ORC_EXP(gl_p[g]);
+    s_c[g] = ORC_EXP(gl_c[g]);
+  }
+  double sum = 0;
+  for (int g_c = 0; g_c < 3; g_c++)
+    for (int g_p = 0; g_p < 3; g_p++)
+      sum += orc_joint_geno_prob(hap_freq, g_p, g_c, F) * s_p[g_p] * s_c[g_c];
+  return ORC_LOG(sum) - orc_calc_emission(gl_p, maf_p, F, bad);
+}
+
 /* shared/HMM.cpp:6-28 */
 int orc_forward(double* Fw, const double q[2], double alpha, const double* e_prob,
                 const double* pos_dist, uint64_t S, double* lkl) {
@@ -488,6 +583,69 @@ int orc_em_mstep_freq(orc_em* em, int freq_est, int n_threads) {
     free(indF);
   }
   em->maf_passes += passes;
+  return rc;
+}
+
+/* EM.cpp:210-272 with --freq_est 2 and / or --e_prob 2 as INTENDED.  The reference aborts at
+ * s = 1 (haplo_freq is handed freq[0] = -1), its log-space pair iteration loses a logsum
+ * (gen_func.cpp:1160), and the LD emission of :258-260 sits inside an `if (e_prob_calc == 1
+ * || s == 1)` that it can never pass.  Intended here = the loop exactly as written -- sites
+ * in order, frequencies updated IN PLACE, so that site s sees the new freq[s-1] and the old
+ * freq[s] -- with those three repaired the smallest way: no haplotype step at the first site
+ * (it has no previous one; the code already special-cases s == 1 for est_maf and the
+ * emissions), the normal-space iteration on the exponentiated posteriors, and the LD emission
+ * reachable for s > 1.  PARITY UNPINNED: there is no reference output to compare with.
+ * freq_est, e_prob_calc: 1 or 2.  Returns 0, -3 (invalid MAF), -5 (invalid allele
+ * frequencies). */
+int orc_em_mstep_freq_ld(orc_em* em, int freq_est, int e_prob_calc) {
+  const uint64_t I = em->I, S = em->S;
+  if ((freq_est != 1 && freq_est != 2) || (e_prob_calc != 1 && e_prob_calc != 2)) return -6;
+  double prior[3], hap_freq[4] = {0, 0, 0, 0};
+  double* indF = (double*)malloc(I * sizeof(double));
+  double* prev_site = (double*)malloc(I * 3 * sizeof(double));
+  double* curr_site = (double*)malloc(I * 3 * sizeof(double));
+  int rc = 0;
+  for (uint64_t s = 0; s < S && rc == 0; s++) { /* reference site s + 1 */
+    for (uint64_t i = 0; i < I; i++) {
+      indF[i] = em->marg[(i * S + s) * 2 + 1];
+      if (s >= 1) {
+        orc_calc_hwe(prior, em->freq[s - 1], em->marg[(i * S + s - 1) * 2 + 1], 1);
+        orc_post_prob(prev_site + 3 * i, em->gl + ((s - 1) * I + i) * 3, prior);
+      }
+      orc_calc_hwe(prior, em->freq[s], em->marg[(i * S + s) * 2 + 1], 1);
+      orc_post_prob(curr_site + 3 * i, em->gl + (s * I + i) * 3, prior);
+    }
+    if (s >= 1 && (freq_est == 2 || e_prob_calc == 2)) {
+      conv_space_exp(prev_site, (int)(3 * I));
+      conv_space_exp(curr_site, (int)(3 * I));
+      if (orc_haplo_freq(hap_freq, prev_site, curr_site, em->freq[s - 1], em->freq[s], I) < 0) {
+        rc = -5;
+        break;
+      }
+    }
+    const double maf_p = s >= 1 ? em->freq[s - 1] : -1; /* before freq[s] is overwritten */
+    if (freq_est == 1 || s == 0) {
+      int np = 0;
+      em->freq[s] = orc_est_maf(I, em->gl + s * I * 3, indF, &np);
+      em->maf_passes += (uint64_t)np;
+    } else {
+      em->freq[s] = hap_freq[1] + hap_freq[3];
+    }
+    for (uint64_t i = 0; i < I && rc == 0; i++)
+      for (int k = 0; k < 2; k++) {
+        int bad = 0;
+        double* e = em->e_prob + (i * S + s) * 2 + k;
+        if (e_prob_calc == 1 || s == 0)
+          *e = orc_calc_emission(em->gl + (s * I + i) * 3, em->freq[s], k, &bad);
+        else
+          *e = orc_calc_emission_ld(hap_freq, em->gl + ((s - 1) * I + i) * 3,
+                                    em->gl + (s * I + i) * 3, maf_p, em->freq[s], k, &bad);
+        if (bad) rc = -3;
+      }
+  }
+  free(indF);
+  free(prev_site);
+  free(curr_site);
   return rc;
 }
 

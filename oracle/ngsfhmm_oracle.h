@@ -70,6 +70,18 @@ double orc_calc_emission(const double gl[3], double maf, int k, int* bad);
  * the number of passes over the individuals. */
 double orc_est_maf(uint64_t n_ind, const double* gl_site, const double* indF, int* n_passes);
 
+/* ---- --freq_est 2 / --e_prob 2 as INTENDED (opt-in; parity unpinned: the reference aborts) ----
+ * shared/gen_func.cpp:1076-1119: one normal-space EM iteration of the haplotype frequencies
+ * f[4] of a site pair; s1, s2 = [n][3] genotype probabilities.  Returns n. */
+uint64_t orc_pair_freq_iter(double f[4], const double* s1, const double* s2, uint64_t n);
+/* shared/gen_func.cpp:1027-1063 on that iteration; iterations made, or -5 */
+int orc_haplo_freq(double hap_freq[4], const double* gl1, const double* gl2, double maf1,
+                   double maf2, uint64_t n_ind);
+/* shared/HMM.cpp:216-236 and :175-212 */
+double orc_joint_geno_prob(const double h[4], int g_p, int g_c, int F);
+double orc_calc_emission_ld(const double hap_freq[4], const double gl_p[3], const double gl_c[3],
+                            double maf_p, double maf_c, int F, int* bad);
+
 /* shared/HMM.cpp:6-28.  e_prob = [S][2] log emissions of one individual,
  * pos_dist = [S]; Fw = [(S+1)][2] or NULL (likelihood only).  Returns 0, or -1
  * when a NaN appears ("invalid Lkl found!"). */
@@ -126,6 +138,9 @@ int orc_em_estep(orc_em* em, int n_threads);
 int orc_em_mstep_indf(orc_em* em, int indF_fixed, int alpha_fixed, int n_threads);
 /* the allele-frequency M-step + emission refresh only (EM.cpp:210-272) */
 int orc_em_mstep_freq(orc_em* em, int freq_est, int n_threads);
+/* EM.cpp:210-272 with --freq_est 2 and / or --e_prob 2 as intended (see the .c file; parity
+ * unpinned: the reference aborts); freq_est, e_prob_calc in {1, 2} */
+int orc_em_mstep_freq_ld(orc_em* em, int freq_est, int e_prob_calc);
 /* EM.cpp:27-135 EM(): loop + convergence test; returns number of iterations run or <0 */
 int orc_em_run(orc_em* em, int freq_est, int indF_fixed, int alpha_fixed, int min_iters,
                int max_iters, double min_epsilon, int n_threads);

@@ -71,6 +71,11 @@ class Oracle:
             "orc_em_estep": (i32, [C.c_void_p, i32]),
             "orc_em_mstep_indf": (i32, [C.c_void_p, i32, i32, i32]),
             "orc_em_mstep_freq": (i32, [C.c_void_p, i32, i32]),
+            "orc_em_mstep_freq_ld": (i32, [C.c_void_p, i32, i32]),
+            "orc_pair_freq_iter": (u64, [dp, dp, dp, u64]),
+            "orc_haplo_freq": (i32, [dp, dp, dp, d, d, u64]),
+            "orc_joint_geno_prob": (d, [dp, i32, i32, i32]),
+            "orc_calc_emission_ld": (d, [dp, dp, dp, d, d, i32, ip]),
             "orc_em_run": (i32, [C.c_void_p, i32, i32, i32, i32, i32, d, i32]),
             "orc_em_viterbi": (i32, [C.c_void_p, C.POINTER(C.c_uint8), i32]),
             "orc_em_geno_post": (None, [C.c_void_p, C.POINTER(C.c_uint8), dp]),
@@ -95,6 +100,14 @@ class Oracle:
         self.lib.orc_calc_hwe(_dp(out), maf, F, int(log_scale))
         return out
 
+    def post_prob(self, lkl, prior=None):
+        """shared/gen_func.cpp:920-932: normalised log posterior of one cell."""
+        lkl = np.ascontiguousarray(lkl, dtype=np.float64)
+        pp = np.empty(3)
+        pr = None if prior is None else np.ascontiguousarray(prior, dtype=np.float64)
+        self.lib.orc_post_prob(_dp(pp), _dp(lkl), _dp(pr) if pr is not None else None)
+        return pp
+
     def calc_emission(self, gl, maf, k):
         gl = np.ascontiguousarray(gl, dtype=np.float64)
         bad = C.c_int(0)
@@ -114,6 +127,23 @@ class Oracle:
         n = C.c_int(0)
         f = self.lib.orc_est_maf(len(indF), _dp(gl_site), _dp(indF), C.byref(n))
         return f, n.value
+
+    # --freq_est 2 / --e_prob 2 as intended (parity unpinned: the reference aborts)
+    def haplo_freq(self, p1, p2, maf1, maf2):
+        """p1, p2: [n][3] genotype probabilities (normal space) -> (hap_freq[4], iterations)."""
+        p1 = np.ascontiguousarray(p1, dtype=np.float64)
+        p2 = np.ascontiguousarray(p2, dtype=np.float64)
+        hap = np.zeros(4)
+        it = self.lib.orc_haplo_freq(_dp(hap), _dp(p1), _dp(p2), float(maf1), float(maf2), len(p1))
+        return hap, it
+
+    def calc_emission_ld(self, hap, gl_p, gl_c, maf_p, maf_c, F):
+        hap = np.ascontiguousarray(hap, dtype=np.float64)
+        gl_p = np.ascontiguousarray(gl_p, dtype=np.float64)
+        gl_c = np.ascontiguousarray(gl_c, dtype=np.float64)
+        bad = C.c_int(0)
+        return self.lib.orc_calc_emission_ld(_dp(hap), _dp(gl_p), _dp(gl_c), float(maf_p),
+                                             float(maf_c), int(F), C.byref(bad))
 
     def forward(self, q, alpha, e_prob, pos_dist, store=True):
         e_prob = np.ascontiguousarray(e_prob, dtype=np.float64)
@@ -205,6 +235,10 @@ class OracleEM:
 
     def mstep_freq(self, freq_est=1, n_threads=1):
         return self.orc.lib.orc_em_mstep_freq(self.h, freq_est, n_threads)
+
+    def mstep_freq_ld(self, freq_est=2, e_prob_calc=1):
+        """--freq_est 2 / --e_prob 2 as intended (parity unpinned: the reference aborts)."""
+        return self.orc.lib.orc_em_mstep_freq_ld(self.h, freq_est, e_prob_calc)
 
     def run(self, freq_est=1, indF_fixed=False, alpha_fixed=False, min_iters=10, max_iters=100,
             min_epsilon=1e-5, n_threads=1):
@@ -310,6 +344,11 @@ class HpAnchor:
                                           C.c_double, C.c_double, c_double_p]
         L.hp_est_maf.restype = C.c_double
         L.hp_est_maf.argtypes = [C.c_uint64, c_double_p, c_double_p, C.POINTER(C.c_int)]
+        L.hp_haplo_freq.restype = C.c_int
+        L.hp_haplo_freq.argtypes = [c_double_p, c_double_p, c_double_p, C.c_double, C.c_double,
+                                    C.c_uint64]
+        L.hp_emission_ld.restype = C.c_double
+        L.hp_emission_ld.argtypes = [c_double_p, c_double_p, c_double_p, C.c_double, C.c_int]
 
     def forward_backward(self, gl_ind, freq, pos_dist, indF, alpha, want_post=True):
         """gl_ind [S][3] log GLs of one individual -> (log-likelihood, posteriors [S] or None)."""
@@ -328,3 +367,16 @@ class HpAnchor:
         n = C.c_int(0)
         f = self.lib.hp_est_maf(len(indF), _dp(gl_site), _dp(indF), C.byref(n))
         return f, n.value
+
+    def haplo_freq(self, p1, p2, maf1, maf2):
+        p1 = np.ascontiguousarray(p1, dtype=np.float64)
+        p2 = np.ascontiguousarray(p2, dtype=np.float64)
+        hap = np.zeros(4)
+        it = self.lib.hp_haplo_freq(_dp(hap), _dp(p1), _dp(p2), float(maf1), float(maf2), len(p1))
+        return hap, it
+
+    def emission_ld(self, hap, gl_p, gl_c, maf_p, F):
+        hap = np.ascontiguousarray(hap, dtype=np.float64)
+        gl_p = np.ascontiguousarray(gl_p, dtype=np.float64)
+        gl_c = np.ascontiguousarray(gl_c, dtype=np.float64)
+        return self.lib.hp_emission_ld(_dp(hap), _dp(gl_p), _dp(gl_c), float(maf_p), int(F))

@@ -98,3 +98,96 @@ def test_brute_force_agrees_with_the_anchor(hp):
     lk, post = hp.forward_backward(gl, freq, d, F, al)
     assert abs(lk - math.log(tot)) < 1e-13 * abs(lk)
     np.testing.assert_allclose(post, w1 / tot, rtol=1e-12)
+
+
+def test_intended_ld_frequency_step_against_binary128(pkg, orc_libm):
+    """--freq_est 2 / --e_prob 2 as INTENDED (opt-in; PARITY UNPINNED: the reference aborts on
+    both, SURVEY.md finding 3): the oracle's restatement of the normal-space pair iteration
+    (gen_func.cpp:1076-1119 under haplo_freq, :1027-1063) and of calc_emissionLD (HMM.cpp:175-236)
+    against the same MODEL in binary128 (oracle/hp_anchor.c: another arrangement of the sums, no
+    shared code): haplotype frequencies within 1e-13 with the same iteration count, LD emissions
+    within 1e-12, on pairs of sites in linkage disequilibrium and in equilibrium, with missing
+    cells and with certain genotypes."""
+    hp = orclib.HpAnchor()
+    rng = np.random.default_rng(12)
+    for n, ld in ((40, 0.0), (200, 0.8), (1000, 0.4), (7, 0.95)):
+        # two sites with allele frequencies f1, f2 and a fraction `ld` of haplotypes carrying the
+        # same allele at both; genotype probabilities from noisy reads
+        f1, f2 = rng.uniform(0.05, 0.6, 2)
+        hap = np.empty((n, 2, 2), dtype=int)
+        hap[..., 0] = rng.random((n, 2)) < f1
+        copy = rng.random((n, 2)) < ld
+        hap[..., 1] = np.where(copy, hap[..., 0], rng.random((n, 2)) < f2)
+        g = hap.sum(axis=1)                                      # [n][site] in 0..2
+        p = np.full((2, n, 3), 0.02)
+        for s in range(2):
+            p[s, np.arange(n), g[:, s]] = 0.96
+        p[:, : n // 10] = 1 / 3                                  # missing individuals
+        if n >= 40:
+            p[0, -1] = (0.0, 0.0, 1.0)                           # a certain genotype
+        p /= p.sum(axis=2, keepdims=True)
+        m1, m2 = g[:, 0].mean() / 2 + 1e-3, g[:, 1].mean() / 2 + 1e-3
+        h_orc, it_orc = orc_libm.haplo_freq(p[0], p[1], m1, m2)
+        h_hp, it_hp = hp.haplo_freq(p[0], p[1], m1, m2)
+        assert it_orc == it_hp and 0 < it_orc < 100
+        np.testing.assert_allclose(h_orc, h_hp, rtol=1e-13, atol=1e-15)
+        assert abs(h_orc.sum() - 1) < 1e-14
+        if ld > 0.5:     # the pair is in LD: D = P_ba - maf1 maf2 clearly positive
+            assert h_orc[3] - (h_orc[2] + h_orc[3]) * (h_orc[1] + h_orc[3]) > 0.02
+        gl = np.log(np.maximum(p, 1e-300))
+        for i in (0, n // 2, n - 1):
+            for F in (0, 1):
+                e_orc = orc_libm.calc_emission_ld(h_orc, gl[0, i], gl[1, i], m1, m2, F)
+                e_hp = hp.emission_ld(h_orc, gl[0, i], gl[1, i], m1, F)
+                if np.isfinite(e_hp):
+                    assert abs(e_orc - e_hp) <= 1e-12 * max(1.0, abs(e_hp)), (n, i, F)
+    # no information (every genotype equally likely everywhere): the starting point, the
+    # product of the marginal frequencies, is a fixed point and the loop ends at once
+    p = np.full((50, 3), 1 / 3)
+    h, it = orc_libm.haplo_freq(p, p, 0.3, 0.2)
+    np.testing.assert_allclose(h, [0.56, 0.14, 0.24, 0.06], rtol=1e-12)
+    assert it == 0
+
+
+def test_intended_ld_m_step_of_the_oracle(pkg, orc_libm):
+    """orc_em_mstep_freq_ld (EM.cpp:210-272 as intended): site 1 takes est_maf as the
+    reference's own `freq_est == 1 || s == 1` says, every later site the haplotype route with
+    the NEW frequency of its predecessor (the loop updates freq in place); with --e_prob 2 the
+    emissions of s > 1 come from calc_emissionLD.  Checked against a step-by-step recomputation
+    in Python from the oracle's scalar routines."""
+    I, S = 9, 40
+    d = pkg.simulate.simulate(I, S, seed=5, missing_rate=0.1)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    for freq_est, e_prob in ((2, 1), (2, 2), (1, 2)):
+        em = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
+        em.set_params(0.2, 0.1, 0.15)
+        assert em.init_emission() == 0 and em.estep() == 0
+        marg, freq0 = em.marg.copy(), em.freq.copy()
+        assert em.mstep_freq_ld(freq_est, e_prob) == 0
+        freq = freq0.copy()
+        for s in range(S):
+            post = np.empty((2, I, 3))
+            for i in range(I):
+                for j, ss in enumerate((s - 1, s)):
+                    if ss < 0:
+                        continue
+                    prior = orc_libm.calc_hwe(freq[ss], marg[i, ss], True)
+                    pp = orc_libm.post_prob(gl[ss, i], prior)
+                    post[j, i] = [orc_libm.lib.orc_exp(float(v)) for v in pp]   # the C library's exp
+            if s >= 1:
+                hap, _ = orc_libm.haplo_freq(post[0], post[1], freq[s - 1], freq[s])
+            if freq_est == 1 or s == 0:
+                freq[s] = orc_libm.est_maf(gl[s], marg[:, s])[0]
+            else:
+                freq[s] = hap[1] + hap[3]
+            for i in range(I):
+                for k in range(2):
+                    if e_prob == 1 or s == 0:
+                        want = orc_libm.calc_emission(gl[s, i], freq[s], k)[0]
+                    else:
+                        want = orc_libm.calc_emission_ld(hap, gl[s - 1, i], gl[s, i], freq[s - 1],
+                                                         freq[s], k)
+                    assert em.e_prob[i, s, k] == want, (freq_est, e_prob, s, i, k)
+        assert np.array_equal(em.freq, freq)
+        assert np.all((freq > 0) & (freq < 1))
+        em.close()
