@@ -16,6 +16,10 @@
 #include <zlib.h>
 
 #include <charconv>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -118,6 +122,107 @@ void chomp(char* s) {
   size_t n = strlen(s);
   while (n && (s[n - 1] == '\n' || s[n - 1] == '\r')) s[--n] = '\0';
 }
+
+// --- the same tokens, fast: strtod is ~100 ns per number and a BEAGLE file of BASELINE
+// configs[2] holds 3 x 10^9 of them.  A plain decimal token -- [sign] digits [. digits]
+// [e [sign] digits] -- with at most 15 significant digits and a decimal exponent within
+// +-22 is ONE correctly rounded IEEE operation on two exactly representable doubles
+// (integer significand, power of ten: Clinger's fast path), i.e. bit for bit what strtod
+// returns; every other token (17-digit output of printf("%.17g"), nan, inf, hex floats,
+// junk) goes to strtod itself.
+const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// token [p, e): true and *out if it is a number in strtod's sense covering the whole token
+inline bool parse_token(char* p, char* e, double* out) {
+  const char* q = p;
+  bool neg = false;
+  if (q < e && (*q == '-' || *q == '+')) neg = (*q++ == '-');
+  uint64_t m = 0;
+  int nd = 0, dec_exp = 0;
+  bool any = false, fast = true;
+  for (; q < e && *q >= '0' && *q <= '9'; ++q) {
+    any = true;
+    if (m || *q != '0') {
+      if (++nd > 15) fast = false;
+      else m = m * 10 + (uint64_t)(*q - '0');
+    }
+  }
+  if (q < e && *q == '.') {
+    ++q;
+    for (; q < e && *q >= '0' && *q <= '9'; ++q) {
+      any = true;
+      if (m || *q != '0') {
+        if (++nd > 15) fast = false;
+        else m = m * 10 + (uint64_t)(*q - '0');
+      }
+      --dec_exp;
+    }
+  }
+  if (any && fast && q < e && (*q == 'e' || *q == 'E')) {
+    const char* r = q + 1;
+    bool eneg = false;
+    if (r < e && (*r == '-' || *r == '+')) eneg = (*r++ == '-');
+    int ex = 0, ed = 0;
+    for (; r < e && *r >= '0' && *r <= '9' && ed < 5; ++r, ++ed) ex = ex * 10 + (*r - '0');
+    if (ed == 0 || ed >= 5) fast = false;  // "1e" / absurd exponents: strtod decides
+    else {
+      dec_exp += eneg ? -ex : ex;
+      q = r;
+    }
+  }
+  if (any && fast && q == e && dec_exp >= -22 && dec_exp <= 22) {
+    double v = (double)m;
+    if (dec_exp < 0) v /= kPow10[-dec_exp];
+    else if (dec_exp > 0) v *= kPow10[dec_exp];
+    *out = neg ? -v : v;
+    return true;
+  }
+  const char saved = *e;  // the chunk is ours: terminate in place for strtod
+  *e = '\0';
+  char* end = nullptr;
+  const double v = strtod(p, &end);
+  const bool ok = (end != p && end == e);
+  *e = saved;
+  if (ok) *out = v;
+  return ok;
+}
+
+// numeric tokens of the line [p, e) on the separators ' ' and '\t' (gen_func.cpp:390-417)
+inline size_t split_doubles_fast(char* p, char* e, std::vector<double>& out) {
+  out.clear();
+  while (p < e) {
+    while (p < e && (*p == ' ' || *p == '\t')) ++p;
+    if (p >= e) break;
+    char* t = p;
+    while (t < e && *t != ' ' && *t != '\t') ++t;
+    double v;
+    if (parse_token(p, t, &v)) out.push_back(v);
+    p = t;
+  }
+  return out.size();
+}
+
+// what the text reader went through, for the --verbose 2 timing line
+uint64_t g_text_bytes = 0;
+unsigned g_text_threads = 0;
+
+// One piece of the text input on its way through the reader's pipeline: whole lines as
+// gzgets would hand them out (at most kBuffLen - 1 characters each, shared/gen_func.hpp:17),
+// then what a worker made of them.
+struct TextChunk {
+  std::vector<char> text;                      // len characters + one spare byte (see parse_token)
+  size_t len = 0;
+  std::vector<uint32_t> line_begin, line_end;  // [line]: offsets into text, newline excluded
+  // per line: number of numeric fields; UINT32_MAX marks an empty line
+  std::vector<uint32_t> n_fields;
+  std::vector<uint8_t> bad_geno;               // a genotype > 2 on the line
+  // the last I * n_geno fields of every line that has them, in line order
+  std::vector<double> rows;
+  std::vector<int8_t> grows;
+  std::vector<uint32_t> row_of_line;           // index into rows / grows, or UINT32_MAX
+  bool parsed = false;
+};
 
 // shared/read_data.cpp:165-218 + ngsF-HMM.cpp:75-86
 void read_dist(Params& P) {
@@ -228,78 +333,277 @@ int load_geno(Params& P, Cohort& C, bool packed) {
       rc = send_gl(s0, ns, buf.data(), space, 1);
     }
   } else {
+    // Text input as a pipeline: ONE thread inflates (a gzip stream is sequential) and cuts the
+    // text into pieces of whole lines, W workers tokenise the pieces in parallel, and this
+    // thread takes the pieces back IN FILE ORDER, applies the reader's line rules
+    // (shared/read_data.cpp:52-110: headers, empty lines, field counts -- they depend on how
+    // many sites have been consumed, so they stay sequential) and sends runs of sites to the
+    // device.  Same values, same messages, same first error as the line-by-line loop.
     const bool as_codes = packed && !P.in_lkl;  // called genotypes straight to 2-bit codes
     const int space = (P.in_lkl && !P.in_loglkl) ? NGHMM_GL_NORMAL_TEXT : NGHMM_GL_LOG;
-    std::vector<double> dbuf(as_codes ? 0 : (size_t)block * I * 3);
-    std::vector<int8_t> gbuf(as_codes ? (size_t)block * I : 0);
-    std::vector<char> buf(kBuffLen);
-    std::vector<double> t;
-    uint64_t s0 = 0, filled = 0;  // the block covers sites [s0, s0 + filled)
+    size_t chunk_bytes = 8u << 20;
+    if (const char* env = getenv("NGHMM_HOST_CHUNK_BYTES")) chunk_bytes = strtoull(env, nullptr, 10);  // tests
+    if (chunk_bytes < 16) chunk_bytes = 16;
+    unsigned W = std::thread::hardware_concurrency();
+    if (W > 16) W = 16;  // an 8-GPU node runs several of these; inflate is the limit anyway
+    if (W < 1) W = 1;
+    g_text_threads = W;
+    g_text_bytes = 0;
+    const size_t max_inflight = 2 * W + 2;
+
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_room;
+    std::deque<std::shared_ptr<TextChunk>> todo;      // cut, not yet taken by a worker
+    std::deque<std::shared_ptr<TextChunk>> in_order;  // every piece, in file order
+    bool eof = false, stop = false;
+    const char* read_error = nullptr;
+
+    auto cut_lines = [&](TextChunk& ck) {  // gzgets semantics: '\n' ends a line, so does length
+      const size_t n = ck.len;
+      size_t b = 0;
+      while (b < n) {
+        const char* nl = (const char*)memchr(ck.text.data() + b, '\n', n - b);
+        size_t e = nl ? (size_t)(nl - ck.text.data()) : n;
+        if (e - b > kBuffLen - 1) e = b + (kBuffLen - 1);  // an overlong line comes in pieces
+        size_t stop_at = e;
+        while (stop_at > b && (ck.text[stop_at - 1] == '\r')) --stop_at;  // chomp
+        ck.line_begin.push_back((uint32_t)b);
+        ck.line_end.push_back((uint32_t)stop_at);
+        b = (nl && e == (size_t)(nl - ck.text.data())) ? e + 1 : e;
+      }
+    };
+
+    std::thread inflater([&] {
+      std::vector<char> carry;  // the unfinished last line of the previous piece
+      for (;;) {
+        auto ck = std::make_shared<TextChunk>();
+        ck->text.resize(carry.size() + chunk_bytes);
+        if (!carry.empty()) memcpy(ck->text.data(), carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        bool at_eof = false;
+        while (have < ck->text.size()) {
+          const int got = gzread(fh, ck->text.data() + have, (unsigned)(ck->text.size() - have));
+          if (got < 0) {
+            std::lock_guard<std::mutex> lk(mu);
+            read_error = "cannot read GZip GENO file. Check GENO file and number of sites!";
+            eof = true;
+            cv_work.notify_all();
+            cv_done.notify_all();
+            return;
+          }
+          if (got == 0) {
+            at_eof = true;
+            break;
+          }
+          have += (size_t)got;
+        }
+        ck->text.resize(have);
+        if (!at_eof) {  // keep the unfinished last line for the next piece
+          size_t cut = have;
+          while (cut > 0 && ck->text[cut - 1] != '\n') --cut;
+          if (cut == 0 && have >= kBuffLen - 1) cut = have - (have % (kBuffLen - 1));  // no newline in sight
+          carry.assign(ck->text.begin() + cut, ck->text.end());
+          ck->text.resize(cut);
+        }
+        ck->len = ck->text.size();
+        g_text_bytes += ck->len;
+        ck->text.push_back('\0');  // the spare byte parse_token may overwrite behind the last token
+        if (ck->len) {
+          cut_lines(*ck);
+          std::unique_lock<std::mutex> lk(mu);
+          cv_room.wait(lk, [&] { return stop || in_order.size() < max_inflight; });
+          if (stop) return;
+          todo.push_back(ck);
+          in_order.push_back(ck);
+          cv_work.notify_one();
+        }
+        if (at_eof) {
+          std::lock_guard<std::mutex> lk(mu);
+          eof = true;
+          cv_work.notify_all();
+          cv_done.notify_all();
+          return;
+        }
+      }
+    });
+
+    auto worker = [&] {
+      std::vector<double> t;
+      for (;;) {
+        std::shared_ptr<TextChunk> ck;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv_work.wait(lk, [&] { return stop || !todo.empty() || eof; });
+          if (stop || (todo.empty() && eof)) return;
+          ck = todo.front();
+          todo.pop_front();
+        }
+        const size_t nl = ck->line_begin.size();
+        ck->n_fields.assign(nl, 0);
+        ck->bad_geno.assign(nl, 0);
+        ck->row_of_line.assign(nl, UINT32_MAX);
+        uint32_t n_rows = 0;
+        for (size_t l = 0; l < nl; ++l) {
+          char* b = ck->text.data() + ck->line_begin[l];
+          char* e = ck->text.data() + ck->line_end[l];
+          if (b == e) {
+            ck->n_fields[l] = UINT32_MAX;
+            continue;
+          }
+          const size_t nf = split_doubles_fast(b, e, t);
+          ck->n_fields[l] = (uint32_t)nf;
+          if (nf < I * n_geno) continue;
+          const double* ptr = t.data() + (nf - I * n_geno);  // last I * n_geno columns
+          ck->row_of_line[l] = n_rows;
+          if (P.in_lkl) {
+            ck->rows.insert(ck->rows.end(), ptr, ptr + I * 3);
+          } else if (as_codes) {
+            const size_t o = ck->grows.size();
+            ck->grows.resize(o + I);
+            for (uint64_t i = 0; i < I; i++) {
+              const int gg = (int)ptr[i];
+              if (gg > 2) ck->bad_geno[l] = 1;
+              ck->grows[o + i] = (int8_t)(gg < 0 ? -1 : gg);
+            }
+          } else {
+            const size_t o = ck->rows.size();
+            ck->rows.resize(o + I * 3);
+            for (uint64_t i = 0; i < I; i++) {
+              const int gg = (int)ptr[i];
+              double* g = &ck->rows[o + i * 3];
+              if (gg > 2) {
+                ck->bad_geno[l] = 1;
+              } else if (gg >= 0) {
+                g[0] = g[1] = g[2] = -kINF;  // read_data.cpp:21
+                g[gg] = log(1);
+              } else {
+                g[0] = g[1] = g[2] = log((double)1 / 3);
+              }
+            }
+          }
+          ++n_rows;
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          ck->parsed = true;
+        }
+        cv_done.notify_all();
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < W; ++w) pool.emplace_back(worker);
+    auto shut_down = [&] {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+      }
+      cv_work.notify_all();
+      cv_room.notify_all();
+      inflater.join();
+      for (auto& th : pool) th.join();
+    };
+    // errors must not leave threads behind: fatal() exits the process
+    auto die = [&](const char* msg) {
+      shut_down();
+      fatal("load_geno", msg);
+    };
+
+    // the sites of the current run [s0, s0 + filled) on their way to the device
+    std::vector<double> dbuf;
+    std::vector<int8_t> gbuf;
+    uint64_t s0 = 0, filled = 0, s = 0;
     auto flush = [&]() {
       if (!filled || rc != NGHMM_OK) return;
       rc = as_codes ? send_geno(s0, filled, gbuf.data()) : send_gl(s0, filled, dbuf.data(), space, 0);
       s0 += filled;
       filled = 0;
+      dbuf.clear();
+      gbuf.clear();
     };
-    for (uint64_t s = 0; s < S && rc == NGHMM_OK;) {
-      if (gzgets(fh, buf.data(), (int)kBuffLen) == nullptr)
-        fatal(__FUNCTION__, gzeof(fh)
-                                ? "GENO file at premature EOF. Check GENO file and number of sites!"
-                                : "cannot read GZip GENO file. Check GENO file and number of sites!");
-      chomp(buf.data());
-      double* row = as_codes ? nullptr : &dbuf[filled * I * 3];
-      if (buf[0] == '\0') {
-        // (sic) an empty line still consumes a site, as in the reference (read_data.cpp:60-61):
-        // its cells stay "unread", which 2-bit codes cannot express
-        if (as_codes) {
-          rc = NGHMM_ERR_NOT_PACKABLE;
+    bool trailing_data = false;
+    for (;;) {
+      std::shared_ptr<TextChunk> ck;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return (!in_order.empty() && in_order.front()->parsed) ||
+                                      (in_order.empty() && eof); });
+        if (read_error) {
+          lk.unlock();
+          die(read_error);
+        }
+        if (in_order.empty()) break;  // end of file
+        ck = in_order.front();
+        in_order.pop_front();
+        cv_room.notify_one();
+      }
+      if (s >= S) {  // all sites are in: anything further is "not at EOF"
+        trailing_data = true;
+        break;
+      }
+      const size_t nl = ck->line_begin.size();
+      for (size_t l = 0; l < nl && rc == NGHMM_OK; ++l) {
+        if (s >= S) {
+          trailing_data = true;
           break;
         }
-        for (uint64_t k = 0; k < I * 3; k++) row[k] = unread;
-      } else {
-        const size_t n_fields = split_doubles(buf.data(), " \t", t);
-        if (!n_fields || (s == 0 && n_fields < I * n_geno)) {
-          fprintf(stderr, "> Header found! Skipping line...\n");
-          if (s != 0) warn(__FUNCTION__, " header found but not on first line. Is this an error?");
-          continue;
-        }
-        if (n_fields < I * n_geno)
-          fatal(__FUNCTION__, "wrong GENO file format. Less fields than expected!");
-        const double* ptr = t.data() + (n_fields - I * n_geno);  // last I*n_geno columns
-        for (uint64_t i = 0; i < I; i++) {
-          if (P.in_lkl) {
-            for (int k = 0; k < 3; k++) row[i * 3 + k] = ptr[i * 3 + k];
-          } else {
-            const int gg = (int)ptr[i];
-            if (gg > 2)
-              fatal(__FUNCTION__, "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
-            if (as_codes) {
-              gbuf[filled * I + i] = (int8_t)(gg < 0 ? -1 : gg);
-            } else if (gg >= 0) {
-              double* g = row + i * 3;
-              g[0] = g[1] = g[2] = -kINF;  // read_data.cpp:21
-              g[gg] = log(1);
-            } else {
-              double* g = row + i * 3;
-              g[0] = g[1] = g[2] = log((double)1 / 3);
-            }
+        const uint32_t nf = ck->n_fields[l];
+        if (nf == UINT32_MAX) {
+          // (sic) an empty line still consumes a site, as in the reference (read_data.cpp:60-61):
+          // its cells stay "unread", which 2-bit codes cannot express
+          if (as_codes) {
+            rc = NGHMM_ERR_NOT_PACKABLE;
+            break;
           }
+          dbuf.insert(dbuf.end(), I * 3, unread);
+        } else {
+          if (!nf || (s == 0 && nf < I * n_geno)) {
+            fprintf(stderr, "> Header found! Skipping line...\n");
+            if (s != 0) warn("load_geno", " header found but not on first line. Is this an error?");
+            continue;
+          }
+          if (nf < I * n_geno) die("wrong GENO file format. Less fields than expected!");
+          if (ck->bad_geno[l])
+            die("wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+          const uint32_t r = ck->row_of_line[l];
+          if (as_codes)
+            gbuf.insert(gbuf.end(), ck->grows.begin() + (size_t)r * I,
+                        ck->grows.begin() + (size_t)(r + 1) * I);
+          else
+            dbuf.insert(dbuf.end(), ck->rows.begin() + (size_t)r * I * 3,
+                        ck->rows.begin() + (size_t)(r + 1) * I * 3);
         }
+        s++;
+        if (++filled == block) flush();
       }
-      s++;
-      if (++filled == block) flush();
+      if (rc != NGHMM_OK || trailing_data) break;
+      flush();  // a piece's sites go out together: the next piece is being tokenised meanwhile
     }
     flush();
+    shut_down();
+    if (rc == NGHMM_ERR_NOT_PACKABLE) {
+      gzclose(fh);
+      return rc;
+    }
+    check(rc, "read_geno");
+    if (s < S)
+      fatal(__FUNCTION__, "GENO file at premature EOF. Check GENO file and number of sites!");
+    if (trailing_data)
+      fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
+    gzclose(fh);
+    fh = nullptr;
   }
   if (rc == NGHMM_ERR_NOT_PACKABLE) {
-    gzclose(fh);
+    if (fh) gzclose(fh);
     return rc;
   }
   check(rc, "read_geno");
-  char c;
-  gzread(fh, &c, 1);
-  if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
-  gzclose(fh);
+  if (fh) {  // binary input (the text pipeline has done its own end-of-file check)
+    char c;
+    gzread(fh, &c, 1);
+    if (!gzeof(fh)) fatal(__FUNCTION__, "GENO file not at EOF. Check GENO file and number of sites!");
+    gzclose(fh);
+  }
   for (nghmm_t* h : C.hs) {
     rc = nghmm_load_end(h);
     if (rc == NGHMM_ERR_NOT_PACKABLE) return rc;
@@ -527,8 +831,10 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       {"no_pack", no_argument, nullptr, 1003},        {"n_starts", required_argument, nullptr, 1004},
       {"keep_starts", no_argument, nullptr, 1005},    {"n_gpus", required_argument, nullptr, 1006},
       {"devices", required_argument, nullptr, 1007},  {"ld_intended", no_argument, nullptr, 1008},
+      {"parse_kat", no_argument, nullptr, 1009},
       {0, 0, 0, 0}};
   long taus_kat = 0;
+  bool parse_kat = false;
   P.seed = rand() % 1000;  // parse_args.cpp:30 (unseeded rand(): a constant)
   int c;
   while ((c = getopt_long_only(argc, argv, "g:Z:lLn:s:Gf:F:e:i:IAo:X:b:m:M:E:x:V:S:", long_options,
@@ -557,6 +863,7 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
       case 'V': P.verbose = atoi(optarg); break;
       case 'S': P.seed = atoi(optarg); break;
       case 1008: P.ld_intended = true; break;
+      case 1009: parse_kat = true; break;
       case 1000:
         if (!strcmp(optarg, "exact")) P.mode = NGHMM_MODE_EXACT;
         else if (!strcmp(optarg, "fast")) P.mode = NGHMM_MODE_FAST;
@@ -577,6 +884,26 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
         break;
       default: exit(-1);
     }
+  if (parse_kat) {  // the fast tokenizer against strtod's, line by line on standard input
+    std::vector<char> line(kBuffLen);
+    std::vector<double> a, b;
+    unsigned long n_tok = 0, n_line = 0;
+    while (fgets(line.data(), (int)kBuffLen, stdin)) {
+      chomp(line.data());
+      const size_t len = strlen(line.data());
+      std::vector<char> copy(line.data(), line.data() + len + 1);
+      split_doubles(line.data(), " \t", a);
+      split_doubles_fast(copy.data(), copy.data() + len, b);
+      if (a.size() != b.size() || (a.size() && memcmp(a.data(), b.data(), a.size() * sizeof(double)))) {
+        printf("parse_kat MISMATCH on line %lu: %s\n", n_line + 1, line.data());
+        exit(1);
+      }
+      n_tok += a.size();
+      ++n_line;
+    }
+    printf("parse_kat ok %lu tokens %lu lines\n", n_tok, n_line);
+    exit(0);
+  }
   if (taus_kat > 0) {  // known-answer check of the generator: the N-th raw output for --seed
     Taus rng(P.seed);
     uint32_t v = 0;
@@ -766,10 +1093,19 @@ int main(int argc, char** argv) {
             "nghmm_create");
   };
   create_all(packed);
+  const double t_read0 = omp_get_wtime();
   if (load_geno(P, C, packed) == NGHMM_ERR_NOT_PACKABLE) {
     packed = false;
     create_all(false);
     check(load_geno(P, C, false), "read_geno");
+  }
+  if (P.verbose >= 2) {  // (not a line of the reference's)
+    const double dt = omp_get_wtime() - t_read0;
+    if (g_text_bytes)
+      printf("> GENO data on the device in %.2f s: %.1f MB of text inflated, tokenised (%u threads) "
+             "and loaded at %.0f MB/s\n", dt, g_text_bytes / 1e6, g_text_threads, g_text_bytes / 1e6 / dt);
+    else
+      printf("> GENO data on the device in %.2f s\n", dt);
   }
   // one handle: a group of one; several: shard configuration and the site-shard copies
   check(nghmm_group_setup(C.hs.data(), C.n()), "nghmm_group_setup");

@@ -78,6 +78,6 @@ def expected_files(tot_lkl, indF, alpha, freq, ind_lkl, path, marg, geno_post):
     return f_indF, f_ibd, f_geno
 
 
-def run_cli(args, check=True):
+def run_cli(args, check=True, env=None):
     return subprocess.run([BINARY] + [str(a) for a in args], capture_output=True, text=True,
-                          check=check)
+                          check=check, env=env)

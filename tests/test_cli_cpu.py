@@ -75,6 +75,46 @@ def test_taus_known_answer(binary):
         assert cli(seed, n) == v
 
 
+def test_fast_tokenizer_equals_strtod():
+    """The text reader's tokenizer (host/ngsF-HMM.cpp: parse_token -- plain decimals of up to 15
+    significant digits and |exponent| <= 22 as one correctly rounded operation, anything else
+    through strtod) against the strtod-per-token loop of the line-by-line reader: the same
+    tokens kept, the same tokens dropped, the same bits -- on likelihood-file numbers (6 and
+    17 digits, exponents), on the edges of the fast path and on junk."""
+    import random
+    import subprocess
+    rnd = random.Random(5)
+    toks = ["0", "-0", "-0.0", "+3", ".5", "5.", ".", "-", "+", "e5", "1e", "1e+", "1e5", "1E-5", "1e22",
+            "1e23", "1e-22", "1e-23", "123456789012345", "1234567890123456", "0.000000000000001",
+            "0.0000000000000012345678901234", "9007199254740993", "4.9e-324", "1e400", "-1e400",
+            "nan", "NaN", "inf", "-inf", "infinity", "0x1p-3", "0x10", "1_000", "1,5", "12abc", "abc",
+            "1e5x", "1.2.3", "--1", "1e99999", "0.1e-21", "00012.5000", "1e0005", "1e00005",
+            "2.2250738585072014e-308", "1.7976931348623157e308", "0.3333333333333333",
+            "0.33333333333333331", "marker", "chr1_1000", "A", "T", "1e-06", "9.99999e-01"]
+    lines = [" ".join(toks), "\t".join(toks), "  " + " \t ".join(toks[::-1]) + "  \t", ""]
+    for _ in range(400):
+        row = []
+        for _ in range(60):
+            kind = rnd.random()
+            if kind < 0.35:
+                row.append("%.6f" % rnd.random())
+            elif kind < 0.55:
+                row.append(repr(rnd.random() * 10 ** rnd.randint(-30, 30)))
+            elif kind < 0.7:
+                row.append("%.*e" % (rnd.randint(0, 18), rnd.uniform(-1, 1) * 10 ** rnd.randint(-25, 25)))
+            elif kind < 0.8:
+                row.append(str(rnd.randint(-3, 10 ** rnd.randint(1, 18))))
+            elif kind < 0.9:
+                row.append("%d.%0*d" % (rnd.randint(0, 999), rnd.randint(1, 16), rnd.randint(0, 10 ** 9)))
+            else:
+                row.append(rnd.choice(toks))
+        lines.append(rnd.choice([" ", "\t"]).join(row))
+    r = subprocess.run([cli_util.BINARY, "--parse_kat"], input="\n".join(lines) + "\n",
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("parse_kat ok"), r.stdout[-500:]
+    assert int(r.stdout.split()[2]) > 20000
+
+
 def test_host_under_address_sanitizer(pkg, tmp_path):
     """The C++ host built with -fsanitize=address,undefined against tests/stub/nghmm_stub.cpp
     (a stand-in that checks arguments and touches every byte it is handed, computing nothing):
@@ -116,6 +156,9 @@ def test_host_under_address_sanitizer(pkg, tmp_path):
     ]
     for k, extra in enumerate(runs):
         out = str(tmp_path / f"asan_{k}")
+        # the text reader's pipeline in pieces of 8 MB (one piece here), 1000 and 50 bytes
+        # (every line in pieces of its own, carried over from read to read)
+        env["NGHMM_HOST_CHUNK_BYTES"] = ("8388608", "1000", "50")[k % 3]
         r = subprocess.run([exe] + [str(a) for a in base + extra + ["--out", out]], env=env,
                            capture_output=True, text=True)
         assert r.returncode == 0, (extra, r.stderr[-3000:])

@@ -37,6 +37,9 @@ def _oracle_outputs(orc_det, orc_libm, gl, d, freq0, indF0, alpha0, min_iters, m
 
 
 CASES = [
+    # GL_beagle_pieces: the text reader's pipeline in pieces of 777 bytes (every line cut across
+    # reads) and device blocks of 13 sites
+    ("GL_beagle_pieces", ["--lkl"], "beagle_gz", False, False),
     ("GL_text", ["--loglkl"], "glf_gz", False, False),
     ("GL_bin", ["--loglkl"], "glf_bin", False, False),
     ("GL_callgeno", ["--loglkl", "--call_geno"], "glf_gz", True, False),
@@ -53,16 +56,19 @@ def test_cli_outputs_byte_identical(pkg, orc_det, orc_libm, data, name, flags, k
     space = 0
     if called:
         raw = cli_util.raw_called_genotypes(d.geno)
-    elif name == "GL_beagle":
+    elif name.startswith("GL_beagle"):
         raw, space = np.exp(d.gl), 2      # normal-space values of a text file: plain log
     else:
         raw = d.gl
     gl = orc_det.prepare_gl(raw, space, call_geno=call)
     out = os.path.join(tmp, "out_" + name)
+    env = None
+    if name == "GL_beagle_pieces":
+        env = dict(os.environ, NGHMM_HOST_CHUNK_BYTES="777", NGHMM_HOST_BLOCK_SITES="13")
     r = cli_util.run_cli(["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I,
                           "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
                           "--min_iters", 3, "--max_iters", 5, "--mode", "exact", "--seed", 12345,
-                          "--n_threads", 4 if name != "TG" else 1, "--verbose", 1])
+                          "--n_threads", 4 if name != "TG" else 1, "--verbose", 1], env=env)
     n, (f_indF, f_ibd, f_geno) = _oracle_outputs(orc_det, orc_libm, gl, d, 0.1, 0.1, 0.2, 3, 5)
     assert f"Iteration {n}:" in r.stdout and f"Iteration {n + 1}:" not in r.stdout
     assert open(out + ".indF", "rb").read() == f_indF
