@@ -307,6 +307,9 @@ int nghmm_group_mstep_freq(nghmm_t** handles, int n, int freq_est);
  *   estmaf_interp     0: every est_maf pass evaluated over all individuals (default 1)
  *   estmaf_sitemajor  1: est_maf on a site-major copy of the posteriors
  *   estmaf_no_rows    1: small cohorts take a wave per site instead of four sites per wave
+ *   no_xdeg2          1: the alpha probes' exp((alpha_0 - alpha_probe) d) always by the
+ *                     degree-4 polynomial (default: degree 2 where |.| <= 1e-5, the same to
+ *                     half an ulp)
  *   exact_serial      1: exact-mode recursions as one lane per chain (kernels_exact.hip)
  *                     instead of producer-consumer workgroups (kernels_exact_pc.hip): same bits
  *   timing            1: host-side phase times of every M-step on stderr

@@ -226,9 +226,15 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return r;
 }
 
-// exp(x) for |x| <= 1e-3 to < 1e-16 relative (x^5/120 is the first dropped term)
-__device__ __forceinline__ double exp_small4(double x) {
-  return fma(x, fma(x, fma(x, fma(x, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0);
+// exp(x) of the alpha probes, x = (alpha_0 - alpha_probe) d: degree 4 for |x| <= 1e-3 (x^5/120
+// is the first dropped term), degree 2 for |x| <= 1e-5 (x^3/6 <= 1.7e-16: below half an ulp of
+// the result) -- the probes sit eh = (1e-8 (alpha + 1))^0.67 <= 2.3e-5 from alpha
+// (shared/bfgs.cpp:33), so degree 2 serves every data set whose largest finite distance is
+// below ~0.4 Mb; the host picks per group (fd_pattern)
+template <int DEG>
+__device__ __forceinline__ double exp_small(double x) {
+  if constexpr (DEG == 2) return fma(x, fma(x, 0.5, 1.0), 1.0);
+  else return fma(x, fma(x, fma(x, fma(x, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0);
 }
 
 // exp(y) for -2^-6 <= y <= 0 without range reduction (y^8/8! < 1e-19)
@@ -247,9 +253,10 @@ __device__ __forceinline__ double exp_tiny7(double y) {
 // shared/bfgs.cpp:22-43 -- point 0 = x, then NF probes that differ from it in F only,
 // then NA probes that differ in alpha only, by so little that exp(-(alpha +- eh) d) =
 // exp(-alpha d) * exp(-+ eh d) with a tiny second argument.
-constexpr uint32_t FD_FLAG = 0x100, FD_SMALL = 0x200;
-__host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small) {
-  return FD_FLAG | (small ? FD_SMALL : 0u) | ((uint32_t)nf << 2) | (uint32_t)na;
+constexpr uint32_t FD_FLAG = 0x100, FD_SMALL = 0x200, FD_XDEG2 = 0x400;
+__host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small, bool xdeg2 = false) {
+  return FD_FLAG | (small ? FD_SMALL : 0u) | (xdeg2 ? FD_XDEG2 : 0u) | ((uint32_t)nf << 2) |
+         (uint32_t)na;
 }
 
 // Where a forward walk gets its per-site inputs from.  Plain: the materialised emission
@@ -422,7 +429,7 @@ using SrcOf = std::conditional_t<SRC == SRC_PLAIN, SrcPlain,
 // one exp (a degree-7 polynomial when alpha * d_max <= 2^-6: SMALL), the products shared
 // by all points, 12 instructions per F-probe and 20 per alpha-probe; one exponent (point
 // 0's) rescales all points, which are perturbations of each other.
-template <int NF, int NA, bool SMALL, bool EMIT, typename Src>
+template <int NF, int NA, bool SMALL, bool EMIT, int XDEG, typename Src>
 __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc& G,
                                            Op (&R)[MAXP], EmitPtrs emit, uint64_t wave,
                                            int lane) {
@@ -479,7 +486,7 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
         for (int a = 0; a < NA; ++a) {
           // |x| <= 1e-3 on every finite distance (checked by the host); at d = 1e30 the
           // polynomial is huge but finite and multiplies c0 = 0
-          const double m = exp_small4(dal[a] * d);
+          const double m = exp_small<XDEG>(dal[a] * d);
           const double am = fma(-c0, m, 1.0);
           op_step(R[1 + NF + a], ce0 * m, ce1 * m, am * eq0, am * eq1);
         }
@@ -531,7 +538,7 @@ __device__ __forceinline__ void lkl_store_wave_op(Op r, int lane, double* __rest
 // One kernel per loop-body version (each gets its own register allocation); the host
 // sorts the groups of a round by mode and launches every version on its range
 // [g_begin, g_begin + gridDim.x / C).
-template <int NF, int NA, bool SMALL, bool EMIT, int SRC>
+template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
               uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
@@ -551,7 +558,7 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
   const uint64_t pos_base = ((uint64_t)c * T) * 64 + lane;
   using Src = SrcOf<SRC>;
   Src src(arr, wave_base, pos_base);
-  lkl_run_fd<NF, NA, SMALL, EMIT>(src, T, G, R, emit, i * C + c, lane);
+  lkl_run_fd<NF, NA, SMALL, EMIT, XDEG>(src, T, G, R, emit, i * C + c, lane);
   if constexpr (SRC != SRC_PLAIN) {  // fresh walk: the wave's part of sum log e0
     const double bl = wave_sum(src.base.log_value());
     if (lane == 0) arr.base_c[i * C + c] = bl + (arr.gl_scale_c ? arr.gl_scale_c[i * C + c] : 0.0);
@@ -1482,19 +1489,22 @@ __device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
 // to num/den; r_k creeps towards its limit like 1/k, so nearly every site runs into the
 // 100-pass cap.  Both sums are rational functions of r whose poles all lie in Re r <= 0
 // (their denominators sA + r sb + r^2 sC have non-negative coefficients), hence analytic
-// in a disc of radius >= r around any r > 0: on an interval [lo, hi] with hi - lo <=
-// 0.55 lo, a 16-point Chebyshev interpolant reproduces them to rounding error (the
-// Bernstein-ellipse parameter is > 8; 8^-16 = 4e-15 before the constant, ~1e-15
-// measured).  So after a few exact passes the kernel evaluates the sums exactly at the 16
-// Chebyshev nodes of an interval ahead of r_k (as expensive as 16 passes), CHECKS the
-// interpolant against the next exact pass (relative 1e-13, else the site stays on exact
-// passes), and hands the site to k_fast_estmaf_interp, where one LANE per site runs the
+// in a disc of radius >= r around any r > 0.  In the Moebius variable of the build below an
+// interval of ratio hi / lo = 2 has Bernstein-ellipse parameter 11.7: EN = 12 Chebyshev nodes
+// reproduce the sums to 11.7^-12 = 1.5e-13 before the constant (measured against all-exact
+// passes at five full-size shapes: frequencies within 6.7e-13; 14 nodes, the previous
+// default, 8e-15 -- three and a half orders inside the 1e-9 the frequencies are held to,
+// for two evaluations of all individuals fewer per site: est_maf 8.8 -> 8.1 ms at 1000 x 1M).
+// So after a few exact passes the kernel evaluates the sums exactly at the EN Chebyshev nodes
+// of an interval ahead of r_k (as expensive as EN passes), CHECKS the interpolant against the
+// next exact pass (relative EST_TOL = 1e-11, else the site stays on exact passes), and hands
+// the site to k_fast_estmaf_interp, where one LANE per site runs the
 // remaining passes on the barycentric formula: the same recursion, same pass count,
 // same stopping rule, at ~1/60 of the cost per pass.  A pass whose stopping decision
 // would be closer than 1e-9 (relative) to the threshold, or whose r leaves the
 // interval, goes back to exact evaluation (one more build is allowed per site).
 #ifndef NGHMM_EST_EN
-#define NGHMM_EST_EN 14
+#define NGHMM_EST_EN 12
 #endif
 constexpr int EN = NGHMM_EST_EN;        // Chebyshev nodes per interval
 constexpr int EST_SCALARS = 8;          // num, den, pnum, pden, iters, mid, half, tF
@@ -1523,7 +1533,7 @@ constexpr double EST_MULT = NGHMM_EST_MULT;  // ... and about this many current 
 constexpr double EST_FIT = NGHMM_EST_FIT;    // build once k * step <= EST_FIT * EST_DMAX * r ...
 constexpr int EST_KMAX = NGHMM_EST_KMAX;     // ... or after this many passes at the latest
 #ifndef NGHMM_EST_TOL
-#define NGHMM_EST_TOL 1e-13
+#define NGHMM_EST_TOL 1e-11
 #endif
 constexpr double EST_TOL = NGHMM_EST_TOL;  // interpolant vs exact pass, relative
 constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back to exact
@@ -2477,6 +2487,7 @@ const SwitchName kSwitches[] = {
     {"bg_parts", &Switches::bg_parts}, {"no_fuse", &Switches::no_fuse},
     {"eager_emission", &Switches::eager_emission}, {"estmaf_interp", &Switches::estmaf_interp},
     {"estmaf_sitemajor", &Switches::estmaf_sitemajor}, {"estmaf_no_rows", &Switches::estmaf_no_rows},
+    {"no_xdeg2", &Switches::no_xdeg2},
     {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}};
@@ -2705,10 +2716,12 @@ bool fast_refresh_emissions(FastState& fs, hipStream_t st, const double* d_freq,
 
 // Recognise the finite-difference pattern of one objective + gradient evaluation
 // (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
-// close enough for exp_small4 on every finite distance of this data set.
-static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits) {
+// close enough for exp_small<4> (or <2>) on every finite distance of this data set.
+static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits,
+                           bool allow_xdeg2) {
   if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
   int nf = 0, na = 0;
+  double xmax = 0;  // largest |alpha_0 - alpha_probe| d over the data's finite distances
   for (uint32_t p = 1; p < G.np; ++p) {
     if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
       if (na) return 0;  // F probes come first
@@ -2725,6 +2738,7 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool for
       ++nf;
     } else if (G.F[p] == G.F[0] && std::fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
       ++na;
+      xmax = std::fmax(xmax, std::fabs(G.A[p] - G.A[0]) * dmax);
     } else {
       return 0;
     }
@@ -2732,7 +2746,7 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool for
   const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
                   (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
   if (!ok) return 0;
-  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625);
+  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625, allow_xdeg2 && na > 0 && xmax <= 1e-5);
 }
 
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
@@ -2761,7 +2775,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed);
+    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed, !fs.sw.no_xdeg2);
     groups.push_back(G);
   }
   // one kernel per loop-body version: sort the groups by mode (stable, so still in
@@ -2779,8 +2793,8 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
     for (const auto& r : L.mode_ranges) {
       if (r.mode)
-        std::fprintf(stderr, " %uF%uA%s x%u", (r.mode >> 2) & 3, r.mode & 3,
-                     (r.mode & FD_SMALL) ? "s" : "", r.count);
+        std::fprintf(stderr, " %uF%uA%s%s x%u", (r.mode >> 2) & 3, r.mode & 3,
+                     (r.mode & FD_SMALL) ? "s" : "", (r.mode & FD_XDEG2) ? "2" : "", r.count);
       else
         std::fprintf(stderr, " general x%u", r.count);
     }
@@ -2828,32 +2842,36 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
                                    : EmitPtrs{nullptr, nullptr};
   const bool fresh = emit_estep && fs.e_stale;
   if (fs.e_stale && !fresh) return false;  // the caller refreshes the emissions first
+  // (the kernel versions of one round side by side on helper streams, so that they share one
+  // partly filled last wave batch: measured, no gain -- 26.6-26.9 vs 27.0-27.1 ms per iteration
+  // at 1000 x 1M)
   for (const auto& r : L.mode_ranges) {
     const dim3 grid(r.count * fs.C), block(64);
     switch (r.mode) {
-#define FD_LAUNCH(NF, NA, SM, EM, FR)                                                          \
-  hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR>), grid, block, 0, st, arr, fs.T, fs.C, \
-                     dg, r.begin, L.part, emit)
-#define FD_CASE(NF, NA)                                                \
-  case fd_mode(NF, NA, false):                                         \
-    if (fresh && fs.packed) FD_LAUNCH(NF, NA, false, true, SRC_FRESH_PACKED); \
-    else if (fresh) FD_LAUNCH(NF, NA, false, true, SRC_FRESH);         \
-    else if (emit_estep) FD_LAUNCH(NF, NA, false, true, SRC_PLAIN);    \
-    else FD_LAUNCH(NF, NA, false, false, SRC_PLAIN);                   \
-    break;                                                             \
-  case fd_mode(NF, NA, true):                                          \
-    if (fresh && fs.packed) FD_LAUNCH(NF, NA, true, true, SRC_FRESH_PACKED); \
-    else if (fresh) FD_LAUNCH(NF, NA, true, true, SRC_FRESH);          \
-    else if (emit_estep) FD_LAUNCH(NF, NA, true, true, SRC_PLAIN);     \
-    else FD_LAUNCH(NF, NA, true, false, SRC_PLAIN);                    \
+#define FD_LAUNCH(NF, NA, SM, EM, FR, XD)                                                    \
+  hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR, XD>), grid, block, 0, st, arr, fs.T,    \
+                     fs.C, dg, r.begin, L.part, emit)
+#define FD_CASE1(NF, NA, SM, XD)                                              \
+  case fd_mode(NF, NA, SM, XD == 2):                                          \
+    if (fresh && fs.packed) FD_LAUNCH(NF, NA, SM, true, SRC_FRESH_PACKED, XD); \
+    else if (fresh) FD_LAUNCH(NF, NA, SM, true, SRC_FRESH, XD);               \
+    else if (emit_estep) FD_LAUNCH(NF, NA, SM, true, SRC_PLAIN, XD);          \
+    else FD_LAUNCH(NF, NA, SM, false, SRC_PLAIN, XD);                         \
     break;
+#define FD_CASE(NF, NA)       \
+  FD_CASE1(NF, NA, false, 4)  \
+  FD_CASE1(NF, NA, true, 4)   \
+  FD_CASE1(NF, NA, false, 2)  \
+  FD_CASE1(NF, NA, true, 2)
       FD_CASE(2, 2)
       FD_CASE(1, 2)
       FD_CASE(2, 1)
       FD_CASE(1, 1)
-      FD_CASE(2, 0)
       FD_CASE(0, 2)
 #undef FD_CASE
+      FD_CASE1(2, 0, false, 4)  // no alpha probe: nothing for the degree to choose
+      FD_CASE1(2, 0, true, 4)
+#undef FD_CASE1
 #undef FD_LAUNCH
       default:
         if (fresh && fs.packed)

@@ -23,6 +23,7 @@ struct Switches {
   int estmaf_interp = 1;      // 0: every est_maf pass evaluated over all individuals
   int estmaf_sitemajor = 0;   // est_maf on a site-major copy of the posteriors
   int estmaf_no_rows = 0;     // small cohorts: a wave per site instead of four sites per wave
+  int no_xdeg2 = 0;           // alpha probes always by the degree-4 polynomial
   int fast_c = 0;             // waves per individual (0: by cohort size); at creation only
   int exact_serial = 0;       // exact mode: one lane per chain instead of producer-consumer
   int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
@@ -78,6 +79,7 @@ struct FastState {
   };
   LklLane lanes[2];
   int cur_lane = 0;
+
   double dmax_finite = 0;         // largest finite distance of the loaded data
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;

@@ -3,7 +3,7 @@
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only \
         ngsf-hmm_amd/csrc/kernels_fast.hip -o /tmp/kf.s
-  python tools/isa_report.py /tmp/kf.s > profiles/r02_isa_summary.txt
+  python tools/isa_report.py /tmp/kf.s > profiles/r03_isa_summary.txt
 
 For each kernel: registers / scratch / occupancy as the assembler reports them, and every
 basic block of >= 60 instructions with its opcode histogram (the loop bodies)."""
@@ -12,10 +12,10 @@ import sys
 from collections import Counter
 
 KERNELS = {
-    "later objective rounds: k_fast_lkl_fd<2, 2, true, false, SRC_PLAIN> (8 sites per loop body)":
-        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb0ELi0EEE",
-    "fresh forward walk: k_fast_lkl_fd<2, 2, true, true, SRC_FRESH>":
-        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb1ELi1EEE",
+    "later objective rounds: k_fast_lkl_fd<2, 2, true, false, SRC_PLAIN, 2> (8 sites per loop body)":
+        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb0ELi0ELi2EEE",
+    "fresh forward walk: k_fast_lkl_fd<2, 2, true, true, SRC_FRESH, 2>":
+        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb1ELi1ELi2EEE",
     "est_maf: k_fast_estmaf<16, 64, true> (1000 individuals per site: 16 per lane)":
         "_ZN5nghmm12_GLOBAL__N_113k_fast_estmafILi16ELi64ELb1EEE",
     "backward sweep: k_fast_bwd_recompute8 (4 waves = 8 individuals x 32 lane-chunks, LDS staging)":
