@@ -59,54 +59,92 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
-LIMITER_NOTES = {
-    "est_maf": "FP64-VALU-issue bound, not HBM bound: the reference's est_maf makes ~100 passes "
-               "per site; ~21 of them are evaluated over in-register data, the rest on a checked "
-               "Chebyshev interpolant of the per-pass sums (DESIGN.md section 4)",
-    "lkl_batch": "objective rounds of the L-BFGS-B M-step.  Round 1 of an iteration is also the "
-                 "E-step's forward walk and the emission refresh (16 B GL read, 8 B emission ratio "
-                 "+ 4 B checkpoints written per site and individual: HBM-bound, ~5.4 TB/s); later "
-                 "rounds read 8 B per site and still-active individual and are FP64-VALU-issue "
-                 "bound (~90 instructions per site for 5 probe points)",
-    "forward": "E-step after the shared forward walk: boundary vectors + backward sweep with "
-               "block-wise forward recomputation (8 B emission ratio + 4 B checkpoints read, 8 B "
-               "posteriors written)",
+FP64_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 256 CUs x 4 SIMDs, an FP64 (or any
+                                        # VALU) instruction of a 64-wide wave takes 4 cycles;
+                                        # x 64 lanes x 2 flop = the 78.6 TFLOP/s FP64 vector peak
+
+# The kernels of one fast-mode EM iteration, what bounds each and their
+# instruction counts per site from the device assembly (profiles/r03_isa_summary.txt, made by
+# tools/isa_report.py from `hipcc -S` of this build): loop body of 8 sites / 8.
+KERNELS = {
+    "lkl_later_rounds": dict(
+        bound="fp64_valu", fp64_per_site=698 / 8.0, valu_per_site=722 / 8.0,
+        kernel="k_fast_lkl_fd<2,2,true,false,SRC_PLAIN,2>",
+        note="objective rounds 2.. of the L-BFGS-B M-step: 5 probe points share one pass over "
+             "the 8 B emission ratio of every still-active individual; 87 FP64 instructions per "
+             "site, 104 VGPRs, 4 waves per SIMD; the chip runs it at ~1.7 GHz (power limit), "
+             "where this rate is ~85 % of what a register-resident FP64 stream sustains"),
+    "lkl_first_round": dict(
+        bound="fp64_valu", fp64_per_site=855 / 8.0, valu_per_site=1021 / 8.0,
+        kernel="k_fast_lkl_fd<2,2,true,true,SRC_FRESH,2>",
+        note="round 1 = E-step's forward walk = emission refresh: reads the 16 B relative "
+             "likelihoods, writes the 8 B emission ratio and 4 B of checkpoints; VALU-issue "
+             "bound (128 VALU per site: the 5-point walk, the emissions, their ratio, the "
+             "decode of the 16 B cells), 163 VGPRs, 3 waves per SIMD"),
+    "est_maf": dict(
+        bound="fp64_valu", kernel="k_fast_estmaf<16,64,true> + _interp + _resume",
+        note="the reference's ~100 passes per site: 3 evaluated over all individuals, 12 "
+             "Chebyshev nodes of a checked interpolant, the rest on the interpolant; 256 VGPRs, "
+             "2 waves per SIMD, SQ_ACTIVE_INST_VALU 0.44 per wave"),
+    "backward_sweep": dict(
+        bound="hbm", kernel="k_fast_bounds + k_fast_bwd_recompute8",
+        note="boundary vectors + backward sweep with block-wise forward recomputation: 8 B "
+             "emission ratio + 4 B checkpoints read, 8 B posteriors written per site and "
+             "individual; a copy kernel reaches 6.29 TB/s on this chip"),
 }
 
 
-def pmc_traffic(family, args, I, S, C, rounds, ind_rounds, K):
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC
-    passes (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950
-    correction).  Only valid for the workload it was collected on (c3, fast mode); else None.
-    lkl_batch: the pass holds other iterations than the timed ones (more rounds early in a
-    run), so its bytes are re-weighted: measured bytes of a fresh first round x K iterations
-    + measured bytes per individual of a later round x the timed individual-rounds."""
-    if args.workload != "c3" or args.mode != "fast":
-        return None
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    if not os.path.exists(path):
-        return None
-    summ = json.load(open(path))
-    if family != "lkl_batch":
-        f = summ.get("families", {}).get(family)
-        return f["hbm_bytes_per_em_iteration"] if f and f.get("hbm_bytes_per_em_iteration") else None
+def estmaf_instr_per_site(i_tot):
+    """VALU / FP64 wave-instructions est_maf issues per site (profiles/r03_isa_summary.txt:
+    set-up block 283 / 150 for 16 individuals per lane, an exact pass 375 / 295 in three blocks,
+    a node evaluation 165 / 160; 3 exact passes and 12 nodes per site), scaled to the
+    individuals per lane of the cohort."""
+    ni = min(16, -(-i_tot // 64))
+    waves = max(1, -(-i_tot // 1024))
+    sc = ni / 16.0
+    valu = waves * (283 * sc + 3 * (185 * sc + 104 + 86) + 12 * (165 * sc))
+    fp64 = waves * (150 * sc + 3 * (166 * sc + 51 + 78) + 12 * (160 * sc))
+    return valu, fp64
+
+
+def pmc_summary():
+    """The committed rocprofv3 --pmc passes of the default workload (profiles/collect.sh ->
+    profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction), or
+    None.  Collected in the same session and from the same build as profiles/r03_bench_*.json."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def pmc_traffic(summ, I, C):
+    """HBM bytes the PMC passes saw, per unit that does not depend on which iterations a pass
+    happened to hold: a fresh first round per launch (all individuals), a later round per
+    individual in it, est_maf and the backward sweep per EM iteration."""
+    if not summ:
+        return {}
     fresh_b = fresh_n = plain_b = plain_ind = 0.0
     for k, d in summ.items():
-        if not k.startswith(("k_fast_lkl_fd<", "k_fast_lkl_chunks<")) or "hbm_bytes_per_launch" not in d:
+        if not k.startswith("k_fast_lkl_fd<") or "hbm_bytes_per_launch" not in d:
             continue
         n = d["launches_fetch_pass"]
         targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
-        emit, src = targs[-2], targs[-1]      # <..., EMIT, SRC>: SRC 0 = stored emissions
-        if src != "0":                 # a fresh first round (dense or packed source), everyone
+        emit, src = targs[3], targs[4]      # <NF, NA, SMALL, EMIT, SRC, XDEG>: SRC 0 = stored emissions
+        inds = n * d["avg_grid_threads"] / 64.0 / C
+        if src != "0":
             fresh_b += d["hbm_bytes_per_launch"] * n
-            fresh_n += n * (d["avg_grid_threads"] / 64.0 / C) / I
-        elif emit == "false":          # later rounds
+            fresh_n += inds / I
+        elif emit == "false":
             plain_b += d["hbm_bytes_per_launch"] * n
-            plain_ind += n * d["avg_grid_threads"] / 64.0 / C
-    if not fresh_n or not plain_ind or not rounds:
-        return None
-    total = fresh_b / fresh_n * K + plain_b / plain_ind * max(ind_rounds - I * K, 0)
-    return total / rounds
+            plain_ind += inds
+    out = {}
+    if fresh_n:
+        out["lkl_first_round_per_launch"] = fresh_b / fresh_n
+    if plain_ind:
+        out["lkl_later_rounds_per_individual"] = plain_b / plain_ind
+    fam = summ.get("families", {})
+    for key, name in (("est_maf", "est_maf_per_iteration"), ("forward", "backward_sweep_per_iteration")):
+        if fam.get(key, {}).get("hbm_bytes_per_em_iteration"):
+            out[name] = fam[key]["hbm_bytes_per_em_iteration"]
+    return out
 
 
 def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
@@ -161,6 +199,14 @@ def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
         "sample": f"same {n_ind} x {n_sites} sample, {it2} iterations in {dt2:.1f} s, allele-frequency "
                   f"loop threaded over sites as well ({thr2} threads): not the reference's "
                   f"behaviour (its loop is serial, EM.cpp:224), same arithmetic"}
+    # BASELINE.md section 4's full-size CPU numbers (configs[1] in full, a 1000 x 10k slice of
+    # configs[2], one thread, the "improved CPU") take minutes: measured once per round on the
+    # GPU box's host with tools/cpu_baseline.py and committed; this run's sample above is the
+    # live cross-check of the same code on this host
+    committed = os.path.join(ROOT, "profiles", "r03_cpu_baseline.json")
+    if os.path.exists(committed):
+        out["baseline_md_section4"] = dict(json.load(open(committed)),
+                                           source="profiles/r03_cpu_baseline.json (tools/cpu_baseline.py)")
     if full_c2:
         v3, it3, dt3, thr3, _, _ = timed(100, 100_000, 1, 1e9, False)
         out["configs1_full"] = {
@@ -215,6 +261,11 @@ def main():
                     help="N = 1 only: R concurrent EM runs over the same data (multi-start, "
                          "ngsF-HMM.sh: 20 replicates), one host thread and HIP stream each; "
                          "value counts all R runs")
+    ap.add_argument("--emulate_ranks", type=int, default=1,
+                    help="N = 1 only: time the COMPUTE of one rank of a V-rank strong-scaling run "
+                         "of the workload (its individuals for all sites + the frequency step on "
+                         "its S / V sites over all individuals; exchanges are local copies): the "
+                         "line's `predicted` object, not a measurement of V GPUs")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: shard the workload's individuals over the ranks (strong, "
                          "BASELINE configs[3]) or give every rank the full number (weak)")
@@ -279,19 +330,25 @@ def main():
         if I % world or S % world:
             raise SystemExit(f"--scaling strong: {I} individuals / {S} sites do not divide by {world}")
         I //= world           # per rank; the job's total stays wl["n_ind"]
+    V = args.emulate_ranks
+    if V > 1:
+        if world > 1 or I % V or S % V or args.replicas > 1:
+            raise SystemExit("--emulate_ranks V needs --gpus 1 and V dividing individuals and sites")
+        I //= V               # the emulated rank's individuals
     I_tot = I * world
     mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
     call_geno = bool(wl.get("call_geno"))
     if call_geno:
         mode |= pkg.GENO_PACKED
-    if I * S * (29.5 if call_geno else 100.0) > 270e9:
+    if I * S * (24.0 if call_geno else 90.0) > 270e9:   # 21 / 84 B per cell + exchange
         raise SystemExit(f"workload {args.workload}: {I} x {S} per GPU does not fit one MI355X "
                          f"(use more ranks: --gpus 8)")
 
     # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
     # every rank simulates its own individuals on the same sites
     dd = importlib.import_module("ngsf-hmm_amd.distributed")
-    em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world)
+    em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world,
+                      emulate_ranks=V)
     if call_geno:   # a block of sites at a time, called and packed on the way in
         pos, chunks = pkg.simulate.simulate_torch_chunks(
             I, S, device, seed=12345 + rank, pos_seed=None if world == 1 else 777,
@@ -402,45 +459,99 @@ def main():
             "emission": (8.0 * S if fast else (glb + 16.0) * S * I),
             "lkl_first": (glq + 12.0) * S * I,
         }
-        dom = max((k for k in fam if k != "lkl_first"), key=lambda k: fam[k])
-        avg_ms = fam[dom] / max(launches[dom], 1)
-        achieved = algo[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = pmc_traffic(dom, args, I, S, em.hmm.layout()[0], launches["lkl_batch"],
-                              ind_rounds, K)
-        # every kernel family against the HBM roof (the dominant one is repeated above)
-        fam_roof = {}
-        for k in fam:
-            if launches[k] and fam[k] > 0:
-                gbs = algo[k] / (fam[k] / launches[k] * 1e-3) / 1e9
-                fam_roof[k] = {"achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
-                               "avg_launch_ms": fam[k] / launches[k], "launches": launches[k]}
-        # the objective family split into its HBM-bound first round (also forward walk and
-        # emission refresh) and its FP64-issue-bound later rounds; FP64 vector issue peak =
-        # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction (78.6 TFLOP/s FMA)
-        fp64_peak = 256 * 4 * 2.4e9 / 4
-        if fast and launches["lkl_first"] and fam["lkl_batch"] > fam["lkl_first"] > 0:
-            later_ms = fam["lkl_batch"] - fam["lkl_first"]
-            later_ind_rounds = max(ind_rounds - I * launches["lkl_first"], 0)
-            winstr = 89.5 * S * later_ind_rounds / 64.0       # per site
-            fam_roof["lkl_later_rounds"] = {
-                "achieved_GBps": 8.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9,
-                "frac": 8.0 * S * later_ind_rounds / (later_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "ms_per_em_iteration": later_ms / K,
-                "fp64_issue": {"wave_instr_per_s": winstr / (later_ms * 1e-3), "peak": fp64_peak,
-                               "frac": winstr / (later_ms * 1e-3) / fp64_peak,
-                               "instr_per_site": 89.5}}
-            if "est_maf" in fam_roof:
-                # per site: 17 evaluations (2 exact passes, 14 interval nodes, the check) of
-                # 8.06 instructions per individual + ~45, and ~22 per individual to set up
-                i_tot = I_tot
-                ni = min(16, -(-i_tot // 64))
-                waves = max(1, -(-i_tot // 1024))
-                per_site = waves * (17 * (8.06 * ni + 45) + 22 * ni)
-                sites = S / world
-                rate = per_site * sites * launches["est_maf"] / (fam["est_maf"] * 1e-3)
-                fam_roof["est_maf"]["fp64_issue"] = {"wave_instr_per_s": rate, "peak": fp64_peak,
-                                                     "frac": rate / fp64_peak,
-                                                     "instr_per_site": per_site}
+        # ---- every kernel of the iteration against BOTH roofs; `bound` names its limiter ----
+        # times: HIP events on the library's stream around each kernel family (nghmm_kernel_ms)
+        C_waves = em.hmm.layout()[0]
+        pmc = pmc_traffic(pmc_summary() if (args.workload == "c3" and fast and world == 1 and V == 1 and
+                                            not args.n_ind and not args.n_sites) else None,
+                          I, C_waves)
+        rows = {}
+        n_first = launches["lkl_first"]
+        later_ms = fam["lkl_batch"] - fam["lkl_first"]
+        later_ind = max(ind_rounds - I * n_first, 0)
+        later_launches = max(launches["lkl_batch"] - n_first, 0)
+        if fast:
+            if n_first and fam["lkl_first"] > 0:
+                rows["lkl_first_round"] = dict(ms=fam["lkl_first"], launches=n_first,
+                                               bytes=(glq + 12.0) * S * I * n_first, sites_ind=S * I * n_first,
+                                               traffic=pmc.get("lkl_first_round_per_launch"))
+            if later_launches and later_ms > 0:
+                t = pmc.get("lkl_later_rounds_per_individual")
+                rows["lkl_later_rounds"] = dict(ms=later_ms, launches=later_launches,
+                                                bytes=8.0 * S * later_ind, sites_ind=S * later_ind,
+                                                traffic=t * later_ind / later_launches if t else None)
+            if launches["est_maf"] and fam["est_maf"] > 0:
+                t = pmc.get("est_maf_per_iteration")
+                rows["est_maf"] = dict(ms=fam["est_maf"], launches=launches["est_maf"],
+                                       bytes=(glb + 8.0) * (S / (world * V)) * I_tot * V * launches["est_maf"],
+                                       sites=(S / (world * V)) * launches["est_maf"], traffic=t)
+            if launches["forward"] and fam["forward"] > 0:
+                rows["backward_sweep"] = dict(ms=fam["forward"], launches=launches["forward"],
+                                              bytes=20.0 * S * I * launches["forward"],
+                                              traffic=pmc.get("backward_sweep_per_iteration"))
+        roof_all = {}
+        for name, r in rows.items():
+            meta = KERNELS[name]
+            secs = r["ms"] * 1e-3
+            gbs = r["bytes"] / secs / 1e9
+            e = {"bound": meta["bound"], "kernel": meta["kernel"],
+                 "ms_per_em_iteration": r["ms"] / K, "launches": r["launches"],
+                 "avg_launch_ms": r["ms"] / r["launches"],
+                 "hbm": {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
+                         "traffic_bytes_per_launch": r["traffic"]},
+                 "note": meta["note"]}
+            if name == "est_maf":
+                valu, fp64 = estmaf_instr_per_site(I_tot * V)
+                w_valu, w_fp64, per = valu * r["sites"], fp64 * r["sites"], {"valu": valu, "fp64": fp64}
+            elif "valu_per_site" in meta:
+                w_valu = meta["valu_per_site"] * r["sites_ind"] / 64.0
+                w_fp64 = meta["fp64_per_site"] * r["sites_ind"] / 64.0
+                per = {"valu": meta["valu_per_site"], "fp64": meta["fp64_per_site"]}
+            else:
+                w_valu = w_fp64 = None
+            if w_valu:
+                e["fp64_valu"] = {"achieved_wave_instr_per_s": w_fp64 / secs, "peak": FP64_ISSUE_PEAK,
+                                  "frac": w_fp64 / secs / FP64_ISSUE_PEAK,
+                                  "valu_issue_frac": w_valu / secs / FP64_ISSUE_PEAK,
+                                  "instr_per_site": per,
+                                  "source": "profiles/r03_isa_summary.txt (device assembly of this build)"}
+            roof_all[name] = e
+        if not fast:   # exact mode: latency-bound chains, not a roofline candidate
+            for k in ("forward", "backward", "lkl_batch", "est_maf"):
+                if launches[k] and fam[k] > 0:
+                    roof_all[k] = {"bound": "latency", "ms_per_em_iteration": fam[k] / K,
+                                   "launches": launches[k]}
+        # the contract's object: the kernel that takes the most time, against ITS roof
+        dom = max(roof_all, key=lambda k: roof_all[k]["ms_per_em_iteration"]) if roof_all else None
+        if dom and roof_all[dom]["bound"] == "fp64_valu":
+            d = roof_all[dom]
+            roofline = {"bound": "fp64_valu", "kernel": dom, "achieved": d["fp64_valu"]["achieved_wave_instr_per_s"],
+                        "peak": FP64_ISSUE_PEAK, "unit": "FP64 wave-instructions/s",
+                        "frac": d["fp64_valu"]["frac"],
+                        "valu_issue_frac": d["fp64_valu"]["valu_issue_frac"],
+                        "hbm_frac": d["hbm"]["frac"], "hbm_achieved_GBps": d["hbm"]["achieved_GBps"],
+                        "traffic": d["hbm"]["traffic_bytes_per_launch"],
+                        "algorithmic_bytes_per_launch": d["hbm"]["algorithmic_bytes_per_launch"],
+                        "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                        "device_kernel": d["kernel"], "note": d["note"]}
+        elif dom and roof_all[dom]["bound"] == "hbm":
+            d = roof_all[dom]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["hbm"]["achieved_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["hbm"]["frac"],
+                        "traffic": d["hbm"]["traffic_bytes_per_launch"],
+                        "algorithmic_bytes_per_launch": d["hbm"]["algorithmic_bytes_per_launch"],
+                        "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                        "device_kernel": d["kernel"], "note": d["note"]}
+        else:
+            roofline = {"bound": "latency", "kernel": dom, "achieved": None, "peak": None, "unit": None,
+                        "frac": None, "traffic": None,
+                        "note": "exact mode: sequential log-space chains (DESIGN.md section 4)"}
+        if roofline.get("traffic") is not None:
+            roofline["traffic_source"] = ("profiles/r03_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / "
+                                          "WRITE_SIZE passes of this workload and build "
+                                          "(profiles/collect.sh), not measured in this run")
+        fam_roof = roof_all
         out = {
             "metric": "site-ind updates/sec (EM iterations x individuals x sites / s), 1M sites x 1k ind",
             "value": units / dt,
@@ -470,16 +581,17 @@ def main():
                                     f"{I} of {I_tot} individuals per GPU for all sites; allele-"
                                     f"frequency step on {S // world} sites x all individuals per "
                                     f"GPU (all-to-all of posteriors, all-gather of frequencies)")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": launches[dom],
-                         "algorithmic_bytes_per_launch": algo[dom],
-                         "traffic_source": ("committed rocprofv3 --pmc passes of this workload "
-                                            "(profiles/), not measured in this run"
-                                            if traffic is not None else None),
-                         "note": LIMITER_NOTES.get(dom, "")},
+            "roofline": roofline,
             "roofline_all_kernels": fam_roof,
             "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
+            "predicted": (None if V == 1 else {
+                "emulated_rank_of": V,
+                "what": f"compute of ONE rank of a {V}-rank strong-scaling run of this workload on "
+                        f"one GPU ({I} of {I * V} individuals for all sites, est_maf on {S // V} "
+                        f"sites x {I * V} individuals), exchanges replaced by local copies: "
+                        f"`value` and `ms_per_step` of this line are that rank's, NOT a cohort's",
+                "rank_ms_per_iteration": dt / K * 1e3,
+                "whole_job_site_ind_updates_per_s_if_communication_is_hidden": float(I * V) * S * K / dt}),
             "preflight": preflight,
             "collective_bytes_per_iter": (None if world == 1 else dict(
                 em.collective_bytes_per_iter(),

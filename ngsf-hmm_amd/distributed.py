@@ -202,7 +202,16 @@ class ShardedEM:
     """iter_EM across `world` ranks (world == 1: plain single-GPU path)."""
 
     def __init__(self, pkg, n_ind, n_sites, device_index=0, mode=None, rank=0, world=1,
-                 backend=None):
+                 backend=None, emulate_ranks=1):
+        # emulate_ranks = V (world == 1 only): this process does the COMPUTE of rank 0 of a
+        # V-rank run -- its n_ind individuals for all sites, and the frequency step on its
+        # n_sites / V sites over V x n_ind individuals -- with the exchanges replaced by local
+        # copies of the same size (the other ranks' posterior blocks and likelihood columns are
+        # copies of its own; frequencies outside its site range keep their values).  For
+        # predicting a rank's time on a one-GPU box; the results are not a cohort's.
+        self.emulate = int(emulate_ranks) if world == 1 else 1
+        if self.emulate > 1:
+            world = self.emulate
         self.rank, self.world = rank, world
         self.n_ind, self.n_sites = n_ind, n_sites
         self.backend = backend or GpuBackend(pkg, n_ind, n_sites, device_index,
@@ -231,7 +240,13 @@ class ShardedEM:
     def load_device(self, gl, pos):
         """gl: tensor [S][I_local][3]; pos: tensor [S] (on the backend's device)."""
         self.backend.load_device(gl, pos)
-        if self.world > 1:
+        if self.emulate > 1:
+            lo, hi = self.ranges[self.rank]
+            shard = gl[lo:hi].repeat(1, self.world, 1).contiguous()   # [S_own][V I][3]
+            self._sync()
+            self.backend.load_site_shard_device(shard)
+            del shard
+        elif self.world > 1:
             self._exchange_site_shard(gl)
 
     def load_chunks_device(self, pos, chunks, space=0, call_geno=False):
@@ -239,6 +254,8 @@ class ShardedEM:
         ranks the handle must be packed: the site shards are then built from the genotype
         codes (a dense handle's shard needs the whole matrix: use load_device)."""
         self.backend.load_chunks_device(pos, chunks, space=space, call_geno=call_geno)
+        if self.emulate > 1:
+            raise ValueError("emulate_ranks works on likelihood data loaded with load_device")
         if self.world > 1:
             if not getattr(self.backend, "packed", False):
                 raise ValueError("chunked loading on several ranks needs a packed handle")
@@ -277,6 +294,8 @@ class ShardedEM:
 
     # -- one EM iteration ------------------------------------------------------
     def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        if self.emulate > 1:
+            return self._iter_em_emulated(freq_est, indF_fixed, alpha_fixed)
         if self.world == 1:
             st, self.ind_lkl = self.backend.iter_em_local(freq_est, indF_fixed, alpha_fixed)
             return st
@@ -320,6 +339,27 @@ class ShardedEM:
         if self._ev is None:
             self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         return self._ev
+
+    def _iter_em_emulated(self, freq_est, indF_fixed, alpha_fixed):
+        """Rank 0's kernels of a `world`-rank iteration; every exchange a local copy."""
+        def after_estep():
+            if freq_est:
+                self.backend.pack_posteriors(0, self.n_sites, self._send)
+                self._sync()
+                for q in range(self.world):        # "receive" a block from every rank
+                    self._recv[q].copy_(self._send[self.rank])
+        st, self.ind_lkl = self.backend.estep_mstep(indF_fixed, alpha_fixed, after_estep)
+        if freq_est:
+            self._sync()
+            self.backend.mstep_freq_sites(self._recv, self._freq_own)
+            lo, hi = self.ranges[self.rank]
+            if not getattr(self, "_freq_all_filled", False):   # the other ranges keep these values
+                self._freq_all.copy_(self.backend.torch.from_numpy(self.hmm.freq).to(self._freq_all.device))
+                self._freq_all_filled = True
+            self._freq_all[lo:hi] = self._freq_own
+            self._sync()
+            self.backend.set_freq(self._freq_all)
+        return st
 
     def start_posterior_exchange(self):
         import torch.distributed as dist
