@@ -203,9 +203,201 @@ inline size_t split_doubles_fast(char* p, char* e, std::vector<double>& out) {
   return out.size();
 }
 
+// --- block-compressed input (BGZF: what bgzip and ANGSD write -- a series of gzip members of
+// at most 64 KB of data each, every header carrying its member's size in a 'BC' extra field).
+// A plain gzip stream can only be inflated by one thread, about 1 GB/s of text with zlib;
+// BGZF members are independent, so a dispatcher reads the compressed file, cuts it at member
+// boundaries (no inflating needed: sizes are in the headers, uncompressed sizes in the
+// trailers) and hands groups of members to T inflating threads; read() delivers the text in
+// file order.  Every member's CRC-32 and length are checked, as gzread would.
+class BgzfSource {
+ public:
+  // true if the file starts with a BGZF member
+  static bool detect(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    unsigned char h[18];
+    const bool ok = fread(h, 1, 18, f) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 &&
+                    (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    fclose(f);
+    return ok;
+  }
+  BgzfSource(const char* path, unsigned n_threads) : f_(fopen(path, "rb")) {
+    dispatcher_ = std::thread([this] { dispatch(); });
+    for (unsigned t = 0; t < n_threads; ++t) workers_.emplace_back([this] { work(); });
+  }
+  ~BgzfSource() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_job_.notify_all();
+    cv_out_.notify_all();
+    cv_room_.notify_all();
+    dispatcher_.join();
+    for (auto& th : workers_) th.join();
+    if (f_) fclose(f_);
+  }
+  // up to `want` bytes of text in file order; 0 at the end of the file, -1 on a damaged file
+  long read(char* dst, size_t want) {
+    size_t got = 0;
+    while (got < want) {
+      if (!cur_ || cur_pos_ == cur_->out.size()) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cur_.reset();
+        cv_out_.wait(lk, [&] { return stop_ || failed_ || (!order_.empty() && order_.front()->done) ||
+                                      (order_.empty() && dispatched_all_); });
+        if (failed_) return -1;
+        if (stop_ || order_.empty()) break;
+        cur_ = order_.front();
+        order_.pop_front();
+        cur_pos_ = 0;
+        cv_room_.notify_one();
+        if (cur_->bad) return -1;
+      }
+      const size_t n = std::min(want - got, cur_->out.size() - cur_pos_);
+      if (n) memcpy(dst + got, cur_->out.data() + cur_pos_, n);
+      cur_pos_ += n;
+      got += n;
+    }
+    return (long)got;
+  }
+
+ private:
+  struct Job {
+    std::vector<unsigned char> in;                    // whole members, back to back
+    std::vector<uint32_t> off, csize, isize, out_off;  // per member: offset in `in`, sizes
+    std::vector<char> out;
+    bool done = false, bad = false;
+  };
+  void dispatch() {
+    std::vector<unsigned char> buf;
+    size_t have = 0, pos = 0;
+    bool at_eof = !f_;
+    auto job = std::make_shared<Job>();
+    size_t job_out = 0;
+    auto flush = [&]() -> bool {  // false: stopping
+      if (job->off.empty()) return true;
+      job->out.resize(job_out);
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_room_.wait(lk, [&] { return stop_ || order_.size() < kMaxJobs; });
+      if (stop_) return false;
+      todo_.push_back(job);
+      order_.push_back(job);
+      cv_job_.notify_one();
+      job = std::make_shared<Job>();
+      job_out = 0;
+      return true;
+    };
+    for (;;) {
+      if (have - pos < 65536 + 64 && !at_eof) {  // refill: keep a whole member in the buffer
+        buf.erase(buf.begin(), buf.begin() + pos);
+        have -= pos;
+        pos = 0;
+        buf.resize(have + (4u << 20));
+        const size_t got = fread(buf.data() + have, 1, buf.size() - have, f_);
+        if (got < buf.size() - have) at_eof = true;
+        have += got;
+      }
+      if (have - pos == 0) break;
+      const unsigned char* h = buf.data() + pos;
+      bool ok = have - pos >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4);
+      uint32_t bsize = 0, xlen = 0;
+      if (ok) {
+        xlen = h[10] | (h[11] << 8);
+        ok = false;
+        for (uint32_t x = 0; x + 4 <= xlen && 12 + x + 4 <= have - pos;) {  // the 'BC' subfield
+          const unsigned char* sf = h + 12 + x;
+          const uint32_t slen = sf[2] | (sf[3] << 8);
+          if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && 12 + x + 6 <= have - pos) {
+            bsize = (sf[4] | (sf[5] << 8)) + 1u;
+            ok = true;
+            break;
+          }
+          x += 4 + slen;
+        }
+      }
+      if (!ok || bsize < xlen + 20 || bsize > have - pos) {
+        std::lock_guard<std::mutex> lk(mu_);
+        failed_ = true;  // not BGZF all the way, or cut short
+        cv_out_.notify_all();
+        return;
+      }
+      const uint32_t isz = h[bsize - 4] | (h[bsize - 3] << 8) | (h[bsize - 2] << 16) |
+                           ((uint32_t)h[bsize - 1] << 24);
+      job->off.push_back((uint32_t)job->in.size());
+      job->csize.push_back(bsize);
+      job->isize.push_back(isz);
+      job->out_off.push_back((uint32_t)job_out);
+      job->in.insert(job->in.end(), h, h + bsize);
+      job_out += isz;
+      pos += bsize;
+      if (job->off.size() >= kMembersPerJob && !flush()) return;
+    }
+    if (!flush()) return;
+    std::lock_guard<std::mutex> lk(mu_);
+    dispatched_all_ = true;
+    cv_out_.notify_all();
+    cv_job_.notify_all();
+  }
+  void work() {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    inflateInit2(&zs, -15);  // raw deflate: header and trailer are handled here
+    for (;;) {
+      std::shared_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_job_.wait(lk, [&] { return stop_ || !todo_.empty() || dispatched_all_ || failed_; });
+        if (stop_ || failed_ || todo_.empty()) {
+          if (stop_ || failed_ || dispatched_all_) break;
+          continue;
+        }
+        job = todo_.front();
+        todo_.pop_front();
+      }
+      for (size_t m = 0; m < job->off.size() && !job->bad; ++m) {
+        const unsigned char* h = job->in.data() + job->off[m];
+        const uint32_t xlen = h[10] | (h[11] << 8), bsize = job->csize[m];
+        inflateReset(&zs);
+        zs.next_in = (Bytef*)(h + 12 + xlen);
+        zs.avail_in = bsize - xlen - 20;
+        unsigned char spare;  // an empty member (the one that ends the file) has nowhere to write
+        zs.next_out = job->isize[m] ? (Bytef*)(job->out.data() + job->out_off[m]) : &spare;
+        zs.avail_out = job->isize[m] ? job->isize[m] : 1;
+        const int rc = inflate(&zs, Z_FINISH);
+        const uint32_t crc = h[bsize - 8] | (h[bsize - 7] << 8) | (h[bsize - 6] << 16) |
+                             ((uint32_t)h[bsize - 5] << 24);
+        if (rc != Z_STREAM_END || zs.total_out != job->isize[m] ||
+            crc32(crc32(0, nullptr, 0), (const Bytef*)(job->out.data() + job->out_off[m]),
+                  job->isize[m]) != crc)
+          job->bad = true;
+      }
+      job->in.clear();
+      job->in.shrink_to_fit();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        job->done = true;
+      }
+      cv_out_.notify_all();
+    }
+    inflateEnd(&zs);
+  }
+  static constexpr size_t kMembersPerJob = 64, kMaxJobs = 48;
+  FILE* f_;
+  std::mutex mu_;
+  std::condition_variable cv_job_, cv_out_, cv_room_;
+  std::deque<std::shared_ptr<Job>> todo_, order_;
+  bool stop_ = false, failed_ = false, dispatched_all_ = false;
+  std::shared_ptr<Job> cur_;
+  size_t cur_pos_ = 0;
+  std::thread dispatcher_;
+  std::vector<std::thread> workers_;
+};
+
 // what the text reader went through, for the --verbose 2 timing line
 uint64_t g_text_bytes = 0;
-unsigned g_text_threads = 0;
+unsigned g_text_threads = 0, g_inflate_threads = 1;
 
 // One piece of the text input on its way through the reader's pipeline: whole lines as
 // gzgets would hand them out (at most kBuffLen - 1 characters each, shared/gen_func.hpp:17),
@@ -373,6 +565,15 @@ int load_geno(Params& P, Cohort& C, bool packed) {
       }
     };
 
+    // a BGZF file is inflated by several threads, anything else by gzread on this one
+    std::unique_ptr<BgzfSource> bgzf;
+    g_inflate_threads = 1;
+    if (BgzfSource::detect(P.in_geno) && !getenv("NGHMM_HOST_NO_BGZF")) {
+      g_inflate_threads = W >= 8 ? 8 : W;
+      if (const char* e = getenv("NGHMM_HOST_INFLATE_THREADS"))  // measurement
+        g_inflate_threads = (unsigned)std::max(1, std::min(64, atoi(e)));
+      bgzf.reset(new BgzfSource(P.in_geno, g_inflate_threads));
+    }
     std::thread inflater([&] {
       std::vector<char> carry;  // the unfinished last line of the previous piece
       for (;;) {
@@ -383,7 +584,9 @@ int load_geno(Params& P, Cohort& C, bool packed) {
         carry.clear();
         bool at_eof = false;
         while (have < ck->text.size()) {
-          const int got = gzread(fh, ck->text.data() + have, (unsigned)(ck->text.size() - have));
+          const long got = bgzf ? bgzf->read(ck->text.data() + have, ck->text.size() - have)
+                                : (long)gzread(fh, ck->text.data() + have,
+                                               (unsigned)(ck->text.size() - have));
           if (got < 0) {
             std::lock_guard<std::mutex> lk(mu);
             read_error = "cannot read GZip GENO file. Check GENO file and number of sites!";
@@ -1102,8 +1305,9 @@ int main(int argc, char** argv) {
   if (P.verbose >= 2) {  // (not a line of the reference's)
     const double dt = omp_get_wtime() - t_read0;
     if (g_text_bytes)
-      printf("> GENO data on the device in %.2f s: %.1f MB of text inflated, tokenised (%u threads) "
-             "and loaded at %.0f MB/s\n", dt, g_text_bytes / 1e6, g_text_threads, g_text_bytes / 1e6 / dt);
+      printf("> GENO data on the device in %.2f s: %.1f MB of text inflated (%u thread%s), tokenised "
+             "(%u threads) and loaded at %.0f MB/s\n", dt, g_text_bytes / 1e6, g_inflate_threads,
+             g_inflate_threads > 1 ? "s: BGZF" : "", g_text_threads, g_text_bytes / 1e6 / dt);
     else
       printf("> GENO data on the device in %.2f s\n", dt);
   }

@@ -81,3 +81,21 @@ def expected_files(tot_lkl, indF, alpha, freq, ind_lkl, path, marg, geno_post):
 def run_cli(args, check=True, env=None):
     return subprocess.run([BINARY] + [str(a) for a in args], capture_output=True, text=True,
                           check=check, env=env)
+
+
+def write_bgzf(path, data, block=0xff00):
+    """`data` (bytes) as a BGZF file: gzip members of at most `block` bytes of data, each with
+    the 'BC' extra field holding the member's size - 1, and the empty member that ends the file
+    (the SAM specification's section on BGZF; what bgzip and ANGSD write)."""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        for o in list(range(0, len(data), block)) + [None]:
+            piece = b"" if o is None else data[o:o + block]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            z = c.compress(piece) + c.flush()
+            bsize = 18 + len(z) + 8
+            assert bsize <= 65536
+            fh.write(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0]) + b"BC" +
+                     struct.pack("<HH", 2, bsize - 1) + z +
+                     struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))

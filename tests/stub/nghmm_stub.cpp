@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,10 +29,12 @@ struct nghmm_handle {
 };
 
 static thread_local std::string g_err;
-static uint64_t touch(const void* p, size_t n) {
+// position-weighted byte sum: the same data gives the same total however the host cuts it into
+// blocks, a byte in another place does not
+static uint64_t touch(const void* p, size_t n, uint64_t at = 0) {
   const unsigned char* c = static_cast<const unsigned char*>(p);
   uint64_t s = 0;
-  for (size_t k = 0; k < n; ++k) s += c[k];
+  for (size_t k = 0; k < n; ++k) s += c[k] * (at + k + 1) * 0x9e3779b97f4a7c15ull;
   return s;
 }
 
@@ -94,7 +97,7 @@ int nghmm_load_gl_raw_sites(nghmm_t* h, uint64_t s0, uint64_t n, const double* g
   int rc = mark(h, s0, n);
   if (rc) return rc;
   if (!gl || space < 0 || space > 2) return NGHMM_ERR_ARG;
-  h->checksum += touch(gl, n * h->I * 3 * sizeof(double));
+  h->checksum += touch(gl, n * h->I * 3 * sizeof(double), s0 * h->I * 3 * sizeof(double));
   if (h->packed && !call_geno) {  // likelihoods into a packed handle: the host must fall back
     g_err = "not a called genotype (stub)";
     return NGHMM_ERR_NOT_PACKABLE;
@@ -107,7 +110,7 @@ int nghmm_load_geno_sites(nghmm_t* h, uint64_t s0, uint64_t n, const int8_t* gen
   if (!geno) return NGHMM_ERR_ARG;
   for (uint64_t k = 0; k < n * h->I; ++k)
     if (geno[k] < -1 || geno[k] > 2) return NGHMM_ERR_ARG;
-  h->checksum += touch(geno, n * h->I);
+  h->checksum += touch(geno, n * h->I, s0 * h->I);
   return NGHMM_OK;
 }
 int nghmm_load_end(nghmm_t* h) {
@@ -119,6 +122,7 @@ int nghmm_load_end(nghmm_t* h) {
     }
   h->loading = false;
   h->loaded = true;
+  if (getenv("NGHMM_STUB_CHECKSUM")) fprintf(stderr, "stub checksum %016llx\n", (unsigned long long)h->checksum);
   return NGHMM_OK;
 }
 int nghmm_set_params(nghmm_t* h, const double* F, const double* A, const double* f) {

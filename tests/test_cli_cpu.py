@@ -115,21 +115,29 @@ def test_fast_tokenizer_equals_strtod():
     assert int(r.stdout.split()[2]) > 20000
 
 
-def test_host_under_address_sanitizer(pkg, tmp_path):
+@pytest.fixture(scope="module")
+def asan_host(tmp_path_factory):
     """The C++ host built with -fsanitize=address,undefined against tests/stub/nghmm_stub.cpp
-    (a stand-in that checks arguments and touches every byte it is handed, computing nothing):
+    (a stand-in that checks arguments and touches every byte it is handed, computing nothing)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "ngsf-hmm_amd", "csrc", "host", "ngsF-HMM.cpp")
+    stub = os.path.join(root, "tests", "stub", "nghmm_stub.cpp")
+    exe = str(tmp_path_factory.mktemp("asan") / "ngsF-HMM_asan")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=undefined", host, stub, "-o", exe, "-lz", "-lpthread"],
+                   check=True)
+    return exe
+
+
+def test_host_under_address_sanitizer(pkg, tmp_path, asan_host):
+    """Under AddressSanitizer and UBSan:
     block readers for every input type, the column split of --n_gpus, the packed fall-back on
     an empty line, output batching, multi-start threads.  GPU AddressSanitizer is not
     available on this pool; this covers the host side of the boundary."""
     import gzip
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    host = os.path.join(root, "ngsf-hmm_amd", "csrc", "host", "ngsF-HMM.cpp")
-    stub = os.path.join(root, "tests", "stub", "nghmm_stub.cpp")
-    exe = str(tmp_path / "ngsF-HMM_asan")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined",
-                    "-fno-sanitize-recover=undefined", host, stub, "-o", exe, "-lz", "-lpthread"],
-                   check=True)
+    exe = asan_host
     I, S = 6, 522          # divisible by 2 and 3 (--n_gpus), by nothing a block size is
     d = pkg.simulate.simulate(I, S, seed=3, n_chrom=3, missing_rate=0.1)
     p = cli_util.write_inputs(str(tmp_path), d, d.gl)
@@ -164,3 +172,53 @@ def test_host_under_address_sanitizer(pkg, tmp_path):
         assert r.returncode == 0, (extra, r.stderr[-3000:])
         assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
         assert os.path.getsize(out + ".ibd") > 0 and os.path.getsize(out + ".geno") == S * I * 24
+
+
+def test_bgzf_input_is_inflated_in_parallel_to_the_same_bytes(pkg, tmp_path, asan_host):
+    """A BGZF file (bgzip / ANGSD: gzip members of <= 64 KB with their size in the header) goes
+    through several inflating threads; what reaches nghmm_load_* is, byte for byte and site for
+    site, what the one-thread gzread route delivers from the same text (the stub's
+    position-weighted checksum of everything loaded), whatever the block and piece sizes.  A
+    file cut short, one with a damaged block and one whose later members are not BGZF are
+    refused with the reference's message.  Under AddressSanitizer / UBSan."""
+    import gzip
+    import re
+    import subprocess
+    I, S = 7, 1500
+    d = pkg.simulate.simulate(I, S, seed=5, n_chrom=2, missing_rate=0.1)
+    p = cli_util.write_inputs(str(tmp_path), d, d.gl)
+    text = gzip.open(p["beagle_gz"], "rb").read()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", OMP_NUM_THREADS="2",
+               NGHMM_STUB_CHECKSUM="1")
+
+    def run(geno, **more):
+        r = subprocess.run([asan_host, "--geno", geno, "--lkl", "--pos", p["pos_gz"], "--n_ind", str(I),
+                            "--n_sites", str(S), "--freq", "0.1", "--min_iters", "2", "--max_iters", "3",
+                            "--verbose", "2", "--out", str(tmp_path / "o")],
+                           env=dict(env, **more), capture_output=True, text=True)
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        return r
+
+    def checksum(r):
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+        return re.search(r"stub checksum ([0-9a-f]{16})", r.stderr).group(1)
+
+    plain = run(p["beagle_gz"])
+    assert "inflated (1 thread)" in plain.stdout
+    want = checksum(plain)
+    for k, block in enumerate((0xff00, 700, 33)):
+        path = str(tmp_path / f"b{block}.beagle.gz")
+        cli_util.write_bgzf(path, text, block)
+        assert gzip.open(path, "rb").read() == text           # any gzip reader sees one stream
+        r = run(path, NGHMM_HOST_CHUNK_BYTES=("8388608", "1000", "50")[k])
+        assert "BGZF" in r.stdout and checksum(r) == want
+        assert checksum(run(path, NGHMM_HOST_NO_BGZF="1")) == want
+    good = open(str(tmp_path / "b700.beagle.gz"), "rb").read()
+    bad = {"cut": good[: len(good) * 2 // 3],
+           "damaged": good[:5000] + bytes([good[5000] ^ 0x55]) + good[5001:],
+           "mixed": good[:-28] + open(p["beagle_gz"], "rb").read()}
+    for name, blob in bad.items():
+        path = str(tmp_path / f"{name}.beagle.gz")
+        open(path, "wb").write(blob)
+        r = run(path)
+        assert r.returncode != 0 and "cannot read GZip GENO file" in (r.stdout + r.stderr), (name, r.stdout[-500:])

@@ -45,6 +45,8 @@ CASES = [
     ("GL_callgeno", ["--loglkl", "--call_geno"], "glf_gz", True, False),
     ("TG", [], "geno_gz", False, True),
     ("GL_beagle", ["--lkl"], "beagle_gz", False, False),
+    # the same text as a BGZF file (bgzip / ANGSD) in blocks of 500 bytes: parallel inflate
+    ("GL_beagle_bgzf", ["--lkl"], "beagle_gz", False, False),
 ]
 
 
@@ -65,12 +67,19 @@ def test_cli_outputs_byte_identical(pkg, orc_det, orc_libm, data, name, flags, k
     env = None
     if name == "GL_beagle_pieces":
         env = dict(os.environ, NGHMM_HOST_CHUNK_BYTES="777", NGHMM_HOST_BLOCK_SITES="13")
-    r = cli_util.run_cli(["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I,
+    geno_path = paths[key]
+    if name == "GL_beagle_bgzf":
+        import gzip
+        geno_path = os.path.join(tmp, "bgzf.beagle.gz")
+        cli_util.write_bgzf(geno_path, gzip.open(paths[key], "rb").read(), 500)
+    r = cli_util.run_cli(["--geno", geno_path, *flags, "--pos", paths["pos_gz"], "--n_ind", I,
                           "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
                           "--min_iters", 3, "--max_iters", 5, "--mode", "exact", "--seed", 12345,
-                          "--n_threads", 4 if name != "TG" else 1, "--verbose", 1], env=env)
+                          "--n_threads", 4 if name != "TG" else 1,
+                          "--verbose", 2 if name == "GL_beagle_bgzf" else 1], env=env)
     n, (f_indF, f_ibd, f_geno) = _oracle_outputs(orc_det, orc_libm, gl, d, 0.1, 0.1, 0.2, 3, 5)
     assert f"Iteration {n}:" in r.stdout and f"Iteration {n + 1}:" not in r.stdout
+    assert (": BGZF)" in r.stdout) == (name == "GL_beagle_bgzf")
     assert open(out + ".indF", "rb").read() == f_indF
     assert open(out + ".ibd", "rb").read() == f_ibd
     assert open(out + ".geno", "rb").read() == f_geno

@@ -1,10 +1,10 @@
 // make_beagle -- a synthetic BEAGLE-style genotype-likelihood file at BASELINE configs[2]'s
 // encoding (header + 3 id columns + 3 x I normal-space likelihoods per line, gzip), and its
 // positions file, fast enough for 10^9 cells: lines are formatted and deflated in parallel,
-// each block of lines a gzip member of its own (a multi-member file is what bgzip / ANGSD write
-// too; any gzip reader sees one stream).
+// in BGZF blocks (what bgzip / ANGSD write; any gzip reader sees one stream) or, with "members",
+// as one plain gzip member per 256 lines.
 //
-//   make_beagle N_IND N_SITES OUT_PREFIX [SEED]      ->  OUT_PREFIX.beagle.gz, OUT_PREFIX.pos.gz
+//   make_beagle N_IND N_SITES OUT_PREFIX [SEED [bgzf|members]]  ->  OUT_PREFIX.beagle.gz, OUT_PREFIX.pos.gz
 //
 // Data model: scripts/ngsF-HMMsim.R's, simplified (site frequency 0.2, no IBD tracts: this file
 // exercises the READER; the EM kernels are measured on bench.py's data): genotypes from HWE,
@@ -47,7 +47,44 @@ static inline char* put6(char* p, double v) {  // "%.6f" of v in [0, 1]
   return p;
 }
 
+static bool g_bgzf = true;
+
+// BGZF (the SAM specification's block format, what bgzip and ANGSD write): gzip members of at
+// most 64 KB, each with an extra field 'B','C' holding the member's size - 1
+static void bgzf_block(const char* text, size_t n, std::vector<unsigned char>& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);  // raw deflate
+  const size_t at = out.size(), bound = deflateBound(&zs, n);
+  out.resize(at + 18 + bound + 8);
+  zs.next_in = (Bytef*)text;
+  zs.avail_in = (uInt)n;
+  zs.next_out = out.data() + at + 18;
+  zs.avail_out = (uInt)bound;
+  deflate(&zs, Z_FINISH);
+  const size_t c = zs.total_out, bsize = 18 + c + 8;
+  deflateEnd(&zs);
+  if (bsize > 65536) {
+    fprintf(stderr, "BGZF block too large\n");
+    exit(1);
+  }
+  const unsigned char head[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                                  (unsigned char)((bsize - 1) & 0xff), (unsigned char)((bsize - 1) >> 8)};
+  memcpy(out.data() + at, head, 18);
+  const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef*)text, (uInt)n), isz = (uint32_t)n;
+  unsigned char* t = out.data() + at + 18 + c;
+  for (int k = 0; k < 4; k++) t[k] = (crc >> (8 * k)) & 0xff, t[4 + k] = (isz >> (8 * k)) & 0xff;
+  out.resize(at + bsize);
+}
+
 static std::vector<unsigned char> gz_member(const std::vector<char>& text) {
+  if (g_bgzf) {
+    std::vector<unsigned char> out;
+    const size_t piece = 0xff00;  // bgzip's block size: the deflated block always fits 64 KB
+    for (size_t o = 0; o < text.size(); o += piece)
+      bgzf_block(text.data() + o, std::min(piece, text.size() - o), out);
+    return out;
+  }
   z_stream zs;
   memset(&zs, 0, sizeof zs);
   deflateInit2(&zs, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);  // level 1, gzip wrapper
@@ -64,13 +101,14 @@ static std::vector<unsigned char> gz_member(const std::vector<char>& text) {
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    fprintf(stderr, "usage: make_beagle N_IND N_SITES OUT_PREFIX [SEED]\n");
+    fprintf(stderr, "usage: make_beagle N_IND N_SITES OUT_PREFIX [SEED [bgzf|members]]\n");
     return 2;
   }
   const uint64_t I = strtoull(argv[1], nullptr, 10), S = strtoull(argv[2], nullptr, 10);
   const std::string prefix = argv[3];
   const uint64_t seed = argc > 4 ? strtoull(argv[4], nullptr, 10) : 1;
-  const uint64_t per = 256;  // sites per gzip member
+  g_bgzf = !(argc > 5 && !strcmp(argv[5], "members"));  // members: plain gzip members of 256 lines
+  const uint64_t per = 256;  // sites formatted and deflated per task
   const uint64_t n_blocks = (S + per - 1) / per;
   FILE* fo = fopen((prefix + ".beagle.gz").c_str(), "wb");
   if (!fo) return 1;
@@ -135,6 +173,11 @@ int main(int argc, char** argv) {
       fwrite(z[k].data(), 1, z[k].size(), fo);
       text_bytes += tb[k];
     }
+  }
+  if (g_bgzf) {  // the empty block that ends a BGZF file
+    std::vector<unsigned char> eof;
+    bgzf_block("", 0, eof);
+    fwrite(eof.data(), 1, eof.size(), fo);
   }
   fclose(fo);
   gzFile fp = gzopen((prefix + ".pos.gz").c_str(), "wb1");
