@@ -266,6 +266,12 @@ def main():
                          "of the workload (its individuals for all sites + the frequency step on "
                          "its S / V sites over all individuals; exchanges are local copies): the "
                          "line's `predicted` object, not a measurement of V GPUs")
+    ap.add_argument("--shard", default=None, choices=["sites", "individuals"],
+                    help="N > 1 (or --emulate_ranks): what a rank holds -- a contiguous range of "
+                         "SITES for all individuals (fast mode's default: the ranges exchange six "
+                         "doubles per individual and objective point, the frequency step nothing) "
+                         "or a range of INDIVIDUALS for all sites (exact mode's only choice; every "
+                         "posterior crosses the links once per iteration)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: shard the workload's individuals over the ranks (strong, "
                          "BASELINE configs[3]) or give every rank the full number (weak)")
@@ -326,16 +332,31 @@ def main():
         wl["n_sites"] = args.n_sites
     I, S = wl["n_ind"], wl["n_sites"]
     strong = args.scaling == "strong"
-    if world > 1 and strong:
-        if I % world or S % world:
-            raise SystemExit(f"--scaling strong: {I} individuals / {S} sites do not divide by {world}")
-        I //= world           # per rank; the job's total stays wl["n_ind"]
     V = args.emulate_ranks
-    if V > 1:
-        if world > 1 or I % V or S % V or args.replicas > 1:
-            raise SystemExit("--emulate_ranks V needs --gpus 1 and V dividing individuals and sites")
-        I //= V               # the emulated rank's individuals
-    I_tot = I * world
+    by_sites = (args.shard or ("sites" if args.mode == "fast" else "individuals")) == "sites" and \
+        (world > 1 or V > 1)
+    if by_sites and args.mode != "fast":
+        raise SystemExit("--shard sites is a fast-mode layout")
+    if V > 1 and (world > 1 or args.replicas > 1):
+        raise SystemExit("--emulate_ranks V needs --gpus 1 and no replicas")
+    S_job = S                 # the job's sites; S becomes what one rank's handle holds
+    if by_sites:
+        if not strong:
+            S_job = S * world          # weak: every rank the workload's sites, the chain N times as long
+        dd = importlib.import_module("ngsf-hmm_amd.distributed")
+        lo, hi = dd.site_ranges_ragged(S_job, world * V)[rank]
+        S = hi - lo
+        I_tot = I
+    else:
+        if world > 1 and strong:
+            if I % world or S % world:
+                raise SystemExit(f"--scaling strong: {I} individuals / {S} sites do not divide by {world}")
+            I //= world           # per rank; the job's total stays wl["n_ind"]
+        if V > 1:
+            if I % V or S % V:
+                raise SystemExit("--emulate_ranks V needs V dividing individuals and sites")
+            I //= V               # the emulated rank's individuals
+        I_tot = I * world
     mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
     call_geno = bool(wl.get("call_geno"))
     if call_geno:
@@ -345,19 +366,33 @@ def main():
                          f"(use more ranks: --gpus 8)")
 
     # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
-    # every rank simulates its own individuals on the same sites
     dd = importlib.import_module("ngsf-hmm_amd.distributed")
-    em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world,
-                      emulate_ranks=V)
+    if by_sites:
+        # every rank simulates all individuals on its own site range (a chain of independently
+        # simulated segments; the distance in front of a later range's first site is an
+        # ordinary one, not a chromosome start)
+        em = dd.SiteShardedEM(pkg, I, S_job, device_index=local_rank, mode=mode, rank=rank,
+                              world=world, emulate_ranks=V)
+        assert em.S_own == S
+    else:
+        # every rank simulates its own individuals on the same sites
+        em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world,
+                          emulate_ranks=V)
+    pos_seed = None if (world == 1 or by_sites) else 777
+    n_chrom = wl.get("n_chrom", 1)
+    if by_sites:
+        n_chrom = max(1, n_chrom // (world * V))
     if call_geno:   # a block of sites at a time, called and packed on the way in
         pos, chunks = pkg.simulate.simulate_torch_chunks(
-            I, S, device, seed=12345 + rank, pos_seed=None if world == 1 else 777,
-            n_chrom=wl.get("n_chrom", 1), chunk_sites=50_000)
+            I, S, device, seed=12345 + rank, pos_seed=pos_seed, n_chrom=n_chrom, chunk_sites=50_000)
+        if by_sites and rank > 0:
+            pos[0] = 0.1
         em.load_chunks_device(pos, chunks, space=0, call_geno=True)
     else:
-        gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank,
-                                              pos_seed=None if world == 1 else 777,
-                                              n_chrom=wl.get("n_chrom", 1))
+        gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank, pos_seed=pos_seed,
+                                              n_chrom=n_chrom)
+        if by_sites and rank > 0:
+            pos[0] = 0.1
         torch.cuda.synchronize()
         em.load_device(gl, pos)
         del gl
@@ -428,20 +463,30 @@ def main():
         # (HIP events on the library's stream), the exchange (duration and the part of it the
         # host actually waited for), the frequency step on the own site range
         K_ = max(args.steps, 1)
-        mine = {"rank": rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
-                "exchange_ms_per_iter": {
-                    "all_to_all": em.timing["a2a_ms"] / K_,
-                    "all_to_all_exposed": em.timing["a2a_exposed_ms"] / K_,
-                    "all_to_all_hidden": max(em.timing["a2a_ms"] - em.timing["a2a_exposed_ms"], 0.0) / K_,
-                    "all_gather": em.timing["allgather_ms"] / K_,
-                    "freq_step_call": em.timing["freq_step_ms"] / K_},
-                "rounds_per_iter": rounds / K_}
+        if by_sites:
+            ex = em.exchange
+            mine = {"rank": rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
+                    "exchange_ms_per_iter": {"all_gather_host_calls": ex.host_ms / K_},
+                    "all_gathers_per_iter": ex.calls / K_, "all_gather_bytes_per_iter": ex.bytes / K_,
+                    "rounds_per_iter": rounds / K_}
+        else:
+            mine = {"rank": rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
+                    "exchange_ms_per_iter": {
+                        "all_to_all": em.timing["a2a_ms"] / K_,
+                        "all_to_all_exposed": em.timing["a2a_exposed_ms"] / K_,
+                        "all_to_all_hidden": max(em.timing["a2a_ms"] - em.timing["a2a_exposed_ms"], 0.0) / K_,
+                        "all_gather": em.timing["allgather_ms"] / K_,
+                        "freq_step_call": em.timing["freq_step_ms"] / K_},
+                    "rounds_per_iter": rounds / K_}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         K = max(args.steps, 1)
-        units = float(I_tot) * S * K * args.replicas
+        # site shards: all individuals x the job's sites (an emulated rank: x its own range)
+        units = float(I_tot) * (S_job if by_sites and V == 1 else S) * K * args.replicas
+        est_sites = S if by_sites else S / (world * V)       # what one rank's est_maf covers
+        est_inds = I if by_sites else I_tot * V
         # dominant kernel family by measured time, and its algorithmic traffic per launch
         # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
         # fast mode: the first objective round of an iteration (all I individuals) reads the
@@ -453,7 +498,7 @@ def main():
         algo = {
             "lkl_batch": (((glq + 12.0) * S * I * K + 8.0 * S * max(ind_rounds - I * K, 0)) if fast
                           else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
-            "est_maf": (glb + 8.0) * (S / world) * I_tot,   # S/N own sites x all individuals per rank
+            "est_maf": (glb + 8.0) * est_sites * est_inds,   # own sites x all individuals per rank
             "forward": (20.0 if fast else 40.0) * S * I,
             "backward": 48.0 * S * I,
             "emission": (8.0 * S if fast else (glb + 16.0) * S * I),
@@ -483,8 +528,8 @@ def main():
             if launches["est_maf"] and fam["est_maf"] > 0:
                 t = pmc.get("est_maf_per_iteration")
                 rows["est_maf"] = dict(ms=fam["est_maf"], launches=launches["est_maf"],
-                                       bytes=(glb + 8.0) * (S / (world * V)) * I_tot * V * launches["est_maf"],
-                                       sites=(S / (world * V)) * launches["est_maf"], traffic=t)
+                                       bytes=(glb + 8.0) * est_sites * est_inds * launches["est_maf"],
+                                       sites=est_sites * launches["est_maf"], traffic=t)
             if launches["forward"] and fam["forward"] > 0:
                 rows["backward_sweep"] = dict(ms=fam["forward"], launches=launches["forward"],
                                               bytes=20.0 * S * I * launches["forward"],
@@ -502,7 +547,7 @@ def main():
                          "traffic_bytes_per_launch": r["traffic"]},
                  "note": meta["note"]}
             if name == "est_maf":
-                valu, fp64 = estmaf_instr_per_site(I_tot * V)
+                valu, fp64 = estmaf_instr_per_site(est_inds)
                 w_valu, w_fp64, per = valu * r["sites"], fp64 * r["sites"], {"valu": valu, "fp64": fp64}
             elif "valu_per_site" in meta:
                 w_valu = meta["valu_per_site"] * r["sites_ind"] / 64.0
@@ -576,9 +621,14 @@ def main():
             "config": {"workload": wl["name"] + (f", {args.replicas} concurrent multi-start "
                                                  f"replicas" if args.replicas > 1 else ""),
                        "n_ind_total": I_tot, "n_ind_per_gpu": I,
-                       "n_sites": S, "mode": args.mode, "freq_est": 1,
+                       "n_sites": S_job if by_sites else S, "n_sites_per_gpu": S,
+                       "mode": args.mode, "freq_est": 1,
                        "sharding": (None if world == 1 else
-                                    f"{I} of {I_tot} individuals per GPU for all sites; allele-"
+                                    (f"sites: {S} of {S_job} sites per GPU for all {I} individuals; "
+                                     f"the ranges exchange six doubles per individual and E-step "
+                                     f"and per objective point and round (one small all-gather "
+                                     f"each), the allele-frequency step nothing") if by_sites else
+                                    f"individuals: {I} of {I_tot} individuals per GPU for all sites; allele-"
                                     f"frequency step on {S // world} sites x all individuals per "
                                     f"GPU (all-to-all of posteriors, all-gather of frequencies)")},
             "roofline": roofline,
@@ -586,16 +636,28 @@ def main():
             "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
             "predicted": (None if V == 1 else {
                 "emulated_rank_of": V,
-                "what": f"compute of ONE rank of a {V}-rank strong-scaling run of this workload on "
+                "shard": "sites" if by_sites else "individuals",
+                "what": (f"compute of ONE rank of a {V}-rank strong-scaling run of this workload on "
+                         f"one GPU (all {I} individuals for {S} of {S_job} sites; every all-gather "
+                         f"replaced by {V} local copies of the same size on the handle's stream: "
+                         f"{em.exchange.calls / K:.1f} per iteration, "
+                         f"{em.exchange.bytes / K / 1e3:.0f} kB per iteration from each rank): "
+                         f"`value` and `ms_per_step` "
+                         f"of this line are that rank's, NOT a cohort's") if by_sites else
+                        f"compute of ONE rank of a {V}-rank strong-scaling run of this workload on "
                         f"one GPU ({I} of {I * V} individuals for all sites, est_maf on {S // V} "
                         f"sites x {I * V} individuals), exchanges replaced by local copies: "
                         f"`value` and `ms_per_step` of this line are that rank's, NOT a cohort's",
                 "rank_ms_per_iteration": dt / K * 1e3,
-                "whole_job_site_ind_updates_per_s_if_communication_is_hidden": float(I * V) * S * K / dt}),
+                "whole_job_site_ind_updates_per_s_if_communication_is_hidden":
+                    float(I) * S_job * K / dt if by_sites else float(I * V) * S * K / dt}),
             "preflight": preflight,
             "collective_bytes_per_iter": (None if world == 1 else dict(
                 em.collective_bytes_per_iter(),
-                note="bytes leaving each GPU per EM iteration: posterior slices to the other "
+                note=("bytes leaving each GPU per EM iteration: its part of every all-gather (six "
+                      "doubles per individual and E-step / per objective point and round) to the "
+                      "other ranks") if by_sites else
+                     "bytes leaving each GPU per EM iteration: posterior slices to the other "
                      "ranks' site ranges (all-to-all, issued right after the E-step, under the "
                      "remaining objective rounds) and the own frequencies (all-gather)")),
             "exchange_ms": (None if world == 1 else {

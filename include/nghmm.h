@@ -294,6 +294,46 @@ int nghmm_group_iter_em(nghmm_t** handles, int n, int freq_est, int indF_fixed, 
  * handles hold: all zero before the first E-step, which is `--freq e` */
 int nghmm_group_mstep_freq(nghmm_t** handles, int n, int freq_est);
 
+/* ---- multi-GPU, fast mode: shard the SITES instead ----
+ * (what bench.py --gpus N and ngsf-hmm_amd/distributed.py use by default.)  A handle holds ALL
+ * individuals for a contiguous range of sites -- created and loaded like a data set of its
+ * own, with the true distance in front of its first site (+inf only at a chromosome start) --
+ * and the ranges follow each other in rank order.  A run of sites is a product of 2x2
+ * operators, so what the ranges owe each other is six doubles per individual and E-step, and
+ * per objective point and round: forward / backward vectors, log-likelihoods and objective
+ * values are then those of the whole chain, and every handle computes the same values and
+ * takes the same L-BFGS-B steps for all individuals (shared/HMM.cpp:6-60 and EM.cpp:423-464
+ * over all sites).  The allele-frequency step (EM.cpp:224-247) has every individual of a
+ * handle's sites at hand: no posterior ever leaves the GPU (the individual shards above move
+ * 8 bytes per site and individual per iteration, 8 GB at 1000 x 1M, over one xGMI link per GPU
+ * pair).  Not for NGHMM_MODE_EXACT: its log-space recursion is one chain of roundings over all
+ * sites.
+ *
+ * nghmm_site_shard_setup: send_dev / recv_dev are the caller's device buffers of
+ * nghmm_site_shard_bytes(h) and world times that many bytes; `allgather(user, n)` must make
+ * recv_dev = [rank][n bytes] of every handle's first n bytes of send_dev, ORDERED ON THE
+ * HANDLE'S STREAM (nghmm_stream): the library has enqueued the writes of send_dev there before
+ * the call and enqueues the reads of recv_dev after it; the function may block (a host-staged
+ * exchange) or only enqueue (an RCCL all-gather on that stream).  It is called from inside
+ * nghmm_estep / _lkl_batch / _mstep_indf / _estep_mstep / _iter_em, by every handle of the
+ * chain the same number of times with the same n.  Non-zero return = failure (NGHMM_ERR_HIP).
+ * world == 1 detaches.  Everything else (est_maf, emissions, posteriors, parameters, output
+ * formatting) works on the handle's own sites as on any handle; nghmm_get_params' indF / alpha
+ * are the cohort's and equal on all handles.
+ *
+ * Viterbi (shared/HMM.cpp:98-125) over the chain: nghmm_viterbi_shard_forward in rank order
+ * (scores_in = NULL on the first handle, else the scores_out [I][2] of the handle before), then
+ * nghmm_viterbi_shard_back in reverse order (state_after = NULL on the last handle, else the
+ * state_before [I] of the handle after); path = [I][n_sites of the handle].  The same
+ * operations in the same order per individual as nghmm_viterbi on one handle over all sites. */
+typedef int (*nghmm_allgather_fn)(void* user, uint64_t n_bytes);
+uint64_t nghmm_site_shard_bytes(nghmm_t* h);
+int nghmm_site_shard_setup(nghmm_t* h, int rank, int world, void* send_dev, void* recv_dev,
+                           uint64_t bytes_per_rank, nghmm_allgather_fn allgather, void* user);
+int nghmm_viterbi_shard_forward(nghmm_t* h, const double* scores_in, double* scores_out);
+int nghmm_viterbi_shard_back(nghmm_t* h, const uint8_t* state_after, uint8_t* state_before,
+                             uint8_t* path);
+
 /* Measurement and debugging switches of a handle.  None changes a result beyond rounding (the
  * kernels, their order on the stream or what is printed; DESIGN.md section 7 says what each is
  * for).  A handle reads them from the environment ONCE, in nghmm_create -- NGHMM_<NAME> with

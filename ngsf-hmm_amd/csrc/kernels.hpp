@@ -96,6 +96,15 @@ void launch_emission_ld_exact(hipStream_t st, const GlView& gl, const double* fr
 // Viterbi (shared/HMM.cpp:98-125): bp [viterbi_blocked_bytes + I] scratch bytes, path_sites
 // [viterbi_blocked_bytes] bytes blocked [site/16][I][16] (launch_unblock_path gives [I][S]),
 // scratch [chunk_sites*I*4 + I*2] doubles (chunk_sites from viterbi_chunk_sites)
+// the two halves of launch_viterbi_exact, for a handle whose sites continue another's (a site
+// shard): chain_start false = scratch's state doubles hold the scores the range before ended
+// with; the I last-state bytes behind bp may be overwritten between the halves; state_before
+// receives the state at the site in front of the handle's first
+void launch_viterbi_fwd_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                             uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
+                             double* scratch, uint64_t chunk_sites, bool chain_start);
+void launch_viterbi_back_exact(hipStream_t st, uint8_t* bp, uint64_t S, uint64_t I,
+                               uint8_t* path_sites, uint8_t* state_before);
 void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                           uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
                           uint8_t* path_sites, double* scratch, uint64_t chunk_sites);

@@ -302,11 +302,13 @@ __global__ void __launch_bounds__(64)
 k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__ tl, uint64_t s0,
                     uint64_t n_s, uint64_t S, uint64_t I, const double* __restrict__ indF,
                     double* __restrict__ state, uint8_t* __restrict__ bp,
-                    uint8_t* __restrict__ last_state) {
+                    uint8_t* __restrict__ last_state, int chain_start) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I) return;
   double v0, v1;
-  if (s0 == 0) {
+  // chain_start == 0: the sites continue another handle's (a site shard): `state` holds the
+  // scores it ended with
+  if (s0 == 0 && chain_start) {
     const double f = indF[i];
     v0 = det_log(1 - f);  // HMM.cpp:101-102
     v1 = det_log(f);
@@ -389,7 +391,7 @@ k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__
 // sites per load/store; only the 1-bit select chain is sequential.
 __global__ void __launch_bounds__(64)
 k_viterbi_back(const uint8_t* __restrict__ bp, const uint8_t* __restrict__ last_state, uint64_t S,
-               uint64_t I, uint8_t* __restrict__ path16) {
+               uint64_t I, uint8_t* __restrict__ path16, uint8_t* __restrict__ state_before) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I || S == 0) return;
   int st = last_state[i];
@@ -413,6 +415,8 @@ k_viterbi_back(const uint8_t* __restrict__ bp, const uint8_t* __restrict__ last_
     *reinterpret_cast<uint4*>(path16 + (blk * I + i) * 16) = uint4{o[0], o[1], o[2], o[3]};
     cur = nxt;
   }
+  // path[0] of the reference; for a site shard the state at the last site of the range before
+  if (state_before) state_before[i] = (uint8_t)st;
 }
 
 // blocked [site/16][individual][16] -> [individual][site]
@@ -729,9 +733,9 @@ void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* m
                      marg_sites, S_own, I_tot, freq_out, passes_out);
 }
 
-void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
-                          uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites) {
+void launch_viterbi_fwd_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                             uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
+                             double* scratch, uint64_t chunk_sites, bool chain_start) {
   if (I == 0 || S == 0) return;
   // bp holds ceil(S/16)*16*I back-pointer bytes (blocked) followed by I last-state
   // bytes; scratch holds chunk_sites*I*4 transition logs followed by I*2 state doubles
@@ -745,10 +749,23 @@ void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos
     hipLaunchKernelGGL(k_trans_log_exact, dim3((unsigned)blocks), dim3(256), 0, st, pos, indF,
                        alpha, s0, n_s, I, tl);
     hipLaunchKernelGGL(k_viterbi_fwd_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob,
-                       tl, s0, n_s, S, I, indF, state, bp, last_state);
+                       tl, s0, n_s, S, I, indF, state, bp, last_state, chain_start ? 1 : 0);
   }
+}
+
+void launch_viterbi_back_exact(hipStream_t st, uint8_t* bp, uint64_t S, uint64_t I,
+                               uint8_t* path_sites, uint8_t* state_before) {
+  if (I == 0 || S == 0) return;
+  uint8_t* last_state = bp + ((S + 15) / 16) * 16 * I;
   hipLaunchKernelGGL(k_viterbi_back, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, bp,
-                     last_state, S, I, path_sites);
+                     last_state, S, I, path_sites, state_before);
+}
+
+void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
+                          uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
+                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites) {
+  launch_viterbi_fwd_exact(st, eprob, pos, S, I, indF, alpha, bp, scratch, chunk_sites, true);
+  launch_viterbi_back_exact(st, bp, S, I, path_sites, nullptr);
 }
 
 void launch_unblock_path(hipStream_t st, const uint8_t* path16, uint64_t S, uint64_t I,

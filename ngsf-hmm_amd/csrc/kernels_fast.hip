@@ -662,7 +662,11 @@ __device__ __forceinline__ double base_sum(const double* __restrict__ base_c, ui
 
 // lkl = log( q . prod_c R_c . 1 ): one workgroup per group, one wave per point; lane l holds the
 // ordered product of the operators of chunks l*K .. l*K + K - 1 of the wave's point (K =
-// ceil(C / 64): one chunk per lane up to 64 chunks) and an ordered shuffle tree multiplies them
+// ceil(C / 64): one chunk per lane up to 64 chunks) and an ordered shuffle tree multiplies them.
+// SHARD (a handle that holds a site range of a larger data set, SiteShard): the product and
+// the sum of log e0 of this range go to the send buffer instead, six doubles per point in point
+// order; k_fast_shard_combine finishes the value once every range's part has arrived.
+template <bool SHARD>
 __global__ void __launch_bounds__(64 * MAXP)
 k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint32_t C,
                   const double* __restrict__ part, const double* __restrict__ base_c,
@@ -687,15 +691,139 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
       if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
     }
     if (lane == 0) {
-      const double q0 = 1 - G.F[p], q1 = G.F[p];
-      const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
-      const double l = base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
-      lkl_out[G.out_idx[p]] = l;
-      // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
-      // in linear space; the host re-evaluates such points with the general kernel
-      if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
+      if constexpr (SHARD) {
+        double* o = lkl_out + (uint64_t)G.out_idx[p] * 6;
+        o[0] = m.a00;
+        o[1] = m.a01;
+        o[2] = m.a10;
+        o[3] = m.a11;
+        o[4] = (double)m.ex;
+        o[5] = base;
+      } else {
+        const double q0 = 1 - G.F[p], q1 = G.F[p];
+        const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
+        const double l = base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
+        lkl_out[G.out_idx[p]] = l;
+        // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
+        // in linear space; the host re-evaluates such points with the general kernel
+        if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
+      }
     }
   }
+}
+
+// ---- site shards ------------------------------------------------------------
+// A run of sites is the product of its operators, so the SITE axis can be cut between GPUs as
+// it is cut between lane-chunks: every handle holds all individuals for a contiguous site
+// range, walks it as if it were a data set of its own, and what the ranges owe each other per
+// individual is one 2x2 operator (+ exponent, + the range's sum of log e0): six doubles.  They
+// travel by an all-gather the caller provides (SiteShard::allgather, stream-ordered); every
+// handle then multiplies the ranges' operators in rank order, so all of them see the same
+// bits and run the same L-BFGS-B steps.  est_maf has every individual of its sites at hand:
+// the frequency step needs no exchange at all.
+//
+// recv = [world][n][6]; one thread per point: lkl = sum_r base_r + log(q . prod_r M_r . 1)
+__global__ void __launch_bounds__(256)
+k_fast_shard_combine(const GroupDesc* __restrict__ groups, uint32_t n_groups,
+                     const double* __restrict__ recv, uint32_t world, uint64_t n,
+                     double* __restrict__ lkl_out, int* __restrict__ flags) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = (uint32_t)(t / MAXP), p = (uint32_t)(t % MAXP);
+  if (g >= n_groups) return;
+  const GroupDesc& G = groups[g];
+  if (p >= G.np) return;
+  const uint64_t idx = G.out_idx[p];
+  Op m = op_load(recv + idx * 6);
+  double base = recv[idx * 6 + 5];
+  for (uint32_t r = 1; r < world; ++r) {
+    const double* o = recv + ((uint64_t)r * n + idx) * 6;
+    m = op_mul(m, op_load(o));
+    base += o[5];
+  }
+  const double q0 = 1 - G.F[p], q1 = G.F[p];
+  const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
+  const double l = base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
+  lkl_out[idx] = l;
+  if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
+}
+
+// E-step: the operator of the handle's whole site range per individual (ordered product of its
+// lane-chunk operators) and the range's sum of log e0 -> send[i][6]; one wave per individual
+__global__ void __launch_bounds__(64)
+k_fast_shard_reduce(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
+                    const double* __restrict__ base_c, double* __restrict__ send) {
+  const uint64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* ops = lane_ops + (i * J + (uint64_t)lane * C) * 5;
+  constexpr uint32_t PF = 8;
+  Op L{1.0, 0.0, 0.0, 1.0, 0};
+  for (uint32_t k0 = 0; k0 < C; k0 += PF) {
+    Op o[PF];
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u)
+      o[u] = op_load(ops + (uint64_t)(k0 + u < C ? k0 + u : C - 1) * 5);
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u)
+      if (k0 + u < C) L = op_mul(L, o[u]);
+  }
+  for (int off = 1; off < 64; off <<= 1) {
+    const Op o = op_shfl_down(L, off);
+    if ((lane & (2 * off - 1)) == 0) L = op_mul(L, o);
+  }
+  const double base = base_sum(base_c + i * C, C, lane);
+  if (lane == 0) {
+    double* o = send + i * 6;
+    o[0] = L.a00;
+    o[1] = L.a01;
+    o[2] = L.a10;
+    o[3] = L.a11;
+    o[4] = (double)L.ex;
+    o[5] = base;
+  }
+}
+
+// edges[i][8] = the row vector entering this range from the left (u0, u1, exponent), the column
+// vector entering it from the right (x0, x1, exponent), the sum of log e0 over all ranges
+__global__ void __launch_bounds__(256)
+k_fast_shard_edges(const double* __restrict__ recv, uint32_t world, uint32_t rank, uint64_t I,
+                   const double* __restrict__ indF, double* __restrict__ edges) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  const double f = indF[i];
+  double u0 = 1 - f, u1 = f;
+  int uex = 0;
+  double base = 0.0;
+  for (uint32_t r = 0; r < world; ++r) {
+    const double* o = recv + ((uint64_t)r * I + i) * 6;
+    base += o[5];
+    if (r < rank) {
+      const Op m = op_load(o);
+      const double n0 = fma(u0, m.a00, u1 * m.a10), n1 = fma(u0, m.a01, u1 * m.a11);
+      u0 = n0;
+      u1 = n1;
+      uex += m.ex;
+      renorm2(u0, u1, uex);
+    }
+  }
+  double x0 = 1.0, x1 = 1.0;
+  int xex = 0;
+  for (uint32_t r = world; r-- > rank + 1;) {
+    const Op m = op_load(recv + ((uint64_t)r * I + i) * 6);
+    const double n0 = fma(m.a00, x0, m.a01 * x1), n1 = fma(m.a10, x0, m.a11 * x1);
+    x0 = n0;
+    x1 = n1;
+    xex += m.ex;
+    renorm2(x0, x1, xex);
+  }
+  double* e = edges + i * 8;
+  e[0] = u0;
+  e[1] = u1;
+  e[2] = (double)uex;
+  e[3] = x0;
+  e[4] = x1;
+  e[5] = (double)xex;
+  e[6] = base;
+  e[7] = 0.0;
 }
 
 // ---- E-step ---------------------------------------------------------------
@@ -779,11 +907,24 @@ __device__ __forceinline__ Op op_shfl_up(const Op& m, int off) {
 __global__ void __launch_bounds__(64)
 k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
               const double* __restrict__ indF, const double* __restrict__ base_c,
-              double* __restrict__ bound, double* __restrict__ ind_lkl, int* __restrict__ flags) {
+              double* __restrict__ bound, double* __restrict__ ind_lkl, int* __restrict__ flags,
+              const double* __restrict__ edges) {
   const uint64_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const double f = indF[i];
-  const double q0 = 1 - f, q1 = f;
+  // what enters the handle's sites from the left and from the right: the initial distribution
+  // and (1, 1), or -- a site shard -- the other ranges' products (k_fast_shard_edges)
+  double q0 = 1 - f, q1 = f, x0 = 1.0, x1 = 1.0;
+  int uex = 0, xex = 0;
+  if (edges) {
+    const double* e = edges + i * 8;
+    q0 = e[0];
+    q1 = e[1];
+    uex = (int)e[2];
+    x0 = e[3];
+    x1 = e[4];
+    xex = (int)e[5];
+  }
   const double LN2 = 0.6931471805599453094;
   const double* ops = lane_ops + (i * J + (uint64_t)lane * C) * 5;
   double* bd = bound + (i * J + (uint64_t)lane * C) * 4;
@@ -812,7 +953,7 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   Op E = op_shfl_up(P, 1);
   if (lane == 0) E = Op{1.0, 0.0, 0.0, 1.0, 0};
   double v0 = fma(q0, E.a00, q1 * E.a10), v1 = fma(q0, E.a01, q1 * E.a11);
-  int ex = E.ex;
+  int ex = E.ex + uex;
   renorm2(v0, v1, ex);
   for (uint32_t k0 = 0; k0 < C; k0 += PF) {
     Op o[PF];
@@ -834,7 +975,8 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
       }
     }
   }
-  const double lf = __shfl(log(v0 + v1) + (double)ex * LN2, 63);  // lane 63 has walked it all
+  // (x = (1, 1): v0 + v1 exactly)
+  const double lf = __shfl(log(fma(v0, x0, v1 * x1)) + (double)(ex + xex) * LN2, 63);  // lane 63 has walked it all
 
   // backward: product of the lanes to the right
   Op Sx = L;
@@ -844,8 +986,8 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   }
   Op X = op_shfl_down(Sx, 1);
   if (lane == 63) X = Op{1.0, 0.0, 0.0, 1.0, 0};
-  double w0 = X.a00 + X.a01, w1 = X.a10 + X.a11;
-  int exb = X.ex;
+  double w0 = fma(X.a00, x0, X.a01 * x1), w1 = fma(X.a10, x0, X.a11 * x1);
+  int exb = X.ex + xex;
   renorm2(w0, w1, exb);
   for (uint32_t kk0 = C; kk0 > 0; kk0 = kk0 > PF ? kk0 - PF : 0) {
     Op o[PF];  // operators kk0-1, kk0-2, ...
@@ -867,9 +1009,9 @@ k_fast_bounds(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
       }
     }
   }
-  const double lb = __shfl(log(fma(q0, w0, q1 * w1)) + (double)exb * LN2, 0);
+  const double lb = __shfl(log(fma(q0, w0, q1 * w1)) + (double)(exb + uex) * LN2, 0);
   // the walks ran on the emissions (1, rho): add sum log e0 (as k_fast_lkl_finish does)
-  const double base = base_sum(base_c + i * C, C, lane);
+  const double base = edges ? edges[i * 8 + 6] : base_sum(base_c + i * C, C, lane);
   if (lane == 0) {
     ind_lkl[i] = base + lf;
     if (lf != lf || lb != lb || base != base) flags[FLAG_INVALID_LKL] = 1;
@@ -2628,7 +2770,7 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
 void fast_destroy(FastState& fs) {
   void* run[] = {fs.e_il, fs.base_c, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.lanes[0].part,
                  fs.lanes[0].grp_dev, fs.lanes[1].part, fs.lanes[1].grp_dev, fs.redo, fs.est_status,
-                 fs.est_state};
+                 fs.est_state, fs.shard.edges};
   for (void* p : run)
     if (p) (void)hipFree(p);
   if (fs.owns_data) {
@@ -2753,6 +2895,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
                       const double* h_F, const double* h_A, bool force_general) {
   FastState::LklLane& L = fs.lanes[fs.cur_lane];
   L.n_groups = 0;
+  L.n_pts = n_pts;
   if (n_pts == 0) return true;
   // group the points by individual (<= MAXP per group): stable counting sort on the
   // individual index (the caller has checked ind < I)
@@ -2886,8 +3029,21 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     }
   }
   if (fresh) fs.e_stale = false;
-  hipLaunchKernelGGL(k_fast_lkl_finish, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part, fs.base_c,
-                     d_lkl, d_flags);
+  if (fs.shard.world > 1) {
+    // this handle's sites are a range of the data set's: its operators to everybody, theirs back
+    SiteShard& sh = fs.shard;
+    if ((uint64_t)L.n_pts * 6 > sh.cap) return false;
+    hipLaunchKernelGGL(k_fast_lkl_finish<true>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part,
+                       fs.base_c, sh.send, d_flags);
+    if (hipGetLastError() != hipSuccess) return false;
+    if (sh.allgather(sh.user, (uint64_t)L.n_pts * 6 * sizeof(double)) != 0) return false;
+    ++sh.n_gathers;
+    hipLaunchKernelGGL(k_fast_shard_combine, dim3(((unsigned)ng * MAXP + 255) / 256), dim3(256), 0, st, dg,
+                       ng, sh.recv, sh.world, (uint64_t)L.n_pts, d_lkl, d_flags);
+    return hipGetLastError() == hipSuccess;
+  }
+  hipLaunchKernelGGL(k_fast_lkl_finish<false>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part,
+                     fs.base_c, d_lkl, d_flags);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -2906,8 +3062,21 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
   if (!have_forward_walk)
     hipLaunchKernelGGL(k_fast_chunk_ops, dim3(waves), dim3(64), 0, st, e2, fs.pos_il, fs.T, fs.C,
                        d_indF, d_alpha, EmitPtrs{fs.lane_ops, ck});
+  const double* edges = nullptr;
+  if (fs.shard.world > 1) {
+    SiteShard& sh = fs.shard;
+    if (fs.I * 6 > sh.cap) return false;
+    hipLaunchKernelGGL(k_fast_shard_reduce, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J,
+                       fs.C, fs.base_c, sh.send);
+    if (hipGetLastError() != hipSuccess) return false;
+    if (sh.allgather(sh.user, fs.I * 6 * sizeof(double)) != 0) return false;
+    ++sh.n_gathers;
+    hipLaunchKernelGGL(k_fast_shard_edges, dim3((unsigned)((fs.I + 255) / 256)), dim3(256), 0, st,
+                       sh.recv, sh.world, sh.rank, fs.I, d_indF, sh.edges);
+    edges = sh.edges;
+  }
   hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J, fs.C,
-                     d_indF, fs.base_c, fs.bound, d_ind_lkl, d_flags);
+                     d_indF, fs.base_c, fs.bound, d_ind_lkl, d_flags, edges);
   if (kPost8)
     hipLaunchKernelGGL(k_fast_bwd_recompute8, dim3((unsigned)(((fs.I + 7) / 8) * fs.C * 2)), dim3(256),
                        0, st, e2, fs.pos_il, fs.T, fs.C, fs.S, fs.I, d_indF, d_alpha, fs.bound, ck,
@@ -3095,6 +3264,19 @@ bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const dou
   launch_emission_exact(st, fs.gl_log, d_freq, eprob_log, fs.S, fs.I, d_flags);
   launch_viterbi_exact(st, eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites,
                        d_scratch, chunk_sites);
+  const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  (void)hipFree(eprob_log);
+  return ok;
+}
+
+bool fast_viterbi_forward(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
+                          const double* d_alpha, uint8_t* d_bp, int* d_flags, double* d_scratch,
+                          uint64_t chunk_sites, bool chain_start) {
+  double* eprob_log = nullptr;
+  if (!dalloc(&eprob_log, (size_t)fs.I * fs.S * 2)) return false;
+  launch_emission_exact(st, fs.gl_log, d_freq, eprob_log, fs.S, fs.I, d_flags);
+  launch_viterbi_fwd_exact(st, eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_scratch,
+                           chunk_sites, chain_start);
   const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
   (void)hipFree(eprob_log);
   return ok;

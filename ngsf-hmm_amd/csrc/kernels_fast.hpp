@@ -34,8 +34,24 @@ struct Switches {
   bool set(const char* name, long value);
 };
 
+// A handle that holds a contiguous SITE range (all individuals) of a data set whose sites are
+// split over `world` handles, one per GPU (kernels_fast.hip, "site shards"; nghmm_site_shard_setup)
+struct SiteShard {
+  uint32_t rank = 0, world = 1;
+  double* send = nullptr;   // the caller's device buffers: cap doubles, world * cap doubles
+  double* recv = nullptr;
+  uint64_t cap = 0;
+  // all-gather of the first n_bytes of `send` into recv = [rank][n_bytes], ordered on the
+  // handle's stream (it may block, it need not); non-zero = failure
+  int (*allgather)(void* user, uint64_t n_bytes) = nullptr;
+  void* user = nullptr;
+  double* edges = nullptr;  // [I][8], owned: what enters the range from both sides (k_fast_shard_edges)
+  uint64_t n_gathers = 0;   // accounting
+};
+
 struct FastState {
   Switches sw;
+  SiteShard shard;
   uint64_t I = 0, S = 0;
   uint64_t T = 0;     // sites walked by one lane
   uint32_t C = 0;     // waves (chunks of 64 lanes) per individual
@@ -75,6 +91,7 @@ struct FastState {
     size_t grp_cap = 0;
     std::vector<unsigned char> grp_host;
     uint32_t n_groups = 0;
+    uint32_t n_pts = 0;
     std::vector<ModeRange> mode_ranges;  // groups sorted by loop-body version
   };
   LklLane lanes[2];
@@ -132,6 +149,10 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_lin_sites,
 bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
                   const double* d_alpha, uint8_t* d_bp, uint8_t* d_path_sites, int* d_flags,
                   double* d_scratch, uint64_t chunk_sites);
+// the forward half of fast_viterbi (site shards: launch_viterbi_fwd_exact)
+bool fast_viterbi_forward(FastState& fs, hipStream_t st, const double* d_freq, const double* d_indF,
+                          const double* d_alpha, uint8_t* d_bp, int* d_flags, double* d_scratch,
+                          uint64_t chunk_sites, bool chain_start);
 // log of the stored linear emissions as [I][S][2] (device), for host read-back
 bool fast_export_emissions(FastState& fs, hipStream_t st, double* d_out);
 

@@ -721,7 +721,7 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
     set_error("nghmm_create_replica: the parent must be a loaded handle that is not itself a replica");
     return NGHMM_ERR_ARG;
   }
-  if (parent->I_tot != parent->I) {
+  if (parent->I_tot != parent->I || parent->fast.shard.world > 1) {
     set_error("nghmm_create_replica: sharded handles have no replicas");
     return NGHMM_ERR_ARG;
   }
@@ -1929,6 +1929,106 @@ int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uin
   return NGHMM_OK;
 }
 
+// ---- site shards (fast mode): kernels_fast.hip, "site shards" ----
+uint64_t nghmm_site_shard_bytes(nghmm_t* h) {
+  // an objective round: <= 5 points per individual, six doubles each (the E-step: six per
+  // individual); nghmm_lkl_batch calls with more points than that are refused
+  return h ? (uint64_t)(h->I * 30 + 64) * sizeof(double) : 0;
+}
+
+int nghmm_site_shard_setup(nghmm_t* h, int rank, int world, void* send_dev, void* recv_dev,
+                           uint64_t bytes_per_rank, nghmm_allgather_fn fn, void* user) {
+  g_last_error.clear();
+  if (!h || world < 1 || rank < 0 || rank >= world) return NGHMM_ERR_ARG;
+  if (h->mode != NGHMM_MODE_FAST) {
+    set_error("site shards are a fast-mode layout: the exact-mode recursion is one chain of "
+              "roundings over all sites (shard by individual: nghmm_shard_config)");
+    return NGHMM_ERR_ARG;
+  }
+  if (h->parent || h->n_replicas.load() > 0 || h->I_tot != h->I || h->g_n) {
+    set_error("nghmm_site_shard_setup: not on a replica, a handle with replicas, an individual "
+              "shard or a group member");
+    return NGHMM_ERR_ARG;
+  }
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  SiteShard& sh = h->fast.shard;
+  if (world == 1) {
+    sh = SiteShard{};
+    return NGHMM_OK;
+  }
+  if (!send_dev || !recv_dev || !fn || bytes_per_rank < nghmm_site_shard_bytes(h)) {
+    set_error("nghmm_site_shard_setup: buffers of nghmm_site_shard_bytes() (x world for recv) and "
+              "an all-gather are needed");
+    return NGHMM_ERR_ARG;
+  }
+  if (!sh.edges && (rc = dev_alloc(&sh.edges, (size_t)h->I * 8))) return rc;
+  sh.rank = (uint32_t)rank;
+  sh.world = (uint32_t)world;
+  sh.send = static_cast<double*>(send_dev);
+  sh.recv = static_cast<double*>(recv_dev);
+  sh.cap = bytes_per_rank / sizeof(double);
+  sh.allgather = fn;
+  sh.user = user;
+  return NGHMM_OK;
+}
+
+// Viterbi over a chain of site shards: forward in rank order (every handle starts from the
+// scores the one before ended with), then back in reverse order (every handle starts from the
+// state the one after found for the site in front of its first).  Same kernels, same order of
+// operations per individual as one handle over all sites: the same path.
+int nghmm_viterbi_shard_forward(nghmm_t* h, const double* scores_in, double* scores_out) {
+  g_last_error.clear();
+  if (!h || !h->loaded || !scores_out || h->mode != NGHMM_MODE_FAST) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  const size_t blocked = viterbi_blocked_bytes(h->S, h->I);
+  if (!h->d_bp && (rc = dev_alloc(&h->d_bp, blocked + h->I))) return rc;
+  if (!h->d_path_sites && (rc = dev_alloc(&h->d_path_sites, blocked))) return rc;
+  if (!h->d_path && (rc = dev_alloc(&h->d_path, (size_t)h->I * h->S))) return rc;
+  const uint64_t chunk = viterbi_chunk_sites(h->S, h->I);
+  if (!h->d_vit && (rc = dev_alloc(&h->d_vit, (size_t)chunk * h->I * 4 + h->I * 2))) return rc;
+  double* d_state = h->d_vit + (size_t)chunk * h->I * 4;
+  if (scores_in)
+    HIP_TRY(hipMemcpyAsync(d_state, scores_in, h->I * 2 * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+  if ((rc = clear_flags(h))) return rc;
+  tic(h);
+  if (!fast_viterbi_forward(h->fast, h->stream, h->d_freq, h->d_indF, h->d_alpha, h->d_bp, h->d_flags,
+                            h->d_vit, chunk, scores_in == nullptr))
+    return NGHMM_ERR_HIP;
+  if ((rc = toc(h, SLOT_VITERBI, false))) return rc;
+  if ((rc = check_flags(h))) return rc;  // "invalid MAF!" (HMM.cpp:145-146)
+  HIP_TRY(hipMemcpyAsync(scores_out, d_state, h->I * 2 * sizeof(double), hipMemcpyDeviceToHost,
+                         h->stream));
+  HIP_TRY(sync_stream(h));
+  return NGHMM_OK;
+}
+
+int nghmm_viterbi_shard_back(nghmm_t* h, const uint8_t* state_after, uint8_t* state_before,
+                             uint8_t* path) {
+  g_last_error.clear();
+  if (!h || !h->loaded || !h->d_bp || !state_before || !path) return NGHMM_ERR_ARG;
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  uint8_t* d_last = h->d_bp + viterbi_blocked_bytes(h->S, h->I);
+  if (state_after)  // else: the last range, whose forward half left the arg max there
+    HIP_TRY(hipMemcpyAsync(d_last, state_after, h->I, hipMemcpyHostToDevice, h->stream));
+  uint8_t* d_before = nullptr;
+  if ((rc = dev_alloc(&d_before, (size_t)h->I))) return rc;
+  launch_viterbi_back_exact(h->stream, h->d_bp, h->S, h->I, h->d_path_sites, d_before);
+  launch_unblock_path(h->stream, h->d_path_sites, h->S, h->I, h->d_path);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(state_before, d_before, h->I, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(path, h->d_path, (size_t)h->I * h->S, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = sync_stream(h);
+  (void)hipFree(d_before);
+  HIP_TRY(e);
+  return NGHMM_OK;
+}
+
 int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
   g_last_error.clear();
   if (!h || !gl_site_shard) return NGHMM_ERR_ARG;
@@ -2124,7 +2224,8 @@ int nghmm_group_setup(nghmm_t** hs, int n) {
   nghmm_t* h0 = hs[0];
   for (int r = 0; r < n; ++r) {
     nghmm_t* h = hs[r];
-    if (!h || !h->loaded || (n > 1 && (h->parent || h->n_replicas.load() > 0)) || h->I != h0->I ||
+    if (!h || !h->loaded || (n > 1 && (h->parent || h->n_replicas.load() > 0)) ||
+        h->fast.shard.world > 1 || h->I != h0->I ||
         h->S != h0->S || h->mode != h0->mode ||
         h->packed != h0->packed) {
       set_error("nghmm_group_setup: the handles must be loaded and agree in size, mode and packing");

@@ -416,3 +416,219 @@ class ShardedEM:
             self.hmm.close()
         elif hasattr(self.backend, "close"):
             self.backend.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# Fast mode: shard the SITES (include/nghmm.h, "shard the SITES instead")
+# ---------------------------------------------------------------------------------------------
+# A run of sites is a product of 2x2 operators, so in fast mode the site axis can be cut between
+# GPUs the way it is cut between lane-chunks inside one: every rank holds ALL individuals for a
+# contiguous range of sites, and the ranges owe each other six doubles per individual and E-step
+# and per objective point and round -- a few hundred KB through one small all-gather, where the
+# individual shards above move every posterior (8 GB per iteration at 1000 x 1M, and between
+# two GPUs over ONE xGMI link).  The frequency step has every individual of its sites at hand
+# and exchanges nothing; every rank runs the same L-BFGS-B steps for all individuals from the
+# same gathered bits.
+
+
+def site_ranges_ragged(n_sites: int, world: int):
+    """Contiguous site ranges of near-equal length (multiples of 16 sites except the last, so
+    that the blocked Viterbi back-pointers of neighbouring ranges do not share a block)."""
+    if world < 1 or n_sites < world:
+        raise ValueError(f"{n_sites} sites over {world} ranks")
+    cuts = [0]
+    for r in range(1, world):
+        c = (n_sites * r // world) // 16 * 16
+        cuts.append(max(c, cuts[-1] + 1))
+    cuts.append(n_sites)
+    if any(b <= a for a, b in zip(cuts[:-1], cuts[1:])):
+        raise ValueError(f"{n_sites} sites are too few for {world} ranks")
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+class SiteExchange:
+    """The all-gather a site-shard handle asks for (nghmm_allgather_fn): the first n bytes of
+    `send` of every rank into `recv` = [rank][n], ordered on the handle's HIP stream.
+
+    * process group nccl (= RCCL), device buffers: `all_gather_into_tensor` issued with the
+      handle's stream as torch's current stream -- the collective waits for what the library
+      enqueued before, the library's next kernels wait for the collective; the host waits for
+      nothing;
+    * process group gloo: through the host, synchronous (CPU buffers directly);
+    * no process group, `emulate` = V: V copies of the own part on the handle's stream (one
+      rank's compute of a V-rank run on a one-GPU box)."""
+
+    def __init__(self, send, recv, rank, world, stream_ptr=None, emulate=False):
+        self.send, self.recv = send, recv
+        self.rank, self.world = rank, world
+        self.emulate = emulate
+        self.calls = 0
+        self.bytes = 0
+        self.host_ms = 0.0
+        self._stream = None
+        if send.is_cuda and stream_ptr is not None:
+            import torch
+            self._stream = torch.cuda.ExternalStream(stream_ptr, device=send.device)
+
+    def __call__(self, n_bytes):
+        import time
+        import torch
+        t0 = time.perf_counter()
+        if n_bytes % 8 or n_bytes * self.world > self.recv.numel() * 8:
+            raise ValueError(f"site-shard exchange of {n_bytes} bytes does not fit the buffers")
+        k = n_bytes // 8
+        part, whole = self.send[:k], self.recv[:k * self.world]
+        if self.emulate:
+            with torch.cuda.stream(self._stream):
+                whole.view(self.world, k).copy_(part.expand(self.world, k))
+        else:
+            import torch.distributed as dist
+            if dist.get_backend() == "gloo" and part.is_cuda:
+                torch.cuda.synchronize(part.device)      # the library's stream has written `send`
+                w = torch.empty(k * self.world, dtype=part.dtype)
+                dist.all_gather_into_tensor(w, part.cpu())
+                whole.copy_(w)
+                torch.cuda.synchronize(part.device)
+            elif part.is_cuda:
+                with torch.cuda.stream(self._stream):
+                    dist.all_gather_into_tensor(whole, part)
+            else:
+                dist.all_gather_into_tensor(whole, part)
+        self.calls += 1
+        self.bytes += n_bytes
+        self.host_ms += (time.perf_counter() - t0) * 1e3
+
+
+class SiteShardedEM:
+    """iter_EM over `world` ranks, rank r holding all `n_ind` individuals for the site range
+    site_ranges_ragged(n_sites, world)[r]; NGHMM_MODE_FAST (dense or packed).  world == 1 with
+    emulate_ranks = V: rank 0's compute of a V-rank run, the exchanges V local copies."""
+
+    def __init__(self, pkg, n_ind, n_sites, device_index=0, mode=None, rank=0, world=1,
+                 emulate_ranks=1):
+        import torch
+        self.emulate = int(emulate_ranks) if world == 1 else 1
+        if self.emulate > 1:
+            world = self.emulate
+        self.pkg = pkg
+        self.rank, self.world = rank, world
+        self.n_ind, self.n_sites = n_ind, n_sites
+        self.ranges = site_ranges_ragged(n_sites, world)
+        self.site_lo, self.site_hi = self.ranges[rank]
+        self.S_own = self.site_hi - self.site_lo
+        mode = pkg.MODE_FAST if mode is None else mode
+        if (mode & 3) != pkg.MODE_FAST:
+            raise ValueError("site shards are a fast-mode layout (exact mode: ShardedEM)")
+        self.hmm = pkg.NgsFHMM(n_ind, self.S_own, device=device_index, mode=mode)
+        self.device = torch.device("cuda", device_index)
+        self.ind_lkl = None
+        self.exchange = None
+        self.timing = dict(iterations=0)
+        if world > 1:
+            nbytes = self.hmm.site_shard_bytes()
+            self._send = torch.zeros(nbytes // 8, dtype=torch.float64, device=self.device)
+            self._recv = torch.zeros(world * (nbytes // 8), dtype=torch.float64, device=self.device)
+            torch.cuda.synchronize(self.device)
+            self.exchange = SiteExchange(self._send, self._recv, rank, world,
+                                         stream_ptr=self.hmm.lib.nghmm_stream(self.hmm.handle),
+                                         emulate=self.emulate > 1)
+            self.hmm.site_shard_setup(rank, world, self._send.data_ptr(), self._recv.data_ptr(),
+                                      nbytes, self.exchange)
+
+    # -- data: the rank's own site range, all individuals ------------------------------------
+    def load_device(self, gl, pos):
+        """gl: device tensor [S_own][n_ind][3]; pos: [S_own] distances in Mb, the first one the
+        true distance to the range before (+inf only at a chromosome start)."""
+        import torch
+        torch.cuda.synchronize(self.device)
+        self.hmm.load_device(gl.data_ptr(), pos.data_ptr())
+
+    def load_chunks_device(self, pos, chunks, space=0, call_geno=False):
+        def feed():
+            import torch
+            for lo, c in chunks:          # one chunk alive at a time
+                torch.cuda.synchronize(self.device)   # the library reads on its own stream
+                yield lo, c.shape[0], c.data_ptr()
+        self.hmm.load_chunks_device(pos.data_ptr(), feed(), space=space, call_geno=call_geno)
+
+    def set_params(self, indF, alpha, freq):
+        self.hmm.set_params(indF, alpha, freq)
+
+    def init_emission(self):
+        self.hmm.init_emission()
+
+    def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        st = self.hmm.iter_EM(freq_est, indF_fixed, alpha_fixed)
+        self.ind_lkl = self.hmm.ind_lkl          # the chain's: the same on every rank
+        self.timing["iterations"] += 1
+        return st
+
+    def reset_timing(self):
+        self.timing["iterations"] = 0
+        if self.exchange:
+            self.exchange.calls = self.exchange.bytes = 0
+            self.exchange.host_ms = 0.0
+
+    def collective_bytes_per_iter(self):
+        """Bytes that leave this rank's GPU per EM iteration (measured: the own part of every
+        all-gather, to world - 1 ranks)."""
+        it = max(self.timing["iterations"], 1)
+        if not self.exchange:
+            return {"all_to_all_out": 0, "all_gather_out": 0, "all_gathers": 0}
+        return {"all_to_all_out": 0,
+                "all_gather_out": self.exchange.bytes * (self.world - 1) / it,
+                "all_gathers": self.exchange.calls / it}
+
+    # -- results ------------------------------------------------------------------------------
+    def _bcast(self, a, src):
+        """numpy array of rank `src` to every rank."""
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dist.get_backend() == "nccl":
+            t = t.to(self.device)
+        dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
+    def viterbi(self):
+        """Most probable path of the own site range, [n_ind][S_own]: the forward halves in rank
+        order, the backward halves in reverse order, the boundary scores / states by broadcast
+        (include/nghmm.h, nghmm_viterbi_shard_forward / _back)."""
+        if self.emulate > 1:
+            raise ValueError("emulate_ranks has no chain to decode")
+        if self.world == 1:
+            return self.hmm.viterbi()
+        scores = None
+        for r in range(self.world):
+            out = self.hmm.viterbi_shard_forward(scores) if r == self.rank else \
+                np.empty((self.n_ind, 2))
+            got = self._bcast(out, r)
+            if r + 1 == self.rank:
+                scores = got
+        state, path = None, None
+        for r in reversed(range(self.world)):
+            if r == self.rank:
+                before, path = self.hmm.viterbi_shard_back(state)
+            else:
+                before = np.empty(self.n_ind, dtype=np.uint8)
+            got = self._bcast(before, r)
+            if r - 1 == self.rank:
+                state = got
+        return path
+
+    def gather_freq(self):
+        """freq of all sites on every rank (the .indF file's frequency block)."""
+        import torch
+        import torch.distributed as dist
+        mine = np.ascontiguousarray(self.hmm.freq)
+        if self.world == 1 or self.emulate > 1:
+            return mine
+        parts = []
+        for r, (lo, hi) in enumerate(self.ranges):
+            parts.append(self._bcast(mine if r == self.rank else np.empty(hi - lo), r))
+        return np.concatenate(parts)
+
+    def close(self):
+        if self.hmm is not None:
+            self.hmm.close()
+            self.hmm = None

@@ -32,6 +32,7 @@ _LIB = None
 
 c_double_p = C.POINTER(C.c_double)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)   # nghmm_hook_fn
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)   # nghmm_allgather_fn
 
 
 class NgsFHMMError(RuntimeError):
@@ -122,6 +123,11 @@ def load_library():
         "nghmm_synchronize": (i32, [vp]),
         "nghmm_kernel_ms": (i32, [vp, i32, dp, C.POINTER(u32)]),
         "nghmm_set_switch": (i32, [vp, C.c_char_p, C.c_long]),
+        "nghmm_site_shard_bytes": (u64, [vp]),
+        "nghmm_site_shard_setup": (i32, [vp, i32, i32, vp, vp, u64, ALLGATHER_FN, vp]),
+        "nghmm_viterbi_shard_forward": (i32, [vp, dp, dp]),
+        "nghmm_viterbi_shard_back": (i32, [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                                           C.POINTER(C.c_uint8)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -154,6 +160,8 @@ EXPORTED_SYMBOLS = [
     "nghmm_fast_layout", "nghmm_stream",
     "nghmm_synchronize",
     "nghmm_kernel_ms", "nghmm_set_switch",
+    "nghmm_site_shard_bytes", "nghmm_site_shard_setup", "nghmm_viterbi_shard_forward",
+    "nghmm_viterbi_shard_back",
 ]
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_void_p)
@@ -203,6 +211,11 @@ class NgsFHMM:
 
     # -- plumbing ---------------------------------------------------------
     def _check(self, rc):
+        err = getattr(self, "_shard_err", None)
+        if err:                      # raised inside the site-shard all-gather callback
+            e = err[0]
+            del err[:]
+            raise e
         if rc != 0:
             msg = self.lib.nghmm_last_error().decode() or self.lib.nghmm_strerror(rc).decode()
             raise NgsFHMMError(rc, msg)
@@ -478,6 +491,54 @@ class NgsFHMM:
                 callback(it, self)
         self.iterations = it
         return it
+
+    # -- site shards (include/nghmm.h, "shard the SITES") ----------------------
+    def site_shard_bytes(self):
+        return int(self.lib.nghmm_site_shard_bytes(self._h))
+
+    def site_shard_setup(self, rank, world, send_ptr, recv_ptr, nbytes, allgather):
+        """This handle's sites are range `rank` of `world`; ``allgather(n_bytes)`` gathers the
+        first n_bytes of the send buffer of every range into the receive buffer, ordered on
+        the handle's stream (nghmm_site_shard_setup).  An exception raised in it makes the
+        library call that needed it fail; it is re-raised by _check."""
+        self._shard_err = []
+
+        def _cb(_user, n):
+            try:
+                allgather(int(n))
+                return 0
+            except BaseException as e:      # must not propagate through the C frame
+                self._shard_err.append(e)
+                return 1
+
+        self._shard_cb = ALLGATHER_FN(_cb) if world > 1 else C.cast(None, ALLGATHER_FN)
+        self._check(self.lib.nghmm_site_shard_setup(self._h, int(rank), int(world), C.c_void_p(send_ptr),
+                                                    C.c_void_p(recv_ptr), int(nbytes), self._shard_cb,
+                                                    None))
+
+    def viterbi_shard_forward(self, scores_in=None):
+        """Forward half of the decoding over a chain of site shards: scores_in = what the range
+        before ended with ([I][2]; None on the first range); returns this range's."""
+        out = np.empty((self.n_ind, 2))
+        if scores_in is not None:
+            scores_in = np.ascontiguousarray(scores_in, dtype=np.float64).reshape(self.n_ind, 2)
+        self._check(self.lib.nghmm_viterbi_shard_forward(
+            self._h, _dp(scores_in) if scores_in is not None else None, _dp(out)))
+        return out
+
+    def viterbi_shard_back(self, state_after=None):
+        """Backward half: state_after = the state the range after found for this range's last
+        site ([I]; None on the last range); returns (state at the site in front of this range's
+        first [I], path [I][n_sites])."""
+        u8p = C.POINTER(C.c_uint8)
+        before = np.empty(self.n_ind, dtype=np.uint8)
+        path = np.empty((self.n_ind, self.n_sites), dtype=np.uint8)
+        if state_after is not None:
+            state_after = np.ascontiguousarray(state_after, dtype=np.uint8).reshape(self.n_ind)
+        self._check(self.lib.nghmm_viterbi_shard_back(
+            self._h, state_after.ctypes.data_as(u8p) if state_after is not None else None,
+            before.ctypes.data_as(u8p), path.ctypes.data_as(u8p)))
+        return before, path
 
     def viterbi(self):
         """[I][S] most probable IBD path (EM.cpp:105-116)."""

@@ -195,3 +195,134 @@ def test_site_ranges(pkg):
     assert dd.site_ranges(12, 4) == [(0, 3), (3, 6), (6, 9), (9, 12)]
     with pytest.raises(ValueError):
         dd.site_ranges(10, 4)
+
+
+# ---- site shards (fast mode): ngsf-hmm_amd/distributed.py SiteExchange / SiteShardedEM ----
+SITE_WORKER = r'''
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, ROOT)
+dd = importlib.import_module("ngsf-hmm_amd.distributed")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cap = 6 * 40
+send = torch.zeros(cap, dtype=torch.float64)
+recv = torch.full((world * cap,), float("nan"), dtype=torch.float64)
+ex = dd.SiteExchange(send, recv, rank, world)
+for k in (6, 6 * 7, cap):                 # one point, an odd number of points, the whole buffer
+    send[:k] = 1000.0 * rank + torch.arange(k, dtype=torch.float64) + 0.5 * k
+    ex(8 * k)
+    want = torch.cat([1000.0 * r + torch.arange(k, dtype=torch.float64) + 0.5 * k for r in range(world)])
+    assert torch.equal(recv[:world * k], want), (rank, k)
+assert ex.calls == 3 and ex.bytes == 8 * (6 + 42 + cap)
+for bad in (7, 8 * (cap + 6)):            # not whole doubles / more than the buffers hold
+    try:
+        ex(bad)
+    except ValueError:
+        pass
+    else:
+        raise SystemExit("an exchange that does not fit was accepted")
+print("SITE_EXCHANGE_OK", rank, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_site_exchange_two_ranks_gloo(tmp_path):
+    """The all-gather a site-shard handle asks for, between two processes over gloo (CPU
+    buffers): rank-major parts of every size, accounting, and sizes that do not fit refused."""
+    world = 2
+    script = tmp_path / "site_worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\n" + SITE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and f"SITE_EXCHANGE_OK {r}" in outs[r], outs[r]
+
+
+def test_site_ranges_ragged(pkg):
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    for S, V in ((1_000_000, 8), (1000, 3), (5000, 2), (33, 2), (100_003, 7)):
+        rg = dd.site_ranges_ragged(S, V)
+        assert rg[0][0] == 0 and rg[-1][1] == S and len(rg) == V
+        assert all(a[1] == b[0] for a, b in zip(rg[:-1], rg[1:]))
+        assert all(lo % 16 == 0 for lo, _ in rg)           # Viterbi back-pointer blocks stay whole
+        sizes = [hi - lo for lo, hi in rg]
+        assert min(sizes) > 0 and max(sizes) - min(sizes) <= 32
+    with pytest.raises(ValueError):
+        dd.site_ranges_ragged(3, 4)
+
+
+def test_site_shard_algebra_against_the_oracle(pkg, orc_libm):
+    """What the site-shard kernels compute, restated in numpy on a small case and held against
+    the oracle's log-space recursions: a range of sites is the ordered product of its 2x2
+    operators M_s = (c I + (1 - c) 1 q^T) diag(e_s); the row vector entering range r is
+    q . prod_{r' < r} M_r', the column vector entering it from the right prod_{r' > r} M_r' . 1
+    (k_fast_shard_edges); the log-likelihood is log(q . prod_r M_r . 1) (k_fast_shard_combine)
+    and the posterior of a site the normalised product of the two vectors meeting there."""
+    import orclib
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    I, S, V = 4, 330, 3
+    d = pkg.simulate.simulate(I, S, seed=77, n_chrom=2, missing_rate=0.1, indF="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    em = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
+    rng = np.random.default_rng(1)
+    F, A = rng.uniform(0.05, 0.6, I), rng.uniform(0.05, 3.0, I)
+    em.set_params(F, A, rng.uniform(0.05, 0.45, S))
+    assert em.init_emission() == 0 and em.estep() == 0
+    e = np.exp(em.e_prob)                                      # [I][S][2]
+    ranges = dd.site_ranges_ragged(S, V)
+    for i in range(I):
+        q = np.array([1 - F[i], F[i]])
+
+        def op(s):
+            c = np.exp(-A[i] * d.pos_dist_mb[s])               # exp(-inf) = 0 at a chromosome start
+            return (c * np.eye(2) + (1 - c) * np.outer(np.ones(2), q)) * e[i, s][None, :]
+        M, scale = [], []
+        for lo, hi in ranges:                                  # each range's operator, rescaled
+            m, ex = np.eye(2), 0.0
+            for s in range(lo, hi):
+                m = m @ op(s)
+                k = m.max()
+                m, ex = m / k, ex + np.log(k)
+            M.append(m)
+            scale.append(ex)
+        tot = np.eye(2)
+        for m in M:
+            tot = tot @ m
+        lkl = np.log(q @ tot @ np.ones(2)) + sum(scale)
+        np.testing.assert_allclose(lkl, em.ind_lkl[i], rtol=1e-12)
+        for r, (lo, hi) in enumerate(ranges):
+            u = q.copy()
+            for m in M[:r]:
+                u = u @ m
+                u /= u.max()
+            x = np.ones(2)
+            for m in reversed(M[r + 1:]):
+                x = m @ x
+                x /= x.max()
+            # forward vectors of the range from u, backward vectors from x
+            fw = np.empty((hi - lo, 2))
+            v = u
+            for s in range(lo, hi):
+                v = v @ op(s)
+                v /= v.max()
+                fw[s - lo] = v
+            w = x
+            for s in range(hi - 1, lo - 1, -1):
+                p = fw[s - lo] * w
+                p = p[1] / p.sum()
+                p = 0.0 if p < 1e-5 else 1.0 if p > 1 - 1e-5 else p      # check_interv
+                assert abs(p - em.marg[i, s]) < 1e-9, (i, s)
+                w = op(s) @ w
+                w /= w.max()

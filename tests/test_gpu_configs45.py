@@ -192,27 +192,42 @@ def test_config5_hundred_iterations(pkg):
     h.close()
 
 
-def test_bench_four_ranks_on_the_full_workload(pkg):
+@pytest.mark.parametrize("shard", ["sites", "individuals"])
+def test_bench_four_ranks_on_the_full_workload(pkg, shard):
     """`python bench.py --gpus 4 --workload c3` as the driver starts it: four rank processes,
-    250 of the 1000 individuals each for all 10^6 sites, the collectives' known-answer
-    preflight, the all-to-all / all-gather of every iteration (gloo through the host here:
-    one GPU; nccl = RCCL on a node), and the accounting the scaling line carries."""
+    the collectives' known-answer preflight, the exchanges of every iteration (gloo through the
+    host here: one GPU; nccl = RCCL on a node), and the accounting the scaling line carries.
+    sites (the default): all 1000 individuals for 250 000 sites each, one small all-gather per
+    E-step and objective round; individuals: 250 of the 1000 for all 10^6 sites, the all-to-all
+    of posteriors and the all-gather of frequencies."""
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c3",
            "--steps", "2", "--warmup", "1", "--no_cpu_baseline"]
+    if shard == "individuals":
+        cmd += ["--shard", "individuals"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 4 and out["ranks"] == 4 and out["scaling"] == "strong"
     cfg = out["config"]
-    assert cfg["n_ind_total"] == 1000 and cfg["n_ind_per_gpu"] == 250 and cfg["n_sites"] == 1_000_000
+    assert cfg["n_ind_total"] == 1000 and cfg["n_sites"] == 1_000_000
     assert out["preflight"]["world"] == 4 and "all_to_all_single float64" in out["preflight"]["checked"]
     cb = out["collective_bytes_per_iter"]
-    assert cb["all_to_all_out"] == 8 * 250_000 * 250 * 3 and cb["all_gather_out"] == 8 * 250_000 * 3
     assert len(out["per_rank"]) == 4 and sorted(p["rank"] for p in out["per_rank"]) == [0, 1, 2, 3]
     for p in out["per_rank"]:
         assert p["kernel_ms_per_iter"]["lkl_batch"] > 0 and p["kernel_ms_per_iter"]["est_maf"] > 0
-        assert p["exchange_ms_per_iter"]["all_to_all"] > 0
-    assert out["exchange_ms"]["all_to_all"] > 0 and out["value"] > 0
+    if shard == "sites":
+        assert cfg["n_ind_per_gpu"] == 1000 and cfg["n_sites_per_gpu"] == 250_000
+        assert cfg["sharding"].startswith("sites:")
+        # <= 5 points x 1000 individuals x 48 B per round and rank, a handful of rounds
+        assert cb["all_to_all_out"] == 0 and 0 < cb["all_gather_out"] < 3 * 5e6 and cb["all_gathers"] >= 2
+        assert len({p["rounds_per_iter"] for p in out["per_rank"]}) == 1     # the same steps everywhere
+    else:
+        assert cfg["n_ind_per_gpu"] == 250
+        assert cb["all_to_all_out"] == 8 * 250_000 * 250 * 3 and cb["all_gather_out"] == 8 * 250_000 * 3
+        for p in out["per_rank"]:
+            assert p["exchange_ms_per_iter"]["all_to_all"] > 0
+        assert out["exchange_ms"]["all_to_all"] > 0
+    assert out["value"] > 0
     print(json.dumps({k: out[k] for k in ("value", "ms_per_step", "exchange_ms", "collectives")}))

@@ -95,17 +95,32 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
     one = run()
-    two = run("--gpus", "2")
+    two = run("--gpus", "2", "--shard", "individuals")
     assert one["n_gpus"] == 1 and one["ranks"] == 1 and one["config"]["n_ind_per_gpu"] == 64
     assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["scaling"] == "strong"
     assert two["config"]["n_ind_total"] == 64 and two["config"]["n_ind_per_gpu"] == 32
     assert "gloo" in two["collectives"] and two["value"] > 0
-    weak = run("--gpus", "2", "--scaling", "weak")
+    weak = run("--gpus", "2", "--scaling", "weak", "--shard", "individuals")
     assert weak["config"]["n_ind_total"] == 128 and weak["scaling"] == "weak"
+    # the default in fast mode: SITE shards -- every rank all 64 individuals for half the sites,
+    # one small all-gather per E-step and per objective round, nothing for the frequency step
+    st = run("--gpus", "2")
+    c = st["config"]
+    assert st["n_gpus"] == 2 and st["scaling"] == "strong" and c["sharding"].startswith("sites:")
+    assert c["n_ind_total"] == 64 and c["n_ind_per_gpu"] == 64
+    assert c["n_sites"] == one["config"]["n_sites"] and c["n_sites_per_gpu"] * 2 == c["n_sites"]
+    cb = st["collective_bytes_per_iter"]
+    assert cb["all_to_all_out"] == 0 and cb["all_gathers"] >= 2 and 0 < cb["all_gather_out"] < 1e6
+    assert [p["all_gathers_per_iter"] for p in st["per_rank"]] == [cb["all_gathers"]] * 2
+    assert st["per_rank"][0]["rounds_per_iter"] == st["per_rank"][1]["rounds_per_iter"]
+    sw = run("--gpus", "2", "--scaling", "weak")
+    assert sw["config"]["n_sites"] == 2 * one["config"]["n_sites"] and sw["config"]["n_ind_total"] == 64
     # BASELINE configs[4]'s path at smoke size: --call_geno, 2-bit packed handles, the site
     # shards built from exchanged genotype codes
-    cg = run("--gpus", "2", workload="tinycg")
+    cg = run("--gpus", "2", "--shard", "individuals", workload="tinycg")
     assert cg["n_gpus"] == 2 and cg["value"] > 0 and "packed" in cg["config"]["workload"]
+    cg = run("--gpus", "2", workload="tinycg")           # ... and as site shards
+    assert cg["n_gpus"] == 2 and cg["value"] > 0 and cg["config"]["sharding"].startswith("sites:")
     # a rank count that does not match --gpus is an error, not a silent N = 1 run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
                           "--workload", "tiny", "--no_cpu_baseline"],

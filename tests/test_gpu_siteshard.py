@@ -1,0 +1,232 @@
+"""Site shards (include/nghmm.h, "shard the SITES instead") on ONE GPU: V handles of one process
+play the V ranks -- each holds all individuals for a contiguous site range and runs in a thread
+of its own; the all-gather the library asks for is done by the test (barrier + device copies) --
+and the chain must reproduce one handle that holds every site."""
+import importlib
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+class Chain:
+    """V site-shard handles on cuda:0 with a thread-barrier all-gather."""
+
+    def __init__(self, pkg, gl, pos, V, mode=None, raw=None):
+        import torch
+        dd = importlib.import_module("ngsf-hmm_amd.distributed")
+        self.torch = torch
+        self.V = V
+        S, I = gl.shape[0] if gl is not None else raw.shape[0], (gl if gl is not None else raw).shape[1]
+        self.ranges = dd.site_ranges_ragged(S, V)
+        self.barrier = threading.Barrier(V)
+        dev = torch.device("cuda", 0)
+        self.h, self.send, self.recv = [], [], []
+        self.gathers = [0] * V
+        for r, (lo, hi) in enumerate(self.ranges):
+            h = pkg.NgsFHMM(I, hi - lo, mode=pkg.MODE_FAST if mode is None else mode)
+            if raw is not None:
+                h.load_raw(np.ascontiguousarray(raw[lo:hi]), np.ascontiguousarray(pos[lo:hi]),
+                           space=0, call_geno=True)
+            else:
+                h.load(np.ascontiguousarray(gl[lo:hi]), np.ascontiguousarray(pos[lo:hi]))
+            n = h.site_shard_bytes()
+            self.send.append(torch.zeros(n // 8, dtype=torch.float64, device=dev))
+            self.recv.append(torch.zeros(V * (n // 8), dtype=torch.float64, device=dev))
+            self.h.append(h)
+        torch.cuda.synchronize()
+        for r, h in enumerate(self.h):
+            h.site_shard_setup(r, V, self.send[r].data_ptr(), self.recv[r].data_ptr(),
+                               h.site_shard_bytes(), self._gather(r))
+
+    def _gather(self, r):
+        def cb(n):
+            k = n // 8
+            self.h[r].synchronize()            # this handle's stream has written send[r]
+            self.barrier.wait()
+            for q in range(self.V):
+                self.recv[r][q * k:(q + 1) * k].copy_(self.send[q][:k])
+            self.torch.cuda.synchronize()
+            self.barrier.wait()                # nobody rewrites its send before all have read it
+            self.gathers[r] += 1
+        return cb
+
+    def each(self, fn):
+        """fn(r, handle) on every handle, one thread each; returns the results in rank order."""
+        out, err = [None] * self.V, []
+
+        def run(r):
+            try:
+                out[r] = fn(r, self.h[r])
+            except BaseException as e:
+                err.append(e)
+                self.barrier.abort()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(self.V)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def set_params(self, F, A, freq):
+        for (lo, hi), h in zip(self.ranges, self.h):
+            h.set_params(F, A, np.broadcast_to(freq, (self.ranges[-1][1],))[lo:hi])
+            h.init_emission()
+
+    def viterbi(self):
+        scores = None
+        for h in self.h:
+            scores = h.viterbi_shard_forward(scores)
+        state, parts = None, [None] * self.V
+        for r in reversed(range(self.V)):
+            state, parts[r] = self.h[r].viterbi_shard_back(state)
+        return np.concatenate(parts, axis=1)
+
+    def close(self):
+        for h in self.h:
+            h.close()
+
+
+@pytest.mark.parametrize("V", [2, 3])
+def test_site_shards_reproduce_one_handle(pkg, orc_libm, V):
+    I, S = 37, 5000
+    d = pkg.simulate.simulate(I, S, seed=11 + V, n_chrom=3, missing_rate=0.05, indF="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    rng = np.random.default_rng(5)
+    F, A = rng.uniform(0.02, 0.6, I), rng.uniform(0.01, 2.0, I)
+    freq = rng.uniform(0.05, 0.45, S)
+
+    whole = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST)
+    whole.load(gl, d.pos_dist_mb)
+    whole.set_params(F, A, freq)
+    whole.init_emission()
+    ch = Chain(pkg, gl, d.pos_dist_mb, V)
+    ch.set_params(F, A, freq)
+
+    # E-step: the chain's log-likelihoods on every handle, the posteriors of the own sites
+    whole.estep()
+    lk = ch.each(lambda r, h: (h.estep(), h.ind_lkl.copy())[1])
+    for r in range(1, V):
+        assert np.array_equal(lk[r], lk[0])                    # the same bits everywhere
+    np.testing.assert_allclose(lk[0], whole.ind_lkl, rtol=1e-12)
+    post = np.concatenate([h.marg_prob for h in ch.h], axis=1)
+    np.testing.assert_allclose(post, whole.marg_prob, atol=1e-10)
+    assert min(ch.gathers) == max(ch.gathers) == 1
+
+    # objective values at arbitrary points (several per individual, some alone)
+    ind = np.concatenate([np.repeat(np.arange(I), 3), [4, 4, 9]]).astype(np.uint32)
+    pF = rng.uniform(0.001, 0.9, ind.size)
+    pA = rng.uniform(0.001, 5.0, ind.size)
+    want = whole.lkl(ind, pF, pA)
+    got = ch.each(lambda r, h: h.lkl(ind, pF, pA))
+    for r in range(1, V):
+        assert np.array_equal(got[r], got[0])
+    np.testing.assert_allclose(got[0], want, rtol=1e-12)
+    em = __import__("orclib").OracleEM(orc_libm, gl, d.pos_dist_mb)
+    em.set_params(F, A, freq)
+    assert em.init_emission() == 0
+    e = em.e_prob
+    np.testing.assert_allclose(got[0], [-orc_libm.lkl([f, a], e[int(i)], d.pos_dist_mb)
+                                        for i, f, a in zip(ind, pF, pA)], rtol=1e-11)
+
+    # whole iterations, teacher-forced (the optimizer amplifies last-bit noise; a shard cuts the
+    # site axis into other lane-chunks than the whole does)
+    for it in range(3):
+        whole.set_params(F, A, freq)
+        whole.init_emission()
+        ch.set_params(F, A, freq)
+        whole.iter_EM(1)
+        st = ch.each(lambda r, h: h.iter_EM(1))
+        pars = [(h.indF, h.alpha, h.ind_lkl.copy()) for h in ch.h]
+        for r in range(1, V):                                  # every handle took the same steps
+            assert np.array_equal(pars[r][0], pars[0][0]) and np.array_equal(pars[r][1], pars[0][1])
+            assert np.array_equal(pars[r][2], pars[0][2])
+            assert st[r].rounds == st[0].rounds and st[r].points == st[0].points
+        np.testing.assert_allclose(pars[0][2], whole.ind_lkl, rtol=1e-12)
+        np.testing.assert_allclose(pars[0][0], whole.indF, atol=2e-6)
+        np.testing.assert_allclose(pars[0][1], whole.alpha, rtol=2e-4, atol=2e-6)
+        f_chain = np.concatenate([h.freq for h in ch.h])
+        np.testing.assert_allclose(f_chain, whole.freq, rtol=1e-9, atol=1e-12)
+        post = np.concatenate([h.marg_prob for h in ch.h], axis=1)
+        np.testing.assert_allclose(post, whole.marg_prob, atol=1e-9)
+        F, A, freq = whole.indF, whole.alpha, whole.freq
+
+    # fixed indF / alpha: nothing to amplify
+    whole.set_params(F, A, freq)
+    whole.init_emission()
+    ch.set_params(F, A, freq)
+    for it in range(2):
+        whole.iter_EM(1, True, True)
+        ch.each(lambda r, h: h.iter_EM(1, True, True))
+    np.testing.assert_allclose(np.concatenate([h.freq for h in ch.h]), whole.freq, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(ch.h[0].ind_lkl, whole.ind_lkl, rtol=1e-12)
+
+    # decoding over the chain: the same path, cell for cell
+    whole.set_params(F, A, whole.freq)
+    ch.set_params(F, A, whole.freq)
+    assert np.array_equal(ch.viterbi(), whole.viterbi())
+    ch.close()
+    whole.close()
+
+
+def test_site_shards_of_called_genotypes(pkg):
+    """Packed handles (2-bit codes) as site shards: est_maf on the codes, the forward walk on
+    the class table."""
+    I, S, V = 150, 4000, 2
+    d = pkg.simulate.simulate(I, S, seed=3, n_chrom=2, missing_rate=0.05, indF="r")
+    whole = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST | pkg.GENO_PACKED)
+    whole.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=True)
+    whole.set_params(0.1, 0.2, 0.1)
+    whole.init_emission()
+    ch = Chain(pkg, None, d.pos_dist_mb, V, mode=pkg.MODE_FAST | pkg.GENO_PACKED, raw=d.gl)
+    ch.set_params(0.1, 0.2, 0.1)
+    for it in range(2):
+        whole.iter_EM(1, True, True)
+        ch.each(lambda r, h: h.iter_EM(1, True, True))
+    np.testing.assert_allclose(ch.h[1].ind_lkl, whole.ind_lkl, rtol=1e-12)
+    np.testing.assert_allclose(np.concatenate([h.freq for h in ch.h]), whole.freq, rtol=1e-11, atol=1e-14)
+    assert np.array_equal(ch.viterbi(), whole.viterbi())
+    ch.close()
+    whole.close()
+
+
+def test_site_shards_are_a_fast_mode_layout(pkg):
+    import torch
+    h = pkg.NgsFHMM(4, 64, mode=pkg.MODE_EXACT)
+    buf = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    with pytest.raises(pkg.NgsFHMMError, match="fast-mode layout"):
+        h.site_shard_setup(0, 2, buf.data_ptr(), buf.data_ptr(), 8 * 1024, lambda n: None)
+    h.close()
+    # a buffer smaller than nghmm_site_shard_bytes() is refused too
+    h = pkg.NgsFHMM(4, 64, mode=pkg.MODE_FAST)
+    with pytest.raises(pkg.NgsFHMMError, match="nghmm_site_shard_bytes"):
+        h.site_shard_setup(0, 2, buf.data_ptr(), buf.data_ptr(), 64, lambda n: None)
+    h.close()
+
+
+def test_a_failing_exchange_fails_the_call(pkg):
+    """An exception inside the all-gather callback must surface from the library call that
+    needed the exchange, not vanish in the C frame."""
+    import torch
+    I, S = 6, 800
+    d = pkg.simulate.simulate(I, S, seed=2)
+    h = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST)
+    h.load(pkg.simulate.normalise_log_gl(d.gl), d.pos_dist_mb)
+    n = h.site_shard_bytes()
+    send = torch.zeros(n // 8, dtype=torch.float64, device="cuda")
+    recv = torch.zeros(2 * (n // 8), dtype=torch.float64, device="cuda")
+
+    def boom(nbytes):
+        raise RuntimeError("link down")
+    h.site_shard_setup(0, 2, send.data_ptr(), recv.data_ptr(), n, boom)
+    h.set_params(0.1, 0.2, 0.1)
+    h.init_emission()
+    with pytest.raises(RuntimeError, match="link down"):
+        h.estep()
+    h.close()
