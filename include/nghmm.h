@@ -334,6 +334,22 @@ int nghmm_viterbi_shard_forward(nghmm_t* h, const double* scores_in, double* sco
 int nghmm_viterbi_shard_back(nghmm_t* h, const uint8_t* state_after, uint8_t* state_before,
                              uint8_t* path);
 
+/* ---- one process, several GPUs, fast mode: a CHAIN of site shards ----
+ * n handles of one process (one per GPU, or several on one), handle r holding all individuals
+ * for the r-th site range: nghmm_chain_setup installs the all-gather of nghmm_site_shard_setup
+ * among them (direct device-to-device copies between the handles' buffers -- over the GPU
+ * pair's xGMI link where the devices differ -- between two barriers of the handles' host
+ * threads) and owns the buffers; nghmm_chain_iter_em = iter_EM (EM.cpp:139-289) for the whole
+ * chain, every handle on a host thread of its own; ind_lkl [I] (host, may be NULL).
+ * nghmm_chain_mstep_freq: the allele-frequency step alone (`--freq e`), every handle on its
+ * own sites.  nghmm_chain_viterbi: path [I][all sites] (host).  n == 1 is the plain handle.
+ * This is what the C++ host's --n_gpus N uses; destroying a member dissolves the chain. */
+int nghmm_chain_setup(nghmm_t** handles, int n);
+int nghmm_chain_iter_em(nghmm_t** handles, int n, int freq_est, int indF_fixed, int alpha_fixed,
+                        double* ind_lkl, nghmm_mstep_stats* stats);
+int nghmm_chain_mstep_freq(nghmm_t** handles, int n, int freq_est);
+int nghmm_chain_viterbi(nghmm_t** handles, int n, uint8_t* path);
+
 /* Measurement and debugging switches of a handle.  None changes a result beyond rounding (the
  * kernels, their order on the stream or what is printed; DESIGN.md section 7 says what each is
  * for).  A handle reads them from the environment ONCE, in nghmm_create -- NGHMM_<NAME> with

@@ -14,10 +14,10 @@ This package holds only what the hot path needs:
 There is no CPU fallback: if ``libnghmm.so`` or a HIP device is missing, creating
 an :class:`NgsFHMM` raises.
 """
-from .hmm import (NgsFHMM, NgsFHMMError, Group, MODE_EXACT, MODE_FAST, GENO_PACKED, LD_INTENDED, EPROB_LD, library_path,
+from .hmm import (NgsFHMM, NgsFHMMError, Group, Chain, MODE_EXACT, MODE_FAST, GENO_PACKED, LD_INTENDED, EPROB_LD, library_path,
                   load_library,
                   build_library)
 from . import simulate
 
-__all__ = ["NgsFHMM", "NgsFHMMError", "Group", "MODE_EXACT", "MODE_FAST", "GENO_PACKED", "LD_INTENDED", "EPROB_LD", "library_path",
+__all__ = ["NgsFHMM", "NgsFHMMError", "Group", "Chain", "MODE_EXACT", "MODE_FAST", "GENO_PACKED", "LD_INTENDED", "EPROB_LD", "library_path",
            "load_library", "build_library", "simulate"]

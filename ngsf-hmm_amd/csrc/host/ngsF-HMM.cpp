@@ -62,7 +62,7 @@ struct Params {  // ngsF-HMM.hpp:13-52
   bool no_pack = false;          // --no_pack: never keep called genotypes as 2-bit codes
   unsigned n_starts = 1;         // --n_starts R: R replicates from seeds seed, seed+1, ... (ngsF-HMM.sh)
   bool keep_starts = false;      // --keep_starts: write every replicate's files, PREFIX.REP_rr.*
-  unsigned n_gpus = 1;           // --n_gpus N: the individuals split over N handles, one per device
+  unsigned n_gpus = 1;           // --n_gpus N: the sites split over N handles, one per device
   std::vector<int> devices;      // --devices a,b,..: the device of each handle (default 0..N-1)
   FILE* out = stdout;            // where this run's progress lines go (replicates: a buffer)
   std::string prefix;            // output prefix of this run
@@ -72,12 +72,20 @@ struct Params {  // ngsF-HMM.hpp:13-52
   double tot_lkl = 0, prev_tot_lkl = 0;
 };
 
-// The cohort on the device(s): handle r holds the individuals [r I_loc, (r+1) I_loc) for all
-// sites (one handle unless --n_gpus N; include/nghmm.h "a GROUP of n handles").
+// The cohort on the device(s): handle r holds ALL individuals for the sites [lo[r], lo[r + 1])
+// (one handle unless --n_gpus N; include/nghmm.h "a CHAIN of site shards").  The site axis is
+// the one the input files are ordered by, so a block of sites read goes to the handle that owns
+// it as it is.
 struct Cohort {
   std::vector<nghmm_t*> hs;
-  uint64_t I_loc = 0;
+  std::vector<uint64_t> lo;   // n() + 1 cuts; multiples of 16 sites except the last
   int n() const { return (int)hs.size(); }
+  uint64_t sites(int r) const { return lo[r + 1] - lo[r]; }
+  void cut(uint64_t S, unsigned n) {
+    lo.assign(1, 0);
+    for (unsigned r = 1; r < n; r++) lo.push_back(std::max<uint64_t>(S * r / n / 16 * 16, lo.back() + 1));
+    lo.push_back(S);
+  }
 };
 
 [[noreturn]] void fatal(const char* func, const char* msg) {  // gen_func.cpp:12-18
@@ -467,37 +475,25 @@ int load_geno(Params& P, Cohort& C, bool packed) {
   const uint64_t unread_bits = NGHMM_GL_UNREAD_BITS;
   memcpy(&unread, &unread_bits, sizeof unread);
   const int N = C.n();
-  const uint64_t I_loc = C.I_loc;
-  for (nghmm_t* h : C.hs) check(nghmm_load_begin(h, P.pos_dist.data()), "read_geno");
-  // a block [ns][I][..] goes to handle r as its columns [ns][I_loc][..]
-  std::vector<double> part_d;
-  std::vector<int8_t> part_g;
+  // the distance in front of a later handle's first site is the file's (+inf only at a
+  // chromosome start)
+  for (int r = 0; r < N; r++) check(nghmm_load_begin(C.hs[r], P.pos_dist.data() + C.lo[r]), "read_geno");
+  // a block [ns][I][..] of sites goes to the handle(s) whose range it lies in, as it is
   auto send_gl = [&](uint64_t s0, uint64_t ns, const double* blockbuf, int space, int check_nan) {
     int rc = NGHMM_OK;
     for (int r = 0; r < N && rc == NGHMM_OK; r++) {
-      const double* src = blockbuf;
-      if (N > 1) {
-        part_d.resize((size_t)ns * I_loc * 3);
-        for (uint64_t s = 0; s < ns; s++)
-          memcpy(&part_d[s * I_loc * 3], blockbuf + (s * I + (uint64_t)r * I_loc) * 3,
-                 I_loc * 3 * sizeof(double));
-        src = part_d.data();
-      }
-      rc = nghmm_load_gl_raw_sites(C.hs[r], s0, ns, src, space, P.call_geno ? 1 : 0, check_nan);
+      const uint64_t a = std::max(s0, C.lo[r]), b = std::min(s0 + ns, C.lo[r + 1]);
+      if (a < b)
+        rc = nghmm_load_gl_raw_sites(C.hs[r], a - C.lo[r], b - a, blockbuf + (a - s0) * I * 3, space,
+                                     P.call_geno ? 1 : 0, check_nan);
     }
     return rc;
   };
   auto send_geno = [&](uint64_t s0, uint64_t ns, const int8_t* blockbuf) {
     int rc = NGHMM_OK;
     for (int r = 0; r < N && rc == NGHMM_OK; r++) {
-      const int8_t* src = blockbuf;
-      if (N > 1) {
-        part_g.resize((size_t)ns * I_loc);
-        for (uint64_t s = 0; s < ns; s++)
-          memcpy(&part_g[s * I_loc], blockbuf + s * I + (uint64_t)r * I_loc, I_loc);
-        src = part_g.data();
-      }
-      rc = nghmm_load_geno_sites(C.hs[r], s0, ns, src);
+      const uint64_t a = std::max(s0, C.lo[r]), b = std::min(s0 + ns, C.lo[r + 1]);
+      if (a < b) rc = nghmm_load_geno_sites(C.hs[r], a - C.lo[r], b - a, blockbuf + (a - s0) * I);
     }
     return rc;
   };
@@ -912,8 +908,7 @@ bool init_values(Params& P, Cohort& C) {
     for (uint64_t s = 0; s < S; s++) P.freq[s] = clampd(atof(P.in_freq.c_str()), q_min, q_max);
   }
   for (int r = 0; r < C.n(); r++)
-    check(nghmm_set_params(C.hs[r], P.indF.data() + (size_t)r * C.I_loc,
-                           P.alpha.data() + (size_t)r * C.I_loc, P.freq.data()),
+    check(nghmm_set_params(C.hs[r], P.indF.data(), P.alpha.data(), P.freq.data() + C.lo[r]),
           "init_output");
   return estimate;
 }
@@ -970,14 +965,28 @@ void print_iter(const Params& P, Cohort& C) {
   {
     uint64_t batch = (256ull << 20) / (9 * S);
     if (batch < 1) batch = 1;
-    if (batch > C.I_loc) batch = C.I_loc;
-    std::vector<char> text(batch * 9 * S);
-    for (nghmm_t* h : C.hs)   // individuals in order: handle by handle
-      for (uint64_t i0 = 0; i0 < C.I_loc; i0 += batch) {
-        const uint64_t nb = (C.I_loc - i0) < batch ? (C.I_loc - i0) : batch;
-        check(nghmm_format_posteriors(h, i0, nb, text.data()), "print_iter");
-        fwrite(text.data(), 1, nb * 9 * S, fh);
+    if (batch > I) batch = I;
+    std::vector<char> text(batch * 9 * S), piece(C.n() > 1 ? batch * 9 * C.sites(0) + 9 * 16 * batch : 0);
+    for (uint64_t i0 = 0; i0 < I; i0 += batch) {
+      const uint64_t nb = (I - i0) < batch ? (I - i0) : batch;
+      if (C.n() == 1) {
+        check(nghmm_format_posteriors(C.hs[0], i0, nb, text.data()), "print_iter");
+      } else {
+        // a line is the handles' pieces one after the other: a piece's closing newline becomes
+        // the tab in front of the next piece's first value
+        for (int r = 0; r < C.n(); r++) {
+          const uint64_t Sr = C.sites(r);
+          if (piece.size() < nb * 9 * Sr) piece.resize(nb * 9 * Sr);
+          check(nghmm_format_posteriors(C.hs[r], i0, nb, piece.data()), "print_iter");
+          for (uint64_t i = 0; i < nb; i++) {
+            char* dst = &text[(i * S + C.lo[r]) * 9];
+            memcpy(dst, &piece[i * 9 * Sr], 9 * Sr);
+            if (r + 1 < C.n()) dst[9 * Sr - 1] = '\t';
+          }
+        }
       }
+      fwrite(text.data(), 1, nb * 9 * S, fh);
+    }
   }
   fclose(fh);
 
@@ -986,19 +995,15 @@ void print_iter(const Params& P, Cohort& C) {
   if (!fh) fatal(__FUNCTION__, "cannot open GENO output file!");
   setvbuf(fh, nullptr, _IOFBF, 1 << 22);
   const uint64_t chunk = 4096;  // sites per block
-  std::vector<double> blk(chunk * I * 3), part(C.n() > 1 ? chunk * C.I_loc * 3 : 0);
+  std::vector<double> blk(chunk * I * 3);
   for (uint64_t s0 = 0; s0 < S; s0 += chunk) {
     const uint64_t ns = (S - s0) < chunk ? (S - s0) : chunk;
-    // EM.cpp:367-376 on the device, from the decoded path and the final frequencies
-    if (C.n() == 1) {
-      check(nghmm_geno_posteriors(C.hs[0], s0, ns, blk.data()), "print_iter");
-    } else {
-      for (int r = 0; r < C.n(); r++) {   // the file is site-major over ALL individuals
-        check(nghmm_geno_posteriors(C.hs[r], s0, ns, part.data()), "print_iter");
-        for (uint64_t s = 0; s < ns; s++)
-          memcpy(&blk[(s * I + (uint64_t)r * C.I_loc) * 3], &part[s * C.I_loc * 3],
-                 C.I_loc * 3 * sizeof(double));
-      }
+    // EM.cpp:367-376 on the device, from the decoded path and the final frequencies; the file
+    // is site-major over all individuals: a block comes from the handle(s) that own its sites
+    for (int r = 0; r < C.n(); r++) {
+      const uint64_t a = std::max(s0, C.lo[r]), b = std::min(s0 + ns, C.lo[r + 1]);
+      if (a < b)
+        check(nghmm_geno_posteriors(C.hs[r], a - C.lo[r], b - a, &blk[(a - s0) * I * 3]), "print_iter");
     }
     fwrite(blk.data(), sizeof(double), ns * I * 3, fh);
   }
@@ -1007,13 +1012,12 @@ void print_iter(const Params& P, Cohort& C) {
 
 void sync_outputs(Params& P, Cohort& C, bool with_viterbi) {
   P.path.resize((size_t)P.n_ind * P.n_sites, 0);
-  for (int r = 0; r < C.n(); r++) {
-    const size_t i0 = (size_t)r * C.I_loc;
-    check(nghmm_get_params(C.hs[r], P.indF.data() + i0, P.alpha.data() + i0,
-                           r == 0 ? P.freq.data() : nullptr),
+  // indF / alpha are the cohort's on every handle; the frequencies those of its own sites
+  for (int r = 0; r < C.n(); r++)
+    check(nghmm_get_params(C.hs[r], r == 0 ? P.indF.data() : nullptr, r == 0 ? P.alpha.data() : nullptr,
+                           P.freq.data() + C.lo[r]),
           "print_iter");
-    if (with_viterbi) check(nghmm_viterbi(C.hs[r], P.path.data() + i0 * P.n_sites), "viterbi");
-  }
+  if (with_viterbi) check(nghmm_chain_viterbi(C.hs.data(), C.n(), P.path.data()), "viterbi");
 }
 
 void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-225
@@ -1151,8 +1155,8 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
   if (P.devices.empty())
     for (unsigned r = 0; r < P.n_gpus; r++) P.devices.push_back(P.n_gpus == 1 ? P.device : (int)r);
   if (P.n_gpus > 1) {
-    if (P.n_ind % P.n_gpus || P.n_sites % P.n_gpus)
-      fatal(__FUNCTION__, "--n_gpus must divide the number of individuals and of sites!");
+    if (P.n_sites < 32ull * P.n_gpus)
+      fatal(__FUNCTION__, "too few sites for --n_gpus (the site axis is what the GPUs share)!");
     if (P.mode != NGHMM_MODE_FAST) fatal(__FUNCTION__, "--n_gpus > 1 needs --mode fast!");
     if (P.n_starts > 1) fatal(__FUNCTION__, "--n_starts and --n_gpus > 1 cannot be combined!");
   }
@@ -1163,7 +1167,7 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
 void run_em(Params& P, Cohort& C) {
   const bool estimate_freq = init_values(P, C);
   if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
-    check(nghmm_group_mstep_freq(C.hs.data(), C.n(), 1), "init_output");
+    check(nghmm_chain_mstep_freq(C.hs.data(), C.n(), 1), "init_output");
   if (P.verbose >= 1) fprintf(P.out, "==> Calculating initial emission probabilities\n");
   for (nghmm_t* h : C.hs) check(nghmm_emission(h), "calc_emission");
 
@@ -1202,7 +1206,7 @@ void run_em(Params& P, Cohort& C) {
     int freq_step = P.freq_est;
     if (P.ld_intended && (P.freq_est == 2 || P.e_prob_calc == 2) && P.freq_est != 0)
       freq_step |= NGHMM_LD_INTENDED | (P.e_prob_calc == 2 ? NGHMM_EPROB_LD : 0);
-    check(nghmm_group_iter_em(C.hs.data(), C.n(), freq_step, P.indF_fixed, P.alpha_fixed,
+    check(nghmm_chain_iter_em(C.hs.data(), C.n(), freq_step, P.indF_fixed, P.alpha_fixed,
                               P.ind_lkl.data(), &stats),
           "iter_EM");
     P.prev_tot_lkl = P.tot_lkl;
@@ -1286,12 +1290,12 @@ int main(int argc, char** argv) {
   // mode).  An input the codes cannot express (an empty text line) falls back to likelihoods.
   bool packed = (P.call_geno || !P.in_lkl) && !P.no_pack;
   Cohort C;
-  C.I_loc = P.n_ind / P.n_gpus;
+  C.cut(P.n_sites, P.n_gpus);
   auto create_all = [&](bool pk) {
     for (nghmm_t* h : C.hs) nghmm_destroy(h);
     C.hs.assign(P.n_gpus, nullptr);
     for (unsigned r = 0; r < P.n_gpus; r++)
-      check(nghmm_create(&C.hs[r], C.I_loc, P.n_sites, P.devices[r],
+      check(nghmm_create(&C.hs[r], P.n_ind, C.sites((int)r), P.devices[r],
                          P.mode | (pk ? NGHMM_GENO_PACKED : 0)),
             "nghmm_create");
   };
@@ -1311,8 +1315,8 @@ int main(int argc, char** argv) {
     else
       printf("> GENO data on the device in %.2f s\n", dt);
   }
-  // one handle: a group of one; several: shard configuration and the site-shard copies
-  check(nghmm_group_setup(C.hs.data(), C.n()), "nghmm_group_setup");
+  // several handles: the chain's exchange (one handle: nothing to set up)
+  check(nghmm_chain_setup(C.hs.data(), C.n()), "nghmm_chain_setup");
   nghmm_t* h = C.hs[0];
   if (P.n_starts == 1) {
     run_em(P, C);
@@ -1340,8 +1344,7 @@ int main(int argc, char** argv) {
     std::vector<Cohort> cs(R);
     for (unsigned r = 0; r < R; r++) {
       cs[r].hs = {hs[r]};
-      cs[r].I_loc = P.n_ind;
-      if (r) check(nghmm_group_setup(cs[r].hs.data(), 1), "nghmm_group_setup");
+      cs[r].cut(P.n_sites, 1);
     }
     std::vector<std::thread> th;
     for (unsigned r = 0; r < R; r++) th.emplace_back([&, r] { run_em(runs[r], cs[r]); });

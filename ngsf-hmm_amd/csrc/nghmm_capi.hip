@@ -20,7 +20,9 @@
 #include <cstring>
 #include <new>
 #include <functional>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -60,6 +62,7 @@ enum Slot { SLOT_EMISSION = 0, SLOT_FORWARD = 1, SLOT_BACKWARD = 2, SLOT_LKL = 3
 
 }  // namespace
 
+struct ChainCtx;   // nghmm_chain_setup
 struct nghmm_handle {
   uint64_t I = 0, S = 0;
   int device = 0, mode = NGHMM_MODE_EXACT;
@@ -142,6 +145,10 @@ struct nghmm_handle {
   int g_n = 0, g_rank = 0;
   double *g_send = nullptr, *g_recv = nullptr, *g_freq_own = nullptr, *g_freq_all = nullptr;
   hipStream_t g_xstream = nullptr;
+  // member of an in-process chain of site shards (nghmm_chain_setup): the exchange buffers of
+  // fast.shard on this handle's device and the chain's shared state
+  struct ChainCtx* chain = nullptr;
+  double *c_send = nullptr, *c_recv = nullptr;
   bool loading = false;
   // sites that have arrived since nghmm_load_begin, as disjoint [begin, end) runs: every site
   // must arrive exactly once (a repeated site would OR two codes into a packed cell)
@@ -667,6 +674,10 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
   return NGHMM_OK;
 }
 
+namespace {
+void chain_release(nghmm_t* h);  // leaves its chain (the others' chain is then no chain any more)
+}
+
 int nghmm_destroy(nghmm_t* h) {
   if (!h) return NGHMM_OK;
   if (h->n_replicas.load() > 0) {
@@ -675,6 +686,7 @@ int nghmm_destroy(nghmm_t* h) {
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  chain_release(h);
   void* own[] = {h->d_freq, h->d_eprob, h->d_fw, h->d_marg, h->d_indF,
                  h->d_alpha, h->d_ind_lkl, h->d_flags, h->d_pt_ind, h->d_pt_F, h->d_pt_A,
                  h->d_pt_lkl, h->d_bp, h->d_path_sites, h->d_path, h->d_tmp, h->d_passes, h->d_vit,
@@ -2395,6 +2407,218 @@ int nghmm_group_mstep_freq(nghmm_t** hs, int n, int freq_est) {
   });
   if (rc != NGHMM_OK) return rc;
   return group_freq_phases(hs, n);
+}
+
+// ---- one process, several GPUs, fast mode: a CHAIN of site shards ----
+// (include/nghmm.h; between processes ngsf-hmm_amd/distributed.py does the same over RCCL.)
+// The all-gather of nghmm_site_shard_setup among the handles of one process: every handle runs
+// on a host thread of its own; at an exchange it waits for its stream (its part of the send
+// buffers is complete), meets the others at a barrier, copies every handle's part into its own
+// receive buffer -- direct device-to-device copies, over the GPU pair's xGMI link where the
+// devices differ --, waits for the copies and meets the others again (nobody rewrites its part
+// before everyone has read it).  A handle that fails aborts the barrier for the others.
+struct ChainCtx {
+  std::vector<nghmm_t*> hs;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool aborted = false;
+  int refs = 0;
+  // false: somebody aborted
+  bool wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
+    const uint64_t gen = generation;
+    if (++arrived == (int)hs.size()) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(lk, [&] { return generation != gen || aborted; });
+    return !aborted;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = true;
+    cv.notify_all();
+  }
+  void reset() {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = false;
+    arrived = 0;
+  }
+};
+
+namespace {
+
+int chain_allgather(void* user, uint64_t n_bytes) {
+  nghmm_t* h = static_cast<nghmm_t*>(user);
+  ChainCtx* cx = h->chain;
+  const int n = (int)cx->hs.size();
+  bool ok = hipStreamSynchronize(h->stream) == hipSuccess;
+  if (!ok) cx->abort();
+  if (!cx->wait()) return 1;
+  for (int q = 0; q < n && ok; ++q) {
+    nghmm_t* o = cx->hs[q];
+    char* dst = reinterpret_cast<char*>(h->c_recv) + (size_t)q * n_bytes;
+    const hipError_t e = o->device == h->device
+                             ? hipMemcpyAsync(dst, o->c_send, n_bytes, hipMemcpyDeviceToDevice, h->stream)
+                             : hipMemcpyPeerAsync(dst, h->device, o->c_send, o->device, n_bytes, h->stream);
+    ok = e == hipSuccess;
+  }
+  if (ok) ok = hipStreamSynchronize(h->stream) == hipSuccess;
+  if (!ok) cx->abort();
+  return cx->wait() && ok ? 0 : 1;
+}
+
+void chain_release(nghmm_t* h) {
+  if (!h->chain) return;
+  ChainCtx* cx = h->chain;
+  h->chain = nullptr;
+  h->fast.shard.world = 1;
+  h->fast.shard.allgather = nullptr;
+  bool last;
+  {
+    std::lock_guard<std::mutex> lk(cx->mu);
+    for (auto& m : cx->hs)
+      if (m == h) m = nullptr;
+    last = --cx->refs == 0;
+  }
+  if (last) delete cx;
+  if (h->c_send) (void)hipFree(h->c_send);
+  if (h->c_recv) (void)hipFree(h->c_recv);
+  h->c_send = h->c_recv = nullptr;
+}
+
+bool is_chain(nghmm_t** hs, int n) {
+  if (!hs || n < 1 || !hs[0]) return false;
+  if (n == 1) return hs[0]->chain == nullptr || hs[0]->chain->hs.size() == 1;
+  ChainCtx* cx = hs[0]->chain;
+  if (!cx || (int)cx->hs.size() != n) return false;
+  for (int r = 0; r < n; ++r)
+    if (hs[r] != cx->hs[r]) return false;
+  return true;
+}
+
+}  // namespace
+
+int nghmm_chain_setup(nghmm_t** hs, int n) {
+  g_last_error.clear();
+  if (!hs || n < 1) return NGHMM_ERR_ARG;
+  for (int r = 0; r < n; ++r) {
+    nghmm_t* h = hs[r];
+    if (!h || h->I != hs[0]->I || h->mode != hs[0]->mode || h->packed != hs[0]->packed || h->parent ||
+        h->n_replicas.load() > 0 || h->g_n > 1 || h->I_tot != h->I) {
+      set_error("nghmm_chain_setup: plain handles of the same individuals, mode and packing are needed");
+      return NGHMM_ERR_ARG;
+    }
+  }
+  if (n > 1 && hs[0]->mode != NGHMM_MODE_FAST) {
+    set_error("nghmm_chain_setup: site shards are a fast-mode layout");
+    return NGHMM_ERR_ARG;
+  }
+  for (int r = 0; r < n; ++r) chain_release(hs[r]);
+  if (n == 1) return NGHMM_OK;
+  int rc;
+  for (int r = 0; r < n; ++r)
+    for (int q = 0; q < n; ++q)
+      if (hs[r]->device != hs[q]->device) {
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, hs[r]->device, hs[q]->device));
+        if (!can) {
+          set_error("nghmm_chain_setup: device %d cannot access device %d", hs[r]->device, hs[q]->device);
+          return NGHMM_ERR_HIP;
+        }
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        const hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+        (void)hipGetLastError();
+      }
+  ChainCtx* cx = new (std::nothrow) ChainCtx;
+  if (!cx) return NGHMM_ERR_NOMEM;
+  cx->hs.assign(hs, hs + n);
+  cx->refs = n;
+  for (int r = 0; r < n; ++r) hs[r]->chain = cx;
+  for (int r = 0; r < n; ++r) {
+    nghmm_t* h = hs[r];
+    const uint64_t bytes = nghmm_site_shard_bytes(h);
+    if ((rc = use_device(h)) || (rc = dev_alloc(&h->c_send, (size_t)(bytes / sizeof(double)))) ||
+        (rc = dev_alloc(&h->c_recv, (size_t)(bytes / sizeof(double)) * n)) ||
+        (rc = nghmm_site_shard_setup(h, r, n, h->c_send, h->c_recv, bytes, chain_allgather, h))) {
+      const std::string msg = g_last_error;
+      for (int q = 0; q < n; ++q) chain_release(hs[q]);
+      g_last_error = msg;
+      return rc;
+    }
+  }
+  return NGHMM_OK;
+}
+
+int nghmm_chain_iter_em(nghmm_t** hs, int n, int freq_est, int indF_fixed, int alpha_fixed,
+                        double* ind_lkl, nghmm_mstep_stats* stats) {
+  g_last_error.clear();
+  if (!is_chain(hs, n)) {
+    set_error("nghmm_chain_iter_em: call nghmm_chain_setup on these handles first");
+    return NGHMM_ERR_ARG;
+  }
+  if (n == 1) return nghmm_iter_em(hs[0], freq_est, indF_fixed, alpha_fixed, ind_lkl, stats);
+  if (freq_est & NGHMM_LD_INTENDED) {
+    set_error("the intended --freq_est 2 walks the sites in order on ONE handle: not available "
+              "for a chain of several");
+    return NGHMM_ERR_ARG;
+  }
+  ChainCtx* cx = hs[0]->chain;
+  cx->reset();
+  std::vector<nghmm_mstep_stats> st(n);
+  const int rc = for_each_rank(n, [&](int r) -> int {
+    // every handle computes the chain's log-likelihoods: the first one's go to the caller
+    const int rr = nghmm_iter_em(hs[r], freq_est, indF_fixed, alpha_fixed, r == 0 ? ind_lkl : nullptr,
+                                 &st[r]);
+    if (rr != NGHMM_OK) cx->abort();
+    return rr;
+  });
+  if (stats) *stats = st[0];
+  return rc;
+}
+
+int nghmm_chain_mstep_freq(nghmm_t** hs, int n, int freq_est) {
+  g_last_error.clear();
+  if (!is_chain(hs, n)) {
+    set_error("nghmm_chain_mstep_freq: call nghmm_chain_setup on these handles first");
+    return NGHMM_ERR_ARG;
+  }
+  // every handle has all individuals of its own sites: nothing to exchange
+  return for_each_rank(n, [&](int r) -> int { return nghmm_mstep_freq(hs[r], freq_est); });
+}
+
+int nghmm_chain_viterbi(nghmm_t** hs, int n, uint8_t* path) {
+  g_last_error.clear();
+  if (!is_chain(hs, n) || !path) {
+    set_error("nghmm_chain_viterbi: call nghmm_chain_setup on these handles first");
+    return NGHMM_ERR_ARG;
+  }
+  if (n == 1) return nghmm_viterbi(hs[0], path);
+  const uint64_t I = hs[0]->I;
+  uint64_t S_tot = 0;
+  for (int r = 0; r < n; ++r) S_tot += hs[r]->S;
+  int rc;
+  std::vector<double> scores((size_t)I * 2);
+  for (int r = 0; r < n; ++r)
+    if ((rc = nghmm_viterbi_shard_forward(hs[r], r ? scores.data() : nullptr, scores.data()))) return rc;
+  std::vector<uint8_t> state(I), part;
+  uint64_t hi = S_tot;
+  for (int r = n - 1; r >= 0; --r) {
+    const uint64_t S = hs[r]->S, lo = hi - S;
+    part.resize((size_t)I * S);
+    if ((rc = nghmm_viterbi_shard_back(hs[r], r == n - 1 ? nullptr : state.data(), state.data(),
+                                       part.data())))
+      return rc;
+    for (uint64_t i = 0; i < I; ++i) std::memcpy(path + i * S_tot + lo, part.data() + i * S, S);
+    hi = lo;
+  }
+  return NGHMM_OK;
 }
 
 int nghmm_set_switch(nghmm_t* h, const char* name, long value) {

@@ -125,6 +125,10 @@ def load_library():
         "nghmm_set_switch": (i32, [vp, C.c_char_p, C.c_long]),
         "nghmm_site_shard_bytes": (u64, [vp]),
         "nghmm_site_shard_setup": (i32, [vp, i32, i32, vp, vp, u64, ALLGATHER_FN, vp]),
+        "nghmm_chain_setup": (i32, [C.POINTER(vp), i32]),
+        "nghmm_chain_iter_em": (i32, [C.POINTER(vp), i32, i32, i32, i32, dp, C.POINTER(MstepStats)]),
+        "nghmm_chain_mstep_freq": (i32, [C.POINTER(vp), i32, i32]),
+        "nghmm_chain_viterbi": (i32, [C.POINTER(vp), i32, C.POINTER(C.c_uint8)]),
         "nghmm_viterbi_shard_forward": (i32, [vp, dp, dp]),
         "nghmm_viterbi_shard_back": (i32, [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
                                            C.POINTER(C.c_uint8)]),
@@ -161,7 +165,8 @@ EXPORTED_SYMBOLS = [
     "nghmm_synchronize",
     "nghmm_kernel_ms", "nghmm_set_switch",
     "nghmm_site_shard_bytes", "nghmm_site_shard_setup", "nghmm_viterbi_shard_forward",
-    "nghmm_viterbi_shard_back",
+    "nghmm_viterbi_shard_back", "nghmm_chain_setup", "nghmm_chain_iter_em", "nghmm_chain_mstep_freq",
+    "nghmm_chain_viterbi",
 ]
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_void_p)
@@ -587,3 +592,51 @@ class Group:
             self._arr, len(self.handles), int(freq_est), int(indF_fixed), int(alpha_fixed),
             _dp(self.ind_lkl), C.byref(st)))
         return st
+
+
+class Chain:
+    """n fast-mode handles of one process as one data set cut along the SITE axis
+    (nghmm_chain_setup / nghmm_chain_iter_em): handle r holds all individuals for the r-th
+    site range; log-likelihoods, indF and alpha are the chain's and equal on every handle."""
+
+    def __init__(self, handles):
+        self.handles = list(handles)
+        self.lib = self.handles[0].lib
+        n = len(self.handles)
+        self._arr = (C.c_void_p * n)(*[h._h for h in self.handles])
+        self.handles[0]._check(self.lib.nghmm_chain_setup(self._arr, n))
+        self.n_ind = self.handles[0].n_ind
+        self.n_sites = sum(h.n_sites for h in self.handles)
+        self.ind_lkl = np.full(self.n_ind, -math.inf)
+
+    def _members_open(self):
+        if any(h.closed for h in self.handles):
+            raise NgsFHMMError(-10, "a member of this chain has been closed")
+
+    def mstep_freq(self, freq_est=1):
+        self._members_open()
+        self.handles[0]._check(self.lib.nghmm_chain_mstep_freq(self._arr, len(self.handles),
+                                                               int(freq_est)))
+
+    def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        self._members_open()
+        st = MstepStats()
+        self.handles[0]._check(self.lib.nghmm_chain_iter_em(
+            self._arr, len(self.handles), int(freq_est), int(indF_fixed), int(alpha_fixed),
+            _dp(self.ind_lkl), C.byref(st)))
+        return st
+
+    def viterbi(self):
+        self._members_open()
+        path = np.empty((self.n_ind, self.n_sites), dtype=np.uint8)
+        self.handles[0]._check(self.lib.nghmm_chain_viterbi(
+            self._arr, len(self.handles), path.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return path
+
+    @property
+    def freq(self):
+        return np.concatenate([h.freq for h in self.handles])
+
+    @property
+    def marg_prob(self):
+        return np.concatenate([h.marg_prob for h in self.handles], axis=1)

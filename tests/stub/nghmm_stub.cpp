@@ -141,25 +141,34 @@ int nghmm_get_params(nghmm_t* h, double* F, double* A, double* f) {
 }
 int nghmm_emission(nghmm_t* h) { return h && h->loaded ? NGHMM_OK : NGHMM_ERR_ARG; }
 int nghmm_mstep_freq(nghmm_t* h, int) { return h && h->loaded ? NGHMM_OK : NGHMM_ERR_ARG; }
-int nghmm_group_setup(nghmm_t** hs, int n) {
+// a chain of site shards (what the host's --n_gpus uses): every handle all individuals, the
+// sites one range after the other
+int nghmm_chain_setup(nghmm_t** hs, int n) {
   if (!hs || n < 1) return NGHMM_ERR_ARG;
   for (int r = 0; r < n; ++r) {
-    if (!hs[r] || !hs[r]->loaded || hs[r]->I != hs[0]->I || hs[r]->S != hs[0]->S) return NGHMM_ERR_ARG;
+    if (!hs[r] || !hs[r]->loaded || hs[r]->I != hs[0]->I) return NGHMM_ERR_ARG;
     hs[r]->g_n = n;
   }
   return NGHMM_OK;
 }
-int nghmm_group_mstep_freq(nghmm_t** hs, int n, int) {
+int nghmm_chain_mstep_freq(nghmm_t** hs, int n, int) {
   return hs && n >= 1 && hs[0]->g_n == n ? NGHMM_OK : NGHMM_ERR_ARG;
 }
-int nghmm_group_iter_em(nghmm_t** hs, int n, int, int, int, double* ind_lkl, nghmm_mstep_stats* st) {
+int nghmm_chain_iter_em(nghmm_t** hs, int n, int, int, int, double* ind_lkl, nghmm_mstep_stats* st) {
   if (!hs || n < 1 || hs[0]->g_n != n) return NGHMM_ERR_ARG;
   if (st) std::memset(st, 0, sizeof *st);
   for (int r = 0; r < n; ++r)
     for (uint64_t i = 0; i < hs[r]->I; ++i) {
       hs[r]->indF[i] = 0.25 + 0.5 * hs[r]->indF[i];  // something that converges
-      if (ind_lkl) ind_lkl[(size_t)r * hs[r]->I + i] = -1000.0 - hs[r]->indF[i];
+      if (ind_lkl && r == 0) ind_lkl[i] = -1000.0 - hs[r]->indF[i];
     }
+  return NGHMM_OK;
+}
+int nghmm_chain_viterbi(nghmm_t** hs, int n, uint8_t* path) {
+  if (!hs || n < 1 || hs[0]->g_n != n || !path) return NGHMM_ERR_ARG;
+  uint64_t S = 0;
+  for (int r = 0; r < n; ++r) S += hs[r]->S;
+  for (uint64_t k = 0; k < hs[0]->I * S; ++k) path[k] = (uint8_t)(k & 1);
   return NGHMM_OK;
 }
 int nghmm_viterbi(nghmm_t* h, uint8_t* path) {

@@ -307,11 +307,13 @@ def test_cli_empty_line_in_called_genotype_file(pkg, orc_det, orc_libm, data):
 @pytest.mark.parametrize("key,flags", [("glf_bin", ["--loglkl"]), ("geno_gz", []),
                                        ("glf_gz", ["--loglkl", "--call_geno"])])
 def test_cli_n_gpus_splits_the_cohort(pkg, data, key, flags):
-    """--n_gpus N: the individuals split over N handles (on an 8-GPU node one per GPU; here
-    --devices 0,0: two handles on the one GPU), the frequency step site-sharded with peer
-    copies (include/nghmm.h, "a GROUP of n handles").  Fixed indF/alpha: the files must equal
-    the single-handle run's except for last-bit differences of the frequencies; free
-    parameters: same paths and printed values up to the optimizer's spread."""
+    """--n_gpus N: the SITES split over N handles (on an 8-GPU node one per GPU; here
+    --devices 0,0 / 0,0,0: handles on the one GPU), every handle all individuals, the ranges'
+    operators exchanged by device copies (include/nghmm.h, "a CHAIN of site shards"); blocks of
+    the input go to the handle that owns their sites, output lines are stitched from the
+    handles' pieces.  Fixed indF/alpha: the files must equal the single-handle run's except for
+    last-bit differences of the frequencies; free parameters: same paths and printed values up
+    to the optimizer's spread."""
     d, paths, tmp = data
     base = ["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I, "--n_sites", S,
             "--freq", 0.1, "--min_iters", 2, "--max_iters", 4, "--mode", "fast", "--verbose", 0]
@@ -319,7 +321,9 @@ def test_cli_n_gpus_splits_the_cohort(pkg, data, key, flags):
                         ("free", ["--indF", "0.1,0.2"]), ("freq_e", ["--indF", "0.1,0.2", "--freq", "e"])):
         one, two = os.path.join(tmp, f"g1_{key}_{name}"), os.path.join(tmp, f"g2_{key}_{name}")
         cli_util.run_cli(base + extra + ["--out", one])
-        cli_util.run_cli(base + extra + ["--out", two, "--n_gpus", 2, "--devices", "0,0"])
+        n_dev = 3 if name == "fixed" else 2      # three ranges: none a multiple of the block size
+        cli_util.run_cli(base + extra + ["--out", two, "--n_gpus", n_dev, "--devices",
+                                         ",".join(["0"] * n_dev)])
         a, b = open(one + ".indF").read().split("\n"), open(two + ".indF").read().split("\n")
         assert abs(float(a[0]) - float(b[0])) <= 1e-9 * abs(float(a[0]))
         fa = np.array([float(x) for x in a[1 + I:1 + I + S]])

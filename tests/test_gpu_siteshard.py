@@ -230,3 +230,57 @@ def test_a_failing_exchange_fails_the_call(pkg):
     with pytest.raises(RuntimeError, match="link down"):
         h.estep()
     h.close()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_in_process_chain_equals_one_handle(pkg, packed):
+    """nghmm_chain_setup / _iter_em / _mstep_freq / _viterbi (what the C++ host's --n_gpus uses):
+    four handles on one GPU, the library's own barrier + device-copy all-gather."""
+    I, S, V = 60, 6400, 4
+    d = pkg.simulate.simulate(I, S, seed=21, n_chrom=2, missing_rate=0.05, indF="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    mode = pkg.MODE_FAST | (pkg.GENO_PACKED if packed else 0)
+
+    def make(lo, hi):
+        h = pkg.NgsFHMM(I, hi - lo, mode=mode)
+        if packed:
+            h.load_raw(np.ascontiguousarray(d.gl[lo:hi]), np.ascontiguousarray(d.pos_dist_mb[lo:hi]),
+                       space=0, call_geno=True)
+        else:
+            h.load(np.ascontiguousarray(gl[lo:hi]), np.ascontiguousarray(d.pos_dist_mb[lo:hi]))
+        return h
+    whole = make(0, S)
+    ranges = dd.site_ranges_ragged(S, V)
+    hs = [make(lo, hi) for lo, hi in ranges]
+    ch = pkg.Chain(hs)
+    # --freq e: the frequency step before any E-step, every handle on its own sites
+    for h in [whole] + hs:
+        h.set_params(0.1, 0.2, 0.1)
+    whole.mstep_freq(1)
+    ch.mstep_freq(1)
+    np.testing.assert_allclose(ch.freq, whole.freq, rtol=1e-12)
+    for h in [whole] + hs:
+        h.init_emission()
+    for it in range(3):
+        whole.iter_EM(1, True, True)
+        st = ch.iter_EM(1, True, True)
+    np.testing.assert_allclose(ch.ind_lkl, whole.ind_lkl, rtol=1e-12)
+    np.testing.assert_allclose(ch.freq, whole.freq, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(ch.marg_prob, whole.marg_prob, atol=1e-9)
+    # free parameters: every handle takes the same steps
+    st = ch.iter_EM(1)
+    whole.iter_EM(1)
+    assert st.rounds >= 2
+    for h in hs[1:]:
+        assert np.array_equal(h.indF, hs[0].indF) and np.array_equal(h.alpha, hs[0].alpha)
+    np.testing.assert_allclose(hs[0].indF, whole.indF, atol=5e-6)
+    whole.set_params(hs[0].indF, hs[0].alpha, ch.freq)
+    assert np.array_equal(ch.viterbi(), whole.viterbi())
+    # a closed member dissolves the chain
+    hs[2].close()
+    with pytest.raises(pkg.NgsFHMMError):
+        ch.iter_EM(1)
+    for h in hs[:2] + hs[3:]:
+        h.close()
+    whole.close()
