@@ -2,7 +2,7 @@
 # One session on the GPU box = every number of the round from the same build:
 #   bash profiles/collect_all.sh r03
 # kernel trace + PMC passes of the default workload (profiles/collect.sh), then the bench lines:
-# default (1000 x 1M), one rank's compute of the 2 / 4 / 8-GPU strong-scaling points,
+# default (1000 x 1M), one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (both shardings),
 # configs[1] (100 x 100k) alone and with replicas, config 5's per-GPU share.
 set -e -o pipefail
 TAG=${1:-r03}
@@ -12,9 +12,11 @@ bash profiles/collect.sh $TAG
 # bench.py reads profiles/<tag>_pmc_summary.json for `traffic`: install this session's first
 cp $OUT/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json
 python3 bench.py > $OUT/${TAG}_bench_default_n1.json
-# one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (exchanges as local copies)
+# one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (exchanges as local copies):
+# site shards (fast mode's default) and individual shards
 for v in 2 4 8; do
-  python3 bench.py --emulate_ranks $v --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}.json
+  python3 bench.py --emulate_ranks $v --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_sites.json
+  python3 bench.py --emulate_ranks $v --shard individuals --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_individuals.json
 done
 python3 bench.py --workload c2 --no_cpu_baseline --steps 200 --warmup 20 > $OUT/${TAG}_bench_c2_n1.json
 python3 bench.py --workload c2 --no_cpu_baseline --steps 100 --warmup 10 --replicas 10 > $OUT/${TAG}_bench_c2_replicas10_n1.json

@@ -104,6 +104,71 @@ def test_config4_eight_shards_of_1000_x_1M(pkg):
         h.close()
 
 
+def test_config4_as_a_chain_of_eight_site_shards(pkg):
+    """The same job cut along the SITE axis (what bench.py --gpus 8 and the host's --n_gpus 8 do
+    in fast mode): eight handles of 1000 x 125 000 through nghmm_chain_setup / _iter_em /
+    _viterbi against ONE handle of 1000 x 1 M."""
+    import importlib
+    import torch
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    I, S, n = 1000, 1_000_000, 8
+    dev = torch.device("cuda", 0)
+    gl, pos = pkg.simulate.simulate_torch(I, S, dev, seed=2025)
+    pos[S // 3] = float("inf")
+    pos[2 * S // 3] = float("inf")               # three chromosomes, none starting at a cut
+    torch.cuda.synchronize()
+    whole = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST)
+    whole.load_device(gl.data_ptr(), pos.data_ptr())
+    ranges = dd.site_ranges_ragged(S, n)
+    parts = []
+    for lo, hi in ranges:
+        h = pkg.NgsFHMM(I, hi - lo, mode=pkg.MODE_FAST)
+        h.load_device(gl[lo:hi].data_ptr(), pos[lo:hi].data_ptr())     # contiguous slices
+        parts.append(h)
+    del gl
+    torch.cuda.empty_cache()
+    ch = pkg.Chain(parts)
+
+    def set_all(F, A, f):
+        whole.set_params(F, A, f)
+        whole.init_emission()
+        for (lo, hi), h in zip(ranges, parts):
+            h.set_params(F, A, np.broadcast_to(f, (S,))[lo:hi])
+            h.init_emission()
+    worst = dict(lkl=0.0, freq=0.0, indF=0.0)
+    F, A, f = 0.1, 0.2, 0.1
+    for it in range(3):                            # free parameters, teacher-forced
+        set_all(F, A, f)
+        whole.iter_EM(1)
+        st = ch.iter_EM(1)
+        assert st.rounds > 0
+        for h in parts[1:]:
+            assert np.array_equal(h.indF, parts[0].indF) and np.array_equal(h.alpha, parts[0].alpha)
+        worst["lkl"] = max(worst["lkl"], float(np.max(np.abs(ch.ind_lkl - whole.ind_lkl) / np.abs(whole.ind_lkl))))
+        worst["freq"] = max(worst["freq"], float(np.max(np.abs(ch.freq - whole.freq) / whole.freq)))
+        worst["indF"] = max(worst["indF"], float(np.max(np.abs(parts[0].indF - whole.indF))))
+        F, A, f = whole.indF, whole.alpha, whole.freq
+    print("config 4 as a chain, free parameters (teacher-forced):", worst)
+    assert worst["lkl"] < 1e-12 and worst["freq"] < 1e-9 and worst["indF"] < 1e-4
+    set_all(0.3, 0.05, 0.15)
+    for it in range(3):
+        whole.iter_EM(1, True, True)
+        ch.iter_EM(1, True, True)
+    lk = float(np.max(np.abs(ch.ind_lkl - whole.ind_lkl) / np.abs(whole.ind_lkl)))
+    fr = float(np.max(np.abs(ch.freq - whole.freq) / whole.freq))
+    print("config 4 as a chain, fixed parameters:", dict(lkl=lk, freq=fr))
+    assert lk < 1e-12 and fr < 1e-9
+    # posteriors of a few hundred individuals (the whole matrix twice on the host is 16 GB)
+    pw = whole.marg_prob[::4]
+    pc = np.concatenate([h.marg_prob[::4] for h in parts], axis=1)
+    assert float(np.max(np.abs(pc - pw))) < 1e-9
+    del pw, pc
+    set_all(0.3, 0.05, whole.freq)                 # one set of frequencies for both decoders
+    assert np.array_equal(ch.viterbi(), whole.viterbi())
+    for h in parts + [whole]:
+        h.close()
+
+
 def test_config5_eight_packed_shards(pkg):
     import torch
     I, S, n, nchr = 5000, 625_000, 8, 25
