@@ -266,6 +266,11 @@ def main():
                          "of the workload (its individuals for all sites + the frequency step on "
                          "its S / V sites over all individuals; exchanges are local copies): the "
                          "line's `predicted` object, not a measurement of V GPUs")
+    ap.add_argument("--emulate_rccl", action="store_true",
+                    help="with --emulate_ranks V and site shards: every all-gather also goes through "
+                         "all_gather_into_tensor of a ONE-rank nccl (= RCCL) process group, issued on "
+                         "the handle's stream exactly as a multi-rank run issues it: the code path "
+                         "and its per-call cost on a one-GPU box")
     ap.add_argument("--shard", default=None, choices=["sites", "individuals"],
                     help="N > 1 (or --emulate_ranks): what a rank holds -- a contiguous range of "
                          "SITES for all individuals (fast mode's default: the ranges exchange six "
@@ -291,6 +296,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     backend = None
+    # RCCL prints a version banner on STDOUT when its first communicator comes up: keep the
+    # line contract (one JSON line on stdout) by pointing fd 1 at stderr until the preflight
+    # has run
+    sys.stdout.flush()
+    fd_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # NGHMM_BENCH_BACKEND=gloo + NGHMM_BENCH_ONE_GPU=1: functional test of the
@@ -324,6 +335,11 @@ def main():
             sys.stderr.write(f"bench.py: rank {rank}: {type(e).__name__}: {e}\n")
             sys.stderr.flush()
             os._exit(3)
+    if not (args.emulate_rccl and world == 1):
+        sys.stdout.flush()
+        os.dup2(fd_stdout, 1)
+        os.close(fd_stdout)
+        fd_stdout = None
 
     wl = dict(WORKLOADS[args.workload])
     if args.n_ind:
@@ -371,8 +387,23 @@ def main():
         # every rank simulates all individuals on its own site range (a chain of independently
         # simulated segments; the distance in front of a later range's first site is an
         # ordinary one, not a chromosome start)
+        if args.emulate_rccl:
+            if V < 2:
+                raise SystemExit("--emulate_rccl goes with --emulate_ranks V")
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    device_id=device)
+            preflight = dd.preflight(device)
+            torch.cuda.synchronize()
+            sys.stdout.flush()
+            os.dup2(fd_stdout, 1)
+            os.close(fd_stdout)
+            fd_stdout = None
         em = dd.SiteShardedEM(pkg, I, S_job, device_index=local_rank, mode=mode, rank=rank,
-                              world=world, emulate_ranks=V)
+                              world=world, emulate_ranks=V, emulate_through_group=args.emulate_rccl)
         assert em.S_own == S
     else:
         # every rank simulates its own individuals on the same sites
@@ -396,6 +427,10 @@ def main():
         torch.cuda.synchronize()
         em.load_device(gl, pos)
         del gl
+    if fd_stdout is not None:     # (--emulate_rccl without site shards: nothing used the group)
+        sys.stdout.flush()
+        os.dup2(fd_stdout, 1)
+        os.close(fd_stdout)
     torch.cuda.empty_cache()
     em.set_params(0.1, 0.2, 0.1)
     em.init_emission()
@@ -639,7 +674,9 @@ def main():
                 "shard": "sites" if by_sites else "individuals",
                 "what": (f"compute of ONE rank of a {V}-rank strong-scaling run of this workload on "
                          f"one GPU (all {I} individuals for {S} of {S_job} sites; every all-gather "
-                         f"replaced by {V} local copies of the same size on the handle's stream: "
+                         f"replaced by {V} local copies of the same size on the handle's stream"
+                         + (", after an all_gather_into_tensor of a one-rank RCCL group issued on "
+                            "that stream" if args.emulate_rccl else "") + ": "
                          f"{em.exchange.calls / K:.1f} per iteration, "
                          f"{em.exchange.bytes / K / 1e3:.0f} kB per iteration from each rank): "
                          f"`value` and `ms_per_step` "
@@ -649,6 +686,8 @@ def main():
                         f"sites x {I * V} individuals), exchanges replaced by local copies: "
                         f"`value` and `ms_per_step` of this line are that rank's, NOT a cohort's",
                 "rank_ms_per_iteration": dt / K * 1e3,
+                "all_gather_host_ms_per_call": (em.exchange.host_ms / max(em.exchange.calls, 1)
+                                                if by_sites else None),
                 "whole_job_site_ind_updates_per_s_if_communication_is_hidden":
                     float(I) * S_job * K / dt if by_sites else float(I * V) * S * K / dt}),
             "preflight": preflight,
@@ -674,7 +713,7 @@ def main():
     for h in replicas:
         h.close()
     em.close()
-    if world > 1:
+    if world > 1 or args.emulate_rccl:
         dist.destroy_process_group()
 
 

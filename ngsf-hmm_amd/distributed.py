@@ -455,13 +455,17 @@ class SiteExchange:
       enqueued before, the library's next kernels wait for the collective; the host waits for
       nothing;
     * process group gloo: through the host, synchronous (CPU buffers directly);
-    * no process group, `emulate` = V: V copies of the own part on the handle's stream (one
-      rank's compute of a V-rank run on a one-GPU box)."""
+    * `emulate` (one rank's compute of a V-rank run on a one-GPU box): V copies of the own
+      part on the handle's stream; with `through_group` the part first goes through
+      `all_gather_into_tensor` of the current (one-rank) process group, issued exactly as
+      above -- the nccl code path and its per-call cost on a box with one GPU."""
 
-    def __init__(self, send, recv, rank, world, stream_ptr=None, emulate=False):
+    def __init__(self, send, recv, rank, world, stream_ptr=None, emulate=False, through_group=False):
         self.send, self.recv = send, recv
         self.rank, self.world = rank, world
         self.emulate = emulate
+        self.through_group = through_group
+        self._tmp = send.new_empty(send.numel()) if through_group else None
         self.calls = 0
         self.bytes = 0
         self.host_ms = 0.0
@@ -480,6 +484,10 @@ class SiteExchange:
         part, whole = self.send[:k], self.recv[:k * self.world]
         if self.emulate:
             with torch.cuda.stream(self._stream):
+                if self.through_group:
+                    import torch.distributed as dist
+                    dist.all_gather_into_tensor(self._tmp[:k], part)
+                    part = self._tmp[:k]
                 whole.view(self.world, k).copy_(part.expand(self.world, k))
         else:
             import torch.distributed as dist
@@ -505,7 +513,7 @@ class SiteShardedEM:
     emulate_ranks = V: rank 0's compute of a V-rank run, the exchanges V local copies."""
 
     def __init__(self, pkg, n_ind, n_sites, device_index=0, mode=None, rank=0, world=1,
-                 emulate_ranks=1):
+                 emulate_ranks=1, emulate_through_group=False):
         import torch
         self.emulate = int(emulate_ranks) if world == 1 else 1
         if self.emulate > 1:
@@ -531,7 +539,8 @@ class SiteShardedEM:
             torch.cuda.synchronize(self.device)
             self.exchange = SiteExchange(self._send, self._recv, rank, world,
                                          stream_ptr=self.hmm.lib.nghmm_stream(self.hmm.handle),
-                                         emulate=self.emulate > 1)
+                                         emulate=self.emulate > 1,
+                                         through_group=self.emulate > 1 and emulate_through_group)
             self.hmm.site_shard_setup(rank, world, self._send.data_ptr(), self._recv.data_ptr(),
                                       nbytes, self.exchange)
 
