@@ -17,6 +17,8 @@ python3 bench.py > $OUT/${TAG}_bench_default_n1.json
 for v in 2 4 8; do
   python3 bench.py --emulate_ranks $v --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_sites.json
   python3 bench.py --emulate_ranks $v --shard individuals --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_individuals.json
+  # ... the site shards' all-gathers through a one-rank RCCL group on the handle's stream
+  python3 bench.py --emulate_ranks $v --emulate_rccl --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_sites_rccl_in_loop.json
 done
 python3 bench.py --workload c2 --no_cpu_baseline --steps 200 --warmup 20 > $OUT/${TAG}_bench_c2_n1.json
 python3 bench.py --workload c2 --no_cpu_baseline --steps 100 --warmup 10 --replicas 10 > $OUT/${TAG}_bench_c2_replicas10_n1.json
