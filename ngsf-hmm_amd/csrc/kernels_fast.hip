@@ -782,6 +782,54 @@ k_fast_shard_reduce(const double* __restrict__ lane_ops, uint64_t J, uint32_t C,
   }
 }
 
+// The first objective round of an M-step carries every individual's current parameters as its
+// point 0: that point's gathered operators ARE the ranges' operators the E-step needs, so the
+// E-step's own all-gather is saved (stride 6 doubles per point, n points per rank)
+__global__ void __launch_bounds__(256)
+k_fast_shard_edges_from_round(const GroupDesc* __restrict__ groups, uint32_t n_groups,
+                              const double* __restrict__ recv, uint32_t world, uint32_t rank,
+                              uint64_t n, double* __restrict__ edges) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const GroupDesc& G = groups[g];
+  const uint64_t idx = G.out_idx[0];
+  const double f = G.F[0];
+  double u0 = 1 - f, u1 = f;
+  int uex = 0;
+  double base = 0.0;
+  for (uint32_t r = 0; r < world; ++r) {
+    const double* o = recv + ((uint64_t)r * n + idx) * 6;
+    base += o[5];
+    if (r < rank) {
+      const Op m = op_load(o);
+      const double n0 = fma(u0, m.a00, u1 * m.a10), n1 = fma(u0, m.a01, u1 * m.a11);
+      u0 = n0;
+      u1 = n1;
+      uex += m.ex;
+      renorm2(u0, u1, uex);
+    }
+  }
+  double x0 = 1.0, x1 = 1.0;
+  int xex = 0;
+  for (uint32_t r = world; r-- > rank + 1;) {
+    const Op m = op_load(recv + ((uint64_t)r * n + idx) * 6);
+    const double n0 = fma(m.a00, x0, m.a01 * x1), n1 = fma(m.a10, x0, m.a11 * x1);
+    x0 = n0;
+    x1 = n1;
+    xex += m.ex;
+    renorm2(x0, x1, xex);
+  }
+  double* e = edges + (uint64_t)G.ind * 8;
+  e[0] = u0;
+  e[1] = u1;
+  e[2] = (double)uex;
+  e[3] = x0;
+  e[4] = x1;
+  e[5] = (double)xex;
+  e[6] = base;
+  e[7] = 0.0;
+}
+
 // edges[i][8] = the row vector entering this range from the left (u0, u1, exponent), the column
 // vector entering it from the right (x0, x1, exponent), the sum of log e0 over all ranges
 __global__ void __launch_bounds__(256)
@@ -3040,6 +3088,14 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     ++sh.n_gathers;
     hipLaunchKernelGGL(k_fast_shard_combine, dim3(((unsigned)ng * MAXP + 255) / 256), dim3(256), 0, st, dg,
                        ng, sh.recv, sh.world, (uint64_t)L.n_pts, d_lkl, d_flags);
+    sh.edges_from_round = false;
+#ifndef NGHMM_NO_EDGE_MERGE  // (A/B builds: the E-step with an all-gather of its own)
+    if (emit_estep && !fs.sw.no_fuse) {  // every individual is in the batch: the E-step's edges too
+      hipLaunchKernelGGL(k_fast_shard_edges_from_round, dim3((ng + 255) / 256), dim3(256), 0, st, dg, ng,
+                         sh.recv, sh.world, sh.rank, (uint64_t)L.n_pts, sh.edges);
+      sh.edges_from_round = true;
+    }
+#endif
     return hipGetLastError() == hipSuccess;
   }
   hipLaunchKernelGGL(k_fast_lkl_finish<false>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part,
@@ -3065,14 +3121,17 @@ bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const doubl
   const double* edges = nullptr;
   if (fs.shard.world > 1) {
     SiteShard& sh = fs.shard;
-    if (fs.I * 6 > sh.cap) return false;
-    hipLaunchKernelGGL(k_fast_shard_reduce, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J,
-                       fs.C, fs.base_c, sh.send);
-    if (hipGetLastError() != hipSuccess) return false;
-    if (sh.allgather(sh.user, fs.I * 6 * sizeof(double)) != 0) return false;
-    ++sh.n_gathers;
-    hipLaunchKernelGGL(k_fast_shard_edges, dim3((unsigned)((fs.I + 255) / 256)), dim3(256), 0, st,
-                       sh.recv, sh.world, sh.rank, fs.I, d_indF, sh.edges);
+    if (!(have_forward_walk && sh.edges_from_round)) {
+      if (fs.I * 6 > sh.cap) return false;
+      hipLaunchKernelGGL(k_fast_shard_reduce, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J,
+                         fs.C, fs.base_c, sh.send);
+      if (hipGetLastError() != hipSuccess) return false;
+      if (sh.allgather(sh.user, fs.I * 6 * sizeof(double)) != 0) return false;
+      ++sh.n_gathers;
+      hipLaunchKernelGGL(k_fast_shard_edges, dim3((unsigned)((fs.I + 255) / 256)), dim3(256), 0, st,
+                         sh.recv, sh.world, sh.rank, fs.I, d_indF, sh.edges);
+    }
+    sh.edges_from_round = false;
     edges = sh.edges;
   }
   hipLaunchKernelGGL(k_fast_bounds, dim3((unsigned)fs.I), dim3(64), 0, st, fs.lane_ops, fs.J, fs.C,

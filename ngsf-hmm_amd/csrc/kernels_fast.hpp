@@ -46,6 +46,7 @@ struct SiteShard {
   int (*allgather)(void* user, uint64_t n_bytes) = nullptr;
   void* user = nullptr;
   double* edges = nullptr;  // [I][8], owned: what enters the range from both sides (k_fast_shard_edges)
+  bool edges_from_round = false;  // the last emitting objective round has left `edges` current
   uint64_t n_gathers = 0;   // accounting
 };
 
