@@ -3273,8 +3273,14 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       else if (I_tot <= 512) LAUNCH_TILE(8, 64);
       else if (I_tot <= 768) LAUNCH_TILE(12, 64);
       else if (I_tot <= 1024) LAUNCH_TILE(16, 64);
+      // several waves per site: a lane's slot k holds individual thread + BLOCK k, so a cohort
+      // in the lower half of a size class leaves the upper slots of EVERY lane empty -- 12
+      // instead of 16 slots there (5000 individuals on 512 threads: 9.8 slots in use)
+      else if (I_tot <= 1536) LAUNCH_TILE(12, 128);
       else if (I_tot <= 2048) LAUNCH_TILE(16, 128);
+      else if (I_tot <= 3072) LAUNCH_TILE(12, 256);
       else if (I_tot <= 4096) LAUNCH_TILE(16, 256);
+      else if (I_tot <= 6144) LAUNCH_TILE(12, 512);
       else LAUNCH_TILE(16, 512);
     } else if (I_tot <= 64) LAUNCH_NI(1, 64);
     else if (I_tot <= 128) LAUNCH_NI(2, 64);
@@ -3282,8 +3288,11 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     else if (I_tot <= 512) LAUNCH_NI(8, 64);
     else if (I_tot <= 768) LAUNCH_NI(12, 64);
     else if (I_tot <= 1024) LAUNCH_NI(16, 64);
+    else if (I_tot <= 1536) LAUNCH_NI(12, 128);
     else if (I_tot <= 2048) LAUNCH_NI(16, 128);
+    else if (I_tot <= 3072) LAUNCH_NI(12, 256);
     else if (I_tot <= 4096) LAUNCH_NI(16, 256);
+    else if (I_tot <= 6144) LAUNCH_NI(12, 512);
     else LAUNCH_NI(16, 512);
     return true;
   };

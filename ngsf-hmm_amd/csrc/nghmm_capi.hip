@@ -1308,6 +1308,10 @@ struct MstepRun {
 
   bool wants_two_lanes() const {
     const int pl = h->fast.sw.pipeline;
+    // a site shard: every handle of the chain must make the same sequence of exchanges, and the
+    // rule below looks at the waves per individual, which depend on the handle's own number of
+    // sites -- only the switch (the same environment everywhere) may turn the two lanes on
+    if (h->fast.shard.world > 1) return h->mode == NGHMM_MODE_FAST && h->I >= 2 && pl > 0;
     return h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
            (pl >= 0 ? pl != 0 : (uint64_t)h->I * h->fast.C < 16384);
   }

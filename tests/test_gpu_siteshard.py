@@ -144,10 +144,11 @@ def test_site_shards_reproduce_one_handle(pkg, orc_libm, V):
         whole.iter_EM(1)
         g0 = ch.gathers[0]
         st = ch.each(lambda r, h: h.iter_EM(1))
-        # one all-gather per objective launch (a small cohort's rounds run as two half launches);
-        # the E-step's rides on the first round's (point 0 of every individual is its current
-        # parameters); a re-evaluated launch adds one
-        assert st[0].rounds <= ch.gathers[0] - g0 <= 2 * st[0].rounds + 2 and len(set(ch.gathers)) == 1
+        # one all-gather per objective round (a chain never splits its rounds into two half
+        # launches by itself: that rule looks at the handle's own size); the E-step's rides on the
+        # first round's (point 0 of every individual is its current parameters); a re-evaluated
+        # round adds one
+        assert st[0].rounds <= ch.gathers[0] - g0 <= st[0].rounds + 2 and len(set(ch.gathers)) == 1
         pars = [(h.indF, h.alpha, h.ind_lkl.copy()) for h in ch.h]
         for r in range(1, V):                                  # every handle took the same steps
             assert np.array_equal(pars[r][0], pars[0][0]) and np.array_equal(pars[r][1], pars[0][1])
