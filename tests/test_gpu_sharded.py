@@ -129,10 +129,11 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert bad.returncode != 0 and "WORLD_SIZE is 1" in bad.stderr
 
 
-@pytest.mark.parametrize("I", [40, 100, 200, 400, 600, 700, 1024, 1100, 2100, 4100, 8200])
+@pytest.mark.parametrize("I", [40, 100, 200, 400, 600, 700, 1024, 1100, 1700, 2100, 3500, 4100, 7000, 8200])
 def test_est_maf_register_and_stream_variants(pkg, I):
     """est_maf picks a kernel by the number of individuals (one wave per site with 1..16
-    individuals per lane in registers up to 1024 (12 per lane from 513 to 768), then 2..8 waves per site; beyond 8192
+    individuals per lane in registers up to 1024 (12 per lane from 513 to 768), then 2, 4 or 8 waves
+    per site with 12 individuals per lane in the lower half of each size class and 16 in the upper; beyond 8192
     the streaming kernel), as the site-sharded frequency step of an N-GPU run needs: all
     must agree with the oracle."""
     import orclib
