@@ -14,11 +14,16 @@ cp $OUT/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json
 python3 bench.py > $OUT/${TAG}_bench_default_n1.json
 # one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (exchanges as local copies):
 # site shards (fast mode's default) and individual shards
+# (the driver's N = 1 flags, --steps 20 --warmup 5: the first iterations of a run take more
+# objective rounds than the steady state, and a 10-iteration window right after 3 warm-up ones
+# still catches some of them)
+W="--steps 20 --warmup 5 --no_cpu_baseline"
+python3 bench.py $W > $OUT/${TAG}_bench_n1_steps20.json
 for v in 2 4 8; do
-  python3 bench.py --emulate_ranks $v --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_sites.json
-  python3 bench.py --emulate_ranks $v --shard individuals --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_individuals.json
+  python3 bench.py $W --emulate_ranks $v > $OUT/${TAG}_bench_rank_of_${v}_sites.json
+  python3 bench.py $W --emulate_ranks $v --shard individuals > $OUT/${TAG}_bench_rank_of_${v}_individuals.json
   # ... the site shards' all-gathers through a one-rank RCCL group on the handle's stream
-  python3 bench.py --emulate_ranks $v --emulate_rccl --no_cpu_baseline > $OUT/${TAG}_bench_rank_of_${v}_sites_rccl_in_loop.json
+  python3 bench.py $W --emulate_ranks $v --emulate_rccl > $OUT/${TAG}_bench_rank_of_${v}_sites_rccl_in_loop.json
 done
 python3 bench.py --workload c2 --no_cpu_baseline --steps 200 --warmup 20 > $OUT/${TAG}_bench_c2_n1.json
 python3 bench.py --workload c2 --no_cpu_baseline --steps 100 --warmup 10 --replicas 10 > $OUT/${TAG}_bench_c2_replicas10_n1.json
