@@ -350,6 +350,14 @@ int nghmm_chain_iter_em(nghmm_t** handles, int n, int freq_est, int indF_fixed, 
 int nghmm_chain_mstep_freq(nghmm_t** handles, int n, int freq_est);
 int nghmm_chain_viterbi(nghmm_t** handles, int n, uint8_t* path);
 
+/* Page-locked host memory for buffers the library copies results into (nghmm_get_*,
+ * nghmm_format_posteriors, nghmm_geno_posteriors, nghmm_viterbi ...): copies from the device
+ * into such a buffer run at the PCIe rate instead of through a staging buffer.  Any host memory
+ * works; this is for hosts that move gigabytes (the .ibd / .geno writers).  NULL when it cannot
+ * be had. */
+void* nghmm_alloc_host(uint64_t bytes);
+void nghmm_free_host(void* p);
+
 /* Measurement and debugging switches of a handle.  None changes a result beyond rounding (the
  * kernels, their order on the stream or what is printed; DESIGN.md section 7 says what each is
  * for).  A handle reads them from the environment ONCE, in nghmm_create -- NGHMM_<NAME> with

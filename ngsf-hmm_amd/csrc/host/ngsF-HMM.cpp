@@ -10,11 +10,14 @@
 // Extra options: --mode exact|fast (default fast), --device N.  --n_threads (the
 // reference's pool size) sets the host threads used for input normalisation and output
 // formatting; results do not depend on it.
+#include <fcntl.h>
 #include <getopt.h>
 #include <omp.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <charconv>
 #include <condition_variable>
 #include <deque>
@@ -921,8 +924,122 @@ inline char* put_fixed(char* p, double v, int prec) {
   return r.ptr;
 }
 
+// The .ibd and .geno files of a large run are gigabytes (1000 x 1M: 10 GB and 24 GB) that come
+// off the device a batch at a time.  Every batch has a known place in its file, so it is
+// fetched into one of a few pinned buffers (nghmm_alloc_host: the copy from the device runs at
+// the PCIe rate) and handed to a pool of threads that pwrite() it there, while the main thread
+// fetches the next one: copies into the page cache run in parallel with each other and with the
+// device's formatting.
+class PositionalWriter {
+ public:
+  // one pool for the process (print_iter runs once per --log interval and per replicate):
+  // pinning and unpinning a few hundred MB costs as much as writing a GB
+  static PositionalWriter& get(size_t slot_bytes) {
+    static std::mutex mu;
+    static PositionalWriter* w = nullptr;   // lives until the process ends
+    std::lock_guard<std::mutex> lk(mu);
+    if (!w) w = new PositionalWriter(slot_bytes, 6, 4);
+    if (w->cap_ < slot_bytes) fatal("print_iter", "output buffers of another size are in use!");
+    return *w;
+  }
+  // the writes of one caller: wait() returns when all of them are done
+  struct Job {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t pending = 0;
+    bool failed = false;
+  };
+  size_t slot_bytes() const { return cap_; }
+  // a free buffer (waits for one)
+  int acquire() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_free_.wait(lk, [&] { return !free_.empty(); });
+    const int k = free_.back();
+    free_.pop_back();
+    return k;
+  }
+  char* data(int slot) { return slots_[slot]; }
+  // write the first len bytes of the buffer at `offset` of fd; the buffer is free again afterwards
+  void submit(Job& job, int slot, int fd, uint64_t offset, size_t len) {
+    {
+      std::lock_guard<std::mutex> lk(job.mu);
+      ++job.pending;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      todo_.push_back(Task{&job, slot, fd, offset, len});
+    }
+    cv_todo_.notify_one();
+  }
+  static void wait(Job& job) {
+    std::unique_lock<std::mutex> lk(job.mu);
+    job.cv.wait(lk, [&] { return job.pending == 0; });
+    if (job.failed) fatal("print_iter", "cannot write the output files!");
+  }
+
+ private:
+  PositionalWriter(size_t slot_bytes, int n_slots, int n_threads) : cap_(slot_bytes) {
+    for (int k = 0; k < n_slots; k++) {
+      void* p = nghmm_alloc_host(slot_bytes);
+      if (!p) fatal("print_iter", "cannot allocate output buffers!");
+      slots_.push_back(static_cast<char*>(p));
+      free_.push_back(k);
+    }
+    for (int t = 0; t < n_threads; t++) std::thread([this] { work(); }).detach();
+  }
+  struct Task {
+    Job* job;
+    int slot, fd;
+    uint64_t offset;
+    size_t len;
+  };
+  void work() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_todo_.wait(lk, [&] { return !todo_.empty(); });
+        t = todo_.front();
+        todo_.pop_front();
+      }
+      const char* p = slots_[t.slot];
+      size_t left = t.len;
+      uint64_t off = t.offset;
+      bool ok = true;
+      while (left) {
+        const ssize_t w = pwrite(t.fd, p, left, (off_t)off);
+        if (w <= 0) {
+          ok = false;
+          break;
+        }
+        p += w;
+        off += (uint64_t)w;
+        left -= (size_t)w;
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        free_.push_back(t.slot);
+      }
+      cv_free_.notify_one();
+      {
+        std::lock_guard<std::mutex> lk(t.job->mu);
+        if (!ok) t.job->failed = true;
+        --t.job->pending;
+      }
+      t.job->cv.notify_all();
+    }
+  }
+  size_t cap_;
+  std::vector<char*> slots_;
+  std::vector<int> free_;
+  std::deque<Task> todo_;
+  std::mutex mu_;
+  std::condition_variable cv_free_, cv_todo_;
+};
+
 // EM.cpp:293-380
 void print_iter(const Params& P, Cohort& C) {
+  const double t_p0 = omp_get_wtime();
   const uint64_t I = P.n_ind, S = P.n_sites;
   std::string name = P.prefix + ".indF";
   FILE* fh = fopen(name.c_str(), "w");
@@ -947,57 +1064,28 @@ void print_iter(const Params& P, Cohort& C) {
   }
   fclose(fh);
 
-  name = P.prefix + ".ibd";
-  fh = fopen(name.c_str(), "w");
-  if (!fh) fatal(__FUNCTION__, "cannot open IBD output file!");
-  setvbuf(fh, nullptr, _IOFBF, 1 << 22);
-  fputs("//", fh);
-  for (uint64_t i = 0; i < I; i++) fprintf(fh, "\t%.10f", P.ind_lkl[i]);
-  fputc('\n', fh);
-  std::vector<char> line(S + 1);
-  for (uint64_t i = 0; i < I; i++) {
-    for (uint64_t s = 0; s < S; s++) line[s] = (char)(P.path[i * S + s] + 48);
-    line[S] = '\n';
-    fwrite(line.data(), 1, S + 1, fh);
-  }
-  // posterior lines (EM.cpp:347-353): printf("%f") text formatted on the device, a batch of
-  // individuals (<= 256 MB of text) at a time
-  {
-    uint64_t batch = (256ull << 20) / (9 * S);
-    if (batch < 1) batch = 1;
-    if (batch > I) batch = I;
-    std::vector<char> text(batch * 9 * S), piece(C.n() > 1 ? batch * 9 * C.sites(0) + 9 * 16 * batch : 0);
-    for (uint64_t i0 = 0; i0 < I; i0 += batch) {
-      const uint64_t nb = (I - i0) < batch ? (I - i0) : batch;
-      if (C.n() == 1) {
-        check(nghmm_format_posteriors(C.hs[0], i0, nb, text.data()), "print_iter");
-      } else {
-        // a line is the handles' pieces one after the other: a piece's closing newline becomes
-        // the tab in front of the next piece's first value
-        for (int r = 0; r < C.n(); r++) {
-          const uint64_t Sr = C.sites(r);
-          if (piece.size() < nb * 9 * Sr) piece.resize(nb * 9 * Sr);
-          check(nghmm_format_posteriors(C.hs[r], i0, nb, piece.data()), "print_iter");
-          for (uint64_t i = 0; i < nb; i++) {
-            char* dst = &text[(i * S + C.lo[r]) * 9];
-            memcpy(dst, &piece[i * 9 * Sr], 9 * Sr);
-            if (r + 1 < C.n()) dst[9 * Sr - 1] = '\t';
-          }
-        }
-      }
-      fwrite(text.data(), 1, nb * 9 * S, fh);
-    }
-  }
-  fclose(fh);
+  // batches of about 32 MB: sites per .geno block, individuals per .ibd batch
+  const uint64_t target = 32ull << 20;
+  uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(S, target / (I * 24)));
+  uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(I, target / (9 * S)));
+  const size_t slot = std::max<size_t>(target, std::max<size_t>(chunk * I * 24, batch * 9 * S));
+  const double t_w0 = omp_get_wtime();
+  PositionalWriter& W = PositionalWriter::get(slot);
+  PositionalWriter::Job job;
+  double t_wait = 0, t_dev = 0, t_host = 0;  // waiting for a free buffer / in device calls / host formatting
+  const double t_w1 = omp_get_wtime();
+  auto tick = [](double& acc, double t0) { acc += omp_get_wtime() - t0; };
 
   name = P.prefix + ".geno";
-  fh = fopen(name.c_str(), "wb");
-  if (!fh) fatal(__FUNCTION__, "cannot open GENO output file!");
-  setvbuf(fh, nullptr, _IOFBF, 1 << 22);
-  const uint64_t chunk = 4096;  // sites per block
-  std::vector<double> blk(chunk * I * 3);
+  const int fd_geno = open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd_geno < 0) fatal(__FUNCTION__, "cannot open GENO output file!");
   for (uint64_t s0 = 0; s0 < S; s0 += chunk) {
     const uint64_t ns = (S - s0) < chunk ? (S - s0) : chunk;
+    double t = omp_get_wtime();
+    const int k = W.acquire();
+    tick(t_wait, t);
+    t = omp_get_wtime();
+    double* blk = reinterpret_cast<double*>(W.data(k));
     // EM.cpp:367-376 on the device, from the decoded path and the final frequencies; the file
     // is site-major over all individuals: a block comes from the handle(s) that own its sites
     for (int r = 0; r < C.n(); r++) {
@@ -1005,9 +1093,92 @@ void print_iter(const Params& P, Cohort& C) {
       if (a < b)
         check(nghmm_geno_posteriors(C.hs[r], a - C.lo[r], b - a, &blk[(a - s0) * I * 3]), "print_iter");
     }
-    fwrite(blk.data(), sizeof(double), ns * I * 3, fh);
+    tick(t_dev, t);
+    W.submit(job, k, fd_geno, s0 * I * 3 * sizeof(double), ns * I * 3 * sizeof(double));
   }
-  fclose(fh);
+
+  name = P.prefix + ".ibd";
+  const int fd_ibd = open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd_ibd < 0) fatal(__FUNCTION__, "cannot open IBD output file!");
+  uint64_t at = 0;  // bytes of the file laid out so far
+  {
+    std::string head = "//";
+    char num[64];
+    for (uint64_t i = 0; i < I; i++) {
+      snprintf(num, sizeof num, "\t%.10f", P.ind_lkl[i]);
+      head += num;
+    }
+    head += '\n';
+    for (size_t o = 0; o < head.size(); o += W.slot_bytes()) {
+      const size_t n = std::min(W.slot_bytes(), head.size() - o);
+      const int k = W.acquire();
+      memcpy(W.data(k), head.data() + o, n);
+      W.submit(job, k, fd_ibd, at + o, n);
+    }
+    at += head.size();
+  }
+  {  // the path lines: one digit per site
+    const uint64_t per = std::max<uint64_t>(1, W.slot_bytes() / (S + 1));
+    for (uint64_t i0 = 0; i0 < I; i0 += per) {
+      const uint64_t nb = std::min(per, I - i0);
+      double t = omp_get_wtime();
+      const int k = W.acquire();
+      tick(t_wait, t);
+      t = omp_get_wtime();
+      char* line = W.data(k);
+      for (uint64_t i = 0; i < nb; i++) {
+        char* l = line + i * (S + 1);
+        const char* pth = reinterpret_cast<const char*>(&P.path[(i0 + i) * S]);
+        for (uint64_t s = 0; s < S; s++) l[s] = (char)(pth[s] + 48);
+        l[S] = '\n';
+      }
+      tick(t_host, t);
+      W.submit(job, k, fd_ibd, at + i0 * (S + 1), nb * (S + 1));
+    }
+    at += I * (S + 1);
+  }
+  // posterior lines (EM.cpp:347-353): printf("%f") text formatted on the device, a batch of
+  // individuals at a time
+  {
+    uint64_t widest = 0;
+    for (int r = 0; r < C.n(); r++) widest = std::max(widest, C.sites(r));
+    char* piece = C.n() > 1 ? static_cast<char*>(nghmm_alloc_host(batch * 9 * widest)) : nullptr;
+    if (C.n() > 1 && !piece) fatal(__FUNCTION__, "cannot allocate output buffers!");
+    for (uint64_t i0 = 0; i0 < I; i0 += batch) {
+      const uint64_t nb = (I - i0) < batch ? (I - i0) : batch;
+      double t = omp_get_wtime();
+      const int k = W.acquire();
+      tick(t_wait, t);
+      t = omp_get_wtime();
+      char* text = W.data(k);
+      if (C.n() == 1) {
+        check(nghmm_format_posteriors(C.hs[0], i0, nb, text), "print_iter");
+      } else {
+        // a line is the handles' pieces one after the other: a piece's closing newline becomes
+        // the tab in front of the next piece's first value
+        for (int r = 0; r < C.n(); r++) {
+          const uint64_t Sr = C.sites(r);
+          check(nghmm_format_posteriors(C.hs[r], i0, nb, piece), "print_iter");
+          for (uint64_t i = 0; i < nb; i++) {
+            char* dst = &text[(i * S + C.lo[r]) * 9];
+            memcpy(dst, &piece[i * 9 * Sr], 9 * Sr);
+            if (r + 1 < C.n()) dst[9 * Sr - 1] = '\t';
+          }
+        }
+      }
+      tick(t_dev, t);
+      W.submit(job, k, fd_ibd, at + i0 * 9 * S, nb * 9 * S);
+    }
+    if (piece) nghmm_free_host(piece);
+  }
+  const double t_w2 = omp_get_wtime();
+  PositionalWriter::wait(job);
+  if (P.verbose >= 2)  // (not a line of the reference's)
+    fprintf(P.out, "> output: buffers %.2f s, device calls %.2f s, path lines %.2f s, waiting for a free "
+            "buffer %.2f s, last writes %.2f s\n", t_w1 - t_w0, t_dev, t_host, t_wait, omp_get_wtime() - t_w2);
+  const double t_c0 = omp_get_wtime();
+  if (close(fd_geno) != 0 || close(fd_ibd) != 0) fatal(__FUNCTION__, "cannot write the output files!");
+  if (P.verbose >= 2) fprintf(P.out, "> output: close %.2f s, before the buffers %.2f s\n", omp_get_wtime() - t_c0, t_w0 - t_p0);
 }
 
 void sync_outputs(Params& P, Cohort& C, bool with_viterbi) {
@@ -1239,12 +1410,16 @@ void run_em(Params& P, Cohort& C) {
 // EM.cpp:105-127: decoding and the three output files
 void finish_run(Params& P, Cohort& C) {
   if (P.verbose >= 1) fprintf(P.out, "\n==> Decoding most probable path (Viterbi)\n");
+  const double t0 = omp_get_wtime();
   sync_outputs(P, C, true);
+  const double t1 = omp_get_wtime();
   if (P.verbose >= 1) {
     fprintf(P.out, "Final logLkl: %f\n", P.tot_lkl);
     fprintf(P.out, "Printing final results\n");
   }
   print_iter(P, C);
+  if (P.verbose >= 2)  // (not a line of the reference's)
+    fprintf(P.out, "> decoded in %.2f s, output files written in %.2f s\n", t1 - t0, omp_get_wtime() - t1);
 }
 
 }  // namespace

@@ -2625,6 +2625,19 @@ int nghmm_chain_viterbi(nghmm_t** hs, int n, uint8_t* path) {
   return NGHMM_OK;
 }
 
+void* nghmm_alloc_host(uint64_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void nghmm_free_host(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int nghmm_set_switch(nghmm_t* h, const char* name, long value) {
   g_last_error.clear();
   if (!h || !name) return NGHMM_ERR_ARG;

@@ -123,6 +123,8 @@ def load_library():
         "nghmm_synchronize": (i32, [vp]),
         "nghmm_kernel_ms": (i32, [vp, i32, dp, C.POINTER(u32)]),
         "nghmm_set_switch": (i32, [vp, C.c_char_p, C.c_long]),
+        "nghmm_alloc_host": (vp, [u64]),
+        "nghmm_free_host": (None, [vp]),
         "nghmm_site_shard_bytes": (u64, [vp]),
         "nghmm_site_shard_setup": (i32, [vp, i32, i32, vp, vp, u64, ALLGATHER_FN, vp]),
         "nghmm_chain_setup": (i32, [C.POINTER(vp), i32]),
@@ -166,7 +168,7 @@ EXPORTED_SYMBOLS = [
     "nghmm_kernel_ms", "nghmm_set_switch",
     "nghmm_site_shard_bytes", "nghmm_site_shard_setup", "nghmm_viterbi_shard_forward",
     "nghmm_viterbi_shard_back", "nghmm_chain_setup", "nghmm_chain_iter_em", "nghmm_chain_mstep_freq",
-    "nghmm_chain_viterbi",
+    "nghmm_chain_viterbi", "nghmm_alloc_host", "nghmm_free_host",
 ]
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_void_p)

@@ -171,6 +171,8 @@ int nghmm_chain_viterbi(nghmm_t** hs, int n, uint8_t* path) {
   for (uint64_t k = 0; k < hs[0]->I * S; ++k) path[k] = (uint8_t)(k & 1);
   return NGHMM_OK;
 }
+void* nghmm_alloc_host(uint64_t bytes) { return bytes ? std::malloc(bytes) : nullptr; }
+void nghmm_free_host(void* p) { std::free(p); }
 int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   if (!h || !path) return NGHMM_ERR_ARG;
   for (uint64_t k = 0; k < h->I * h->S; ++k) path[k] = (uint8_t)(k & 1);
