@@ -1336,11 +1336,13 @@ void parse_cmd_args(Params& P, int argc, char** argv) {  // parse_args.cpp:41-22
 
 // One EM analysis on a loaded handle: initial values, the loop of EM.cpp:27-103.
 void run_em(Params& P, Cohort& C) {
+  const double t_init = omp_get_wtime();
   const bool estimate_freq = init_values(P, C);
   if (estimate_freq)  // --freq e: est_maf with F = 0 (parse_args.cpp:312-318); posteriors are still 0
     check(nghmm_chain_mstep_freq(C.hs.data(), C.n(), 1), "init_output");
   if (P.verbose >= 1) fprintf(P.out, "==> Calculating initial emission probabilities\n");
   for (nghmm_t* h : C.hs) check(nghmm_emission(h), "calc_emission");
+  if (P.verbose >= 2) fprintf(P.out, "> initial values and emissions in %.2f s\n", omp_get_wtime() - t_init);
 
   // ---- EM.cpp:27-103 ----
   const uint64_t I = P.n_ind;
@@ -1348,6 +1350,7 @@ void run_em(Params& P, Cohort& C) {
   std::vector<double> prev_ind_lkl(I, -INFINITY), eps(I, -INFINITY);
   double max_lkl_epsilon = -INFINITY;
   uint64_t iter = 0;
+  const double t_loop = omp_get_wtime();
   while ((P.prev_tot_lkl - P.tot_lkl > P.min_epsilon || max_lkl_epsilon > P.min_epsilon ||
           iter < P.min_iters) &&
          iter < P.max_iters) {
@@ -1404,7 +1407,8 @@ void run_em(Params& P, Cohort& C) {
   }
   if (iter >= P.max_iters)
     fprintf(P.out, "WARN: Maximum number of iterations reached! Check if analysis converged... \n");
-
+  if (P.verbose >= 2)  // (not a line of the reference's)
+    fprintf(P.out, "> %lu EM iterations in %.3f s\n", (unsigned long)iter, omp_get_wtime() - t_loop);
 }
 
 // EM.cpp:105-127: decoding and the three output files
