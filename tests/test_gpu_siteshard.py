@@ -256,8 +256,12 @@ def test_in_process_chain_equals_one_handle(pkg, packed):
         else:
             h.load(np.ascontiguousarray(gl[lo:hi]), np.ascontiguousarray(d.pos_dist_mb[lo:hi]))
         return h
-    whole = make(0, S)
     ranges = dd.site_ranges_ragged(S, V)
+    # a chromosome that starts exactly at a cut (the handle's first distance is +inf), one that
+    # starts on the last site of a range, one in the middle of a range
+    d.pos_dist_mb[ranges[1][0]] = np.inf
+    d.pos_dist_mb[ranges[2][1] - 1] = np.inf
+    whole = make(0, S)
     hs = [make(lo, hi) for lo, hi in ranges]
     ch = pkg.Chain(hs)
     # --freq e: the frequency step before any E-step, every handle on its own sites
