@@ -294,3 +294,38 @@ def test_in_process_chain_equals_one_handle(pkg, packed):
     for h in hs[:2] + hs[3:]:
         h.close()
     whole.close()
+
+
+@pytest.mark.parametrize("I,S,V", [(1, 97, 2), (3, 640, 4), (9, 2049, 3), (130, 333, 2), (64, 64, 2),
+                                   (17, 5000, 5)])
+def test_chain_shapes(pkg, I, S, V):
+    """Odd shapes: one individual, ranges of a few sites (fewer than a wave has lanes), more
+    handles than chromosomes, a cohort that takes the four-sites-per-wave est_maf."""
+    d = pkg.simulate.simulate(I, S, seed=I + S, n_chrom=2, missing_rate=0.1, indF="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    ranges = dd.site_ranges_ragged(S, V)
+
+    def make(lo, hi):
+        h = pkg.NgsFHMM(I, hi - lo, mode=pkg.MODE_FAST)
+        h.load(np.ascontiguousarray(gl[lo:hi]), np.ascontiguousarray(d.pos_dist_mb[lo:hi]))
+        h.set_params(0.2, 0.3, 0.15)
+        h.init_emission()
+        return h
+    whole = make(0, S)
+    hs = [make(lo, hi) for lo, hi in ranges]
+    ch = pkg.Chain(hs)
+    for it in range(2):
+        whole.iter_EM(1, True, True)
+        ch.iter_EM(1, True, True)
+    np.testing.assert_allclose(ch.ind_lkl, whole.ind_lkl, rtol=1e-12)
+    np.testing.assert_allclose(ch.freq, whole.freq, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(ch.marg_prob, whole.marg_prob, atol=1e-9)
+    ch.iter_EM(1)
+    for h in hs[1:]:
+        assert np.array_equal(h.indF, hs[0].indF) and np.array_equal(h.alpha, hs[0].alpha)
+    assert np.isfinite(ch.ind_lkl).all()
+    whole.set_params(hs[0].indF, hs[0].alpha, ch.freq)
+    assert np.array_equal(ch.viterbi(), whole.viterbi())
+    for h in hs + [whole]:
+        h.close()
