@@ -297,6 +297,14 @@ k_trans_log_exact(const double* __restrict__ pos, const double* __restrict__ ind
   }
 }
 
+// v_max_f64 of two values known not to be signalling NaNs (the compiler's fmax first
+// canonicalises both operands); a quiet NaN operand is dropped (IEEE maxNum)
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // state [I][2] carries (Vi_prob[0], Vi_prob[1]) between chunks
 __global__ void __launch_bounds__(64)
 k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__ tl, uint64_t s0,
@@ -325,41 +333,44 @@ k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__
   constexpr int UV = 16;
   double2 ecur[UV], enxt[UV];
   double4 tcur[UV], tnxt[UV];
+  // (loads past the chunk's end re-read its last site: an unconditional load with a clamped
+  // address stays in flight across the loop, a conditional one is waited for on the spot)
 #pragma unroll
   for (int u = 0; u < UV; ++u) {
-    const bool v = (uint64_t)u < n_s;
-    ecur[u] = v ? e2[(s0 + u) * I + i] : double2{0, 0};
-    tcur[u] = v ? t4[(uint64_t)u * I + i] : double4{0, 0, 0, 0};
+    const uint64_t r = (uint64_t)u < n_s ? (uint64_t)u : n_s - 1;
+    ecur[u] = e2[(s0 + r) * I + i];
+    tcur[u] = t4[r * I + i];
   }
   uint32_t bpw[4] = {0, 0, 0, 0};
   for (uint64_t r0 = 0; r0 < n_s; r0 += UV) {
 #pragma unroll
     for (int u = 0; u < UV; ++u) {
-      const uint64_t r = r0 + UV + u;
-      const bool v = r < n_s;
-      enxt[u] = v ? e2[(s0 + r) * I + i] : double2{0, 0};
-      tnxt[u] = v ? t4[r * I + i] : double4{0, 0, 0, 0};
+      const uint64_t rr = r0 + UV + u;
+      const uint64_t r = rr < n_s ? rr : n_s - 1;
+      enxt[u] = e2[(s0 + r) * I + i];
+      tnxt[u] = t4[r * I + i];
     }
 #pragma unroll
     for (int u = 0; u < UV; ++u) {
       const uint64_t r = r0 + u;
       if (r < n_s) {
-        // l = 0 (HMM.cpp:105-116)
-        double vmax = -kINF;
-        int k0 = 0;
-        double pval = v0 + tcur[u].x;  // k = 0 -> l = 0
-        if (vmax < pval) { vmax = pval; k0 = 0; }
-        pval = v1 + tcur[u].y;         // k = 1 -> l = 0
-        if (vmax < pval) { vmax = pval; k0 = 1; }
-        v0 = vmax + ecur[u].x;  // in place: l = 1 below reads the NEW v0 (reference behaviour)
-        // l = 1
-        vmax = -kINF;
-        int k1 = 0;
-        pval = v0 + tcur[u].z;         // k = 0 -> l = 1
-        if (vmax < pval) { vmax = pval; k1 = 0; }
-        pval = v1 + tcur[u].w;         // k = 1 -> l = 1
-        if (vmax < pval) { vmax = pval; k1 = 1; }
-        v1 = vmax + ecur[u].y;
+        // HMM.cpp:105-116 per state: vmax = -INF; for k: pval = Vi_prob[k] + T(k,l); if (vmax <
+        // pval) { vmax = pval; best = k; }.  From vmax = -INF the first test leaves max(-INF,
+        // pval) -- a NaN pval fails the test and is dropped by v_max_f64 alike -- with best = 0
+        // either way; the second leaves max(vmax, pval) (equal values: the same number) and best =
+        // 1 exactly when the strict test holds.  Two dependent v_max instead of two compare +
+        // select pairs on the chain that every site waits for; the tests for the back-pointers
+        // are off it.
+        const double c00 = v0 + tcur[u].x;  // k = 0 -> l = 0
+        const double c10 = v1 + tcur[u].y;  // k = 1 -> l = 0
+        const double m0 = vmax_f64(-kINF, c00);
+        const int k0 = m0 < c10;
+        v0 = vmax_f64(m0, c10) + ecur[u].x;  // in place: l = 1 below reads the NEW v0 (reference behaviour)
+        const double c01 = v0 + tcur[u].z;  // k = 0 -> l = 1
+        const double c11 = v1 + tcur[u].w;  // k = 1 -> l = 1
+        const double m1 = vmax_f64(-kINF, c01);
+        const int k1 = m1 < c11;
+        v1 = vmax_f64(m1, c11) + ecur[u].y;
         bpw[u >> 2] |= (uint32_t)(k0 | (k1 << 1)) << (8 * (u & 3));
       }
     }
@@ -396,24 +407,44 @@ k_viterbi_back(const uint8_t* __restrict__ bp, const uint8_t* __restrict__ last_
   if (i >= I || S == 0) return;
   int st = last_state[i];
   const uint64_t nblk = (S + 15) / 16;
-  uint4 cur = *reinterpret_cast<const uint4*>(bp + ((nblk - 1) * I + i) * 16);
-  for (uint64_t bb = nblk; bb >= 1; --bb) {
-    const uint64_t blk = bb - 1;
-    uint4 nxt = uint4{0, 0, 0, 0};
-    if (blk >= 1) nxt = *reinterpret_cast<const uint4*>(bp + ((blk - 1) * I + i) * 16);
-    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-    uint32_t o[4] = {0, 0, 0, 0};
+  // The select chain of a block of 16 sites is ~200 cycles of work, a load from HBM several
+  // times that: the PFB blocks of the NEXT group are requested before the current group is
+  // walked.  Loads are unconditional with clamped block numbers (a conditional load is waited
+  // for on the spot); blocks below 0 are masked out of the walk.
+  constexpr int PFB = 16;
+  uint4 cur[PFB], nxt[PFB];
+  const int64_t top0 = (int64_t)nblk - 1;
 #pragma unroll
-    for (int u = 15; u >= 0; --u) {
-      const uint64_t s = blk * 16 + u;  // 0-based site = reference site s+1
-      if (s < S) {
-        o[u >> 2] |= (uint32_t)st << (8 * (u & 3));           // path[s+1]
-        const uint32_t b = (w[u >> 2] >> (8 * (u & 3))) & 0xff;  // Vi[s+1][.]
-        st = (b >> st) & 1;                                     // path[s] = Vi[s+1][path[s+1]]
-      }
+  for (int k = 0; k < PFB; ++k) {
+    const int64_t b = top0 - k;
+    cur[k] = *reinterpret_cast<const uint4*>(bp + ((uint64_t)(b >= 0 ? b : 0) * I + i) * 16);
+  }
+  for (int64_t top = top0; top >= 0; top -= PFB) {
+#pragma unroll
+    for (int k = 0; k < PFB; ++k) {
+      const int64_t b = top - PFB - k;
+      nxt[k] = *reinterpret_cast<const uint4*>(bp + ((uint64_t)(b >= 0 ? b : 0) * I + i) * 16);
     }
-    *reinterpret_cast<uint4*>(path16 + (blk * I + i) * 16) = uint4{o[0], o[1], o[2], o[3]};
-    cur = nxt;
+#pragma unroll
+    for (int k = 0; k < PFB; ++k) {
+      const int64_t blk = top - k;
+      const bool live = blk >= 0;
+      const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+      uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int u = 15; u >= 0; --u) {
+        const uint64_t s = (uint64_t)(live ? blk : 0) * 16 + u;  // 0-based site = reference site s+1
+        const bool on = live && s < S;
+        o[u >> 2] |= (uint32_t)st << (8 * (u & 3));              // path[s+1]
+        const uint32_t bq = (w[u >> 2] >> (8 * (u & 3))) & 0xff;  // Vi[s+1][.]
+        const int prev = (bq >> st) & 1;                           // path[s] = Vi[s+1][path[s+1]]
+        st = on ? prev : st;
+        if (!on) o[u >> 2] &= ~(0xffu << (8 * (u & 3)));           // bytes past S stay 0
+      }
+      if (live) *reinterpret_cast<uint4*>(path16 + ((uint64_t)blk * I + i) * 16) = uint4{o[0], o[1], o[2], o[3]};
+    }
+#pragma unroll
+    for (int k = 0; k < PFB; ++k) cur[k] = nxt[k];
   }
   // path[0] of the reference; for a site shard the state at the last site of the range before
   if (state_before) state_before[i] = (uint8_t)st;
