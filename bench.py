@@ -18,11 +18,19 @@ launches the N ranks itself as a child `python -m torch.distributed.run ...` BEF
 GPU call and relays the child's JSON line and exit code.  A rank exits non-zero when the
 process group's size is not --gpus.
 
---scaling strong (the default; BASELINE.json configs[3]): the workload's individuals are
-SHARDED over the ranks (1000 / N per GPU, all sites), the frequency step is site-sharded
-(S / N sites x all individuals per GPU): posteriors move by an RCCL all-to-all,
-frequencies by an all-gather.  --scaling weak: every rank owns the workload's full number
-of individuals.
+--scaling strong (the default; BASELINE.json configs[3], the 1000 x 1M job over N GPUs).  What a
+rank holds (--shard):
+  sites (fast mode's default)  all individuals for a contiguous range of S / N sites.  A run of
+      sites is a product of 2x2 operators, so the ranges owe each other six doubles per
+      individual and objective point: one all-gather of ~200 kB per objective round; the
+      allele-frequency step has every individual of its sites at hand and exchanges nothing.
+  individuals (exact mode; what BASELINE.json's wording describes)  1000 / N individuals for
+      all sites, the frequency step on S / N sites x all individuals: every posterior moves
+      once per iteration (all-to-all, 8 GB at 1000 x 1M -- over ONE xGMI link between two
+      GPUs), frequencies by an all-gather.
+  DESIGN.md section 6 has the link arithmetic and one rank's measured compute for both.
+--scaling weak: every rank the workload's full number of sites (or individuals).
+--emulate_ranks V [--emulate_rccl]: N = 1 only, one rank's compute of a V-rank run.
 
 Prints ONE JSON line on rank 0.
 """
