@@ -329,3 +329,48 @@ def test_chain_shapes(pkg, I, S, V):
     assert np.array_equal(ch.viterbi(), whole.viterbi())
     for h in hs + [whole]:
         h.close()
+
+
+def test_chain_of_eight_packed_shards_hundred_iterations(pkg):
+    """BASELINE configs[4]'s recipe (--call_geno, 25 chromosomes, 100 iterations, 8 GPUs) on a
+    chain of eight packed site shards at 625 individuals x 320 000 sites: every handle takes the
+    same steps in every one of the 100 iterations, everything stays finite and in range, the
+    total log-likelihood settles."""
+    import torch
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    I, S, V = 625, 320_000, 8
+    dev = torch.device("cuda", 0)
+    mode = pkg.MODE_FAST | pkg.GENO_PACKED
+    ranges = dd.site_ranges_ragged(S, V)
+    pos, chunks = pkg.simulate.simulate_torch_chunks(I, S, dev, seed=17, n_chrom=25, chunk_sites=40_000)
+    chunks = list(chunks)                      # 8 blocks of 40 000 sites = the ranges
+    assert [lo for lo, _ in chunks] == [lo for lo, _ in ranges]
+    hs = []
+    for (lo, hi), (_, c) in zip(ranges, chunks):
+        h = pkg.NgsFHMM(I, hi - lo, mode=mode)
+        torch.cuda.synchronize()
+        h.load_chunks_device(pos[lo:hi].contiguous().data_ptr(), [(0, hi - lo, c.data_ptr())],
+                             space=0, call_geno=True)
+        h.set_params(0.1, 0.2, 0.1)
+        h.init_emission()
+        hs.append(h)
+    del chunks
+    ch = pkg.Chain(hs)
+    tot = []
+    for it in range(100):
+        st = ch.iter_EM(1)
+        tot.append(float(ch.ind_lkl.sum()))
+        assert np.isfinite(ch.ind_lkl).all() and st.rounds >= 1
+        if it % 25 == 24:
+            for h in hs[1:]:
+                assert np.array_equal(h.indF, hs[0].indF) and np.array_equal(h.alpha, hs[0].alpha)
+    F, A, f = hs[0].indF, hs[0].alpha, ch.freq
+    assert (F >= 0).all() and (F <= 1).all() and (A > 0).all() and (A <= 10).all()
+    assert np.isfinite(f).all() and (f >= 0).all() and (f <= 1).all()
+    tot = np.array(tot)
+    assert np.diff(tot)[10:].min() > -1e-6 * abs(tot[-1])            # no step backwards
+    assert abs(tot[-1] - tot[-2]) < 1e-8 * abs(tot[-1])              # settled
+    path = ch.viterbi()
+    assert path.shape == (I, S) and set(np.unique(path)) <= {0, 1}
+    for h in hs:
+        h.close()
