@@ -102,12 +102,13 @@ void launch_emission_ld_exact(hipStream_t st, const GlView& gl, const double* fr
 // receives the state at the site in front of the handle's first
 void launch_viterbi_fwd_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                              uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                             double* scratch, uint64_t chunk_sites, bool chain_start);
+                             double* scratch, uint64_t chunk_sites, bool chain_start,
+                             bool serial = false);  // serial: one lane per individual, no loader waves
 void launch_viterbi_back_exact(hipStream_t st, uint8_t* bp, uint64_t S, uint64_t I,
                                uint8_t* path_sites, uint8_t* state_before);
 void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                           uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites);
+                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites, bool serial = false);
 uint64_t viterbi_chunk_sites(uint64_t S, uint64_t I);
 uint64_t viterbi_blocked_bytes(uint64_t S, uint64_t I);
 void launch_unblock_path(hipStream_t st, const uint8_t* path16, uint64_t S, uint64_t I,

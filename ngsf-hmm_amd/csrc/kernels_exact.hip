@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "detmath.h"
 #include "glview.hpp"
@@ -397,6 +398,160 @@ k_viterbi_fwd_exact(const double* __restrict__ eprob, const double* __restrict__
   }
 }
 
+// The same sweep with the loads taken off the chain.  k_viterbi_fwd_exact is one lane per
+// individual -- 16 waves on the whole chip for a cohort of 1000 -- and a wave can keep only the
+// 768 B per lane in flight that its registers hold, so it runs at the 0.36 TB/s that HBM latency
+// allows (133 ns per site).  Here a workgroup is ONE consumer wave for 64 individuals and VNL
+// loader waves: loader w owns LDS slot w and the groups of VG sites g = w (mod VNL); it asks for
+// group g + VNL while the consumer walks group g out of its slot, holds the data in registers
+// for VNL - 1 steps and writes it to the slot in the step before it is needed -- VNL - 1 groups
+// in flight per workgroup (5 x 24 KB) on top of what the slots hold.  One barrier per step.  The consumer's
+// arithmetic is the serial kernel's, operation for operation: the same path.
+constexpr int VG = 8;    // sites per group: a block of 16 back-pointers is two groups
+constexpr int VNL = 6;   // loader waves = LDS slots (even: a block's two groups sit in slots 2k, 2k+1)
+struct VitSlot {
+  double2 e[VG][64];
+  double4 t[VG][64];
+};
+constexpr size_t kVitLds = sizeof(VitSlot) * VNL;  // 144 KB of the CU's 160
+
+__global__ void __launch_bounds__(64 * (1 + VNL)) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_viterbi_fwd_pc(const double* __restrict__ eprob, const double* __restrict__ tl, uint64_t s0,
+                 uint64_t n_s, uint64_t S, uint64_t I, const double* __restrict__ indF,
+                 double* __restrict__ state, uint8_t* __restrict__ bp,
+                 uint8_t* __restrict__ last_state, int chain_start) {
+  extern __shared__ __align__(16) unsigned char vit_lds[];
+  VitSlot* slot = reinterpret_cast<VitSlot*>(vit_lds);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint64_t i_raw = (uint64_t)blockIdx.x * 64 + lane;
+  const bool valid = i_raw < I;
+  const uint64_t i = valid ? i_raw : I - 1;  // (idle lanes repeat the last individual, write nothing)
+  const uint64_t ngroups = (n_s + VG - 1) / VG;
+  const double2* e2 = reinterpret_cast<const double2*>(eprob);
+  const double4* t4 = reinterpret_cast<const double4*>(tl);
+
+  if (wv == 0) {
+    double v0, v1;
+    if (s0 == 0 && chain_start) {
+      const double f = indF[i];
+      v0 = det_log(1 - f);  // HMM.cpp:101-102
+      v1 = det_log(f);
+    } else {
+      v0 = state[i * 2];
+      v1 = state[i * 2 + 1];
+    }
+    __syncthreads();  // the loaders have filled slots 0 .. VNL-1 with groups 0 .. VNL-1
+    // half a block of 16 back-pointers per step; `whole`: every site of the group exists (all
+    // groups but possibly the chunk's last), so the walk carries no per-site test; HALF: which
+    // eight bytes of the block's sixteen (static, so the bytes land in fixed registers)
+    uint32_t bpw[4] = {0, 0, 0, 0};
+    auto walk = [&](const VitSlot& sl, uint64_t g, auto whole, auto half) {
+      constexpr int H = decltype(half)::value;
+#pragma unroll
+      for (int u = 0; u < VG; ++u) {
+        const double2 ec = sl.e[u][lane];
+        const double4 tc = sl.t[u][lane];
+        if (decltype(whole)::value || g * VG + u < n_s) {  // (see k_viterbi_fwd_exact for the two v_max per state)
+          const double c00 = v0 + tc.x;
+          const double c10 = v1 + tc.y;
+          const double m0 = vmax_f64(-kINF, c00);
+          const int k0 = m0 < c10;
+          v0 = vmax_f64(m0, c10) + ec.x;
+          const double c01 = v0 + tc.z;
+          const double c11 = v1 + tc.w;
+          const double m1 = vmax_f64(-kINF, c01);
+          const int k1 = m1 < c11;
+          v1 = vmax_f64(m1, c11) + ec.y;
+          constexpr int HB = H * 8;
+          bpw[(HB + u) >> 2] |= (uint32_t)(k0 | (k1 << 1)) << (8 * ((HB + u) & 3));
+        }
+      }
+    };
+    auto flush = [&](uint64_t g) {  // the block that group g belongs to
+      if (valid)
+        *reinterpret_cast<uint4*>(bp + (((s0 + (g & ~1ull) * VG) >> 4) * I + i) * 16) =
+            uint4{bpw[0], bpw[1], bpw[2], bpw[3]};
+      bpw[0] = bpw[1] = bpw[2] = bpw[3] = 0;
+    };
+    uint32_t sidx = 0;  // g % VNL
+    for (uint64_t g = 0; g < ngroups; g += 2) {
+      if ((g + 1) * VG <= n_s) walk(slot[sidx], g, std::true_type{}, std::integral_constant<int, 0>{});
+      else walk(slot[sidx], g, std::false_type{}, std::integral_constant<int, 0>{});
+      __syncthreads();  // end of step g
+      if (g + 1 < ngroups) {
+        if ((g + 2) * VG <= n_s) walk(slot[sidx + 1], g + 1, std::true_type{}, std::integral_constant<int, 1>{});
+        else walk(slot[sidx + 1], g + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        flush(g);
+        __syncthreads();  // end of step g + 1
+      } else {
+        flush(g);
+      }
+      sidx = sidx + 2 == VNL ? 0 : sidx + 2;
+    }
+    if (valid) {
+      state[i * 2] = v0;
+      state[i * 2 + 1] = v1;
+      if (s0 + n_s >= S) {
+        // array_max_pos (gen_func.cpp:73-84): strict >, starting from -inf
+        int res = 0;
+        double mx = NEG_INFINITY;
+        if (v0 > mx) { res = 0; mx = v0; }
+        if (v1 > mx) { res = 1; mx = v1; }
+        last_state[i] = (uint8_t)res;
+      }
+    }
+  } else {
+    const uint64_t w = (uint64_t)(wv - 1);
+    VitSlot& mine = slot[w];
+    double2 re[VG];
+    double4 rt[VG];
+    {  // group w into slot w
+      const uint64_t g_ = w < ngroups ? w : ngroups - 1;
+#pragma unroll
+      for (int u = 0; u < VG; ++u) {
+        const uint64_t rr = g_ * VG + u;
+        const uint64_t r = rr < n_s ? rr : n_s - 1;  // past the chunk: its last site again
+        re[u] = e2[(s0 + r) * I + i];
+        rt[u] = t4[r * I + i];
+      }
+#pragma unroll
+      for (int u = 0; u < VG; ++u) {
+        mine.e[u][lane] = double2{re[u].x, re[u].y};  // (component-wise: a whole-struct copy keeps
+        mine.t[u][lane] = double4{rt[u].x, rt[u].y, rt[u].z, rt[u].w};  // the arrays in scratch)
+      }
+    }
+    __syncthreads();
+    // Steps 0 .. ngroups-1, one barrier each.  This loader asks for a group in the steps g = w
+    // (mod VNL) and writes it to its slot VNL - 1 steps later; the requests sit in straight-line
+    // code (a load under a condition is waited for on the spot, and a loader that waits holds
+    // up the step's barrier for everybody).
+    for (uint64_t g = 0; g < w && g < ngroups; ++g) __syncthreads();
+    for (uint64_t g = w; g < ngroups; g += VNL) {
+      const uint64_t gn = g + VNL;
+      const uint64_t g_ = gn < ngroups ? gn : ngroups - 1;
+#pragma unroll
+      for (int u = 0; u < VG; ++u) {  // step g: the consumer walks this loader's slot
+        const uint64_t rr = g_ * VG + u;
+        const uint64_t r = rr < n_s ? rr : n_s - 1;
+        re[u] = e2[(s0 + r) * I + i];
+        rt[u] = t4[r * I + i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 1; k <= VNL - 2; ++k)
+        if (g + k < ngroups) __syncthreads();     // steps g+1 .. g+VNL-2: the loads are in flight
+      if (g + VNL - 1 < ngroups) {
+#pragma unroll
+        for (int u = 0; u < VG; ++u) {  // step g+VNL-1: group g+VNL, needed in the next step
+          mine.e[u][lane] = double2{re[u].x, re[u].y};
+          mine.t[u][lane] = double4{rt[u].x, rt[u].y, rt[u].z, rt[u].w};
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // Trace back (HMM.cpp:119-122): path of reference site s (1-based) = state at s.
 // Back-pointers and the path are blocked [site/16][individual][16], so a lane moves 16
 // sites per load/store; only the 1-bit select chain is sequential.
@@ -766,21 +921,29 @@ void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* m
 
 void launch_viterbi_fwd_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                              uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                             double* scratch, uint64_t chunk_sites, bool chain_start) {
+                             double* scratch, uint64_t chunk_sites, bool chain_start, bool serial) {
   if (I == 0 || S == 0) return;
   // bp holds ceil(S/16)*16*I back-pointer bytes (blocked) followed by I last-state
   // bytes; scratch holds chunk_sites*I*4 transition logs followed by I*2 state doubles
   uint8_t* last_state = bp + ((S + 15) / 16) * 16 * I;
   double* tl = scratch;
   double* state = scratch + chunk_sites * I * 4;
+  static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(k_viterbi_fwd_pc),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)kVitLds) == hipSuccess;
+  if (!big_lds) (void)hipGetLastError();
   for (uint64_t s0 = 0; s0 < S; s0 += chunk_sites) {
     const uint64_t n_s = (S - s0) < chunk_sites ? (S - s0) : chunk_sites;
     uint64_t blocks = (n_s * I + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_trans_log_exact, dim3((unsigned)blocks), dim3(256), 0, st, pos, indF,
                        alpha, s0, n_s, I, tl);
-    hipLaunchKernelGGL(k_viterbi_fwd_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob,
-                       tl, s0, n_s, S, I, indF, state, bp, last_state, chain_start ? 1 : 0);
+    if (serial || !big_lds)
+      hipLaunchKernelGGL(k_viterbi_fwd_exact, dim3((unsigned)((I + 63) / 64)), dim3(64), 0, st, eprob,
+                         tl, s0, n_s, S, I, indF, state, bp, last_state, chain_start ? 1 : 0);
+    else
+      hipLaunchKernelGGL(k_viterbi_fwd_pc, dim3((unsigned)((I + 63) / 64)), dim3(64 * (1 + VNL)), kVitLds,
+                         st, eprob, tl, s0, n_s, S, I, indF, state, bp, last_state, chain_start ? 1 : 0);
   }
 }
 
@@ -794,8 +957,8 @@ void launch_viterbi_back_exact(hipStream_t st, uint8_t* bp, uint64_t S, uint64_t
 
 void launch_viterbi_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                           uint64_t I, const double* indF, const double* alpha, uint8_t* bp,
-                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites) {
-  launch_viterbi_fwd_exact(st, eprob, pos, S, I, indF, alpha, bp, scratch, chunk_sites, true);
+                          uint8_t* path_sites, double* scratch, uint64_t chunk_sites, bool serial) {
+  launch_viterbi_fwd_exact(st, eprob, pos, S, I, indF, alpha, bp, scratch, chunk_sites, true, serial);
   launch_viterbi_back_exact(st, bp, S, I, path_sites, nullptr);
 }
 

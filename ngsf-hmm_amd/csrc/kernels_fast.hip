@@ -3331,7 +3331,7 @@ bool fast_viterbi(FastState& fs, hipStream_t st, const double* d_freq, const dou
   if (!dalloc(&eprob_log, (size_t)fs.I * fs.S * 2)) return false;
   launch_emission_exact(st, fs.gl_log, d_freq, eprob_log, fs.S, fs.I, d_flags);
   launch_viterbi_exact(st, eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_path_sites,
-                       d_scratch, chunk_sites);
+                       d_scratch, chunk_sites, fs.sw.exact_serial != 0);
   const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
   (void)hipFree(eprob_log);
   return ok;
@@ -3344,7 +3344,7 @@ bool fast_viterbi_forward(FastState& fs, hipStream_t st, const double* d_freq, c
   if (!dalloc(&eprob_log, (size_t)fs.I * fs.S * 2)) return false;
   launch_emission_exact(st, fs.gl_log, d_freq, eprob_log, fs.S, fs.I, d_flags);
   launch_viterbi_fwd_exact(st, eprob_log, fs.d_pos, fs.S, fs.I, d_indF, d_alpha, d_bp, d_scratch,
-                           chunk_sites, chain_start);
+                           chunk_sites, chain_start, fs.sw.exact_serial != 0);
   const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
   (void)hipFree(eprob_log);
   return ok;

@@ -1777,7 +1777,7 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
       return NGHMM_ERR_HIP;
   } else {
     launch_viterbi_exact(h->stream, h->d_eprob, h->d_pos, h->S, h->I, h->d_indF, h->d_alpha,
-                         h->d_bp, h->d_path_sites, h->d_vit, chunk);
+                         h->d_bp, h->d_path_sites, h->d_vit, chunk, h->fast.sw.exact_serial != 0);
   }
   launch_unblock_path(h->stream, h->d_path_sites, h->S, h->I, h->d_path);
   if ((rc = toc(h, SLOT_VITERBI, false))) return rc;
