@@ -28,4 +28,6 @@ done
 python3 bench.py --workload c2 --no_cpu_baseline --steps 200 --warmup 20 > $OUT/${TAG}_bench_c2_n1.json
 python3 bench.py --workload c2 --no_cpu_baseline --steps 100 --warmup 10 --replicas 10 > $OUT/${TAG}_bench_c2_replicas10_n1.json
 python3 bench.py --workload c5share --no_cpu_baseline > $OUT/${TAG}_bench_c5share_n1.json
+# config 5's share as a site shard: all 5000 individuals x 625 000 sites (one of eight ranks)
+python3 bench.py --workload c5 --emulate_ranks 8 --no_cpu_baseline > $OUT/${TAG}_bench_c5_rank_of_8_sites.json
 ls -la $OUT
