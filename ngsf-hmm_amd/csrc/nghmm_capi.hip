@@ -327,6 +327,12 @@ int redo_nonfinite(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     set_error("invalid Lkl found!");
     return NGHMM_ERR_INVALID_LKL;
   }
+  if (h->fast.sw.debug_modes) {
+    std::fprintf(stderr, "[nghmm modes] %zu of %u points came back non-finite:", bad.size(), n_pts);
+    for (size_t k = 0; k < bad.size() && k < 6; ++k)
+      std::fprintf(stderr, " (#%u ind %u F %.17g alpha %.17g -> %g)", bad[k], bind[k], bF[k], bA[k], lkl[bad[k]]);
+    std::fprintf(stderr, "\n");
+  }
   g_last_error.clear();
   int rc;
   if ((rc = ensure_points(h, bad.size()))) return rc;
