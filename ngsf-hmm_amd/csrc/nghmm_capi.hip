@@ -1939,6 +1939,10 @@ int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
 int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uint64_t site_begin,
                        uint64_t n_sites_own) {
   g_last_error.clear();
+  if (h && h->fast.shard.world > 1) {
+    set_error("nghmm_shard_config: the handle is a site shard (one layout at a time)");
+    return NGHMM_ERR_ARG;
+  }
   if (!h || n_ind_total < h->I || ind_begin + h->I > n_ind_total ||
       site_begin + n_sites_own > h->S || n_ind_total % h->I != 0) {
     set_error("nghmm_shard_config: inconsistent shard (equal individuals per rank required)");

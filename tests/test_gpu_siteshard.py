@@ -231,6 +231,10 @@ def test_a_failing_exchange_fails_the_call(pkg):
     def boom(nbytes):
         raise RuntimeError("link down")
     h.site_shard_setup(0, 2, send.data_ptr(), recv.data_ptr(), n, boom)
+    # one layout at a time: a site shard is not an individual shard, has no replicas, joins no group
+    assert h.lib.nghmm_shard_config(h.handle, 2 * I, 0, 0, S // 2) != 0
+    with pytest.raises(pkg.NgsFHMMError):
+        h.replica()
     h.set_params(0.1, 0.2, 0.1)
     h.init_emission()
     with pytest.raises(RuntimeError, match="link down"):
