@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "detmath.h"
 #include "glview.hpp"
@@ -75,6 +76,7 @@ __device__ __forceinline__ void ld_posterior(double g0, double g1, double g2, do
 
 // sum over the workgroup of four per-thread values; fast: DPP-free shuffle tree per wave, the
 // 16 wave totals through LDS, every thread adds them in wave order
+template <int TH>
 __device__ __forceinline__ void ld_block_sum4(double (&v)[4], double (*xw)[4], int tid) {
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -89,7 +91,7 @@ __device__ __forceinline__ void ld_block_sum4(double (&v)[4], double (*xw)[4], i
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     double a = xw[0][k];
-    for (int w = 1; w < LD_THREADS / 64; ++w) a += xw[w][k];
+    for (int w = 1; w < TH / 64; ++w) a += xw[w][k];
     v[k] = a;
   }
 }
@@ -97,21 +99,21 @@ __device__ __forceinline__ void ld_block_sum4(double (&v)[4], double (*xw)[4], i
 // gl: EXACT log GL view / else linear GL view, site-major cells; marg [S][I]; freq_old [S];
 // freq_new [S]: [0] holds site 0's new frequency on entry (est_maf), freq_est == 1: all of it
 // does; hap_out [S][4] (row 0 unused).
-template <bool EXACT, int NI>
-__global__ void __launch_bounds__(LD_THREADS)
+template <bool EXACT, int NI, int TH>
+__global__ void __launch_bounds__(TH)
 k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
                 const double* __restrict__ freq_old, double* __restrict__ freq_new,
                 double* __restrict__ hap_out, uint64_t S, uint64_t I, int freq_est,
                 int* __restrict__ flags) {
-  __shared__ double contrib[EXACT ? LD_THREADS : 1][4];  // one chunk of individuals' tmp / sum
-  __shared__ double xw[LD_THREADS / 64][4];
+  __shared__ double contrib[EXACT ? TH : 1][4];  // one chunk of individuals' tmp / sum
+  __shared__ double xw[TH / 64][4];
   __shared__ double ffs[4];
   const int tid = threadIdx.x;
   double gp[NI][3], Fp[NI];
   bool valid[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const uint64_t i = (uint64_t)tid + (uint64_t)j * LD_THREADS;
+    const uint64_t i = (uint64_t)tid + (uint64_t)j * TH;
     valid[j] = i < I;
     const uint64_t ic = valid[j] ? i : I - 1;
     gl_fetch(gl, ic, gp[j][0], gp[j][1], gp[j][2]);
@@ -129,7 +131,7 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
     double P0[NI][3], P1[NI][3];  // the two sites' genotype probabilities
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const uint64_t i = (uint64_t)tid + (uint64_t)j * LD_THREADS;
+      const uint64_t i = (uint64_t)tid + (uint64_t)j * TH;
       const uint64_t ic = valid[j] ? i : I - 1;
       gl_fetch(gl, s * I + ic, gc[j][0], gc[j][1], gc[j][2]);
       Fc[j] = marg[s * I + ic];
@@ -177,8 +179,8 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
           for (int k = 0; k < 4; ++k) contrib[tid][k] = c[j][k];
           __syncthreads();
           if (tid < 4) {
-            const uint64_t base = (uint64_t)j * LD_THREADS;
-            const int n = base >= I ? 0 : (I - base < (uint64_t)LD_THREADS ? (int)(I - base) : LD_THREADS);
+            const uint64_t base = (uint64_t)j * TH;
+            const int n = base >= I ? 0 : (I - base < (uint64_t)TH ? (int)(I - base) : TH);
             double acc = (j == 0) ? 0.0 : ffs[tid];
 #pragma unroll 8
             for (int t = 0; t < n; ++t) acc += contrib[t][tid];
@@ -193,7 +195,7 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int k = 0; k < 4; ++k) ff[k] += c[j][k];
-        ld_block_sum4(ff, xw, tid);
+        ld_block_sum4<TH>(ff, xw, tid);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) f[k] = ff[k] / two_x;
@@ -288,22 +290,33 @@ bool launch_freq_ld_chain(hipStream_t st, bool exact, const GlView& gl, const do
                           const double* freq_old, double* freq_new, double* hap, uint64_t S,
                           uint64_t I, int freq_est, int* flags) {
   if (S < 2) return true;
-  const uint64_t ni = (I + LD_THREADS - 1) / LD_THREADS;
+  // threads of the one workgroup: every pair iteration ends in a sum over all of them, which a
+  // small workgroup does sooner -- fast mode: 256 threads with up to 8 individuals each up to
+  // 2048 individuals (1000 individuals: 51 -> 30 us per site), 1024 threads beyond; exact mode
+  // keeps 1024 (its per-individual transcendentals weigh more than the sum: 143 -> 276 us with
+  // 256)
+  const bool small = !exact && I <= 2048;
+  const uint64_t th = small ? 256 : LD_THREADS;  // (128 threads: 45 us per site)
+  const uint64_t ni = (I + th - 1) / th;
   if (ni > 8) return false;
-#define LD_LAUNCH(EX, NI)                                                                      \
-  hipLaunchKernelGGL((k_freq_ld_chain<EX, NI>), dim3(1), dim3(LD_THREADS), 0, st, gl, marg,    \
+#define LD_LAUNCH(EX, NI, TH)                                                                  \
+  hipLaunchKernelGGL((k_freq_ld_chain<EX, NI, TH>), dim3(1), dim3(TH), 0, st, gl, marg,        \
                      freq_old, freq_new, hap, S, I, freq_est, flags)
+#define LD_PICK(EX, TH)                     \
+  do {                                      \
+    if (ni <= 1) LD_LAUNCH(EX, 1, TH);      \
+    else if (ni <= 2) LD_LAUNCH(EX, 2, TH); \
+    else if (ni <= 4) LD_LAUNCH(EX, 4, TH); \
+    else LD_LAUNCH(EX, 8, TH);              \
+  } while (0)
   if (exact) {
-    if (ni <= 1) LD_LAUNCH(true, 1);
-    else if (ni <= 2) LD_LAUNCH(true, 2);
-    else if (ni <= 4) LD_LAUNCH(true, 4);
-    else LD_LAUNCH(true, 8);
+    if (small) LD_PICK(true, 256);
+    else LD_PICK(true, LD_THREADS);
   } else {
-    if (ni <= 1) LD_LAUNCH(false, 1);
-    else if (ni <= 2) LD_LAUNCH(false, 2);
-    else if (ni <= 4) LD_LAUNCH(false, 4);
-    else LD_LAUNCH(false, 8);
+    if (small) LD_PICK(false, 256);
+    else LD_PICK(false, LD_THREADS);
   }
+#undef LD_PICK
 #undef LD_LAUNCH
   return true;
 }
