@@ -74,24 +74,27 @@ __device__ __forceinline__ void ld_posterior(double g0, double g1, double g2, do
   }
 }
 
-// sum over the workgroup of four per-thread values; fast: DPP-free shuffle tree per wave, the
-// 16 wave totals through LDS, every thread adds them in wave order
+// sum over the workgroup of four per-thread values; fast: shuffle tree per wave, the wave totals
+// through LDS, every thread adds them in wave order.  xw alternates between two buffers from
+// call to call (`flip`), so ONE barrier per call is enough: a thread that races ahead into the
+// next call writes the other buffer, and the one after that starts behind the next barrier.
 template <int TH>
-__device__ __forceinline__ void ld_block_sum4(double (&v)[4], double (*xw)[4], int tid) {
+__device__ __forceinline__ void ld_block_sum4(double (&v)[4], double (*xw)[TH / 64][4], int tid,
+                                              int flip) {
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off);
   const int wv = tid >> 6;
-  __syncthreads();
+  double (*buf)[4] = xw[flip & 1];
   if ((tid & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xw[wv][k] = v[k];
+    for (int k = 0; k < 4; ++k) buf[wv][k] = v[k];
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    double a = xw[0][k];
-    for (int w = 1; w < TH / 64; ++w) a += xw[w][k];
+    double a = buf[0][k];
+    for (int w = 1; w < TH / 64; ++w) a += buf[w][k];
     v[k] = a;
   }
 }
@@ -106,7 +109,8 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
                 double* __restrict__ hap_out, uint64_t S, uint64_t I, int freq_est,
                 int* __restrict__ flags) {
   __shared__ double contrib[EXACT ? TH : 1][4];  // one chunk of individuals' tmp / sum
-  __shared__ double xw[TH / 64][4];
+  __shared__ double xw[2][TH / 64][4];
+  int flip = 0;
   __shared__ double ffs[4];
   const int tid = threadIdx.x;
   double gp[NI][3], Fp[NI];
@@ -158,6 +162,7 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int h = 0; h < 4; ++h) sum += fkh[k][h] * P0[j][ld_g1(k, h)] * P1[j][ld_g2(k, h)];
+        const double inv_sum = EXACT ? 0.0 : 1.0 / sum;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           double tmp = 0;
@@ -167,7 +172,10 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
             const double x = P0[j][ld_g1(h, k)] * P1[j][ld_g2(h, k)];
             tmp += fkh[k][h] * (x + x);
           }
-          c[j][k] = valid[j] ? tmp / sum : 0.0;
+          // exact: the reference's quotient; fast: one reciprocal per individual and iteration
+          // instead of four divisions (the four share their divisor)
+          if constexpr (EXACT) c[j][k] = valid[j] ? tmp / sum : 0.0;
+          else c[j][k] = valid[j] ? tmp * inv_sum : 0.0;
         }
       }
       if constexpr (EXACT) {
@@ -195,7 +203,7 @@ k_freq_ld_chain(const GlView gl, const double* __restrict__ marg,
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int k = 0; k < 4; ++k) ff[k] += c[j][k];
-        ld_block_sum4<TH>(ff, xw, tid);
+        ld_block_sum4<TH>(ff, xw, tid, flip++);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) f[k] = ff[k] / two_x;
@@ -296,7 +304,7 @@ bool launch_freq_ld_chain(hipStream_t st, bool exact, const GlView& gl, const do
   // keeps 1024 (its per-individual transcendentals weigh more than the sum: 143 -> 276 us with
   // 256)
   const bool small = !exact && I <= 2048;
-  const uint64_t th = small ? 256 : LD_THREADS;  // (128 threads: 45 us per site)
+  const uint64_t th = small ? 256 : LD_THREADS;  // (128 threads: 45 us per site; 512: 27)
   const uint64_t ni = (I + th - 1) / th;
   if (ni > 8) return false;
 #define LD_LAUNCH(EX, NI, TH)                                                                  \
