@@ -254,6 +254,8 @@ __device__ __forceinline__ double exp_tiny7(double y) {
 // then NA probes that differ in alpha only, by so little that exp(-(alpha +- eh) d) =
 // exp(-alpha d) * exp(-+ eh d) with a tiny second argument.
 constexpr uint32_t FD_FLAG = 0x100, FD_SMALL = 0x200, FD_XDEG2 = 0x400;
+// an exponent of its own for every point (below: "Dynamic range"); OR-ed onto an fd_mode
+constexpr uint32_t FD_OWNEX = 0x800;
 __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small, bool xdeg2 = false) {
   return FD_FLAG | (small ? FD_SMALL : 0u) | (xdeg2 ? FD_XDEG2 : 0u) | ((uint32_t)nf << 2) |
          (uint32_t)na;
@@ -429,7 +431,7 @@ using SrcOf = std::conditional_t<SRC == SRC_PLAIN, SrcPlain,
 // one exp (a degree-7 polynomial when alpha * d_max <= 2^-6: SMALL), the products shared
 // by all points, 12 instructions per F-probe and 20 per alpha-probe; one exponent (point
 // 0's) rescales all points, which are perturbations of each other.
-template <int NF, int NA, bool SMALL, bool EMIT, int XDEG, typename Src>
+template <int NF, int NA, bool SMALL, bool EMIT, int XDEG, bool OWNEX, typename Src>
 __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc& G,
                                            Op (&R)[MAXP], EmitPtrs emit, uint64_t wave,
                                            int lane) {
@@ -494,7 +496,20 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
 #pragma unroll
       for (int u = 0; u < UG; ++u) buf[b][u] = src.load(t0 + (uint64_t)(b + NB) * UG + u);
     }
-    {  // rescale every point by point 0's exponent
+    if constexpr (OWNEX) {  // every point by its own exponent (kept in R[p].ex)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const double mx = fmax(fmax(R[p].a00, R[p].a01), fmax(R[p].a10, R[p].a11));
+        const int e = exp_of(mx);
+        const double sc = __builtin_ldexp(1.0, -e);
+        R[p].ex += e;
+        R[p].a00 *= sc;
+        R[p].a01 *= sc;
+        R[p].a10 *= sc;
+        R[p].a11 *= sc;
+      }
+      src.rescale();
+    } else {  // rescale every point by point 0's exponent
       const double mx = fmax(fmax(R[0].a00, R[0].a01), fmax(R[0].a10, R[0].a11));
       const int e = exp_of(mx);
       const double sc = __builtin_ldexp(1.0, -e);
@@ -514,8 +529,10 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
       emit_checkpoint(emit.ckpt, wave, nblk, t0 / CK + 1, lane, R[0]);
     }
   }
+  if constexpr (!OWNEX) {
 #pragma unroll
-  for (int p = 0; p < NPT; ++p) R[p].ex = exc;
+    for (int p = 0; p < NPT; ++p) R[p].ex = exc;
+  }
 }
 
 // ordered product of the 64 lanes' operators; lane 0 stores the wave's operator
@@ -538,7 +555,7 @@ __device__ __forceinline__ void lkl_store_wave_op(Op r, int lane, double* __rest
 // One kernel per loop-body version (each gets its own register allocation); the host
 // sorts the groups of a round by mode and launches every version on its range
 // [g_begin, g_begin + gridDim.x / C).
-template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG>
+template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG, bool OWNEX = false>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
               uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
@@ -558,7 +575,8 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
   const uint64_t pos_base = ((uint64_t)c * T) * 64 + lane;
   using Src = SrcOf<SRC>;
   Src src(arr, wave_base, pos_base);
-  lkl_run_fd<NF, NA, SMALL, EMIT, XDEG>(src, T, G, R, emit, i * C + c, lane);
+  static_assert(!(OWNEX && EMIT), "an emitting round's checkpoints assume point 0's scale");
+  lkl_run_fd<NF, NA, SMALL, EMIT, XDEG, OWNEX>(src, T, G, R, emit, i * C + c, lane);
   if constexpr (SRC != SRC_PLAIN) {  // fresh walk: the wave's part of sum log e0
     const double bl = wave_sum(src.base.log_value());
     if (lane == 0) arr.base_c[i * C + c] = bl + (arr.gl_scale_c ? arr.gl_scale_c[i * C + c] : 0.0);
@@ -2911,6 +2929,7 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool for
                            bool allow_xdeg2) {
   if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
   int nf = 0, na = 0;
+  bool ownex = false;
   double xmax = 0;  // largest |alpha_0 - alpha_probe| d over the data's finite distances
   for (uint32_t p = 1; p < G.np; ++p) {
     if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
@@ -2924,7 +2943,13 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool for
       // data have no forced visits; should a probe overflow there all the same, its value
       // comes back non-finite and the host re-evaluates it with the general kernel.
       const double rho0 = (1 - G.F[p]) / (1 - G.F[0]);
-      if (forced_visits && !(std::fabs(std::log(rho0)) * (double)T <= 600.0)) return 0;
+      if (forced_visits && !(std::fabs(std::log(rho0)) * (double)T <= 600.0)) {
+        // ... or, where the probe stays in range over the eight sites between two rescales
+        // (always, with F inside [1e-15, 1 - 1e-15]), the pattern kernel with an exponent per
+        // point: the shared transition terms are still formed once per site
+        if (!(std::fabs(std::log(rho0)) * 8.0 <= 600.0)) return 0;
+        ownex = true;
+      }
       ++nf;
     } else if (G.F[p] == G.F[0] && std::fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
       ++na;
@@ -2936,7 +2961,8 @@ static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool for
   const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
                   (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
   if (!ok) return 0;
-  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625, allow_xdeg2 && na > 0 && xmax <= 1e-5);
+  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625, allow_xdeg2 && na > 0 && xmax <= 1e-5) |
+         (ownex ? FD_OWNEX : 0u);
 }
 
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
@@ -2984,8 +3010,9 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
     for (const auto& r : L.mode_ranges) {
       if (r.mode)
-        std::fprintf(stderr, " %uF%uA%s%s x%u", (r.mode >> 2) & 3, r.mode & 3,
-                     (r.mode & FD_SMALL) ? "s" : "", (r.mode & FD_XDEG2) ? "2" : "", r.count);
+        std::fprintf(stderr, " %uF%uA%s%s%s x%u", (r.mode >> 2) & 3, r.mode & 3,
+                     (r.mode & FD_SMALL) ? "s" : "", (r.mode & FD_XDEG2) ? "2" : "",
+                     (r.mode & FD_OWNEX) ? "e" : "", r.count);
       else
         std::fprintf(stderr, " general x%u", r.count);
     }
@@ -3038,7 +3065,10 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
   // at 1000 x 1M)
   for (const auto& r : L.mode_ranges) {
     const dim3 grid(r.count * fs.C), block(64);
-    switch (r.mode) {
+    // a group that needs an exponent per point (FD_OWNEX) in a round that also emits the
+    // E-step's by-products goes to the general kernel as before
+    const uint32_t mode = ((r.mode & FD_OWNEX) && emit_estep) ? 0u : r.mode;
+    switch (mode) {
 #define FD_LAUNCH(NF, NA, SM, EM, FR, XD)                                                    \
   hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR, XD>), grid, block, 0, st, arr, fs.T,    \
                      fs.C, dg, r.begin, L.part, emit)
@@ -3048,6 +3078,10 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     else if (fresh) FD_LAUNCH(NF, NA, SM, true, SRC_FRESH, XD);               \
     else if (emit_estep) FD_LAUNCH(NF, NA, SM, true, SRC_PLAIN, XD);          \
     else FD_LAUNCH(NF, NA, SM, false, SRC_PLAIN, XD);                         \
+    break;                                                                    \
+  case fd_mode(NF, NA, SM, XD == 2) | FD_OWNEX:                               \
+    hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, false, SRC_PLAIN, XD, true>), grid, block, 0, st, arr, \
+                       fs.T, fs.C, dg, r.begin, L.part, emit);                \
     break;
 #define FD_CASE(NF, NA)       \
   FD_CASE1(NF, NA, false, 4)  \

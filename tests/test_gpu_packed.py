@@ -117,6 +117,49 @@ def test_packed_fast_mode_per_call(pkg, orc_libm, called, how):
     b.close()
 
 
+def test_packed_probes_at_the_upper_bound_of_F(pkg, orc_libm):
+    """L-BFGS-B's first trial step of an M-step lands on a bound: F = 1 - 1e-15 with a one-sided
+    probe at F - 2 eh.  On called genotypes a forced non-IBD site multiplies that probe's
+    operator by (1 - F_p) / (1 - F_0) ~ 5e10 relative to point 0's, which a common exponent for
+    all points cannot hold over a lane-chunk: such groups run the finite-difference kernel with
+    an exponent PER POINT (FD_OWNEX; the general kernel before).  The groups against the same
+    points sent one at a time (one point per group:
+    the general kernel) and against the oracle."""
+    I2, S2 = 24, 64 * 1200
+    d = pkg.simulate.simulate(I2, S2, seed=5, n_chrom=4, indF=0.6, freq="r", alpha=0.4)
+    h = pkg.NgsFHMM(I2, S2, mode=pkg.MODE_FAST | pkg.GENO_PACKED)
+    h.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=True)
+    h.set_params(0.5, 0.2, 0.2)
+    h.init_emission()
+    T = h.layout()[1]
+    ub = 1 - 1e-15
+    eh_F = (1e-8 * (ub + 1)) ** 0.67
+    assert np.log(2 * eh_F / 1e-15) * T > 600          # beyond what one exponent holds
+    al = 0.7
+    eh_A = (1e-8 * (al + 1)) ** 0.67
+    # f0, backward F probe (bfgs.cpp:38-40), the two alpha probes
+    F5 = np.tile([ub, ub - 2 * eh_F, ub, ub], I2)
+    A5 = np.tile([al, al, al + eh_A, al - eh_A], I2)
+    ind5 = np.repeat(np.arange(I2), 4).astype(np.uint32)
+    h.set_switch("debug_modes", 1)
+    got = h.lkl(ind5, F5, A5)
+    h.set_switch("debug_modes", 0)
+    assert np.isfinite(got).all()
+    one_by_one = np.array([h.lkl(ind5[k:k + 1], F5[k:k + 1], A5[k:k + 1])[0] for k in range(len(ind5))])
+    np.testing.assert_allclose(got, one_by_one, rtol=1e-12)
+    em = orclib.OracleEM(orc_libm, h.gl, d.pos_dist_mb)
+    em.set_params(0.5, 0.2, 0.2)
+    assert em.init_emission() == 0
+    e = em.e_prob
+    want = np.array([-orc_libm.lkl([F5[k], A5[k]], e[ind5[k]], d.pos_dist_mb) for k in range(len(ind5))])
+    np.testing.assert_allclose(got, want, rtol=1e-11)
+    # the finite difference the optimizer forms from them
+    g_got = (got[0::4] - got[1::4]) / (2 * eh_F)
+    g_want = (want[0::4] - want[1::4]) / (2 * eh_F)
+    np.testing.assert_allclose(g_got, g_want, rtol=1e-4, atol=1e-2)
+    h.close()
+
+
 def test_packed_handle_refuses_likelihoods(pkg, called):
     d = called
     with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST | pkg.GENO_PACKED) as h:
