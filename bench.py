@@ -115,12 +115,21 @@ def estmaf_instr_per_site(i_tot):
     return valu, fp64
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (relative path), or None."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    return os.path.relpath(hits[-1], ROOT) if hits else None
+
+
+PMC_SUMMARY = _latest_profile("pmc_summary.json")
+
+
 def pmc_summary():
     """The committed rocprofv3 --pmc passes of the default workload (profiles/collect.sh ->
     profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction), or
-    None.  Collected in the same session and from the same build as profiles/r03_bench_*.json."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
-    return json.load(open(path)) if os.path.exists(path) else None
+    None.  Collected in one session with the round's profiles/rNN_bench_*.json."""
+    return json.load(open(os.path.join(ROOT, PMC_SUMMARY))) if PMC_SUMMARY else None
 
 
 def pmc_traffic(summ, I, C):
@@ -211,10 +220,10 @@ def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
     # configs[2], one thread, the "improved CPU") take minutes: measured once per round on the
     # GPU box's host with tools/cpu_baseline.py and committed; this run's sample above is the
     # live cross-check of the same code on this host
-    committed = os.path.join(ROOT, "profiles", "r03_cpu_baseline.json")
-    if os.path.exists(committed):
-        out["baseline_md_section4"] = dict(json.load(open(committed)),
-                                           source="profiles/r03_cpu_baseline.json (tools/cpu_baseline.py)")
+    committed = _latest_profile("cpu_baseline.json")
+    if committed:
+        out["baseline_md_section4"] = dict(json.load(open(os.path.join(ROOT, committed))),
+                                           source=f"{committed} (tools/cpu_baseline.py)")
     if full_c2:
         v3, it3, dt3, thr3, _, _ = timed(100, 100_000, 1, 1e9, False)
         out["configs1_full"] = {
@@ -249,6 +258,293 @@ def launch_ranks(args):
            os.path.abspath(__file__)] + sys.argv[1:]
     r = subprocess.run(cmd, env=env)
     raise SystemExit(r.returncode)
+
+
+PARITY = {
+    "oracle": "partial: the L-BFGS-B core is pinned bit for bit to the reference's own object code; "
+              "HMM.cpp / gen_func.cpp / EM.cpp cannot be compiled here (GSL absent, no stand-in "
+              "written): restated, anchored by a binary128 model and path enumeration",
+    "exact_mode": "bit-identical to the oracle's det build end to end (every array, Viterbi paths, "
+                  "output files)",
+    "per_call": "1e-9 (tested): fast mode vs the oracle per call and teacher-forced per iteration: "
+                "log-likelihoods 1e-12, posteriors / frequencies 1e-9 relative; Viterbi paths identical",
+    "end_to_end_indF": "3.5e-5 max (median 3.5e-7) vs exact mode after 25 iterations at 200 x 50k; the "
+                       "reference differs from itself by 1e-5 under another compiler flag (SURVEY "
+                       "finding 4): the finite-difference L-BFGS-B amplifies last-bit differences, so "
+                       "1e-9 end to end holds for the likelihood trajectory, not for indF / alpha",
+}
+
+CHECK_REF = os.path.join(ROOT, "profiles", "check_n1.json")
+
+
+class Ctx:
+    """What every part of a run needs: arguments, modules, this process's place in the job."""
+
+
+def shard_shapes(ctx, shard):
+    """What this rank's handle holds under `shard` ("sites" | "individuals" | None = one GPU):
+    the slice of the ONE data set IndexedSim(I_tot, S_job) describes.  The N-rank job processes
+    the data set the N = 1 job processes, whatever the sharding (EM.cpp:151-161: results do not
+    depend on the number of workers)."""
+    args, wl, world, rank = ctx.args, ctx.wl, ctx.world, ctx.rank
+    I, S = wl["n_ind"], wl["n_sites"]
+    V = args.emulate_ranks
+    strong = args.scaling == "strong"
+    sh = {"by_sites": shard == "sites", "shard": shard}
+    if shard == "sites":
+        S_job = S if strong else S * world            # weak: the chain N times as long
+        lo, hi = ctx.dd.site_ranges_ragged(S_job, world * V)[rank]
+        sh.update(I=I, I_tot=I, S=hi - lo, S_job=S_job, ind_range=(0, I), site_range=(lo, hi))
+    elif shard == "individuals":
+        I_tot = I if strong else I * world
+        if I_tot % (world * V) or S % (world * V):
+            raise ValueError(f"individual shards: {I_tot} individuals / {S} sites do not divide by "
+                             f"{world * V}")
+        Il = I_tot // (world * V)
+        sh.update(I=Il, I_tot=I_tot, S=S, S_job=S, ind_range=(rank * Il, (rank + 1) * Il),
+                  site_range=(0, S))
+    else:
+        sh.update(I=I, I_tot=I, S=S, S_job=S, ind_range=(0, I), site_range=(0, S))
+    per_cell = 24.0 if ctx.call_geno else 90.0           # DESIGN.md section 3: 21 / 84 B per cell + exchange
+    if sh["I"] * sh["S"] * per_cell > 270e9:
+        raise ValueError(f"workload {args.workload}: {sh['I']} x {sh['S']} per GPU does not fit one "
+                         f"MI355X (use more ranks: --gpus 8)")
+    return sh
+
+
+def build_run(ctx, shard):
+    """Create the rank's handle(s) for `shard` and load its slice of the synthetic data set,
+    generated on the device (same data model as scripts/ngsF-HMMsim.R, every element a hash of
+    its global indices: simulate.IndexedSim)."""
+    torch, pkg, dd, args = ctx.torch, ctx.pkg, ctx.dd, ctx.args
+    sh = shard_shapes(ctx, shard)
+    V = args.emulate_ranks
+    if sh["by_sites"]:
+        em = dd.SiteShardedEM(pkg, sh["I"], sh["S_job"], device_index=ctx.local_rank, mode=ctx.mode,
+                              rank=ctx.rank, world=ctx.world, emulate_ranks=V,
+                              emulate_through_group=args.emulate_rccl)
+        assert em.S_own == sh["S"]
+    else:
+        em = dd.ShardedEM(pkg, sh["I"], sh["S"], device_index=ctx.local_rank, mode=ctx.mode,
+                          rank=ctx.rank, world=ctx.world, emulate_ranks=V)
+    sim = pkg.simulate.IndexedSim(sh["I_tot"], sh["S_job"], ctx.device, seed=12345,
+                                  n_chrom=ctx.wl.get("n_chrom", 1))
+    pos = sim.pos_dist(*sh["site_range"])
+    if ctx.call_geno:   # a block of sites at a time, called and packed on the way in
+        em.load_chunks_device(pos, sim.chunks(sh["ind_range"], sh["site_range"], chunk_sites=50_000),
+                              space=0, call_geno=True)
+    else:
+        gl = sim.gl(sh["ind_range"], sh["site_range"])
+        torch.cuda.synchronize()
+        em.load_device(gl, pos)
+        del gl
+    del sim, pos
+    torch.cuda.empty_cache()
+    sh["em"] = em
+    return sh
+
+
+def reset_params(em):
+    """examples/test.sh "normal": --freq 0.1 --indF 0.1,0.2."""
+    em.set_params(0.1, 0.2, 0.1)
+    em.init_emission()
+
+
+def barrier(ctx):
+    ctx.torch.cuda.synchronize()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+    ctx.torch.cuda.synchronize()
+
+
+def allreduce(ctx, values, op="sum"):
+    """numpy float64 array reduced over the ranks (identity on one rank)."""
+    import numpy as np
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    if ctx.world == 1:
+        return a
+    torch, dist = ctx.torch, ctx.dist
+    t = torch.from_numpy(a.copy())
+    if dist.get_backend() == "nccl":
+        t = t.to(ctx.device)
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX,
+                           "min": dist.ReduceOp.MIN}[op])
+    return t.cpu().numpy()
+
+
+FAMILIES = ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first")
+
+
+def timed_loop(ctx, run, steps, warmup, replicas=()):
+    """W untimed iterations from the starting values, then EXACTLY K timed ones between
+    barriers; MAX over ranks.  Every iteration's own wall time is kept as well (iter_EM returns
+    after its stream has drained, so the clock reads add no synchronisation): the first
+    iterations of a run are its cold start (L-BFGS-B needs 18, 13, 6 objective rounds there)."""
+    import threading
+    em = run["em"]
+
+    def iterate_all():
+        if not replicas:
+            return em.iter_EM()
+        th = [threading.Thread(target=h.iter_EM) for h in replicas]
+        for t in th:
+            t.start()
+        st = em.iter_EM()
+        for t in th:
+            t.join()
+        return st
+
+    each_ms, each_rounds = [], []
+
+    def one():
+        t = time.perf_counter()
+        st = iterate_all()
+        each_ms.append((time.perf_counter() - t) * 1e3)
+        each_rounds.append(int(st.rounds))
+        return st
+
+    for _ in range(warmup):
+        one()
+    em.reset_timing()
+    fam = {k: 0.0 for k in FAMILIES}
+    launches = dict.fromkeys(fam, 0)
+    rounds = points = ind_rounds = ref_calls = 0
+    barrier(ctx)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = one()
+        rounds += st.rounds
+        points += st.points
+        ind_rounds += st.ind_rounds
+        ref_calls += st.ref_forward_calls
+        for k in fam:
+            ms, n = em.hmm.kernel_ms(k)
+            fam[k] += ms
+            launches[k] += n
+    barrier(ctx)
+    dt = time.perf_counter() - t0
+    if ctx.world > 1:
+        dt = float(allreduce(ctx, [dt], "max")[0])
+    return dict(dt=dt, fam=fam, launches=launches, rounds=rounds, points=points, ind_rounds=ind_rounds,
+                ref_calls=ref_calls, each_ms=each_ms, each_rounds=each_rounds, steps=steps, warmup=warmup)
+
+
+def result_check(ctx, run, iterations=2):
+    """Two EM iterations from the starting values, reduced to numbers that do not depend on how
+    the job is sharded: the N-rank line's `check` must equal the one-GPU line's (log-likelihood
+    1e-12, frequencies 1e-9, the same L-BFGS-B rounds) -- the reference's "results do not depend
+    on the number of workers" (EM.cpp:151-161,198-201), checked by the run that is timed."""
+    import numpy as np
+    em, hmm = run["em"], run["em"].hmm
+    I_tot, S_job = run["I_tot"], run["S_job"]
+    reset_params(em)
+    out = {"iterations": iterations, "tot_lkl": [], "rounds": [], "ind_rounds": [], "points": []}
+    rounds_agree = True
+    for _ in range(iterations):
+        st = em.iter_EM()
+        lkl = np.asarray(em.ind_lkl if em.ind_lkl is not None else hmm.ind_lkl, dtype=np.float64)
+        if run["by_sites"]:            # the chain's values, the same on every rank
+            tot = float(lkl.sum())
+            r = allreduce(ctx, [st.rounds, -float(st.rounds)], "max")
+            rounds_agree = rounds_agree and r[0] == -r[1]
+            out["rounds"].append(int(st.rounds))
+            out["ind_rounds"].append(int(st.ind_rounds))
+            out["points"].append(int(st.points))
+        else:                          # every rank its own individuals
+            tot = float(allreduce(ctx, [lkl.sum()])[0])
+            out["rounds"].append(int(allreduce(ctx, [st.rounds], "max")[0]))
+            c = allreduce(ctx, [st.ind_rounds, st.points])
+            out["ind_rounds"].append(int(c[0]))
+            out["points"].append(int(c[1]))
+        out["tot_lkl"].append(tot)
+    indF, alpha = hmm.indF, hmm.alpha
+    if run["by_sites"]:
+        out["indF_sum"], out["alpha_sum"] = float(indF.sum()), float(alpha.sum())
+        out["rounds_equal_on_all_ranks"] = bool(rounds_agree)
+    else:
+        c = allreduce(ctx, [indF.sum(), alpha.sum()])
+        out["indF_sum"], out["alpha_sum"] = float(c[0]), float(c[1])
+    # frequencies: sum, an index-weighted sum and 16 probe sites, by GLOBAL site index
+    freq = hmm.freq
+    lo = run["site_range"][0] if run["by_sites"] else 0
+    s_glob = lo + np.arange(len(freq), dtype=np.int64)
+    w = ((s_glob * 2654435761) % 1000003) / 1000003.0
+    probes = [(2 * k + 1) * S_job // 32 for k in range(16)]
+    pv = np.array([freq[p - lo] if lo <= p < lo + len(freq) else 0.0 for p in probes])
+    part = np.concatenate([[freq.sum(), (freq * w).sum()], pv])
+    if run["by_sites"]:
+        part = allreduce(ctx, part)
+    out["freq_sum"], out["freq_weighted_sum"] = float(part[0]), float(part[1])
+    out["freq_probe_sites"] = probes
+    out["freq_probes"] = [float(v) for v in part[2:]]
+    out["data"] = f"IndexedSim seed 12345, {I_tot} x {S_job}"
+    return out
+
+
+def compare_checks(got, ref):
+    """Relative differences of two `check` objects (the N-rank line against the one-GPU line)."""
+    def rel(a, b):
+        return abs(a - b) / max(abs(b), 1e-300)
+    d = {
+        "tot_lkl_max_rel_diff": max(rel(a, b) for a, b in zip(got["tot_lkl"], ref["tot_lkl"])),
+        "freq_probe_max_rel_diff": max(rel(a, b) for a, b in zip(got["freq_probes"], ref["freq_probes"])),
+        "freq_sum_rel_diff": rel(got["freq_sum"], ref["freq_sum"]),
+        "freq_weighted_sum_rel_diff": rel(got["freq_weighted_sum"], ref["freq_weighted_sum"]),
+        "indF_sum_rel_diff": rel(got["indF_sum"], ref["indF_sum"]),
+        "alpha_sum_rel_diff": rel(got["alpha_sum"], ref["alpha_sum"]),
+        "rounds_equal": got["rounds"] == ref["rounds"],
+        "rounds": got["rounds"], "rounds_n1": ref["rounds"],
+    }
+    d["ok"] = bool(d["tot_lkl_max_rel_diff"] <= 1e-12 and d["freq_probe_max_rel_diff"] <= 1e-9 and
+                   d["freq_weighted_sum_rel_diff"] <= 1e-9 and d["rounds_equal"])
+    return d
+
+
+def check_key(ctx, run):
+    return (f"{ctx.args.workload}:{ctx.args.mode}:{run['I_tot']}x{run['S_job']}"
+            f":{'cg' if ctx.call_geno else 'gl'}")
+
+
+def exact_mode_line(ctx, budget_s=5.0):
+    """The bit-exact mode (the only one that equals the CPU oracle bit for bit end to end,
+    HMM.cpp:6-60 order preserved) on the first 100 000 sites of the workload's data set, a few
+    iterations within `budget_s` of wall time; and the fast mode's first iteration on the same
+    slice against it."""
+    import numpy as np
+    torch, pkg = ctx.torch, ctx.pkg
+    I, S = ctx.wl["n_ind"], min(100_000, ctx.wl["n_sites"])
+    sim = pkg.simulate.IndexedSim(I, ctx.wl["n_sites"], ctx.device, seed=12345,
+                                  n_chrom=ctx.wl.get("n_chrom", 1))
+    gl, pos = sim.gl((0, I), (0, S)), sim.pos_dist(0, S)
+    torch.cuda.synchronize()
+    res = {}
+    out = {"workload": f"{I} x {S // 1000}k (the first {S} sites of the data set)", "bound": "latency"}
+    for name, mode in (("exact", pkg.MODE_EXACT), ("fast", pkg.MODE_FAST)):
+        with pkg.NgsFHMM(I, S, device=ctx.local_rank, mode=mode) as h:
+            h.load_device(gl.data_ptr(), pos.data_ptr())
+            reset_params(h)
+            ms, rounds, fam = [], [], dict.fromkeys(("forward", "backward", "lkl_batch", "est_maf"), 0.0)
+            t0 = time.perf_counter()
+            while len(ms) < (3 if name == "exact" else 1) and (not ms or time.perf_counter() - t0 < budget_s - 1.5):
+                t = time.perf_counter()
+                st = h.iter_EM()
+                ms.append((time.perf_counter() - t) * 1e3)
+                rounds.append(int(st.rounds))
+                for k in fam:
+                    fam[k] += h.kernel_ms(k)[0]
+                if len(ms) == 1:
+                    res[name] = (h.ind_lkl.copy(), h.freq)
+            if name == "exact":
+                out.update(ms_per_step=sum(ms) / len(ms), iterations_ms=ms, rounds=rounds,
+                           site_ind_updates_per_s=I * S * len(ms) / (sum(ms) * 1e-3),
+                           kernel_ms_per_step={k: v / len(ms) for k, v in fam.items()})
+    a, b = res["exact"], res["fast"]
+    out["fast_vs_exact_first_iteration"] = {
+        "ind_lkl_max_rel_diff": float(np.max(np.abs(a[0] - b[0]) / np.abs(a[0]))),
+        "freq_max_abs_diff": float(np.max(np.abs(a[1] - b[1])))}
+    del gl, pos
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -288,19 +584,53 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: shard the workload's individuals over the ranks (strong, "
                          "BASELINE configs[3]) or give every rank the full number (weak)")
+    ap.add_argument("--no_alt", action="store_true",
+                    help="N > 1, site shards: skip the second, short loop over the same data set in "
+                         "the OTHER layout (individual shards, BASELINE configs[3]'s wording) that "
+                         "the line embeds as `alt_sharding`")
+    ap.add_argument("--no_exact_line", action="store_true",
+                    help="N = 1: skip the bit-exact mode's bounded run (`exact_mode` in the line)")
+    ap.add_argument("--no_check", action="store_true", help="skip the cross-N result check")
+    ap.add_argument("--write_check", action="store_true",
+                    help="N = 1: store this line's `check` in profiles/check_n1.json, which N > 1 "
+                         "lines compare themselves with (`vs_n1`)")
+    ap.add_argument("--timeout_s", type=float,
+                    default=float(os.environ.get("NGHMM_BENCH_TIMEOUT_S", "120")),
+                    help="process-group timeout: a collective (or the rendezvous) that takes longer "
+                         "ends the rank with a non-zero exit code")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)       # does not return
+    if args.gpus == 1:
+        return run_rank(args)
+    # a rank of several: whatever goes wrong ends THIS process with a non-zero code (a fresh exit,
+    # never an exec), and the failure beacon / the process group's timeout end the others
+    try:
+        run_rank(args)
+    except SystemExit:
+        raise
+    except BaseException as e:   # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write(f"bench.py: rank {os.environ.get('RANK', '?')}: {type(e).__name__}: {e}\n")
+        sys.stderr.flush()
+        os._exit(4)
 
+
+def run_rank(args):
+    from datetime import timedelta
     import torch
     import torch.distributed as dist
 
-    pkg = importlib.import_module("ngsf-hmm_amd")
-    rank = int(os.environ.get("RANK", "0"))
+    ctx = Ctx()
+    ctx.args, ctx.torch, ctx.dist = args, torch, dist
+    pkg = ctx.pkg = importlib.import_module("ngsf-hmm_amd")
+    dd = ctx.dd = importlib.import_module("ngsf-hmm_amd.distributed")
+    rank = ctx.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     backend = None
@@ -310,6 +640,15 @@ def main():
     sys.stdout.flush()
     fd_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    def restore_stdout():
+        nonlocal fd_stdout
+        if fd_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(fd_stdout, 1)
+            os.close(fd_stdout)
+            fd_stdout = None
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # NGHMM_BENCH_BACKEND=gloo + NGHMM_BENCH_ONE_GPU=1: functional test of the
@@ -318,139 +657,82 @@ def main():
         backend = os.environ.get("NGHMM_BENCH_BACKEND", "nccl")
         if os.environ.get("NGHMM_BENCH_ONE_GPU"):
             local_rank = 0
+        # a collective that hangs must end the run inside the driver's window, not wait out
+        # torch's default (10 min under the RCCL watchdog, 30 min under gloo)
+        tmo = timedelta(seconds=args.timeout_s)
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=tmo)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=tmo)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, "
                              f"--gpus says {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    ctx.local_rank = local_rank
+    device = ctx.device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     preflight = None
     if world > 1:
         # known-answer all-to-all + all-gather on float64 device tensors through the very
         # calls the iteration makes, BEFORE any data is loaded: a backend that moves wrong
-        # bytes (or none: the nccl path had never run before the driver's 8-GPU node) must
-        # end the run with a message, not a plausible number
-        ddp = importlib.import_module("ngsf-hmm_amd.distributed")
+        # bytes must end the run with a message, not a plausible number
         try:
-            preflight = ddp.preflight(device)
+            preflight = dd.preflight(device)
         except Exception as e:   # noqa: BLE001 - any failure of the collectives ends the run
             sys.stderr.write(f"bench.py: rank {rank}: {type(e).__name__}: {e}\n")
             sys.stderr.flush()
             os._exit(3)
     if not (args.emulate_rccl and world == 1):
-        sys.stdout.flush()
-        os.dup2(fd_stdout, 1)
-        os.close(fd_stdout)
-        fd_stdout = None
+        restore_stdout()
 
-    wl = dict(WORKLOADS[args.workload])
+    wl = ctx.wl = dict(WORKLOADS[args.workload])
     if args.n_ind:
         wl["n_ind"] = args.n_ind
     if args.n_sites:
         wl["n_sites"] = args.n_sites
-    I, S = wl["n_ind"], wl["n_sites"]
-    strong = args.scaling == "strong"
     V = args.emulate_ranks
-    by_sites = (args.shard or ("sites" if args.mode == "fast" else "individuals")) == "sites" and \
-        (world > 1 or V > 1)
-    if by_sites and args.mode != "fast":
+    sharded = world > 1 or V > 1
+    shard = (args.shard or ("sites" if args.mode == "fast" else "individuals")) if sharded else None
+    if shard == "sites" and args.mode != "fast":
         raise SystemExit("--shard sites is a fast-mode layout")
     if V > 1 and (world > 1 or args.replicas > 1):
         raise SystemExit("--emulate_ranks V needs --gpus 1 and no replicas")
-    S_job = S                 # the job's sites; S becomes what one rank's handle holds
-    if by_sites:
-        if not strong:
-            S_job = S * world          # weak: every rank the workload's sites, the chain N times as long
-        dd = importlib.import_module("ngsf-hmm_amd.distributed")
-        lo, hi = dd.site_ranges_ragged(S_job, world * V)[rank]
-        S = hi - lo
-        I_tot = I
-    else:
-        if world > 1 and strong:
-            if I % world or S % world:
-                raise SystemExit(f"--scaling strong: {I} individuals / {S} sites do not divide by {world}")
-            I //= world           # per rank; the job's total stays wl["n_ind"]
-        if V > 1:
-            if I % V or S % V:
-                raise SystemExit("--emulate_ranks V needs V dividing individuals and sites")
-            I //= V               # the emulated rank's individuals
-        I_tot = I * world
-    mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
-    call_geno = bool(wl.get("call_geno"))
-    if call_geno:
-        mode |= pkg.GENO_PACKED
-    if I * S * (24.0 if call_geno else 90.0) > 270e9:   # 21 / 84 B per cell + exchange
-        raise SystemExit(f"workload {args.workload}: {I} x {S} per GPU does not fit one MI355X "
-                         f"(use more ranks: --gpus 8)")
-
-    # synthetic inputs, generated on the device (same data model as scripts/ngsF-HMMsim.R)
-    dd = importlib.import_module("ngsf-hmm_amd.distributed")
-    if by_sites:
-        # every rank simulates all individuals on its own site range (a chain of independently
-        # simulated segments; the distance in front of a later range's first site is an
-        # ordinary one, not a chromosome start)
-        if args.emulate_rccl:
-            if V < 2:
-                raise SystemExit("--emulate_rccl goes with --emulate_ranks V")
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                    device_id=device)
-            preflight = dd.preflight(device)
-            torch.cuda.synchronize()
-            sys.stdout.flush()
-            os.dup2(fd_stdout, 1)
-            os.close(fd_stdout)
-            fd_stdout = None
-        em = dd.SiteShardedEM(pkg, I, S_job, device_index=local_rank, mode=mode, rank=rank,
-                              world=world, emulate_ranks=V, emulate_through_group=args.emulate_rccl)
-        assert em.S_own == S
-    else:
-        # every rank simulates its own individuals on the same sites
-        em = dd.ShardedEM(pkg, I, S, device_index=local_rank, mode=mode, rank=rank, world=world,
-                          emulate_ranks=V)
-    pos_seed = None if (world == 1 or by_sites) else 777
-    n_chrom = wl.get("n_chrom", 1)
-    if by_sites:
-        n_chrom = max(1, n_chrom // (world * V))
-    if call_geno:   # a block of sites at a time, called and packed on the way in
-        pos, chunks = pkg.simulate.simulate_torch_chunks(
-            I, S, device, seed=12345 + rank, pos_seed=pos_seed, n_chrom=n_chrom, chunk_sites=50_000)
-        if by_sites and rank > 0:
-            pos[0] = 0.1
-        em.load_chunks_device(pos, chunks, space=0, call_geno=True)
-    else:
-        gl, pos = pkg.simulate.simulate_torch(I, S, device, seed=12345 + rank, pos_seed=pos_seed,
-                                              n_chrom=n_chrom)
-        if by_sites and rank > 0:
-            pos[0] = 0.1
+    if args.replicas > 1 and world > 1:
+        raise SystemExit("--replicas needs --gpus 1")
+    ctx.mode = pkg.MODE_FAST if args.mode == "fast" else pkg.MODE_EXACT
+    ctx.call_geno = bool(wl.get("call_geno"))
+    if ctx.call_geno:
+        ctx.mode |= pkg.GENO_PACKED
+    if args.emulate_rccl:
+        if V < 2 or shard != "sites":
+            raise SystemExit("--emulate_rccl goes with --emulate_ranks V and site shards")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=device)
+        preflight = dd.preflight(device)
         torch.cuda.synchronize()
-        em.load_device(gl, pos)
-        del gl
-    if fd_stdout is not None:     # (--emulate_rccl without site shards: nothing used the group)
-        sys.stdout.flush()
-        os.dup2(fd_stdout, 1)
-        os.close(fd_stdout)
-    torch.cuda.empty_cache()
-    em.set_params(0.1, 0.2, 0.1)
-    em.init_emission()
+        restore_stdout()
+
+    try:
+        run = build_run(ctx, shard)
+    except ValueError as e:
+        raise SystemExit(f"bench.py: {e}")
+    restore_stdout()
+    em = run["em"]
+    by_sites, I, S, I_tot, S_job = run["by_sites"], run["I"], run["S"], run["I_tot"], run["S_job"]
+    reset_params(em)
 
     # multi-start: R - 1 replicas sharing the likelihoods on the device, each with its own
     # (perturbed) starting values, run next to the main handle from R host threads
     replicas = []
     if args.replicas > 1:
-        if world > 1:
-            raise SystemExit("--replicas needs --gpus 1")
         import numpy as np
-        import threading
         rng = np.random.default_rng(1)
         for r in range(args.replicas - 1):
             h = em.hmm.replica()
@@ -458,78 +740,49 @@ def main():
             h.init_emission()
             replicas.append(h)
 
-    def iterate_all():
-        """One EM iteration of the main run (returned stats) and of every replica."""
-        if not replicas:
-            return em.iter_EM()
-        th = [threading.Thread(target=h.iter_EM) for h in replicas]
-        for t in th:
-            t.start()
-        st = em.iter_EM()
-        for t in th:
-            t.join()
-        return st
+    tl = timed_loop(ctx, run, args.steps, args.warmup, replicas)
+    dt, fam, launches = tl["dt"], tl["fam"], tl["launches"]
+    rounds, points, ind_rounds, ref_calls = tl["rounds"], tl["points"], tl["ind_rounds"], tl["ref_calls"]
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        iterate_all()
-    em.reset_timing()
-    fam = {k: 0.0 for k in ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first")}
-    launches = dict.fromkeys(fam, 0)
-    rounds = points = ind_rounds = ref_calls = 0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = iterate_all()
-        rounds += st.rounds
-        points += st.points
-        ind_rounds += st.ind_rounds
-        ref_calls += st.ref_forward_calls
-        for k in fam:
-            ms, n = em.hmm.kernel_ms(k)
-            fam[k] += ms
-            launches[k] += n
-    barrier()
-    dt = time.perf_counter() - t0
     per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64,
-                         device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # every rank's own clocks, so that the scaling line can be read: kernel families
         # (HIP events on the library's stream), the exchange (duration and the part of it the
         # host actually waited for), the frequency step on the own site range
-        K_ = max(args.steps, 1)
-        if by_sites:
-            ex = em.exchange
-            mine = {"rank": rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
-                    "exchange_ms_per_iter": {"all_gather_host_calls": ex.host_ms / K_},
-                    "all_gathers_per_iter": ex.calls / K_, "all_gather_bytes_per_iter": ex.bytes / K_,
-                    "rounds_per_iter": rounds / K_}
-        else:
-            mine = {"rank": rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
-                    "exchange_ms_per_iter": {
-                        "all_to_all": em.timing["a2a_ms"] / K_,
-                        "all_to_all_exposed": em.timing["a2a_exposed_ms"] / K_,
-                        "all_to_all_hidden": max(em.timing["a2a_ms"] - em.timing["a2a_exposed_ms"], 0.0) / K_,
-                        "all_gather": em.timing["allgather_ms"] / K_,
-                        "freq_step_call": em.timing["freq_step_ms"] / K_},
-                    "rounds_per_iter": rounds / K_}
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+        dist.all_gather_object(per_rank, rank_clocks(ctx, run, tl))
+
+    check = None
+    if not args.no_check and V == 1:
+        check = result_check(ctx, run)
+    collective_bytes = None if world == 1 else em.collective_bytes_per_iter()
+    exch_calls = (em.exchange.calls, em.exchange.bytes, em.exchange.host_ms) if by_sites and em.exchange else None
+    C_waves = em.hmm.layout()[0]
+    for h in replicas:
+        h.close()
+    em.close()
+    run["em"] = em = None
+    torch.cuda.empty_cache()
+
+    # ---- N > 1, site shards: the same data set once more in the OTHER layout ----
+    alt = None
+    if world > 1 and by_sites and not args.no_alt and args.scaling == "strong":
+        alt = alt_sharding(ctx, min(args.steps, 5), min(args.warmup, 2), check)
+
+    exact_line = None
+    if (world == 1 and V == 1 and args.replicas == 1 and args.mode == "fast" and not args.no_exact_line
+            and args.workload == "c3" and rank == 0):
+        exact_line = exact_mode_line(ctx)
 
     if rank == 0:
         K = max(args.steps, 1)
         # site shards: all individuals x the job's sites (an emulated rank: x its own range)
         units = float(I_tot) * (S_job if by_sites and V == 1 else S) * K * args.replicas
+        if not by_sites and V > 1:
+            units = float(I) * S * K
         est_sites = S if by_sites else S / (world * V)       # what one rank's est_maf covers
-        est_inds = I if by_sites else I_tot * V
+        est_inds = I if by_sites else I_tot
+        call_geno = ctx.call_geno
         # dominant kernel family by measured time, and its algorithmic traffic per launch
         # (DESIGN.md section 4); est_maf = 24 B GL + 8 B posterior per site-individual;
         # fast mode: the first objective round of an iteration (all I individuals) reads the
@@ -538,18 +791,8 @@ def main():
         fast = args.mode == "fast"
         glb = 0.25 if call_geno else 24.0     # bytes of genotype likelihoods per cell (est_maf)
         glq = 0.25 if call_geno else 16.0     # ... in the interleaved copy the forward walk reads
-        algo = {
-            "lkl_batch": (((glq + 12.0) * S * I * K + 8.0 * S * max(ind_rounds - I * K, 0)) if fast
-                          else 16.0 * S * ind_rounds) / max(launches["lkl_batch"], 1),
-            "est_maf": (glb + 8.0) * est_sites * est_inds,   # own sites x all individuals per rank
-            "forward": (20.0 if fast else 40.0) * S * I,
-            "backward": 48.0 * S * I,
-            "emission": (8.0 * S if fast else (glb + 16.0) * S * I),
-            "lkl_first": (glq + 12.0) * S * I,
-        }
         # ---- every kernel of the iteration against BOTH roofs; `bound` names its limiter ----
         # times: HIP events on the library's stream around each kernel family (nghmm_kernel_ms)
-        C_waves = em.hmm.layout()[0]
         pmc = pmc_traffic(pmc_summary() if (args.workload == "c3" and fast and world == 1 and V == 1 and
                                             not args.n_ind and not args.n_sites) else None,
                           I, C_waves)
@@ -636,10 +879,25 @@ def main():
                         "frac": None, "traffic": None,
                         "note": "exact mode: sequential log-space chains (DESIGN.md section 4)"}
         if roofline.get("traffic") is not None:
-            roofline["traffic_source"] = ("profiles/r03_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / "
+            roofline["traffic_source"] = (f"{PMC_SUMMARY}: rocprofv3 --pmc FETCH_SIZE / "
                                           "WRITE_SIZE passes of this workload and build "
                                           "(profiles/collect.sh), not measured in this run")
-        fam_roof = roof_all
+        each = tl["each_ms"]
+        n_run = min(20, len(each))
+        vs_n1 = None
+        if check is not None:
+            key = check_key(ctx, run)
+            ref = json.load(open(CHECK_REF)) if os.path.exists(CHECK_REF) else {}
+            if world == 1 and args.write_check and args.replicas == 1:
+                ref[key] = check
+                json.dump(ref, open(CHECK_REF, "w"), indent=1, sort_keys=True)
+            elif world > 1 and key in ref:
+                vs_n1 = dict(compare_checks(check, ref[key]),
+                             source="profiles/check_n1.json: the `check` of a one-GPU run of this "
+                                    "workload (bench.py --write_check)")
+            elif world > 1:
+                vs_n1 = {"ok": None, "note": f"no one-GPU `check` stored for {key}: compare this line's "
+                                             "`check` with the --gpus 1 line's"}
         out = {
             "metric": "site-ind updates/sec (EM iterations x individuals x sites / s), 1M sites x 1k ind",
             "value": units / dt,
@@ -666,6 +924,9 @@ def main():
                        "n_ind_total": I_tot, "n_ind_per_gpu": I,
                        "n_sites": S_job if by_sites else S, "n_sites_per_gpu": S,
                        "mode": args.mode, "freq_est": 1,
+                       "data_set": "simulate.IndexedSim(seed 12345): every element a hash of its global "
+                                   "(individual, site) indices -- the N-rank job holds slices of the "
+                                   "N = 1 job's data set, whatever the sharding",
                        "sharding": (None if world == 1 else
                                     (f"sites: {S} of {S_job} sites per GPU for all {I} individuals; "
                                      f"the ranges exchange six doubles per individual and E-step "
@@ -675,8 +936,22 @@ def main():
                                     f"frequency step on {S // world} sites x all individuals per "
                                     f"GPU (all-to-all of posteriors, all-gather of frequencies)")},
             "roofline": roofline,
-            "roofline_all_kernels": fam_roof,
+            "roofline_all_kernels": roof_all,
             "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
+            # the metric is EM iterations/s and a run is >= 10 iterations from the starting values
+            # (parse_args.cpp:5-34 min_iters 10): `ms_per_step` is the steady state after the
+            # warm-up iterations, these are the run's first iterations themselves
+            "first_iterations_ms": each[:args.warmup] if args.warmup else each[:min(3, len(each))],
+            "first_iterations_rounds": tl["each_rounds"][:max(args.warmup, min(3, len(each)))],
+            "run_of_20_ms_per_iter": (sum(each[:20]) / 20 if len(each) >= 20 else None),
+            "run_ms_per_iter": {"iterations": n_run, "value": sum(each[:n_run]) / max(n_run, 1),
+                                "note": "mean wall time of the run's first iterations, warm-up included "
+                                        "(this rank's clock)"},
+            "check": check,
+            "vs_n1": vs_n1,
+            "alt_sharding": alt,
+            "exact_mode": exact_line,
+            "parity": PARITY,
             "predicted": (None if V == 1 else {
                 "emulated_rank_of": V,
                 "shard": "sites" if by_sites else "individuals",
@@ -685,8 +960,8 @@ def main():
                          f"replaced by {V} local copies of the same size on the handle's stream"
                          + (", after an all_gather_into_tensor of a one-rank RCCL group issued on "
                             "that stream" if args.emulate_rccl else "") + ": "
-                         f"{em.exchange.calls / K:.1f} per iteration, "
-                         f"{em.exchange.bytes / K / 1e3:.0f} kB per iteration from each rank): "
+                         f"{exch_calls[0] / K:.1f} per iteration, "
+                         f"{exch_calls[1] / K / 1e3:.0f} kB per iteration from each rank): "
                          f"`value` and `ms_per_step` "
                          f"of this line are that rank's, NOT a cohort's") if by_sites else
                         f"compute of ONE rank of a {V}-rank strong-scaling run of this workload on "
@@ -694,13 +969,13 @@ def main():
                         f"sites x {I * V} individuals), exchanges replaced by local copies: "
                         f"`value` and `ms_per_step` of this line are that rank's, NOT a cohort's",
                 "rank_ms_per_iteration": dt / K * 1e3,
-                "all_gather_host_ms_per_call": (em.exchange.host_ms / max(em.exchange.calls, 1)
+                "all_gather_host_ms_per_call": (exch_calls[2] / max(exch_calls[0], 1)
                                                 if by_sites else None),
                 "whole_job_site_ind_updates_per_s_if_communication_is_hidden":
                     float(I) * S_job * K / dt if by_sites else float(I * V) * S * K / dt}),
             "preflight": preflight,
             "collective_bytes_per_iter": (None if world == 1 else dict(
-                em.collective_bytes_per_iter(),
+                collective_bytes,
                 note=("bytes leaving each GPU per EM iteration: its part of every all-gather (six "
                       "doubles per individual and E-step / per objective point and round) to the "
                       "other ranks") if by_sites else
@@ -718,11 +993,79 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg, full_c2=args.cpu_full_c2)
         print(json.dumps(out))
-    for h in replicas:
-        h.close()
-    em.close()
+        sys.stdout.flush()
     if world > 1 or args.emulate_rccl:
         dist.destroy_process_group()
+
+
+def rank_clocks(ctx, run, tl):
+    """This rank's own clocks of a timed loop, per iteration."""
+    em, fam = run["em"], tl["fam"]
+    K_ = max(tl["steps"], 1)
+    mine = {"rank": ctx.rank, "kernel_ms_per_iter": {k: fam[k] / K_ for k in fam if k != "lkl_first"},
+            "rounds_per_iter": tl["rounds"] / K_}
+    if run["by_sites"]:
+        ex = em.exchange
+        mine["exchange_ms_per_iter"] = {"all_gather_host_calls": ex.host_ms / K_}
+        mine["all_gathers_per_iter"] = ex.calls / K_
+        mine["all_gather_bytes_per_iter"] = ex.bytes / K_
+    else:
+        mine["exchange_ms_per_iter"] = {
+            "all_to_all": em.timing["a2a_ms"] / K_,
+            "all_to_all_exposed": em.timing["a2a_exposed_ms"] / K_,
+            "all_to_all_hidden": max(em.timing["a2a_ms"] - em.timing["a2a_exposed_ms"], 0.0) / K_,
+            "all_gather": em.timing["allgather_ms"] / K_,
+            "freq_step_call": em.timing["freq_step_ms"] / K_}
+    return mine
+
+
+def alt_sharding(ctx, steps, warmup, main_check):
+    """The job's OTHER layout in the same process group, on the same data set: individual shards
+    (BASELINE configs[3]: "sharded by individual ... RCCL freq all-reduce" -- an all-to-all of
+    every posterior and an all-gather of the frequencies), a short loop and
+    the same result check.  Every rank reports whether its part worked, so that a layout that
+    does not fit (or fails) costs the line this object, not the run."""
+    dist, torch = ctx.dist, ctx.torch
+    out = {"sharding": "individuals", "steps": steps, "warmup": warmup}
+    err, run = None, None
+    try:
+        run = build_run(ctx, "individuals")
+        reset_params(run["em"])
+    except Exception as e:   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    # (building a shard ends in collectives of its own: a rank that failed before them has made
+    # the others time out -- what is caught here is a layout EVERY rank refuses, e.g. a size
+    # that does not divide)
+    bad = allreduce(ctx, [1.0 if err else 0.0], "max")[0]
+    if bad:
+        if run:
+            run["em"].close()
+        out["skipped"] = err or "another rank could not build its individual shard"
+        return out
+    em = run["em"]
+    tl = timed_loop(ctx, run, steps, warmup)
+    K = max(steps, 1)
+    per_rank = [None] * ctx.world
+    dist.all_gather_object(per_rank, rank_clocks(ctx, run, tl))
+    check = None if ctx.args.no_check else result_check(ctx, run)
+    out.update({
+        "ms_per_step": tl["dt"] / K * 1e3,
+        "value": float(run["I_tot"]) * run["S"] * K / tl["dt"],
+        "n_ind_per_gpu": run["I"], "n_sites_per_gpu": run["S"],
+        "first_iterations_ms": tl["each_ms"][:warmup],
+        "exchange_ms": {k: max(r["exchange_ms_per_iter"][k] for r in per_rank)
+                        for k in per_rank[0]["exchange_ms_per_iter"]},
+        "collective_bytes_per_iter": em.collective_bytes_per_iter(),
+        "per_step_kernel_ms": {k: tl["fam"][k] / K for k in tl["fam"] if k != "lkl_first"},
+        "rounds_per_iter": tl["rounds"] / K,
+        "per_rank": per_rank,
+        "check": check,
+        "vs_main_sharding": (compare_checks(check, main_check) if check and main_check else None),
+    })
+    em.close()
+    run["em"] = None
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

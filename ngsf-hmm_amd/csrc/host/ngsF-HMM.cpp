@@ -234,8 +234,11 @@ class BgzfSource {
     return ok;
   }
   BgzfSource(const char* path, unsigned n_threads) : f_(fopen(path, "rb")) {
-    dispatcher_ = std::thread([this] { dispatch(); });
-    for (unsigned t = 0; t < n_threads; ++t) workers_.emplace_back([this] { work(); });
+    // an allocation failure in a pipeline thread (a damaged file can ask for a lot) ends the
+    // read with the reader's "cannot read GZip GENO file", not in std::terminate
+    dispatcher_ = std::thread([this] { guarded([this] { dispatch(); }); });
+    for (unsigned t = 0; t < n_threads; ++t)
+      workers_.emplace_back([this] { guarded([this] { work(); }); });
   }
   ~BgzfSource() {
     {
@@ -275,6 +278,18 @@ class BgzfSource {
   }
 
  private:
+  template <class F>
+  void guarded(F f) {
+    try {
+      f();
+    } catch (const std::exception&) {
+      std::lock_guard<std::mutex> lk(mu_);
+      failed_ = true;
+      cv_out_.notify_all();
+      cv_job_.notify_all();
+      cv_room_.notify_all();
+    }
+  }
   struct Job {
     std::vector<unsigned char> in;                    // whole members, back to back
     std::vector<uint32_t> off, csize, isize, out_off;  // per member: offset in `in`, sizes
@@ -336,6 +351,13 @@ class BgzfSource {
       }
       const uint32_t isz = h[bsize - 4] | (h[bsize - 3] << 8) | (h[bsize - 2] << 16) |
                            ((uint32_t)h[bsize - 1] << 24);
+      if (isz > 65536) {  // a BGZF member holds at most 64 KB: a damaged (or hostile) trailer
+        std::lock_guard<std::mutex> lk(mu_);  // must not size a multi-GB buffer
+        failed_ = true;
+        cv_out_.notify_all();
+        cv_job_.notify_all();
+        return;
+      }
       job->off.push_back((uint32_t)job->in.size());
       job->csize.push_back(bsize);
       job->isize.push_back(isz);

@@ -1053,33 +1053,38 @@ int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, con
   int rc;
   if ((rc = use_device(h))) return rc;
   if ((rc = claim_sites(h, site_begin, n_sites))) return rc;
-  const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
-  if ((rc = ensure_stage8(h, n_cells))) return fail_load(h, rc);
-  HIP_TRY(hipMemcpyAsync(h->d_stage8, geno, n_cells, hipMemcpyHostToDevice, h->stream));
-  if ((rc = clear_flags(h))) return rc;
-  if (h->packed) {
-    // the reader's missing genotype is log(1/3) x 3 (read_data.cpp:94), prepared: row 3 of the
-    // class table as nghmm_create left it; a data set has ONE uniform value
-    unsigned long long cur = ~0ull, want = 0;
-    double u = 0;
-    HIP_TRY(hipMemcpyAsync(&cur, h->d_uniform, sizeof cur, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(&u, h->d_cls_log + 9, sizeof u, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(sync_stream(h));
-    std::memcpy(&want, &u, sizeof want);
-    if (cur == ~0ull)
-      HIP_TRY(hipMemcpyAsync(h->d_uniform, &want, sizeof want, hipMemcpyHostToDevice, h->stream));
-    else if (cur != want) {
-      set_error("nghmm_load_geno_sites: mixed with likelihood chunks whose uniform cells differ");
-      return NGHMM_ERR_ARG;
+  // (every return below goes through fail_load: a failure after claim_sites gives the sites back)
+  auto body = [&]() -> int {
+    const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
+    int rc;
+    if ((rc = ensure_stage8(h, n_cells))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_stage8, geno, n_cells, hipMemcpyHostToDevice, h->stream));
+    if ((rc = clear_flags(h))) return rc;
+    if (h->packed) {
+      // the reader's missing genotype is log(1/3) x 3 (read_data.cpp:94), prepared: row 3 of the
+      // class table as nghmm_create left it; a data set has ONE uniform value
+      unsigned long long cur = ~0ull, want = 0;
+      double u = 0;
+      HIP_TRY(hipMemcpyAsync(&cur, h->d_uniform, sizeof cur, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipMemcpyAsync(&u, h->d_cls_log + 9, sizeof u, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(sync_stream(h));
+      std::memcpy(&want, &u, sizeof want);
+      if (cur == ~0ull)
+        HIP_TRY(hipMemcpyAsync(h->d_uniform, &want, sizeof want, hipMemcpyHostToDevice, h->stream));
+      else if (cur != want) {
+        set_error("nghmm_load_geno_sites: mixed with likelihood chunks whose uniform cells differ");
+        return NGHMM_ERR_ARG;
+      }
+      launch_pack_geno(h->stream, h->d_stage8, n_cells, cell0, h->d_codes, h->d_flags);
+    } else {
+      double* dst = h->d_gl + cell0 * 3;
+      launch_expand_geno(h->stream, h->d_stage8, n_cells, std::log((double)1 / 3), dst, h->d_flags);
+      launch_prepare_gl(h->stream, dst, n_cells, NGHMM_GL_LOG, 0, h->d_flags);
     }
-    launch_pack_geno(h->stream, h->d_stage8, n_cells, cell0, h->d_codes, h->d_flags);
-  } else {
-    double* dst = h->d_gl + cell0 * 3;
-    launch_expand_geno(h->stream, h->d_stage8, n_cells, std::log((double)1 / 3), dst, h->d_flags);
-    launch_prepare_gl(h->stream, dst, n_cells, NGHMM_GL_LOG, 0, h->d_flags);
-  }
-  HIP_TRY(hipGetLastError());
-  return fail_load(h, check_load_flags(h, false));
+    HIP_TRY(hipGetLastError());
+    return check_load_flags(h, false);
+  };
+  return fail_load(h, body());
 }
 
 int nghmm_load_end(nghmm_t* h) {
@@ -1615,7 +1620,10 @@ static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_block
 // place, minus its three defects -- kernels_ld.hip says which; oracle: orc_em_mstep_freq_ld.
 static int mstep_freq_ld_impl(nghmm_t* h, int freq_est, int e_prob) {
   const bool exact = h->mode == NGHMM_MODE_EXACT;
-  if (h->I_tot != h->I) {
+  // an individual shard, a site shard (its range would start a pair chain of its own: est_maf
+  // and no pair step at the range's first site, no f_prev carried in from the range before)
+  // and a chain member all are pieces of a cohort: silently different frequencies
+  if (h->I_tot != h->I || h->fast.shard.world > 1 || h->chain || h->g_n > 1) {
     set_error("the intended --freq_est 2 walks the sites in order on ONE handle: not available "
               "for a sharded cohort");
     return NGHMM_ERR_ARG;
@@ -1743,14 +1751,21 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
       HIP_TRY(hipEventCreate(&h->aux_ev1));
       HIP_TRY(hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
     }
+    // whatever happens from here on, nothing may be left running on the second stream when
+    // this call returns (the caller may destroy the handle or load other data next)
+    struct AuxDrain {
+      hipStream_t s;
+      ~AuxDrain() { (void)hipStreamSynchronize(s); }
+    } drain{h->aux_stream};
     HIP_TRY(hipEventRecord(h->aux_go, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
     HIP_TRY(hipEventRecord(h->aux_ev0, h->aux_stream));
     launch_estmaf_exact(h->aux_stream, own_gl(h), h->d_marg, h->S, h->I, h->d_freq, nullptr);
+    const hipError_t e_launch = hipGetLastError();
     HIP_TRY(hipEventRecord(h->aux_ev1, h->aux_stream));
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(e_launch);
     rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats);
-    HIP_TRY(hipEventSynchronize(h->aux_ev1));  // also when the M-step failed: nothing left running
+    HIP_TRY(hipEventSynchronize(h->aux_ev1));  // also when the M-step failed
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->aux_ev0, h->aux_ev1));
     h->ms[SLOT_ESTMAF] = ms;
@@ -2470,7 +2485,10 @@ namespace {
 int chain_allgather(void* user, uint64_t n_bytes) {
   nghmm_t* h = static_cast<nghmm_t*>(user);
   ChainCtx* cx = h->chain;
+  if (!cx) return 1;
   const int n = (int)cx->hs.size();
+  for (int q = 0; q < n; ++q)
+    if (!cx->hs[q]) return 1;  // (a dissolved chain: chain_release detaches every member)
   bool ok = hipStreamSynchronize(h->stream) == hipSuccess;
   if (!ok) cx->abort();
   if (!cx->wait()) return 1;
@@ -2489,21 +2507,38 @@ int chain_allgather(void* user, uint64_t n_bytes) {
 
 void chain_release(nghmm_t* h) {
   if (!h->chain) return;
+  // One member leaving DISSOLVES the chain (include/nghmm.h): every remaining member goes back
+  // to being a plain handle over its own sites -- no all-gather installed, no exchange buffers,
+  // no context whose barrier could never fill again.  (Leaving the survivors attached made a
+  // direct nghmm_iter_em / nghmm_estep / nghmm_lkl_batch on one of them wait in ChainCtx::wait
+  // for a member that no longer exists.)
   ChainCtx* cx = h->chain;
-  h->chain = nullptr;
-  h->fast.shard.world = 1;
-  h->fast.shard.allgather = nullptr;
-  bool last;
+  cx->abort();
+  std::vector<nghmm_t*> members;
   {
     std::lock_guard<std::mutex> lk(cx->mu);
-    for (auto& m : cx->hs)
-      if (m == h) m = nullptr;
-    last = --cx->refs == 0;
+    members = cx->hs;
+    for (auto& m : cx->hs) m = nullptr;
   }
-  if (last) delete cx;
-  if (h->c_send) (void)hipFree(h->c_send);
-  if (h->c_recv) (void)hipFree(h->c_recv);
-  h->c_send = h->c_recv = nullptr;
+  int dev_before = -1;
+  (void)hipGetDevice(&dev_before);
+  for (nghmm_t* m : members) {
+    if (!m || m->chain != cx) continue;
+    m->chain = nullptr;
+    m->fast.shard.world = 1;
+    m->fast.shard.rank = 0;
+    m->fast.shard.allgather = nullptr;
+    m->fast.shard.user = nullptr;
+    m->fast.shard.send = m->fast.shard.recv = nullptr;
+    m->fast.shard.edges_from_round = false;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->c_send) (void)hipFree(m->c_send);
+    if (m->c_recv) (void)hipFree(m->c_recv);
+    m->c_send = m->c_recv = nullptr;
+  }
+  if (dev_before >= 0) (void)hipSetDevice(dev_before);
+  delete cx;
 }
 
 bool is_chain(nghmm_t** hs, int n) {

@@ -98,6 +98,110 @@ def preflight(device=None):
             "checked": ["all_to_all_single float64", "all_gather_into_tensor float64"]}
 
 
+class FailureBeacon:
+    """Failure propagation between the ranks of one job.
+
+    The reference's fatal conditions (`invalid MAF!`, `invalid Lkl found!`, EM.cpp:400-410) are
+    reachable from user data, and on several GPUs one of them can strike ONE rank -- its site
+    range, its individuals -- between two collectives.  That rank leaves its iteration; the
+    others would wait in their next all-gather / all-to-all for a partner that never comes (ten
+    minutes under RCCL's watchdog, for ever under gloo).  The number of collectives left in an
+    iteration is data dependent (the L-BFGS-B rounds), so a failing rank cannot keep the others
+    company with poison values; instead the failure travels beside the data path:
+
+    * a rank that fails writes ``<rank>: <message>`` under one key of the job's c10d store
+      (``signal``) and raises its exception as usual;
+    * every rank runs a daemon thread that polls that key (collectives release the GIL); when
+      it appears the thread calls ``on_peer_failure(message)`` -- by default: the message on
+      stderr and ``os._exit(5)``, a fresh exit (never an exec) that ends the waiting rank with a
+      non-zero code and the failing rank's message within ``poll_s``.
+
+    Documented behaviour, not a recovery protocol: after a peer's fatal the job is over, as it
+    is in the reference (`error()` + `exit(-1)`, gen_func.cpp:12-18)."""
+
+    KEY = "nghmm_failed_rank"
+
+    def __init__(self, rank, poll_s=0.25, on_peer_failure=None, store=None):
+        import threading
+        import torch.distributed as dist
+        self.rank = rank
+        self.poll_s = poll_s
+        self.on_peer_failure = on_peer_failure or self._exit
+        base = store if store is not None else dist.distributed_c10d._get_default_store()
+        self.store = dist.PrefixStore("nghmm_beacon", base)
+        self._signalled = False
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._watch, name="nghmm-failure-beacon", daemon=True)
+        self._thread.start()
+
+    def _exit(self, message):
+        import os
+        import sys
+        sys.stderr.write(f"ngsf-hmm_amd: rank {self.rank} stops: a peer failed -- rank {message}\n")
+        sys.stderr.flush()
+        os._exit(5)
+
+    def signal(self, message):
+        """This rank has failed: tell the others (idempotent)."""
+        if not self._signalled:
+            self._signalled = True
+            try:
+                self.store.set(self.KEY, f"{self.rank}: {message}")
+            except Exception:       # noqa: BLE001 - the store is gone: the job is ending anyway
+                pass
+
+    def _watch(self):
+        while not self._stop.wait(self.poll_s):
+            try:
+                if not self.store.check([self.KEY]):
+                    continue
+                msg = self.store.get(self.KEY).decode(errors="replace")
+            except Exception:       # noqa: BLE001 - store closed (process group destroyed)
+                return
+            if self._signalled or self._stop.is_set():
+                return              # (our own failure: the main thread is raising it)
+            self.on_peer_failure(msg)
+            return
+
+    def close(self):
+        self._stop.set()
+
+    def guard(self):
+        """Context manager: an exception leaving the block is signalled to the peers first."""
+        beacon = self
+
+        class _G:
+            def __enter__(self):
+                return beacon
+
+            def __exit__(self, et, ev, tb):
+                if ev is not None and not isinstance(ev, (KeyboardInterrupt, GeneratorExit)):
+                    beacon.signal(f"{type(ev).__name__}: {ev}")
+                return False
+        return _G()
+
+
+class _NoBeacon:
+    def guard(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def signal(self, message):
+        pass
+
+    def close(self):
+        pass
+
+
+def make_beacon(rank, world, **kw):
+    """A FailureBeacon when a multi-rank process group is up, else a no-op."""
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return FailureBeacon(rank, **kw)
+    return _NoBeacon()
+
+
 def site_ranges(n_sites: int, world: int):
     """Contiguous, equal site ranges (the all-to-all uses equal splits)."""
     if n_sites % world != 0:
@@ -226,6 +330,7 @@ class ShardedEM:
         self.timing = dict(a2a_ms=0.0, a2a_exposed_ms=0.0, allgather_ms=0.0, freq_step_ms=0.0,
                            iterations=0)
         self._ev = None
+        self.beacon = make_beacon(rank, world if self.emulate == 1 else 1)
         if world > 1:
             self.ranges = site_ranges(n_sites, world)
             lo, hi = self.ranges[rank]
@@ -294,6 +399,13 @@ class ShardedEM:
 
     # -- one EM iteration ------------------------------------------------------
     def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
+        """One EM iteration of the cohort.  A failure of this rank (the reference's fatals are
+        reachable from user data) is signalled to the others before it is raised
+        (:class:`FailureBeacon`): they end with its message instead of waiting in a collective."""
+        with self.beacon.guard():
+            return self._iter_EM(freq_est, indF_fixed, alpha_fixed)
+
+    def _iter_EM(self, freq_est, indF_fixed, alpha_fixed):
         if self.emulate > 1:
             return self._iter_em_emulated(freq_est, indF_fixed, alpha_fixed)
         if self.world == 1:
@@ -412,6 +524,7 @@ class ShardedEM:
             self.backend.sync()
 
     def close(self):
+        self.beacon.close()
         if self.hmm is not None:
             self.hmm.close()
         elif hasattr(self.backend, "close"):
@@ -532,6 +645,7 @@ class SiteShardedEM:
         self.ind_lkl = None
         self.exchange = None
         self.timing = dict(iterations=0)
+        self.beacon = make_beacon(rank, world if self.emulate == 1 else 1)
         if world > 1:
             nbytes = self.hmm.site_shard_bytes()
             self._send = torch.zeros(nbytes // 8, dtype=torch.float64, device=self.device)
@@ -567,7 +681,15 @@ class SiteShardedEM:
         self.hmm.init_emission()
 
     def iter_EM(self, freq_est=1, indF_fixed=False, alpha_fixed=False):
-        st = self.hmm.iter_EM(freq_est, indF_fixed, alpha_fixed)
+        """One EM iteration of the chain.  The intended --freq_est 2 walks the sites in order on
+        ONE handle and is refused here (as nghmm_chain_iter_em refuses it).  A failure of this
+        rank -- a fatal of the reference on its site range, an exception in the exchange -- is
+        signalled to the other ranks before it is raised (:class:`FailureBeacon`)."""
+        if self.world > 1 and (int(freq_est) & (self.pkg.LD_INTENDED | self.pkg.EPROB_LD)):
+            raise self.pkg.NgsFHMMError(-10, "the intended --freq_est 2 walks the sites in order on "
+                                             "ONE handle: not available for a chain of site shards")
+        with self.beacon.guard():
+            st = self.hmm.iter_EM(freq_est, indF_fixed, alpha_fixed)
         self.ind_lkl = self.hmm.ind_lkl          # the chain's: the same on every rank
         self.timing["iterations"] += 1
         return st
@@ -607,6 +729,10 @@ class SiteShardedEM:
             raise ValueError("emulate_ranks has no chain to decode")
         if self.world == 1:
             return self.hmm.viterbi()
+        with self.beacon.guard():
+            return self._viterbi_chain()
+
+    def _viterbi_chain(self):
         scores = None
         for r in range(self.world):
             out = self.hmm.viterbi_shard_forward(scores) if r == self.rank else \
@@ -638,6 +764,7 @@ class SiteShardedEM:
         return np.concatenate(parts)
 
     def close(self):
+        self.beacon.close()
         if self.hmm is not None:
             self.hmm.close()
             self.hmm = None

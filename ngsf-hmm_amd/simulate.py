@@ -234,3 +234,212 @@ def simulate_torch(n_ind: int, n_sites: int, device, *, freq=0.2, indF=0.5, alph
         gl[s0:s0 + c.shape[0]] = c
         del c
     return gl, pos_dist_mb
+
+
+# ---------------------------------------------------------------------------------------------
+# Index-addressed generator: every random number is a hash of (seed, stream, individual, site)
+# ---------------------------------------------------------------------------------------------
+# A multi-GPU job must process the data set the one-GPU job processes (results do not depend on
+# the number of workers: EM.cpp:151-161,198-201), whatever the sharding.  The generators above
+# draw from a sequential stream, so what a rank gets depends on the shapes it asks for; here
+# element (i, s) of every random field is a counter-based hash of its GLOBAL indices, every
+# operation after it is element-wise, and the one sequential object -- the IBD chain, whose
+# state at s is the Bernoulli(F) draw made at the last redraw site <= s -- is resumed exactly
+# by looking back to that site.  Any (individual range) x (site range) slice is therefore bit
+# for bit the slice of the whole data set.
+
+_M64 = (1 << 64) - 1
+
+
+def _i64(c):
+    """A 64-bit constant as the int64 with the same bits."""
+    c &= _M64
+    return c - (1 << 64) if c >> 63 else c
+
+
+_G1, _G2, _G3 = _i64(0x9E3779B97F4A7C15), _i64(0xD1B54A32D192ED03), _i64(0x8CB92BA72F3D8DD7)
+_C1, _C2 = _i64(0xBF58476D1CE4E5B9), _i64(0x94D049BB133111EB)
+
+
+def _lsr(x, k):
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _mix(x):
+    """splitmix64's finaliser on int64 tensors (products wrap)."""
+    x = (x ^ _lsr(x, 30)) * _C1
+    x = (x ^ _lsr(x, 27)) * _C2
+    return x ^ _lsr(x, 31)
+
+
+def _mix_int(x):
+    x &= _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+class IndexedSim:
+    """The ngsF-HMMsim.R data model with every element addressed by its global indices.
+
+    ``IndexedSim(I_tot, S_tot, device, ...)`` describes the whole data set; ``pos_dist(s0, s1)``
+    and ``chunks(ind_range, site_range)`` produce any slice of it.  float parameters or "r"
+    (uniform per individual / per site, ngsF-HMMsim.R:108-148)."""
+
+    LOOKBACK = 16384
+
+    def __init__(self, n_ind, n_sites, device, *, freq=0.2, indF=0.5, alpha=0.01, depth=2.0,
+                 error=0.01, seed=12345, n_chrom=1):
+        import torch
+        self.torch = torch
+        self.I, self.S = int(n_ind), int(n_sites)
+        self.device = device
+        self.seed = int(seed)
+        self.depth, self.error = float(depth), float(error)
+        self.per_chr = -(-self.S // max(1, int(n_chrom)))
+        self.n_chrom = int(n_chrom)
+        self._freq, self._indF, self._alpha = freq, indF, alpha
+        f64 = torch.float64
+        self.p_read = torch.tensor([error, 0.5, 1.0 - error], device=device, dtype=f64)
+        self.lp, self.lq = torch.log(self.p_read), torch.log1p(-self.p_read)
+        # Poisson(depth) by inversion: cdf[k] = P(X <= k)
+        kmax = int(depth + 12.0 * math.sqrt(depth) + 24)
+        pk, cdf, acc = math.exp(-depth), [], 0.0
+        for k in range(kmax):
+            acc += pk
+            cdf.append(min(acc, 1.0))
+            pk *= depth / (k + 1)
+        self.kmax = kmax
+        self.pois_cdf = torch.tensor(cdf, device=device, dtype=f64)
+        # Binomial(d, p_g) by inversion: T[d][g][k] = P(X <= k), 2.0 (never reached) for k >= d
+        T = np.full((kmax + 1, 3, kmax), 2.0)
+        for d in range(kmax + 1):
+            for g, p in enumerate((error, 0.5, 1.0 - error)):
+                acc = 0.0
+                for k in range(d):
+                    acc += math.comb(d, k) * p ** k * (1.0 - p) ** (d - k)
+                    T[d, g, k] = acc
+        self.binom_cdf = torch.tensor(T.reshape(-1), device=device, dtype=f64)
+
+    # -- hashed uniforms ----------------------------------------------------------------------
+    def _key(self, stream):
+        return _i64(_mix_int(self.seed * 0x8CB92BA72F3D8DD7 + stream * 0x9E3779B97F4A7C15 + 1))
+
+    def _u_site(self, stream, s_idx):
+        """uniform [0, 1) per site: s_idx int64 tensor of global site indices."""
+        h = _mix(_mix(s_idx * _G1 + self._key(stream)) + _G3)
+        return _lsr(h, 11).to(self.torch.float64) * (1.0 / 9007199254740992.0)
+
+    def _u(self, stream, i_idx, s_idx):
+        """uniform [0, 1) per (individual, site): i_idx [I, 1], s_idx [1, n] global indices."""
+        h = _mix(_mix(s_idx * _G1 + self._key(stream)) + i_idx * _G2)
+        return _lsr(h, 11).to(self.torch.float64) * (1.0 / 9007199254740992.0)
+
+    def _sites(self, s0, s1):
+        return self.torch.arange(s0, s1, device=self.device, dtype=self.torch.int64)
+
+    def _per_ind(self, what, stream, i_idx):
+        if isinstance(what, str):
+            return self._u_site(stream, i_idx)          # same hash family, another stream
+        return self.torch.full(i_idx.shape, float(what), device=self.device, dtype=self.torch.float64)
+
+    # -- per-site fields ------------------------------------------------------------------------
+    def pos_dist(self, s0, s1):
+        """Distances in Mb of the global sites [s0, s1) to their predecessors: the reader's
+        (shared/read_data.cpp:165-218): d_0 = the first position, +inf at a chromosome change."""
+        torch = self.torch
+        s = self._sites(s0, s1)
+        u1 = 1.0 - self._u_site(1, s)                    # (0, 1]
+        u2 = self._u_site(2, s)
+        z = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * math.pi * u2)
+        gaps = (1e5 + (1e5 / 3.0) * z).to(torch.int64).clamp_(min=1)
+        d = gaps.to(torch.float64) / 1e6
+        if self.n_chrom > 1:
+            d[(s % self.per_chr == 0) & (s > 0)] = float("inf")
+        return d
+
+    def site_freq(self, s0, s1):
+        s = self._sites(s0, s1)
+        if isinstance(self._freq, str):
+            return self._u_site(3, s)
+        return self.torch.full((s1 - s0,), float(self._freq), device=self.device, dtype=self.torch.float64)
+
+    # -- the IBD chain ----------------------------------------------------------------------------
+    def _redraws(self, i_idx, F, A, sa, sb):
+        torch = self.torch
+        s = self._sites(sa, sb)[None, :]
+        X = torch.exp(-A * self.pos_dist(sa, sb)[None, :])          # 0 at chromosome starts
+        redraw = self._u(10, i_idx, s) >= X
+        if sa == 0:
+            redraw[:, 0] = True
+        draws = (self._u(11, i_idx, s) < F).to(torch.int64)
+        idx = torch.where(redraw, torch.arange(sb - sa, device=self.device)[None, :], -1)
+        idx = torch.cummax(idx, dim=1).values
+        return draws, idx
+
+    def _state_before(self, i_idx, F, A, sa):
+        """IBD state of every individual at global site sa - 1."""
+        torch = self.torch
+        if sa <= 0:
+            return torch.zeros((i_idx.shape[0],), device=self.device, dtype=torch.int64)
+        lo = max(0, sa - self.LOOKBACK)
+        draws, idx = self._redraws(i_idx, F, A, lo, sa)
+        last = idx[:, -1]
+        st = torch.gather(draws, 1, last.clamp(min=0)[:, None])[:, 0]
+        if lo > 0 and bool((last < 0).any()):
+            st = torch.where(last >= 0, st, self._state_before(i_idx, F, A, lo))
+        return st
+
+    # -- slices -------------------------------------------------------------------------------
+    def chunks(self, ind_range=None, site_range=None, chunk_sites=20000):
+        """Generator of (site_begin - s0, gl [n][I_loc][3]) over the slice: normalised
+        natural-log likelihoods, float64, file order."""
+        torch = self.torch
+        i0, i1 = ind_range if ind_range is not None else (0, self.I)
+        s0, s1 = site_range if site_range is not None else (0, self.S)
+        i_idx = torch.arange(i0, i1, device=self.device, dtype=torch.int64)[:, None]
+        F = self._per_ind(self._indF, 20, i_idx)
+        A = self._per_ind(self._alpha, 21, i_idx)
+        state = self._state_before(i_idx, F, A, s0)
+        for a in range(s0, s1, chunk_sites):
+            b = min(s1, a + chunk_sites)
+            s = self._sites(a, b)[None, :]
+            draws, idx = self._redraws(i_idx, F, A, a, b)
+            path = torch.where(idx >= 0, torch.gather(draws, 1, idx.clamp(min=0)), state[:, None])
+            state = path[:, -1].clone()
+            fr = self.site_freq(a, b)[None, :]
+            h1 = (self._u(12, i_idx, s) < fr).to(torch.int64)
+            h2 = (self._u(13, i_idx, s) < fr).to(torch.int64)
+            h1 = torch.where(path == 1, h2, h1)
+            geno = h1 + h2                                                   # [I][n]
+            dep = torch.searchsorted(self.pois_cdf, self._u(14, i_idx, s), right=True)
+            dep.clamp_(max=self.kmax)
+            u = self._u(15, i_idx, s)
+            base = (dep * 3 + geno) * self.kmax
+            nA = torch.zeros_like(dep)
+            for k in range(int(dep.max())):
+                nA += (u >= self.binom_cdf[base + k]).to(torch.int64)
+            del draws, idx, path, h1, h2, base, u
+            nA = nA.to(torch.float64)
+            dep = dep.to(torch.float64)
+            ll = nA[..., None] * self.lp + (dep - nA)[..., None] * self.lq   # [I][n][3]
+            del nA, dep, geno
+            for _ in range(2):       # the simulator's normalisation, rounding, the reader's post_prob
+                m = torch.maximum(torch.maximum(ll[..., 0], ll[..., 1]), ll[..., 2])
+                e = torch.exp(ll[..., 0] - m) + torch.exp(ll[..., 1] - m) + torch.exp(ll[..., 2] - m)
+                ll = ll - (m + torch.log(e))[..., None]
+                if _ == 0:
+                    ll = torch.round(ll, decimals=10)
+            out = ll.permute(1, 0, 2).contiguous()
+            del ll, m, e
+            yield a - s0, out
+
+    def gl(self, ind_range=None, site_range=None, chunk_sites=20000):
+        """The slice as one device tensor [n_sites][n_ind][3]."""
+        i0, i1 = ind_range if ind_range is not None else (0, self.I)
+        s0, s1 = site_range if site_range is not None else (0, self.S)
+        out = self.torch.empty((s1 - s0, i1 - i0, 3), device=self.device, dtype=self.torch.float64)
+        for a, c in self.chunks(ind_range, site_range, chunk_sites):
+            out[a:a + c.shape[0]] = c
+            del c
+        return out

@@ -217,6 +217,11 @@ def test_bgzf_input_is_inflated_in_parallel_to_the_same_bytes(pkg, tmp_path, asa
     bad = {"cut": good[: len(good) * 2 // 3],
            "damaged": good[:5000] + bytes([good[5000] ^ 0x55]) + good[5001:],
            "mixed": good[:-28] + open(p["beagle_gz"], "rb").read()}
+    # a member whose ISIZE trailer claims 3 GiB (BGZF's limit is 64 KB): refused at the header
+    # walk, before anything is sized from it
+    import struct
+    bsize0 = struct.unpack("<H", good[16:18])[0] + 1
+    bad["huge_isize"] = good[:bsize0 - 4] + struct.pack("<I", 3 << 30) + good[bsize0:]
     for name, blob in bad.items():
         path = str(tmp_path / f"{name}.beagle.gz")
         open(path, "wb").write(blob)

@@ -326,3 +326,61 @@ def test_site_shard_algebra_against_the_oracle(pkg, orc_libm):
                 assert abs(p - em.marg[i, s]) < 1e-9, (i, s)
                 w = op(s) @ w
                 w /= w.max()
+
+
+# ---- failure propagation between ranks: distributed.FailureBeacon ----
+BEACON_WORKER = r'''
+import importlib, os, sys, time
+import torch
+import torch.distributed as dist
+from datetime import timedelta
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("ngsf-hmm_amd")
+dd = importlib.import_module("ngsf-hmm_amd.distributed")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=300))
+beacon = dd.make_beacon(rank, world, poll_s=0.1)
+assert isinstance(beacon, dd.FailureBeacon)
+part = torch.full((8,), float(rank), dtype=torch.float64)
+whole = torch.empty(8 * world, dtype=torch.float64)
+dist.all_gather_into_tensor(whole, part)        # one good exchange first
+t0 = time.time()
+try:
+    with beacon.guard():
+        if rank == 1:
+            # a fatal of the reference on this rank's site range, between two collectives
+            raise pkg.NgsFHMMError(-3, "invalid MAF!")
+        dist.all_gather_into_tensor(whole, part)   # rank 1 never comes
+        print("RANK0_WAS_NOT_STOPPED", flush=True)
+except pkg.NgsFHMMError as e:
+    print(f"RANK{rank}_RAISED {e}", flush=True)
+    time.sleep(3.0)          # (stay alive while the others read the key: the store is rank 0's)
+    os._exit(4)
+'''
+
+
+def test_a_failing_rank_ends_the_others_instead_of_hanging_them(tmp_path):
+    """One rank hits a fatal between two collectives (`invalid MAF!` on its own site range);
+    the other sits in its next all-gather.  Without the beacon that wait ends with the process
+    group's timeout (300 s here, 10 min under RCCL's watchdog, never under plain gloo); with it
+    the waiting rank exits non-zero with the failing rank's message within seconds."""
+    import time
+    world = 2
+    script = tmp_path / "beacon_worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\n" + BEACON_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", WORLD_SIZE=str(world))
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert time.time() - t0 < 60
+    assert procs[1].returncode == 4 and "RANK1_RAISED" in outs[1] and "invalid MAF!" in outs[1], outs[1]
+    assert procs[0].returncode == 5, outs[0]
+    assert "a peer failed -- rank 1: NgsFHMMError" in outs[0] and "invalid MAF!" in outs[0], outs[0]
+    assert "RANK0_WAS_NOT_STOPPED" not in outs[0]

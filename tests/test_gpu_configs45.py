@@ -257,42 +257,69 @@ def test_config5_hundred_iterations(pkg):
     h.close()
 
 
-@pytest.mark.parametrize("shard", ["sites", "individuals"])
-def test_bench_four_ranks_on_the_full_workload(pkg, shard):
+def test_bench_four_ranks_on_the_full_workload_reproduce_the_one_gpu_job(pkg):
     """`python bench.py --gpus 4 --workload c3` as the driver starts it: four rank processes,
     the collectives' known-answer preflight, the exchanges of every iteration (gloo through the
-    host here: one GPU; nccl = RCCL on a node), and the accounting the scaling line carries.
-    sites (the default): all 1000 individuals for 250 000 sites each, one small all-gather per
-    E-step and objective round; individuals: 250 of the 1000 for all 10^6 sites, the all-to-all
-    of posteriors and the all-gather of frequencies."""
+    host here: one GPU; nccl = RCCL on a node), and the accounting the scaling line carries --
+    in BOTH layouts from one invocation: the site shards the line is about (all 1000 individuals
+    for 250 000 sites each, one small all-gather per E-step and objective round) and, embedded as
+    `alt_sharding`, the individual shards of BASELINE configs[3]'s wording (250 of the 1000 for
+    all 10^6 sites, the all-to-all of posteriors and the all-gather of frequencies).
+
+    Every rank holds a slice of the data set the one-GPU job processes (simulate.IndexedSim), so
+    the line's `check` -- two EM iterations from the starting values -- must equal the --gpus 1
+    line's: total log-likelihood to 1e-12, frequencies to 1e-9, the same number of L-BFGS-B
+    rounds.  The reference's "results do not depend on the number of workers"
+    (EM.cpp:151-161,198-201), asserted on the run that is timed."""
+    sys.path.insert(0, ROOT)
+    import bench
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c3",
-           "--steps", "2", "--warmup", "1", "--no_cpu_baseline"]
-    if shard == "individuals":
-        cmd += ["--shard", "individuals"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    def run(*extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--steps", "2",
+               "--warmup", "1", "--no_cpu_baseline", "--no_exact_line", *extra]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run()
+    out = run("--gpus", "4")
+    assert one["n_gpus"] == 1 and one["check"]["iterations"] == 2 and len(one["first_iterations_ms"]) == 1
     assert out["n_gpus"] == 4 and out["ranks"] == 4 and out["scaling"] == "strong"
     cfg = out["config"]
     assert cfg["n_ind_total"] == 1000 and cfg["n_sites"] == 1_000_000
     assert out["preflight"]["world"] == 4 and "all_to_all_single float64" in out["preflight"]["checked"]
-    cb = out["collective_bytes_per_iter"]
     assert len(out["per_rank"]) == 4 and sorted(p["rank"] for p in out["per_rank"]) == [0, 1, 2, 3]
     for p in out["per_rank"]:
         assert p["kernel_ms_per_iter"]["lkl_batch"] > 0 and p["kernel_ms_per_iter"]["est_maf"] > 0
-    if shard == "sites":
-        assert cfg["n_ind_per_gpu"] == 1000 and cfg["n_sites_per_gpu"] == 250_000
-        assert cfg["sharding"].startswith("sites:")
-        # <= 5 points x 1000 individuals x 48 B per round and rank, a handful of rounds
-        assert cb["all_to_all_out"] == 0 and 0 < cb["all_gather_out"] < 3 * 5e6 and cb["all_gathers"] >= 2
-        assert len({p["rounds_per_iter"] for p in out["per_rank"]}) == 1     # the same steps everywhere
-    else:
-        assert cfg["n_ind_per_gpu"] == 250
-        assert cb["all_to_all_out"] == 8 * 250_000 * 250 * 3 and cb["all_gather_out"] == 8 * 250_000 * 3
-        for p in out["per_rank"]:
-            assert p["exchange_ms_per_iter"]["all_to_all"] > 0
-        assert out["exchange_ms"]["all_to_all"] > 0
-    assert out["value"] > 0
-    print(json.dumps({k: out[k] for k in ("value", "ms_per_step", "exchange_ms", "collectives")}))
+    # -- the line's own layout: site shards
+    cb = out["collective_bytes_per_iter"]
+    assert cfg["n_ind_per_gpu"] == 1000 and cfg["n_sites_per_gpu"] == 250_000
+    assert cfg["sharding"].startswith("sites:")
+    # <= 5 points x 1000 individuals x 48 B per round and rank, a handful of rounds
+    assert cb["all_to_all_out"] == 0 and 0 < cb["all_gather_out"] < 3 * 5e6 and cb["all_gathers"] >= 2
+    assert len({p["rounds_per_iter"] for p in out["per_rank"]}) == 1     # the same steps everywhere
+    assert out["check"]["rounds_equal_on_all_ranks"] is True
+    d = bench.compare_checks(out["check"], one["check"])
+    print("sites vs N=1:", json.dumps(d))
+    assert d["tot_lkl_max_rel_diff"] <= 1e-12 and d["freq_probe_max_rel_diff"] <= 1e-9
+    assert d["freq_weighted_sum_rel_diff"] <= 1e-9 and d["rounds_equal"], d
+    assert d["indF_sum_rel_diff"] < 1e-6 and d["alpha_sum_rel_diff"] < 1e-5
+    # -- the other layout, same process group, same data set
+    alt = out["alt_sharding"]
+    assert alt["sharding"] == "individuals" and "skipped" not in alt, alt
+    assert alt["n_ind_per_gpu"] == 250 and alt["n_sites_per_gpu"] == 1_000_000 and alt["ms_per_step"] > 0
+    acb = alt["collective_bytes_per_iter"]
+    assert acb["all_to_all_out"] == 8 * 250_000 * 250 * 3 and acb["all_gather_out"] == 8 * 250_000 * 3
+    for p in alt["per_rank"]:
+        assert p["exchange_ms_per_iter"]["all_to_all"] > 0
+    assert alt["exchange_ms"]["all_to_all"] > 0
+    d = bench.compare_checks(alt["check"], one["check"])
+    print("individuals vs N=1:", json.dumps(d))
+    assert d["tot_lkl_max_rel_diff"] <= 1e-12 and d["freq_probe_max_rel_diff"] <= 1e-9
+    assert d["freq_weighted_sum_rel_diff"] <= 1e-9 and d["rounds_equal"], d
+    assert alt["vs_main_sharding"]["ok"] is True
+    assert out["value"] > 0 and out["parity"]["per_call"].startswith("1e-9")
+    print(json.dumps({k: out[k] for k in ("value", "ms_per_step", "exchange_ms", "collectives")}),
+          json.dumps({k: alt[k] for k in ("value", "ms_per_step", "exchange_ms")}))

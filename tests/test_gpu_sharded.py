@@ -74,10 +74,10 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     """`python bench.py --gpus 2` as the driver starts it (no torch.distributed environment):
     bench.py launches the two ranks itself before any GPU call; on this one-GPU box both
     ranks share cuda:0 and the collectives go through gloo staged on the host (the line says
-    so).  Strong scaling is the default: the workload's individuals are sharded, and the
-    sharded run must reproduce the N = 1 job (same data seeds are not shared between the two
-    runs, so the check is on the bookkeeping: total individuals, sites, positive rate).
-    Functional check only; the measured multi-GPU configuration uses nccl (= RCCL) and is
+    so).  Strong scaling is the default, and every rank holds a slice of the data set the N = 1
+    job processes (simulate.IndexedSim): the lines' `check` objects -- two EM iterations from the
+    starting values -- agree between one rank, two individual shards, two site shards and the
+    site-shard run's embedded `alt_sharding`.  Functional check only; the measured multi-GPU configuration uses nccl (= RCCL) and is
     run by the driver on an 8-GPU node."""
     import json
     import os
@@ -94,9 +94,19 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
+    sys.path.insert(0, root)
+    import bench
+
+    def same(a, b):
+        d = bench.compare_checks(a, b)
+        assert d["tot_lkl_max_rel_diff"] <= 1e-12 and d["freq_probe_max_rel_diff"] <= 1e-9, d
+        assert d["freq_weighted_sum_rel_diff"] <= 1e-9 and d["rounds_equal"], d
+
     one = run()
     two = run("--gpus", "2", "--shard", "individuals")
     assert one["n_gpus"] == 1 and one["ranks"] == 1 and one["config"]["n_ind_per_gpu"] == 64
+    assert two["alt_sharding"] is None and one["vs_n1"] is None
+    same(two["check"], one["check"])
     assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["scaling"] == "strong"
     assert two["config"]["n_ind_total"] == 64 and two["config"]["n_ind_per_gpu"] == 32
     assert "gloo" in two["collectives"] and two["value"] > 0
@@ -113,6 +123,11 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert cb["all_to_all_out"] == 0 and cb["all_gathers"] >= 2 and 0 < cb["all_gather_out"] < 1e6
     assert [p["all_gathers_per_iter"] for p in st["per_rank"]] == [cb["all_gathers"]] * 2
     assert st["per_rank"][0]["rounds_per_iter"] == st["per_rank"][1]["rounds_per_iter"]
+    same(st["check"], one["check"])
+    alt = st["alt_sharding"]                 # the other layout from the same invocation
+    assert alt["sharding"] == "individuals" and alt["n_ind_per_gpu"] == 32 and alt["ms_per_step"] > 0
+    same(alt["check"], one["check"])
+    assert alt["vs_main_sharding"]["ok"] is True
     sw = run("--gpus", "2", "--scaling", "weak")
     assert sw["config"]["n_sites"] == 2 * one["config"]["n_sites"] and sw["config"]["n_ind_total"] == 64
     # BASELINE configs[4]'s path at smoke size: --call_geno, 2-bit packed handles, the site
