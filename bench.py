@@ -752,11 +752,12 @@ def run_rank(args):
         per_rank = [None] * world
         dist.all_gather_object(per_rank, rank_clocks(ctx, run, tl))
 
+    # (the accounting of the timed loop, before the check's iterations add to it)
+    collective_bytes = None if world == 1 else em.collective_bytes_per_iter()
+    exch_calls = (em.exchange.calls, em.exchange.bytes, em.exchange.host_ms) if by_sites and em.exchange else None
     check = None
     if not args.no_check and V == 1:
         check = result_check(ctx, run)
-    collective_bytes = None if world == 1 else em.collective_bytes_per_iter()
-    exch_calls = (em.exchange.calls, em.exchange.bytes, em.exchange.host_ms) if by_sites and em.exchange else None
     C_waves = em.hmm.layout()[0]
     for h in replicas:
         h.close()
@@ -1047,6 +1048,7 @@ def alt_sharding(ctx, steps, warmup, main_check):
     K = max(steps, 1)
     per_rank = [None] * ctx.world
     dist.all_gather_object(per_rank, rank_clocks(ctx, run, tl))
+    coll = em.collective_bytes_per_iter()
     check = None if ctx.args.no_check else result_check(ctx, run)
     out.update({
         "ms_per_step": tl["dt"] / K * 1e3,
@@ -1055,7 +1057,7 @@ def alt_sharding(ctx, steps, warmup, main_check):
         "first_iterations_ms": tl["each_ms"][:warmup],
         "exchange_ms": {k: max(r["exchange_ms_per_iter"][k] for r in per_rank)
                         for k in per_rank[0]["exchange_ms_per_iter"]},
-        "collective_bytes_per_iter": em.collective_bytes_per_iter(),
+        "collective_bytes_per_iter": coll,
         "per_step_kernel_ms": {k: tl["fam"][k] / K for k in tl["fam"] if k != "lkl_first"},
         "rounds_per_iter": tl["rounds"] / K,
         "per_rank": per_rank,
