@@ -2603,6 +2603,131 @@ k_fast_estmaf_interp(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __r
   status[site] = st;
 }
 
+// ---- est_maf for CALLED genotypes (packed handles): the per-pass sums in closed form ----
+// A called genotype (--call_geno, called-genotype input: gen_func.cpp:886-914,
+// read_data.cpp:88-98) has linear likelihoods (1,0,0), (0,1,0), (0,0,1) or -- missing -- (u,u,u),
+// so the genotype posterior of est_maf's pass (calc_HWE + post_prob, gen_func.cpp:984-1000) is
+// a unit vector whatever the frequency, except for missing cells, where it is HWE itself:
+//   genotype 0:  num += 0         den += 2 - F
+//   genotype 1:  num += 1         den += 2                 (F < 1; at F = 1 the reference's weights
+//                                                           all vanish: the site is redone in its
+//                                                           log-space order, k_fast_estmaf_stream)
+//   genotype 2:  num += 2 - F     den += 2 - F
+//   missing:     num += h1 + h2 (2 - F),  den += 2 h1 + (h0 + h2)(2 - F),  with
+//                h0 = (1-f)^2 + f(1-f)F, h1 = 2 f(1-f)(1-F), h2 = f^2 + f(1-f)F -- polynomials
+//                in f whose coefficients are sums over the site's missing individuals of
+//                (1-F), (2-F) and F(2-F).
+// The whole <= 101-pass recursion of a site is therefore a SCALAR recursion on five sums over
+// its individuals: one sweep over the 2-bit codes and the posteriors (8.25 B per cell, bound by
+// HBM) leaves the sums, and one LANE per site runs the reference's passes -- same recursion,
+// same pass count, same stopping rule as k_fast_estmaf, nothing interpolated.  (The general
+// kernel spends 17 evaluations of every individual per site, 17.5 ps per cell at 5000
+// individuals; this is one load of every cell.)
+constexpr int ESTC_A0 = 0, ESTC_B0 = 1, ESTC_M0 = 2, ESTC_M1 = 3, ESTC_M2 = 4;
+
+template <bool TILE>
+__global__ void __launch_bounds__(64)
+k_fast_estmaf_called_sums(const GlView gl, const double* __restrict__ marg_blocks, uint64_t S_own,
+                          uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
+                          uint8_t* __restrict__ redo, double* __restrict__ state,
+                          uint64_t state_stride, uint64_t blk0) {
+  const int lane = threadIdx.x;
+  uint64_t site;
+  const double* tile_col = nullptr;
+  if constexpr (TILE) {  // the blockIdx -> site map of k_fast_estmaf<.., TILE>
+    const uint64_t b = blockIdx.x + blk0, x = b & 7, k = b >> 3;
+    const uint64_t q = ((k >> 3) << 6) + (x << 3) + (k & 7);
+    const uint64_t tile_row = q >> 6, l = q & 63;
+    const uint64_t c = tile_row / tile_T, t = tile_row - c * tile_T;
+    site = (c * 64 + l) * tile_T + t;
+    if (site >= S_own) return;
+    tile_col = marg_blocks + post_lane_off(tile_row, l, I_tot);
+  } else {
+    site = blockIdx.x;
+  }
+  const uint64_t cell_s = gl.cell0 + site * I_tot;
+  const bool one_block = (I_blk == I_tot);
+  double n1 = 0, s2 = 0, s02 = 0, m0 = 0, m1 = 0, m2 = 0;
+  bool bad = false;
+  auto posterior = [&](uint64_t i) -> double {
+    if constexpr (TILE) return tile_col[post_ind_off(i)];
+    if (one_block) return marg_blocks[site * I_blk + i];
+    const uint64_t q = i / I_blk;  // rank blocks [I_tot / I_blk][S_own][I_blk]
+    return marg_blocks[(q * S_own + site) * I_blk + (i - q * I_blk)];
+  };
+  auto take = [&](uint32_t code, double F) {
+    const double tF = 2 - F;
+    const bool g1 = code == 1, g2 = code == 2, g3 = code == 3;
+    n1 += g1 ? 1.0 : 0.0;
+    bad |= g1 && !(F < 1);
+    s2 += g2 ? tF : 0.0;
+    s02 += (code == 0 || g2) ? tF : 0.0;
+    m0 += g3 ? 1 - F : 0.0;
+    m1 += g3 ? tF : 0.0;
+    m2 += g3 ? F * tF : 0.0;
+  };
+  uint64_t i = lane;
+  for (; i + 192 < I_tot; i += 256) {  // four loads of each kind in flight
+    double F[4];
+    uint32_t cd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      F[j] = posterior(i + 64 * j);
+      cd[j] = gl_code(gl.codes, cell_s + i + 64 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) take(cd[j], F[j]);
+  }
+  for (; i < I_tot; i += 64) take(gl_code(gl.codes, cell_s + i), posterior(i));
+  const double A0 = wave_sum(n1 + s2), B0 = wave_sum(2 * n1 + s02);
+  m0 = wave_sum(m0);
+  m1 = wave_sum(m1);
+  m2 = wave_sum(m2);
+  const bool any_bad = __ballot(bad) != 0;
+  if (lane == 0) {
+    state[ESTC_A0 * state_stride + site] = A0;
+    state[ESTC_B0 * state_stride + site] = B0;
+    state[ESTC_M0 * state_stride + site] = m0;
+    state[ESTC_M1 * state_stride + site] = m1;
+    state[ESTC_M2 * state_stride + site] = m2;
+    redo[site] = any_bad ? 1 : 0;
+  }
+}
+
+// the passes themselves (gen_func.cpp:976-1006): one lane per site
+__global__ void __launch_bounds__(256)
+k_fast_estmaf_called_passes(uint64_t S_own, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
+                            uint8_t* __restrict__ status, const double* __restrict__ state,
+                            uint64_t state_stride, uint64_t tile_T, uint64_t row0, uint64_t row1) {
+  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= S_own || !in_tile_rows(site, tile_T, row0, row1)) return;
+  status[site] = EST_DONE;
+  if (redo[site]) return;
+  const double A0 = state[ESTC_A0 * state_stride + site], B0 = state[ESTC_B0 * state_stride + site];
+  const double m0 = state[ESTC_M0 * state_stride + site], m1 = state[ESTC_M1 * state_stride + site];
+  const double m2 = state[ESTC_M2 * state_stride + site];
+  int iters = 0;
+  double num = 0, den = 0, pnum = 0.01, pden = 1.0;  // freq = 0.01 (gen_func.cpp:976)
+  for (;;) {
+    const double f = pnum / pden, om = 1 - f;
+    const double b = f * om, ff = f * f;
+    const double miss_n = fma(2 * b, m0, fma(ff, m1, b * m2));
+    const double miss_d = fma(4 * b, m0, fma(fma(om, om, ff), m1, 2 * b * m2));
+    num += A0 + miss_n;
+    den += B0 + miss_d;
+    // |prev - freq| > EPSILON (gen_func.cpp:1006), cross-multiplied as in k_fast_estmaf
+    const double lhs = fabs(fma(pnum, den, -(num * pden))), thr = kEPS * (den * pden);
+    const bool again = (lhs > thr) && (iters++ < 100);
+    pnum = num;
+    pden = den;
+    if (!again) break;
+  }
+  const double freq = num / den;
+  const bool ok = freq >= 0 && freq < 1;
+  freq_out[site] = freq;
+  redo[site] = ok ? 0 : 1;
+}
+
 // any number of individuals: re-reads the (L2-resident) site row every pass.  One wave per
 // site; a wave looks at the flags of 64 sites at a time (normally none is set: the launch is
 // then a few thousand waves reading a cache line each, whatever the number of sites) and
@@ -2695,6 +2820,7 @@ const SwitchName kSwitches[] = {
     {"bg_parts", &Switches::bg_parts}, {"no_fuse", &Switches::no_fuse},
     {"eager_emission", &Switches::eager_emission}, {"estmaf_interp", &Switches::estmaf_interp},
     {"estmaf_sitemajor", &Switches::estmaf_sitemajor}, {"estmaf_no_rows", &Switches::estmaf_no_rows},
+    {"estmaf_no_called", &Switches::estmaf_no_called},
     {"no_xdeg2", &Switches::no_xdeg2},
     {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
@@ -2825,6 +2951,7 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
   fs.geno_il = parent.geno_il;
   fs.cls_lin = parent.cls_lin;
   fs.u_lin = parent.u_lin;
+  fs.called_table = parent.called_table;
   fs.gl_lin = parent.gl_lin;
   fs.pos_il = parent.pos_il;
   fs.glq_il = parent.glq_il;
@@ -2867,6 +2994,9 @@ bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double
     if (hipMemcpyAsync(t, fs.cls_lin, sizeof t, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     if (hipStreamSynchronize(st) != hipSuccess) return false;
     fs.u_lin = t[9];
+    // the four classes of a called genotype: unit rows and a uniform one (est_maf's closed form)
+    fs.called_table = t[0] == 1 && t[1] == 0 && t[2] == 0 && t[3] == 0 && t[4] == 1 && t[5] == 0 &&
+                      t[6] == 0 && t[7] == 0 && t[8] == 1 && t[9] > 0 && t[10] == t[9] && t[11] == t[9];
     hipLaunchKernelGGL(k_fast_geno_interleave, dim3(8192), dim3(256), 0, st, gl_log.codes,
                        gl_log.cell0, fs.I, fs.S, fs.T, fs.C, fs.geno_il);
   } else {
@@ -3194,9 +3324,25 @@ bool fast_post_to_site_major(FastState& fs, hipStream_t st, double* d_marg) {
   return hipGetLastError() == hipSuccess;
 }
 
+// called genotypes (a packed handle whose class table is the four unit / uniform rows): est_maf's
+// per-pass sums exist in closed form
+bool fast_estmaf_called(const FastState& fs, const GlView& gl) {
+  return !gl.dense && gl.codes && fs.called_table && !fs.sw.estmaf_no_called;
+}
+
+bool fast_estmaf_in_place(const FastState& fs, uint64_t I_tot) {
+  // est_maf on the E-step's tile-major posteriors, without the site-major copy: the register
+  // kernels up to 4096 individuals (measured at 10^9 site-individuals: in place 13.6 vs 14.4 ms
+  // via the copy at 4000 individuals, 19.7 vs 16.5 ms at 8000: a site group's sectors outgrow
+  // L2); the called-genotype sweep reads every cell once, whole sectors, at any size
+  if (fs.sw.estmaf_sitemajor) return false;
+  return I_tot <= 4096 || (fs.packed && fs.called_table && !fs.sw.estmaf_no_called);
+}
+
 bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major) {
   // the wave-per-site kernels on the E-step's tile-major posteriors: a part is a range of
   // tile rows, i.e. of workgroups
+  if (tile_major && fs.packed && fs.called_table && !fs.sw.estmaf_no_called) return true;
   return tile_major && I_tot > 128 && I_tot <= 8192;
 }
 
@@ -3214,7 +3360,9 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   if (nblk == 0) return true;
   // tile-major posteriors (the E-step's own layout) only for the handle's whole site range
   // and individuals that fit the registers of one workgroup
-  if (tile_major && !(I_tot <= 8192 && I_blk == I_tot && S_own == fs.S)) return false;
+  if (tile_major && !((I_tot <= 8192 || fast_estmaf_called(fs, d_gl_sites)) && I_blk == I_tot &&
+                      S_own == fs.S))
+    return false;
   const uint64_t tile_T = tile_major ? fs.T : 0;
   // k_fast_estmaf_stream, 4 waves per workgroup: a wave per site when it streams every site,
   // else 64 flags per wave and turn
@@ -3233,6 +3381,24 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     if (hipMalloc((void**)&fs.est_state, S_own * EST_FIELDS * sizeof(double)) != hipSuccess)
       return false;
     fs.redo_cap = S_own;
+  }
+  if (fast_estmaf_called(fs, d_gl_sites)) {
+    // called genotypes: the per-pass sums in closed form (k_fast_estmaf_called_sums)
+    if (tile_major)
+      hipLaunchKernelGGL((k_fast_estmaf_called_sums<true>), dim3((unsigned)nblk), dim3(64), 0, st,
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, fs.redo, fs.est_state,
+                         fs.redo_cap, blk0);
+    else
+      hipLaunchKernelGGL((k_fast_estmaf_called_sums<false>), dim3((unsigned)S_own), dim3(64), 0, st,
+                         d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, fs.redo, fs.est_state,
+                         fs.redo_cap, (uint64_t)0);
+    hipLaunchKernelGGL(k_fast_estmaf_called_passes, dim3((unsigned)((S_own + 255) / 256)), dim3(256), 0,
+                       st, S_own, d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap, tile_T,
+                       row0, row1);
+    // a called heterozygote at posterior IBD = 1 (the reference keeps a finite -1e15 there)
+    hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
+                       I_tot, I_blk, tile_T, d_freq_out, fs.redo, row0, row1);
+    return hipGetLastError() == hipSuccess;
   }
   // Interpolated passes (see k_fast_estmaf) unless NGHMM_ESTMAF_INTERP=0, which runs
   // every pass exactly.

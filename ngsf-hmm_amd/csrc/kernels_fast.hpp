@@ -23,6 +23,7 @@ struct Switches {
   int estmaf_interp = 1;      // 0: every est_maf pass evaluated over all individuals
   int estmaf_sitemajor = 0;   // est_maf on a site-major copy of the posteriors
   int estmaf_no_rows = 0;     // small cohorts: a wave per site instead of four sites per wave
+  int estmaf_no_called = 0;   // called genotypes through the general est_maf kernels too
   int no_xdeg2 = 0;           // alpha probes always by the degree-4 polynomial
   int fast_c = 0;             // waves per individual (0: by cohort size); at creation only
   int exact_serial = 0;       // exact mode: one lane per chain instead of producer-consumer
@@ -67,6 +68,7 @@ struct FastState {
   uint32_t* geno_il = nullptr;    // codes interleaved [I][C][T/16][64]: 16 sites of a lane per word
   double* cls_lin = nullptr;      // [4][3] linear likelihoods of the four classes (device)
   double u_lin = 0;               // linear likelihood of a uniform (missing) cell, host copy
+  bool called_table = false;      // packed: the class table is (1,0,0), (0,1,0), (0,0,1), (u,u,u)
   double* gl_lin = nullptr;       // exp(GL), site-major [S][I][3] (emission refresh, est_maf)
   double* e_il = nullptr;         // emission ratios e1/e0, interleaved [I][C][T][64]
   double* base_c = nullptr;       // [I][C]: sum of log e0 over the wave's sites
@@ -143,6 +145,10 @@ GlView fast_gl_lin(const FastState& fs);
 // the E-step's layout (R = C T) -- the caller spreads the parts between other work on the
 // stream; needs fast_estmaf_splittable().  Every site's result is the one the whole call gives.
 bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major);
+// est_maf reads the E-step's tile-major posteriors in place (else: a site-major copy first)
+bool fast_estmaf_in_place(const FastState& fs, uint64_t I_tot);
+// called genotypes: the per-pass sums in closed form (k_fast_estmaf_called_sums)
+bool fast_estmaf_called(const FastState& fs, const GlView& gl);
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_lin_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out, bool tile_major = false, uint32_t part = 0,

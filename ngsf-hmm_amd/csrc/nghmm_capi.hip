@@ -1341,7 +1341,7 @@ struct MstepRun {
     h->launches[SLOT_BACKWARD] = 0;
     h->marg_valid = false;
     h->tmp_is_posteriors = false;
-    tile_major = h->I <= 4096 && !h->fast.sw.estmaf_sitemajor;
+    tile_major = fast_estmaf_in_place(h->fast, h->I);
     bg_parts = 1;
     if (fast_estmaf_splittable(h->fast, h->I, tile_major)) {
       // measured at 1000 x 1M (ms per iteration): 1 part 32.4, 2 parts 32.27, 3 parts 32.35,
@@ -1587,9 +1587,7 @@ static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_block
                                    : gl_dense(h->d_gl_shard);
     bool tile_major = false;
     if (!d_marg_blocks) {  // the handle's own posteriors of its whole site range
-      // measured at 10^9 site-individuals: in place 13.6 vs 14.4 ms via the site-major copy
-      // at 4000 individuals, 19.7 vs 16.5 ms at 8000 (a site group's sectors outgrow L2)
-      tile_major = I_tot <= 4096 && !h->fast.sw.estmaf_sitemajor;
+      tile_major = fast_estmaf_in_place(h->fast, I_tot);
       if (tile_major) {
         d_marg_blocks = h->fast.post;
       } else {

@@ -170,6 +170,48 @@ def test_est_maf_register_and_stream_variants(pkg, I):
     hmm.close()
 
 
+@pytest.mark.parametrize("I", [3, 40, 130, 700, 1024, 1100, 2100, 4100, 5000, 8200, 9000])
+def test_est_maf_called_genotypes_closed_form(pkg, I):
+    """Called genotypes (packed handles): a genotype's posterior in est_maf's pass is a unit
+    vector whatever the frequency, a missing cell's is HWE itself, so the per-pass sums are a
+    constant plus polynomials in f with three per-site coefficients: one sweep over codes and
+    posteriors and a scalar recursion per site (k_fast_estmaf_called_sums / _passes), at any
+    cohort size, in place on the tile-major posteriors.  Against the oracle (1e-9) and against
+    the general kernels on the same handle (switch estmaf_no_called; 1e-12) -- including sites
+    with a called heterozygote at posterior IBD exactly 1, where the reference's weights all
+    vanish and both routes hand the site to the log-space kernel."""
+    import orclib
+    S = 96 if I < 4000 else 24
+    d = pkg.simulate.simulate(I, S, seed=I + 1, missing_rate=0.1, n_chrom=2)
+    orc = orclib.Oracle("libm")
+    gl = orc.prepare_gl(d.gl, 0, call_geno=True)
+    em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
+    # alpha small and F large: long IBD tracts, posteriors snapped to exactly 0 and 1
+    em.set_params(0.6, 0.02, 0.2)
+    em.init_emission()
+    assert em.estep() == 0 and em.mstep_freq(1) == 0
+    het_at_one = ((em.marg == 1.0).T & (np.argmax(gl, axis=2) == 1) & (gl.max(axis=2) == 0)).any(axis=1)
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST | pkg.GENO_PACKED) as hmm:
+        hmm.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=True)
+        got = {}
+        for general in (0, 1):
+            hmm.set_switch("estmaf_no_called", general)
+            hmm.set_params(0.6, 0.02, 0.2)
+            hmm.init_emission()
+            hmm.estep()
+            hmm.mstep_freq(1)
+            got[general] = hmm.freq
+            # the log-space route of a site with a vanishing cell rounds like the reference
+            # (terms of magnitude 1e15): compared where it is not taken, finite everywhere
+            assert np.isfinite(got[general]).all()
+            ok = ~het_at_one
+            np.testing.assert_allclose(got[general][ok], em.freq[ok], rtol=1e-9)
+        np.testing.assert_allclose(got[0], got[1], rtol=1e-12)
+        # --freq e: est_maf at F = 0 for everybody (parse_args.cpp:312-318)
+        hmm.set_switch("estmaf_no_called", 0)
+    print(f"I = {I}: {int(het_at_one.sum())} of {S} sites with a called heterozygote at posterior 1")
+
+
 @pytest.mark.parametrize("n,packed", [(2, False), (4, False), (2, True)])
 def test_group_of_handles_equals_one_handle(pkg, n, packed):
     """nghmm_group_setup / nghmm_group_iter_em (one process, several handles; on an 8-GPU node
