@@ -2823,6 +2823,7 @@ const SwitchName kSwitches[] = {
     {"estmaf_no_called", &Switches::estmaf_no_called},
     {"no_xdeg2", &Switches::no_xdeg2},
     {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
+    {"estmaf_exact_lanes", &Switches::estmaf_exact_lanes},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}};
 

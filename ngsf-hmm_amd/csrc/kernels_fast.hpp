@@ -27,6 +27,7 @@ struct Switches {
   int no_xdeg2 = 0;           // alpha probes always by the degree-4 polynomial
   int fast_c = 0;             // waves per individual (0: by cohort size); at creation only
   int exact_serial = 0;       // exact mode: one lane per chain instead of producer-consumer
+  int estmaf_exact_lanes = -1;  // exact est_maf with a lane per site: -1 by size, 0 off, 1 on
   int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
   int timing = 0;             // host-side phase times of every M-step on stderr
   int debug_modes = 0;        // kernel versions of every objective round on stderr

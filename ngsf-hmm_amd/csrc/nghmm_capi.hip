@@ -1606,7 +1606,8 @@ static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_block
     const GlView lg = !shard ? own_gl(h)
                       : h->packed ? gl_packed(h->d_codes_shard, h->d_cls_log)
                                   : gl_dense(h->d_gl_shard);
-    launch_estmaf_exact(h->stream, lg, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr);
+    launch_estmaf_exact(h->stream, lg, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr,
+                        h->fast.sw.estmaf_exact_lanes);
   }
   if ((rc = toc(h, SLOT_ESTMAF, false))) return rc;
   HIP_TRY(hipGetLastError());
@@ -1644,7 +1645,8 @@ static int mstep_freq_ld_impl(nghmm_t* h, int freq_est, int e_prob) {
   const uint64_t n_est = freq_est == 1 ? h->S : 1;
   tic(h);
   if (exact) {
-    launch_estmaf_exact(h->stream, own_gl(h), h->d_marg, n_est, h->I, h->d_freq_new, nullptr);
+    launch_estmaf_exact(h->stream, own_gl(h), h->d_marg, n_est, h->I, h->d_freq_new, nullptr,
+                        h->fast.sw.estmaf_exact_lanes);
   } else if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast), h->d_marg, n_est, h->I, h->I,
                           h->d_freq_new, false)) {
     return NGHMM_ERR_HIP;
@@ -1758,7 +1760,8 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     HIP_TRY(hipEventRecord(h->aux_go, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
     HIP_TRY(hipEventRecord(h->aux_ev0, h->aux_stream));
-    launch_estmaf_exact(h->aux_stream, own_gl(h), h->d_marg, h->S, h->I, h->d_freq, nullptr);
+    launch_estmaf_exact(h->aux_stream, own_gl(h), h->d_marg, h->S, h->I, h->d_freq, nullptr,
+                        h->fast.sw.estmaf_exact_lanes);
     const hipError_t e_launch = hipGetLastError();
     HIP_TRY(hipEventRecord(h->aux_ev1, h->aux_stream));
     HIP_TRY(e_launch);

@@ -80,6 +80,43 @@ def test_mstep_freq_bitwise(pkg, orc_det, small_sim):
     hmm.close()
 
 
+@pytest.mark.parametrize("shape,packed", [((1, 1), False), ((37, 70), False), ((100, 130), False),
+                                          ((9, 1000), False), ((70, 515), True), ((130, 64), True)])
+def test_mstep_freq_lane_per_site_kernel_bitwise(pkg, orc_det, shape, packed):
+    """est_maf in exact mode with a LANE per site (k_estmaf_exact_lanes: a wave holds 64 sites,
+    a lane walks its site's individuals in order -- the reference's serial sum,
+    gen_func.cpp:984-1003, is the loop itself; what large site counts take by default) against
+    the wave-per-site kernel and the oracle: the same frequencies bit for bit, dense and packed
+    handles, ragged site and individual counts (blocks of 8 individuals staged through LDS,
+    partly filled waves)."""
+    import orclib
+    I, S = shape
+    d = pkg.simulate.simulate(I, S, seed=I * 1000 + S, n_chrom=2, missing_rate=0.07, indF="r", freq="r")
+    gl = orc_det.prepare_gl(d.gl, 0, call_geno=packed)
+    em = orclib.OracleEM(orc_det, gl, d.pos_dist_mb)
+    em.set_params(0.3, 0.1, 0.15)
+    assert em.init_emission() == 0 and em.estep() == 0 and em.mstep_freq(1) == 0
+    got = {}
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT | (pkg.GENO_PACKED if packed else 0)) as hmm:
+        hmm.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=packed)
+        for lanes in (0, 1):
+            hmm.set_switch("estmaf_exact_lanes", lanes)
+            hmm.set_params(0.3, 0.1, 0.15)
+            hmm.init_emission()
+            hmm.estep()
+            hmm.mstep_freq(1)
+            got[lanes] = hmm.freq
+            assert np.array_equal(got[lanes], em.freq), lanes
+        # a whole fused iteration (est_maf on the second stream underneath the rounds)
+        hmm.set_params(0.3, 0.1, 0.15)
+        hmm.init_emission()
+        em.set_params(0.3, 0.1, 0.15)
+        em.init_emission()
+        assert em.iterate() == 0
+        hmm.iter_EM()
+        assert np.array_equal(hmm.freq, em.freq) and np.array_equal(hmm.indF, em.indF)
+
+
 @pytest.mark.parametrize("fixed", [(False, False), (True, False), (False, True), (True, True)])
 def test_mstep_indf_bitwise(pkg, orc_det, small_sim, fixed):
     d, gl = small_sim
