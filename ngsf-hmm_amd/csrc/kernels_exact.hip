@@ -221,9 +221,21 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 // of its individuals, then the 64 terms of a chunk are added to (num, den) in
 // individual order by all lanes redundantly, so the running sums are wave-uniform
 // and round exactly as the reference's `for i` loop (gen_func.cpp:984-1003).
+// BG_WAVES > 0: the version that runs on the second stream UNDERNEATH the objective rounds of a
+// fused iteration.  At its natural 64 VGPRs the kernel holds all eight wave slots of every
+// SIMD, and a round's workgroups (three waves + 60 KB of LDS that must land on one CU together)
+// then wait for slots behind the quarter of a million small workgroups of this launch: measured
+// at 1000 x 1M, the rounds made no progress at all while est_maf ran (45 rounds 17.6 s against
+// 13.5 s alone, est_maf 4.2 s against 2.4 s alone).  Claiming 512 / BG_WAVES registers caps the
+// kernel at BG_WAVES waves per SIMD and leaves the other slots to the chains, whose waves
+// raise their issue priority.
+template <int BG_WAVES>
 __global__ void __launch_bounds__(256)
 k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
                uint64_t I, double* __restrict__ freq_out, uint32_t* __restrict__ passes_out) {
+  if constexpr (BG_WAVES == 4) asm volatile("; occupancy cap" ::: "v127");
+  if constexpr (BG_WAVES == 2) asm volatile("; occupancy cap" ::: "v255");
+  if constexpr (BG_WAVES == 3) asm volatile("; occupancy cap" ::: "v167");
   __shared__ double2 terms[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t site = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1020,15 +1032,24 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
 
 void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out,
-                         int lanes) {
+                         int lanes, int bg_waves) {
   if (S_own == 0) return;
   // a lane per site needs enough sites to fill the chip's lanes (64 sites per wave); the few
   // sites of a small shard or of a short data set take a wave each (lanes: -1 by size, 0 / 1)
   if (lanes < 0 ? S_own >= kEstmafLanesMinSites : lanes != 0)
     hipLaunchKernelGGL(k_estmaf_exact_lanes, dim3((unsigned)((S_own + 63) / 64)), dim3(64), 0, st,
                        gl_sites, marg_sites, S_own, I_tot, freq_out, passes_out);
+  else if (bg_waves == 2)
+    hipLaunchKernelGGL(k_estmaf_exact<2>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
+                       marg_sites, S_own, I_tot, freq_out, passes_out);
+  else if (bg_waves == 3)
+    hipLaunchKernelGGL(k_estmaf_exact<3>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
+                       marg_sites, S_own, I_tot, freq_out, passes_out);
+  else if (bg_waves == 4)
+    hipLaunchKernelGGL(k_estmaf_exact<4>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
+                       marg_sites, S_own, I_tot, freq_out, passes_out);
   else
-    hipLaunchKernelGGL(k_estmaf_exact, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
+    hipLaunchKernelGGL(k_estmaf_exact<0>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
                        marg_sites, S_own, I_tot, freq_out, passes_out);
 }
 

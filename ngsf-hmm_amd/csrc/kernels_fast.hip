@@ -2823,7 +2823,8 @@ const SwitchName kSwitches[] = {
     {"estmaf_no_called", &Switches::estmaf_no_called},
     {"no_xdeg2", &Switches::no_xdeg2},
     {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
-    {"estmaf_exact_lanes", &Switches::estmaf_exact_lanes},
+    {"estmaf_exact_lanes", &Switches::estmaf_exact_lanes}, {"exact_bg_waves", &Switches::exact_bg_waves},
+    {"exact_bg_depth", &Switches::exact_bg_depth},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}};
 

@@ -71,6 +71,8 @@ struct nghmm_handle {
   // exact mode, fused iteration: est_maf on a second stream underneath the objective rounds
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr;
+  static constexpr uint32_t kAuxPieces = 16;   // exact mode: est_maf underneath the rounds, in pieces
+  hipEvent_t aux_piece_ev[kAuxPieces] = {};
   bool blocking_sync = false;
   bool loaded = false;
 
@@ -724,6 +726,8 @@ int nghmm_destroy(nghmm_t* h) {
   fast_destroy(h->fast);
   for (hipEvent_t e : {h->aux_ev0, h->aux_ev1, h->aux_go})
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->aux_piece_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1285,6 +1289,9 @@ struct MstepRun {
   void* user;
 
   BfgsBatch& batch;
+  // called at the start of every objective round (exact mode's fused iteration feeds est_maf
+  // to the second stream a piece at a time)
+  std::function<int()> before_round;
   bool estep_pending = false;
   bool bg_active = false;
   bool tile_major = false;      // est_maf reads the tile-major posteriors in place
@@ -1369,6 +1376,7 @@ struct MstepRun {
 
   int first_or_plain_round() {
     int rc;
+    if (before_round && (rc = before_round())) return rc;
     auto t0 = clock::now();
     const size_t n = batch.gather(ind, F, A);
     lkl.resize(n);
@@ -1532,8 +1540,9 @@ struct MstepRun {
 static int mstep_indf_impl(nghmm_t* h, int indF_fixed, int alpha_fixed, nghmm_mstep_stats* stats,
                            bool fuse_estep, double* ind_lkl, nghmm_hook_fn after_estep = nullptr,
                            void* user = nullptr, bool fuse_freq = false,
-                           bool* freq_done = nullptr) {
+                           bool* freq_done = nullptr, std::function<int()> before_round = nullptr) {
   MstepRun run(h, indF_fixed, alpha_fixed, fuse_estep, ind_lkl, after_estep, user, fuse_freq);
+  run.before_round = std::move(before_round);
   return run.run(stats, freq_done);
 }
 
@@ -1737,19 +1746,26 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
       return rc;
     return freq_done ? NGHMM_OK : nghmm_mstep_freq(h, freq_est);
   }
-  if (h->mode == NGHMM_MODE_EXACT && freq_est == 1 && h->I_tot == h->I) {
+  if (h->mode == NGHMM_MODE_EXACT && freq_est == 1 && h->I_tot == h->I && h->fast.sw.exact_bg_waves >= 0) {
     // Exact mode: est_maf (EM.cpp:209-257) reads the E-step's posteriors and the likelihoods
     // and writes the frequencies; the objective rounds (EM.cpp:198-201) read the emissions of
     // the OLD frequencies.  Neither touches what the other uses, and a round is a few hundred
-    // latency-bound waves on a chip of 1024 SIMDs: est_maf goes onto a second stream right
-    // after the E-step and runs underneath the rounds (whose chain waves raise their issue
-    // priority); the emissions are refreshed when both are done.  Same kernels, same data.
+    // latency-bound waves on a chip of 1024 SIMDs -- but they are the iteration's critical path
+    // (its slowest individual's lock-step rounds x 0.30 s at 10^6 sites), and an est_maf that
+    // holds every wave slot starves them: measured at 1000 x 1M, side by side at full occupancy
+    // is no faster than one after the other (17.0 / 14.0 / 5.2 / 9.7 s either way).  So est_maf
+    // goes onto a second stream in PIECES (ranges of sites): one piece per round, capped at
+    // exact_bg_waves waves per SIMD (k_estmaf_exact<BG_WAVES>) -- the chains, whose waves raise
+    // their issue priority, then lose ~8 % -- and whatever is left when the rounds are over
+    // runs uncapped on the whole chip.  The emissions are refreshed when both are done.  Same
+    // kernels, same data, same bits.
     if ((rc = nghmm_estep(h, ind_lkl))) return rc;
     if (!h->aux_stream) {
       HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreate(&h->aux_ev0));
       HIP_TRY(hipEventCreate(&h->aux_ev1));
       HIP_TRY(hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
+      for (auto& e : h->aux_piece_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // whatever happens from here on, nothing may be left running on the second stream when
     // this call returns (the caller may destroy the handle or load other data next)
@@ -1760,12 +1776,31 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     HIP_TRY(hipEventRecord(h->aux_go, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
     HIP_TRY(hipEventRecord(h->aux_ev0, h->aux_stream));
-    launch_estmaf_exact(h->aux_stream, own_gl(h), h->d_marg, h->S, h->I, h->d_freq, nullptr,
-                        h->fast.sw.estmaf_exact_lanes);
-    const hipError_t e_launch = hipGetLastError();
+    constexpr uint32_t kPieces = nghmm_t::kAuxPieces;
+    const uint32_t n_pieces = h->S >= 64 * kPieces ? kPieces : 1;
+    uint32_t next = 0, finished = 0;
+    const int cap = h->fast.sw.exact_bg_waves;
+    auto push = [&](int bg_waves) -> int {
+      const uint64_t s0 = h->S * next / n_pieces, s1 = h->S * (next + 1) / n_pieces;
+      GlView gl = own_gl(h);
+      gl.cell0 += s0 * h->I;
+      launch_estmaf_exact(h->aux_stream, gl, h->d_marg + s0 * h->I, s1 - s0, h->I, h->d_freq + s0, nullptr,
+                          h->fast.sw.estmaf_exact_lanes, bg_waves);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(h->aux_piece_ev[next], h->aux_stream));
+      ++next;
+      return NGHMM_OK;
+    };
+    auto before_round = [&]() -> int {  // at most two pieces queued underneath a round
+      while (finished < next && hipEventQuery(h->aux_piece_ev[finished]) == hipSuccess) ++finished;
+      (void)hipGetLastError();          // (hipErrorNotReady is not an error)
+      if (next < n_pieces && (int)(next - finished) < h->fast.sw.exact_bg_depth) return push(cap);
+      return NGHMM_OK;
+    };
+    rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, false, nullptr, nullptr, nullptr, false,
+                         nullptr, before_round);
+    while (rc == NGHMM_OK && next < n_pieces) rc = push(0);  // the rest, on the whole chip
     HIP_TRY(hipEventRecord(h->aux_ev1, h->aux_stream));
-    HIP_TRY(e_launch);
-    rc = nghmm_mstep_indf(h, indF_fixed, alpha_fixed, stats);
     HIP_TRY(hipEventSynchronize(h->aux_ev1));  // also when the M-step failed
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->aux_ev0, h->aux_ev1));
