@@ -65,6 +65,7 @@ class BfgsBatch {
   };
   std::vector<Problem> probs_;
   uint64_t n_active_ = 0;
+  double us_per_machine_ = 0;  // host time of the last whole round's scatter per active machine
   uint32_t rounds_ = 0;
   uint64_t points_ = 0, ref_calls_ = 0, ind_rounds_ = 0;
 
