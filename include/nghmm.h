@@ -77,6 +77,11 @@ typedef struct {
                                each costs one pass over that individual's emissions */
 } nghmm_mstep_stats;
 
+/* The message of the last failing call ON THE CALLING THREAD (thread-local storage: handles may
+ * be driven from several host threads -- replicas, the members of a group or chain -- and each
+ * thread sees its own calls' messages; a failure inside a library-owned worker thread of
+ * nghmm_group_* / nghmm_chain_* is carried back to the thread that made the call).  Valid until
+ * that thread's next library call; "" when that call succeeded. */
 const char* nghmm_last_error(void);
 const char* nghmm_strerror(int code);
 /* 1 if the library was built with its HIP kernels (always, for the shipped .so). */
@@ -371,11 +376,18 @@ void nghmm_free_host(void* p);
  *   estmaf_interp     0: every est_maf pass evaluated over all individuals (default 1)
  *   estmaf_sitemajor  1: est_maf on a site-major copy of the posteriors
  *   estmaf_no_rows    1: small cohorts take a wave per site instead of four sites per wave
+ *   estmaf_no_called  1: called genotypes (packed handles) through the general est_maf kernels
+ *                     instead of their closed form (k_fast_estmaf_called_sums)
  *   no_xdeg2          1: the alpha probes' exp((alpha_0 - alpha_probe) d) always by the
  *                     degree-4 polynomial (default: degree 2 where |.| <= 1e-5, the same to
  *                     half an ulp)
  *   exact_serial      1: exact-mode recursions as one lane per chain (kernels_exact.hip)
  *                     instead of producer-consumer workgroups (kernels_exact_pc.hip): same bits
+ *   estmaf_exact_lanes 1: exact-mode est_maf with a lane per site instead of a wave per site
+ *                     (same bits; measured slower, kept for the comparison)
+ *   exact_bg_waves    exact mode, fused iteration: est_maf runs underneath the objective rounds
+ *                     in 16 pieces capped at this many waves per SIMD (default 3; 0: uncapped;
+ *                     -1: after the rounds); exact_bg_depth: pieces queued under a round (3)
  *   timing            1: host-side phase times of every M-step on stderr
  *   debug_modes       1: kernel versions of every objective round on stderr
  * Fixed at creation (environment only): fast_c (waves per individual), spin_sync (replicas
