@@ -72,7 +72,7 @@ FP64_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 256 CUs x 4 SIMDs
                                         # x 64 lanes x 2 flop = the 78.6 TFLOP/s FP64 vector peak
 
 # The kernels of one fast-mode EM iteration, what bounds each and their
-# instruction counts per site from the device assembly (profiles/r03_isa_summary.txt, made by
+# instruction counts per site from the device assembly (profiles/r04_isa_summary.txt, made by
 # tools/isa_report.py from `hipcc -S` of this build): loop body of 8 sites / 8.
 KERNELS = {
     "lkl_later_rounds": dict(
@@ -103,7 +103,7 @@ KERNELS = {
 
 
 def estmaf_instr_per_site(i_tot):
-    """VALU / FP64 wave-instructions est_maf issues per site (profiles/r03_isa_summary.txt:
+    """VALU / FP64 wave-instructions est_maf issues per site (profiles/r04_isa_summary.txt:
     set-up block 283 / 150 for 16 individuals per lane, an exact pass 375 / 295 in three blocks,
     a node evaluation 165 / 160; 3 exact passes and 12 nodes per site), scaled to the
     individuals per lane of the cohort."""
@@ -847,7 +847,7 @@ def run_rank(args):
                                   "frac": w_fp64 / secs / FP64_ISSUE_PEAK,
                                   "valu_issue_frac": w_valu / secs / FP64_ISSUE_PEAK,
                                   "instr_per_site": per,
-                                  "source": "profiles/r03_isa_summary.txt (device assembly of this build)"}
+                                  "source": "profiles/r04_isa_summary.txt (device assembly of this build)"}
             roof_all[name] = e
         if not fast:   # exact mode: latency-bound chains, not a roofline candidate
             for k in ("forward", "backward", "lkl_batch", "est_maf"):

@@ -9,32 +9,9 @@
 // Nothing of size S*I crosses PCIe inside an EM iteration: per round of the
 // indF/alpha M-step only the probe points (20 B each) go down and their
 // log-likelihoods (8 B each) come back.
-#include <hip/hip_runtime.h>
+#include "capi_internal.hpp"
 
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <chrono>
-#include <cstring>
-#include <new>
-#include <functional>
-#include <condition_variable>
-#include <map>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/nghmm.h"
-#include "bfgs_batch.hpp"
-#include "kernels.hpp"
-#include "kernels_fast.hpp"
-
-using namespace nghmm;
-
-namespace {
+namespace capi {
 
 thread_local std::string g_last_error;
 
@@ -47,131 +24,6 @@ void set_error(const char* fmt, ...) {
   g_last_error = buf;
 }
 
-#define HIP_TRY(expr)                                                              \
-  do {                                                                             \
-    hipError_t e__ = (expr);                                                       \
-    if (e__ != hipSuccess) {                                                       \
-      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,  \
-                __LINE__);                                                         \
-      return NGHMM_ERR_HIP;                                                        \
-    }                                                                              \
-  } while (0)
-
-enum Slot { SLOT_EMISSION = 0, SLOT_FORWARD = 1, SLOT_BACKWARD = 2, SLOT_LKL = 3, SLOT_ESTMAF = 4,
-            SLOT_VITERBI = 5, SLOT_LKL_FIRST = 6, NSLOTS = 7 };
-
-}  // namespace
-
-struct ChainCtx;   // nghmm_chain_setup
-struct nghmm_handle {
-  uint64_t I = 0, S = 0;
-  int device = 0, mode = NGHMM_MODE_EXACT;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
-  // exact mode, fused iteration: est_maf on a second stream underneath the objective rounds
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr;
-  static constexpr uint32_t kAuxPieces = 16;   // exact mode: est_maf underneath the rounds, in pieces
-  hipEvent_t aux_piece_ev[kAuxPieces] = {};
-  bool blocking_sync = false;
-  bool loaded = false;
-
-  double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
-         *d_marg = nullptr, *d_indF = nullptr, *d_alpha = nullptr, *d_ind_lkl = nullptr;
-  int* d_flags = nullptr;
-
-  uint32_t* d_pt_ind = nullptr;
-  double *d_pt_F = nullptr, *d_pt_A = nullptr, *d_pt_lkl = nullptr;
-  size_t pt_cap = 0;
-
-  uint8_t *d_bp = nullptr, *d_path_sites = nullptr, *d_path = nullptr;
-  double* d_vit = nullptr;  // Viterbi scratch: transition logs of one site chunk + carry state
-  double* d_tmp = nullptr;  // S*I*2 doubles, transposes for host read-back
-  double* d_geno = nullptr;  // .geno posteriors of one site chunk
-  size_t geno_cap = 0;
-  char* d_text = nullptr;    // formatted posterior lines of one batch of individuals
-  size_t text_cap = 0;
-  bool tmp_is_posteriors = false;  // d_tmp holds the [I][S] posteriors of the last E-step
-  uint32_t* d_passes = nullptr;
-  double *d_freq_new = nullptr, *d_hap = nullptr;  // --freq_est 2 as intended: [S], [S][4]
-
-  // multi-GPU shard
-  uint64_t I_tot = 0, ind_begin = 0, site_begin = 0, S_own = 0;
-  double* d_gl_shard = nullptr;
-
-  // packed handle (NGHMM_GENO_PACKED): called genotypes as 2-bit codes (glview.hpp); d_gl
-  // does not exist
-  bool packed = false;
-  uint32_t* d_codes = nullptr;        // [S][I] cells, 16 per word
-  uint32_t* d_codes_shard = nullptr;  // [S_own][I_tot] cells of the frequency step's site range
-  double* d_cls_log = nullptr;        // [4][3] prepared log likelihoods of the four classes
-  double h_cls_proto[12] = {0};       // ... as nghmm_create prepared them (row 3: the reader's
-                                      // missing genotype); a load starts from these
-  unsigned long long* d_uniform = nullptr;  // the one value every uniform cell carries (~0: none yet)
-  // chunked loading (nghmm_load_begin .. nghmm_load_end)
-  uint64_t lkl_redone = 0;            // objective points re-evaluated by the general kernel
-  // fast-mode M-step after its first round: the individuals in two halves, each with its own
-  // buffers and events, so that the host advances one half's optimizers while the GPU
-  // evaluates the other half's points (mstep_indf_impl)
-  struct LklAsync {
-    double* d_lkl = nullptr;   // device results
-    size_t cap = 0;
-    double* h_lkl = nullptr;   // pinned host results
-    size_t h_cap = 0;
-    int* d_flags = nullptr;
-    int* h_flags = nullptr;    // pinned
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
-    std::vector<uint32_t> ind;
-    std::vector<double> F, A;
-    uint64_t lo = 0, hi = 0;
-    bool pending = false;
-  } lane[2];
-  // Background work of a fused EM iteration (mstep_indf_impl): the E-step's backward sweep and
-  // the allele-frequency step do not depend on the objective rounds after the first, so they
-  // go onto the stream in pieces right behind each round's kernels and run while the host
-  // digests that round's values.  Error flags of their own (the rounds clear theirs), a pool
-  // of timing events (one pair per piece, read when the iteration ends).
-  struct BgSpan {
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int slot = 0;
-  };
-  int* d_flags_bg = nullptr;
-  std::vector<BgSpan> bg_spans;
-  size_t bg_used = 0;
-  // replicas (nghmm_create_replica): share the parent's data arrays (d_gl / d_codes /
-  // d_cls_log / d_pos and the fast-mode layouts of the likelihoods)
-  nghmm_handle* parent = nullptr;
-  std::atomic<int> n_replicas{0};
-  // member of a group (nghmm_group_setup): exchange buffers on this handle's device and a
-  // second stream for the peer copies, which run under the remaining objective rounds
-  int g_n = 0, g_rank = 0;
-  double *g_send = nullptr, *g_recv = nullptr, *g_freq_own = nullptr, *g_freq_all = nullptr;
-  hipStream_t g_xstream = nullptr;
-  // member of an in-process chain of site shards (nghmm_chain_setup): the exchange buffers of
-  // fast.shard on this handle's device and the chain's shared state
-  struct ChainCtx* chain = nullptr;
-  double *c_send = nullptr, *c_recv = nullptr;
-  bool loading = false;
-  // sites that have arrived since nghmm_load_begin, as disjoint [begin, end) runs: every site
-  // must arrive exactly once (a repeated site would OR two codes into a packed cell)
-  std::map<uint64_t, uint64_t> load_cover;
-  double* d_stage = nullptr;          // staging buffer of one chunk of raw likelihoods
-  size_t stage_cap = 0;
-  int8_t* d_stage8 = nullptr;         // ... of one chunk of reader genotypes
-  size_t stage8_cap = 0;
-
-  FastState fast;  // fast-mode layouts (kernels_fast.hip)
-  BfgsBatch batch;  // one L-BFGS-B state machine per individual, storage reused across M-steps
-  // fast mode keeps the posteriors tile-major (fast.post); the site-major copy d_marg is
-  // made on demand (host read-back, multi-GPU packing, est_maf beyond 4096 individuals)
-  bool marg_valid = false;
-
-  std::vector<double> h_indF, h_alpha;
-  double ms[NSLOTS] = {0, 0, 0, 0, 0, 0, 0};
-  uint32_t launches[NSLOTS] = {0, 0, 0, 0, 0, 0, 0};
-};
-
-namespace {
 
 // Wait for the handle's stream.  Handles that run next to others from their own host threads
 // (replicas) wait on a blocking event instead of spinning, so that more waiting threads than
@@ -187,16 +39,6 @@ int use_device(nghmm_t* h) {
   return NGHMM_OK;
 }
 
-template <typename T>
-int dev_alloc(T** p, size_t n) {
-  if (n == 0) n = 1;
-  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
-  if (e != hipSuccess) {
-    set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
-    return NGHMM_ERR_NOMEM;
-  }
-  return NGHMM_OK;
-}
 
 void tic(nghmm_t* h) { (void)hipEventRecord(h->ev0, h->stream); }
 
@@ -222,7 +64,7 @@ int clear_flags(nghmm_t* h) {
 }
 
 // Reads the kernel error flags and maps them to the reference's fatal errors.
-int check_flags(nghmm_t* h, const int* d_flags = nullptr) {
+int check_flags(nghmm_t* h, const int* d_flags) {
   int f[NFLAGS];
   HIP_TRY(hipMemcpyAsync(f, d_flags ? d_flags : h->d_flags, sizeof f, hipMemcpyDeviceToHost,
                          h->stream));
@@ -355,7 +197,7 @@ int redo_nonfinite(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
 }
 
 int lkl_batch_impl(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double* F,
-                   const double* alpha, double* lkl, bool accumulate, bool* emit_estep = nullptr) {
+                   const double* alpha, double* lkl, bool accumulate, bool* emit_estep) {
   if (n_pts == 0) return NGHMM_OK;
   for (uint32_t p = 0; p < n_pts; ++p)
     if (ind[p] >= h->I) {
@@ -576,7 +418,8 @@ int ensure_emissions(nghmm_t* h) {
   return NGHMM_OK;
 }
 
-}  // namespace
+}  // namespace capi
+
 
 extern "C" {
 
@@ -682,9 +525,6 @@ int nghmm_create(nghmm_t** out, uint64_t n_ind, uint64_t n_sites, int device, in
   return NGHMM_OK;
 }
 
-namespace {
-void chain_release(nghmm_t* h);  // leaves its chain (the others' chain is then no chain any more)
-}
 
 int nghmm_destroy(nghmm_t* h) {
   if (!h) return NGHMM_OK;
@@ -799,377 +639,6 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   }
   *out = h;
   return NGHMM_OK;
-}
-
-static int after_gl_load(nghmm_t* h) {
-  h->loaded = true;
-  h->loading = false;
-  h->marg_valid = false;  // nothing derived from earlier data survives a (re)load
-  h->tmp_is_posteriors = false;
-  if (h->packed) {
-    // the value the data's uniform cells carry becomes row 3 of the class table
-    unsigned long long bits = ~0ull;
-    HIP_TRY(hipMemcpyAsync(&bits, h->d_uniform, sizeof bits, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(sync_stream(h));
-    if (bits != ~0ull) {
-      double u;
-      std::memcpy(&u, &bits, sizeof u);
-      const double row[3] = {u, u, u};
-      HIP_TRY(hipMemcpyAsync(h->d_cls_log + 9, row, sizeof row, hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(sync_stream(h));
-    }
-  }
-  if (h->mode == NGHMM_MODE_FAST) {
-    if (!fast_load(h->fast, h->stream, own_gl(h), h->d_pos)) return NGHMM_ERR_HIP;
-    HIP_TRY(sync_stream(h));
-  }
-  return NGHMM_OK;
-}
-
-static int ensure_stage(nghmm_t* h, size_t doubles) {
-  if (doubles <= h->stage_cap) return NGHMM_OK;
-  if (h->d_stage) (void)hipFree(h->d_stage);
-  h->d_stage = nullptr;
-  h->stage_cap = 0;
-  int rc;
-  if ((rc = dev_alloc(&h->d_stage, doubles))) return rc;
-  h->stage_cap = doubles;
-  return NGHMM_OK;
-}
-
-static int ensure_stage8(nghmm_t* h, size_t bytes) {
-  if (bytes <= h->stage8_cap) return NGHMM_OK;
-  if (h->d_stage8) (void)hipFree(h->d_stage8);
-  h->d_stage8 = nullptr;
-  h->stage8_cap = 0;
-  int rc;
-  if ((rc = dev_alloc(&h->d_stage8, bytes))) return rc;
-  h->stage8_cap = bytes;
-  return NGHMM_OK;
-}
-
-// flags a chunk loader looks at after its kernels
-static int check_load_flags(nghmm_t* h, bool check_nan) {
-  int f[NFLAGS];
-  HIP_TRY(hipMemcpyAsync(f, h->d_flags, sizeof f, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(sync_stream(h));
-  if (check_nan && f[FLAG_NAN]) {
-    set_error("NaN found! Is the file format correct?");
-    return NGHMM_ERR_NAN;
-  }
-  if (f[FLAG_BAD_GENO]) {
-    set_error("wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
-    return NGHMM_ERR_ARG;
-  }
-  if (f[FLAG_NOT_PACKABLE]) {
-    set_error("a cell is not a called genotype (one-hot or uniform likelihoods): a packed handle "
-              "(NGHMM_GENO_PACKED) needs --call_geno or called-genotype input");
-    return NGHMM_ERR_NOT_PACKABLE;
-  }
-  return NGHMM_OK;
-}
-
-// One chunk of sites [site_begin, site_begin + n_sites) from d_src (device; dense [n][I][3]):
-// optional preparation, then into d_gl or, packed, into the codes.  d_src may be the staging
-// buffer or the caller's; `prepare` works in place on a copy when the handle is packed.
-static int ingest_chunk(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* d_src,
-                        bool src_is_scratch, bool prepare, int space, int call_geno,
-                        int check_nan) {
-  int rc;
-  const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
-  if ((rc = clear_flags(h))) return rc;
-  if (!h->packed) {
-    double* dst = h->d_gl + cell0 * 3;
-    if (d_src != dst)
-      HIP_TRY(hipMemcpyAsync(dst, d_src, n_cells * 3 * sizeof(double), hipMemcpyDeviceToDevice,
-                             h->stream));
-    if (prepare) launch_prepare_gl(h->stream, dst, n_cells, space, call_geno, h->d_flags);
-  } else {
-    const double* cells = d_src;
-    if (prepare) {
-      if (!src_is_scratch) {  // never modify the caller's buffer
-        if ((rc = ensure_stage(h, n_cells * 3))) return rc;
-        HIP_TRY(hipMemcpyAsync(h->d_stage, d_src, n_cells * 3 * sizeof(double),
-                               hipMemcpyDeviceToDevice, h->stream));
-        cells = h->d_stage;
-      }
-      launch_prepare_gl(h->stream, const_cast<double*>(cells), n_cells, space, call_geno, h->d_flags);
-    }
-    launch_pack_cells(h->stream, cells, n_cells, cell0, h->d_cls_log, h->d_codes, h->d_uniform,
-                      h->d_flags);
-  }
-  HIP_TRY(hipGetLastError());
-  return check_load_flags(h, check_nan != 0);
-}
-
-// sites per chunk when a whole-matrix loader feeds a packed handle through the staging buffer
-static uint64_t stage_sites(const nghmm_t* h) {
-  uint64_t n = (256ull << 20) / (h->I * 24);
-  if (n < 1) n = 1;
-  return n < h->S ? n : h->S;
-}
-
-int nghmm_load_begin(nghmm_t* h, const double* pos) {
-  g_last_error.clear();
-  if (!h || !pos) return NGHMM_ERR_ARG;
-  if (h->parent || h->n_replicas.load() > 0) {
-    set_error("a replica shares its parent's data: load into the parent, before creating replicas");
-    return NGHMM_ERR_ARG;
-  }
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_pos, pos, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (h->packed) {
-    HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_cls_log, h->h_cls_proto, sizeof h->h_cls_proto,
-                           hipMemcpyHostToDevice, h->stream));  // an earlier load's uniform value
-  }
-  HIP_TRY(sync_stream(h));
-  h->loaded = false;
-  h->loading = true;
-  h->load_cover.clear();
-  return NGHMM_OK;
-}
-
-static int load_begin_dev(nghmm_t* h, const double* d_pos) {
-  if (h->parent || h->n_replicas.load() > 0) {
-    set_error("a replica shares its parent's data: load into the parent, before creating replicas");
-    return NGHMM_ERR_ARG;
-  }
-  HIP_TRY(hipMemcpyAsync(h->d_pos, d_pos, h->S * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  if (h->packed) {
-    HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_uniform, 0xff, sizeof(unsigned long long), h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_cls_log, h->h_cls_proto, sizeof h->h_cls_proto,
-                           hipMemcpyHostToDevice, h->stream));
-  }
-  h->loaded = false;
-  h->loading = true;
-  h->load_cover.clear();
-  return NGHMM_OK;
-}
-
-int nghmm_load_begin_dev(nghmm_t* h, const double* d_pos) {
-  g_last_error.clear();
-  if (!h || !d_pos) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = load_begin_dev(h, d_pos))) return rc;
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-// chunked loading: claim the sites [b, b + n) of the current load; overlap is an error
-static int claim_sites(nghmm_t* h, uint64_t b, uint64_t n) {
-  const uint64_t e = b + n;
-  auto it = h->load_cover.upper_bound(b);  // first run that begins after b
-  if (it != h->load_cover.begin()) {
-    auto prev = std::prev(it);
-    if (prev->second > b) {
-      set_error("chunk loader: sites [%llu, %llu) overlap [%llu, %llu), which this load has "
-                "already received: every site exactly once",
-                (unsigned long long)b, (unsigned long long)e, (unsigned long long)prev->first,
-                (unsigned long long)prev->second);
-      return NGHMM_ERR_ARG;
-    }
-  }
-  if (it != h->load_cover.end() && it->first < e) {
-    set_error("chunk loader: sites [%llu, %llu) overlap [%llu, %llu), which this load has "
-              "already received: every site exactly once",
-              (unsigned long long)b, (unsigned long long)e, (unsigned long long)it->first,
-              (unsigned long long)it->second);
-    return NGHMM_ERR_ARG;
-  }
-  // insert, merging with the neighbours it touches
-  uint64_t nb = b, ne = e;
-  if (it != h->load_cover.begin()) {
-    auto prev = std::prev(it);
-    if (prev->second == b) {
-      nb = prev->first;
-      h->load_cover.erase(prev);
-    }
-  }
-  if (it != h->load_cover.end() && it->first == e) {
-    ne = it->second;
-    h->load_cover.erase(it);
-  }
-  h->load_cover[nb] = ne;
-  return NGHMM_OK;
-}
-
-// a chunk that failed half way has left cells behind (a packed handle ORs codes in): the load
-// is over, the caller starts again with nghmm_load_begin
-static int fail_load(nghmm_t* h, int rc) {
-  if (rc != NGHMM_OK) h->loading = false;
-  return rc;
-}
-
-static int load_sites_impl(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* src,
-                           bool src_on_device, bool prepare, int space, int call_geno,
-                           int check_nan) {
-  if (!h || !h->loading || !src || site_begin + n_sites > h->S ||
-      space < NGHMM_GL_LOG || space > NGHMM_GL_NORMAL_TEXT) {
-    set_error("chunk loader: bad argument, or nghmm_load_begin has not been called");
-    return NGHMM_ERR_ARG;
-  }
-  if (n_sites == 0) return NGHMM_OK;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = claim_sites(h, site_begin, n_sites))) return rc;
-  const uint64_t n_cells = n_sites * h->I;
-  if (src_on_device)
-    return fail_load(h, ingest_chunk(h, site_begin, n_sites, src, false, prepare, space,
-                                     call_geno, check_nan));
-  double* dst = h->packed ? nullptr : h->d_gl + site_begin * h->I * 3;
-  if (h->packed) {
-    if ((rc = ensure_stage(h, n_cells * 3))) return fail_load(h, rc);
-    dst = h->d_stage;
-  }
-  if (hipMemcpyAsync(dst, src, n_cells * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream) !=
-      hipSuccess) {
-    set_error("chunk loader: copy to the device failed");
-    return fail_load(h, NGHMM_ERR_HIP);
-  }
-  return fail_load(h, ingest_chunk(h, site_begin, n_sites, dst, true, prepare, space, call_geno,
-                                   check_nan));
-}
-
-int nghmm_load_gl_raw_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const double* gl_raw,
-                            int space, int call_geno, int check_nan) {
-  g_last_error.clear();
-  return load_sites_impl(h, site_begin, n_sites, gl_raw, false, true, space, call_geno, check_nan);
-}
-
-int nghmm_load_gl_raw_sites_dev(nghmm_t* h, uint64_t site_begin, uint64_t n_sites,
-                                const double* d_gl_raw, int space, int call_geno, int check_nan) {
-  g_last_error.clear();
-  return load_sites_impl(h, site_begin, n_sites, d_gl_raw, true, true, space, call_geno, check_nan);
-}
-
-int nghmm_load_geno_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, const int8_t* geno) {
-  g_last_error.clear();
-  if (!h || !h->loading || !geno || site_begin + n_sites > h->S) {
-    set_error("nghmm_load_geno_sites: bad argument, or nghmm_load_begin has not been called");
-    return NGHMM_ERR_ARG;
-  }
-  if (n_sites == 0) return NGHMM_OK;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = claim_sites(h, site_begin, n_sites))) return rc;
-  // (every return below goes through fail_load: a failure after claim_sites gives the sites back)
-  auto body = [&]() -> int {
-    const uint64_t n_cells = n_sites * h->I, cell0 = site_begin * h->I;
-    int rc;
-    if ((rc = ensure_stage8(h, n_cells))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_stage8, geno, n_cells, hipMemcpyHostToDevice, h->stream));
-    if ((rc = clear_flags(h))) return rc;
-    if (h->packed) {
-      // the reader's missing genotype is log(1/3) x 3 (read_data.cpp:94), prepared: row 3 of the
-      // class table as nghmm_create left it; a data set has ONE uniform value
-      unsigned long long cur = ~0ull, want = 0;
-      double u = 0;
-      HIP_TRY(hipMemcpyAsync(&cur, h->d_uniform, sizeof cur, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipMemcpyAsync(&u, h->d_cls_log + 9, sizeof u, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(sync_stream(h));
-      std::memcpy(&want, &u, sizeof want);
-      if (cur == ~0ull)
-        HIP_TRY(hipMemcpyAsync(h->d_uniform, &want, sizeof want, hipMemcpyHostToDevice, h->stream));
-      else if (cur != want) {
-        set_error("nghmm_load_geno_sites: mixed with likelihood chunks whose uniform cells differ");
-        return NGHMM_ERR_ARG;
-      }
-      launch_pack_geno(h->stream, h->d_stage8, n_cells, cell0, h->d_codes, h->d_flags);
-    } else {
-      double* dst = h->d_gl + cell0 * 3;
-      launch_expand_geno(h->stream, h->d_stage8, n_cells, std::log((double)1 / 3), dst, h->d_flags);
-      launch_prepare_gl(h->stream, dst, n_cells, NGHMM_GL_LOG, 0, h->d_flags);
-    }
-    HIP_TRY(hipGetLastError());
-    return check_load_flags(h, false);
-  };
-  return fail_load(h, body());
-}
-
-int nghmm_load_end(nghmm_t* h) {
-  g_last_error.clear();
-  if (!h || !h->loading) {
-    set_error("nghmm_load_end: no load in progress (nghmm_load_begin not called, or a chunk failed)");
-    return NGHMM_ERR_ARG;
-  }
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  // every site exactly once: one run [0, S)
-  if (h->load_cover.size() != 1 || h->load_cover.begin()->first != 0 ||
-      h->load_cover.begin()->second != h->S) {
-    uint64_t got = 0;
-    for (const auto& r : h->load_cover) got += r.second - r.first;
-    set_error("nghmm_load_end: %llu of %llu sites have been loaded", (unsigned long long)got,
-              (unsigned long long)h->S);
-    h->loading = false;
-    return NGHMM_ERR_ARG;
-  }
-  return after_gl_load(h);
-}
-
-// whole-matrix loaders = one begin, chunks, end
-static int load_whole(nghmm_t* h, const double* gl, bool on_device, bool prepare, int space,
-                      int call_geno, int check_nan) {
-  int rc;
-  // a dense handle takes the matrix in one piece; a packed one through the staging buffer
-  const uint64_t step = (h->packed && !(on_device && !prepare)) ? stage_sites(h) : h->S;
-  for (uint64_t s0 = 0; s0 < h->S; s0 += step) {
-    const uint64_t ns = (h->S - s0) < step ? (h->S - s0) : step;
-    if ((rc = load_sites_impl(h, s0, ns, gl + s0 * h->I * 3, on_device, prepare, space, call_geno,
-                              check_nan)))
-      return rc;
-  }
-  return after_gl_load(h);
-}
-
-int nghmm_load_gl(nghmm_t* h, const double* gl, const double* pos) {
-  g_last_error.clear();
-  if (!h || !gl || !pos) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = nghmm_load_begin(h, pos))) return rc;
-  return load_whole(h, gl, false, false, NGHMM_GL_LOG, 0, 0);
-}
-
-int nghmm_load_gl_raw(nghmm_t* h, const double* gl_raw, int space, int call_geno, int check_nan,
-                      const double* pos) {
-  g_last_error.clear();
-  if (!h || !gl_raw || !pos || space < NGHMM_GL_LOG || space > NGHMM_GL_NORMAL_TEXT)
-    return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = nghmm_load_begin(h, pos))) return rc;
-  return load_whole(h, gl_raw, false, true, space, call_geno, check_nan);
-}
-
-int nghmm_get_gl(nghmm_t* h, double* gl) {
-  g_last_error.clear();
-  if (!h || !h->loaded || !gl) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t cells = (size_t)h->I * h->S;
-  const double* src = h->d_gl;
-  if (h->packed) {  // test / debug aid: unpack through the staging buffer
-    if ((rc = ensure_stage(h, cells * 3))) return rc;
-    launch_unpack_cells(h->stream, own_gl(h), cells, h->d_stage);
-    HIP_TRY(hipGetLastError());
-    src = h->d_stage;
-  }
-  HIP_TRY(hipMemcpyAsync(gl, src, cells * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_load_gl_device(nghmm_t* h, const double* d_gl, const double* d_pos) {
-  g_last_error.clear();
-  if (!h || !d_gl || !d_pos) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = load_begin_dev(h, d_pos))) return rc;
-  return load_whole(h, d_gl, true, false, NGHMM_GL_LOG, 0, 0);
 }
 
 int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const double* freq) {
@@ -1581,10 +1050,12 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
   return NGHMM_OK;
 }
 
+}  // extern "C"
+
 // est_maf on the handle's own sites and individuals (shard = false) or on its frequency-step
 // site range over all ranks' individuals (shard = true: the static site-shard copy of the
 // likelihoods, posteriors in rank blocks)
-static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_blocks, uint64_t S_own,
+int capi::estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_blocks, uint64_t S_own,
                               uint64_t I_tot, uint64_t I_blk, double* d_freq_out) {
   int rc;
   tic(h);
@@ -1622,6 +1093,8 @@ static int estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_block
   HIP_TRY(hipGetLastError());
   return NGHMM_OK;
 }
+
+extern "C" {
 
 // --freq_est 2 / --e_prob 2 AS INTENDED (opt-in; PARITY UNPINNED: the reference aborts on
 // both): the loop of EM.cpp:224-263 as written, sites in order with the frequencies updated in
@@ -1846,866 +1319,6 @@ int nghmm_viterbi(nghmm_t* h, uint8_t* path) {
   return NGHMM_OK;
 }
 
-// [I][S] posteriors of the last E-step in d_tmp (transposed once per E-step)
-static int posteriors_ind_major(nghmm_t* h) {
-  int rc;
-  if ((rc = ensure_tmp(h))) return rc;
-  if (h->tmp_is_posteriors) return NGHMM_OK;
-  if ((rc = ensure_marg(h))) return rc;
-  launch_transpose_f64(h->stream, h->d_marg, h->d_tmp, h->S, h->I);
-  HIP_TRY(hipGetLastError());
-  h->tmp_is_posteriors = true;
-  return NGHMM_OK;
-}
-
-int nghmm_get_posteriors(nghmm_t* h, double* marg_ibd) {
-  g_last_error.clear();
-  if (!h || !h->loaded || !marg_ibd) return NGHMM_ERR_ARG;  // zeros before the first E-step
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = posteriors_ind_major(h))) return rc;
-  HIP_TRY(hipMemcpyAsync(marg_ibd, h->d_tmp, (size_t)h->I * h->S * sizeof(double),
-                         hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_format_posteriors(nghmm_t* h, uint64_t ind_begin, uint64_t n_ind, char* out) {
-  g_last_error.clear();
-  if (!h || !h->loaded || !out || ind_begin + n_ind > h->I) return NGHMM_ERR_ARG;
-  if (n_ind == 0) return NGHMM_OK;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = posteriors_ind_major(h))) return rc;
-  const size_t bytes = (size_t)n_ind * 9 * h->S;
-  if (bytes > h->text_cap) {
-    if (h->d_text) (void)hipFree(h->d_text);
-    h->d_text = nullptr;
-    h->text_cap = 0;
-    if ((rc = dev_alloc(&h->d_text, bytes))) return rc;
-    h->text_cap = bytes;
-  }
-  if ((rc = clear_flags(h))) return rc;
-  launch_format_fixed6(h->stream, h->d_tmp + ind_begin * h->S, n_ind, h->S, h->d_text, h->d_flags);
-  HIP_TRY(hipGetLastError());
-  int bad = 0;
-  HIP_TRY(hipMemcpyAsync(&bad, h->d_flags, sizeof bad, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(out, h->d_text, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(sync_stream(h));
-  if (bad) {
-    set_error("nghmm_format_posteriors: a posterior outside [0, 1]");
-    return NGHMM_ERR_ARG;
-  }
-  return NGHMM_OK;
-}
-
-int nghmm_format_fixed6(nghmm_t* h, const double* values, uint64_t rows, uint64_t cols, char* out) {
-  g_last_error.clear();
-  if (!h || !values || !out) return NGHMM_ERR_ARG;
-  if (rows == 0 || cols == 0) return NGHMM_OK;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t n = (size_t)rows * cols;
-  double* d_in = nullptr;
-  char* d_out = nullptr;
-  if ((rc = dev_alloc(&d_in, n))) return rc;
-  if ((rc = dev_alloc(&d_out, n * 9))) {
-    (void)hipFree(d_in);
-    return rc;
-  }
-  int bad = 0;
-  hipError_t e = hipMemcpyAsync(d_in, values, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(h->d_flags, 0, NFLAGS * sizeof(int), h->stream);
-  if (e == hipSuccess) {
-    launch_format_fixed6(h->stream, d_in, rows, cols, d_out, h->d_flags);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(&bad, h->d_flags, sizeof bad, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 9, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = sync_stream(h);
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  if (e != hipSuccess) {
-    set_error("nghmm_format_fixed6: %s", hipGetErrorString(e));
-    return NGHMM_ERR_HIP;
-  }
-  if (bad) {
-    set_error("nghmm_format_fixed6: a value outside [0, 1]");
-    return NGHMM_ERR_ARG;
-  }
-  return NGHMM_OK;
-}
-
-int nghmm_geno_posteriors(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, double* out) {
-  g_last_error.clear();
-  if (!h || !h->loaded || !out || site_begin + n_sites > h->S) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if (!h->d_path_sites) {
-    // not decoded yet: the reference's path[][] is still all zeros then (an intermediate
-    // print_iter, EM.cpp:60-62)
-    const size_t blocked = viterbi_blocked_bytes(h->S, h->I);
-    if ((rc = dev_alloc(&h->d_path_sites, blocked))) return rc;
-    HIP_TRY(hipMemsetAsync(h->d_path_sites, 0, blocked, h->stream));
-  }
-  const size_t n = (size_t)n_sites * h->I * 3;
-  if (n > h->geno_cap) {
-    if (h->d_geno) (void)hipFree(h->d_geno);
-    h->d_geno = nullptr;
-    h->geno_cap = 0;
-    if ((rc = dev_alloc(&h->d_geno, n))) return rc;
-    h->geno_cap = n;
-  }
-  launch_geno_post_exact(h->stream, own_gl(h), h->d_freq, h->d_path_sites, h->I, site_begin, n_sites,
-                         h->d_geno);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out, h->d_geno, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_get_emissions(nghmm_t* h, double* e_prob) {
-  g_last_error.clear();
-  if (!h || !e_prob) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if ((rc = ensure_tmp(h))) return rc;
-  if (h->mode == NGHMM_MODE_FAST) {
-    if ((rc = ensure_emissions(h))) return rc;
-    h->tmp_is_posteriors = false;
-    if (!fast_export_emissions(h->fast, h->stream, h->d_tmp)) return NGHMM_ERR_HIP;
-  } else {
-    h->tmp_is_posteriors = false;
-    launch_transpose_pairs_f64(h->stream, h->d_eprob, h->d_tmp, h->S, h->I);
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(e_prob, h->d_tmp, (size_t)h->I * h->S * 2 * sizeof(double),
-                         hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-// ---------------- multi-GPU ----------------
-
-int nghmm_shard_config(nghmm_t* h, uint64_t n_ind_total, uint64_t ind_begin, uint64_t site_begin,
-                       uint64_t n_sites_own) {
-  g_last_error.clear();
-  if (h && h->fast.shard.world > 1) {
-    set_error("nghmm_shard_config: the handle is a site shard (one layout at a time)");
-    return NGHMM_ERR_ARG;
-  }
-  if (!h || n_ind_total < h->I || ind_begin + h->I > n_ind_total ||
-      site_begin + n_sites_own > h->S || n_ind_total % h->I != 0) {
-    set_error("nghmm_shard_config: inconsistent shard (equal individuals per rank required)");
-    return NGHMM_ERR_ARG;
-  }
-  h->I_tot = n_ind_total;
-  h->ind_begin = ind_begin;
-  h->site_begin = site_begin;
-  h->S_own = n_sites_own;
-  return NGHMM_OK;
-}
-
-// ---- site shards (fast mode): kernels_fast.hip, "site shards" ----
-uint64_t nghmm_site_shard_bytes(nghmm_t* h) {
-  // an objective round: <= 5 points per individual, six doubles each (the E-step: six per
-  // individual); nghmm_lkl_batch calls with more points than that are refused
-  return h ? (uint64_t)(h->I * 30 + 64) * sizeof(double) : 0;
-}
-
-int nghmm_site_shard_setup(nghmm_t* h, int rank, int world, void* send_dev, void* recv_dev,
-                           uint64_t bytes_per_rank, nghmm_allgather_fn fn, void* user) {
-  g_last_error.clear();
-  if (!h || world < 1 || rank < 0 || rank >= world) return NGHMM_ERR_ARG;
-  if (h->mode != NGHMM_MODE_FAST) {
-    set_error("site shards are a fast-mode layout: the exact-mode recursion is one chain of "
-              "roundings over all sites (shard by individual: nghmm_shard_config)");
-    return NGHMM_ERR_ARG;
-  }
-  if (h->parent || h->n_replicas.load() > 0 || h->I_tot != h->I || h->g_n) {
-    set_error("nghmm_site_shard_setup: not on a replica, a handle with replicas, an individual "
-              "shard or a group member");
-    return NGHMM_ERR_ARG;
-  }
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  SiteShard& sh = h->fast.shard;
-  if (world == 1) {
-    sh = SiteShard{};
-    return NGHMM_OK;
-  }
-  if (!send_dev || !recv_dev || !fn || bytes_per_rank < nghmm_site_shard_bytes(h)) {
-    set_error("nghmm_site_shard_setup: buffers of nghmm_site_shard_bytes() (x world for recv) and "
-              "an all-gather are needed");
-    return NGHMM_ERR_ARG;
-  }
-  if (!sh.edges && (rc = dev_alloc(&sh.edges, (size_t)h->I * 8))) return rc;
-  sh.rank = (uint32_t)rank;
-  sh.world = (uint32_t)world;
-  sh.send = static_cast<double*>(send_dev);
-  sh.recv = static_cast<double*>(recv_dev);
-  sh.cap = bytes_per_rank / sizeof(double);
-  sh.allgather = fn;
-  sh.user = user;
-  return NGHMM_OK;
-}
-
-// Viterbi over a chain of site shards: forward in rank order (every handle starts from the
-// scores the one before ended with), then back in reverse order (every handle starts from the
-// state the one after found for the site in front of its first).  Same kernels, same order of
-// operations per individual as one handle over all sites: the same path.
-int nghmm_viterbi_shard_forward(nghmm_t* h, const double* scores_in, double* scores_out) {
-  g_last_error.clear();
-  if (!h || !h->loaded || !scores_out || h->mode != NGHMM_MODE_FAST) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t blocked = viterbi_blocked_bytes(h->S, h->I);
-  if (!h->d_bp && (rc = dev_alloc(&h->d_bp, blocked + h->I))) return rc;
-  if (!h->d_path_sites && (rc = dev_alloc(&h->d_path_sites, blocked))) return rc;
-  if (!h->d_path && (rc = dev_alloc(&h->d_path, (size_t)h->I * h->S))) return rc;
-  const uint64_t chunk = viterbi_chunk_sites(h->S, h->I);
-  if (!h->d_vit && (rc = dev_alloc(&h->d_vit, (size_t)chunk * h->I * 4 + h->I * 2))) return rc;
-  double* d_state = h->d_vit + (size_t)chunk * h->I * 4;
-  if (scores_in)
-    HIP_TRY(hipMemcpyAsync(d_state, scores_in, h->I * 2 * sizeof(double), hipMemcpyHostToDevice,
-                           h->stream));
-  if ((rc = clear_flags(h))) return rc;
-  tic(h);
-  if (!fast_viterbi_forward(h->fast, h->stream, h->d_freq, h->d_indF, h->d_alpha, h->d_bp, h->d_flags,
-                            h->d_vit, chunk, scores_in == nullptr))
-    return NGHMM_ERR_HIP;
-  if ((rc = toc(h, SLOT_VITERBI, false))) return rc;
-  if ((rc = check_flags(h))) return rc;  // "invalid MAF!" (HMM.cpp:145-146)
-  HIP_TRY(hipMemcpyAsync(scores_out, d_state, h->I * 2 * sizeof(double), hipMemcpyDeviceToHost,
-                         h->stream));
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_viterbi_shard_back(nghmm_t* h, const uint8_t* state_after, uint8_t* state_before,
-                             uint8_t* path) {
-  g_last_error.clear();
-  if (!h || !h->loaded || !h->d_bp || !state_before || !path) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  uint8_t* d_last = h->d_bp + viterbi_blocked_bytes(h->S, h->I);
-  if (state_after)  // else: the last range, whose forward half left the arg max there
-    HIP_TRY(hipMemcpyAsync(d_last, state_after, h->I, hipMemcpyHostToDevice, h->stream));
-  uint8_t* d_before = nullptr;
-  if ((rc = dev_alloc(&d_before, (size_t)h->I))) return rc;
-  launch_viterbi_back_exact(h->stream, h->d_bp, h->S, h->I, h->d_path_sites, d_before);
-  launch_unblock_path(h->stream, h->d_path_sites, h->S, h->I, h->d_path);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(state_before, d_before, h->I, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(path, h->d_path, (size_t)h->I * h->S, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = sync_stream(h);
-  (void)hipFree(d_before);
-  HIP_TRY(e);
-  return NGHMM_OK;
-}
-
-int nghmm_load_gl_site_shard(nghmm_t* h, const double* gl_site_shard) {
-  g_last_error.clear();
-  if (!h || !gl_site_shard) return NGHMM_ERR_ARG;
-  if (h->packed) {
-    set_error("packed handle: use nghmm_load_geno_site_shard_dev");
-    return NGHMM_ERR_ARG;
-  }
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t n = (size_t)h->S_own * h->I_tot * 3;
-  if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
-  h->d_gl_shard = nullptr;
-  if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_gl_shard, gl_site_shard, n * sizeof(double), hipMemcpyHostToDevice,
-                         h->stream));
-  if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_get_geno_codes_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, uint8_t* d_out) {
-  g_last_error.clear();
-  if (!h || !h->packed || !h->loaded || !d_out || site_lo > site_hi || site_hi > h->S)
-    return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  launch_codes_to_bytes(h->stream, h->d_codes, site_lo * h->I, (site_hi - site_lo) * h->I, d_out);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_load_geno_site_shard_dev(nghmm_t* h, const uint8_t* d_codes_bytes) {
-  g_last_error.clear();
-  if (!h || !h->packed || !d_codes_bytes) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t n = (size_t)h->S_own * h->I_tot;
-  if (h->d_codes_shard) (void)hipFree(h->d_codes_shard);
-  h->d_codes_shard = nullptr;
-  if ((rc = dev_alloc(&h->d_codes_shard, n / 16 + 2))) return rc;
-  launch_bytes_to_codes(h->stream, d_codes_bytes, n, h->d_codes_shard);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
-  g_last_error.clear();
-  if (!h || !d_gl_site_shard) return NGHMM_ERR_ARG;
-  if (h->packed) {
-    set_error("packed handle: use nghmm_load_geno_site_shard_dev");
-    return NGHMM_ERR_ARG;
-  }
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  const size_t n = (size_t)h->S_own * h->I_tot * 3;
-  if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
-  h->d_gl_shard = nullptr;
-  if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_gl_shard, d_gl_site_shard, n * sizeof(double),
-                         hipMemcpyDeviceToDevice, h->stream));
-  if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_pack_posteriors_dev(nghmm_t* h, uint64_t site_lo, uint64_t site_hi, double* d_out) {
-  g_last_error.clear();
-  if (!h || !d_out || site_lo > site_hi || site_hi > h->S) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if (h->mode == NGHMM_MODE_FAST && site_lo == 0 && site_hi == h->S) {
-    // every destination at once: the send buffer [rank][S_own][I] of equal contiguous site
-    // ranges IS the site-major matrix, so convert the tile-major posteriors straight into it
-    if (!fast_post_to_site_major(h->fast, h->stream, d_out)) return NGHMM_ERR_HIP;
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(sync_stream(h));
-    return NGHMM_OK;
-  }
-  // marg is site-major [S][I]: the slice of a destination rank is contiguous
-  if ((rc = ensure_marg(h))) return rc;
-  launch_copy_f64(h->stream, h->d_marg + site_lo * h->I, d_out, (site_hi - site_lo) * h->I);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_mstep_freq_sites_dev(nghmm_t* h, const double* d_marg_blocks, double* d_freq_out) {
-  g_last_error.clear();
-  if (!h || !d_marg_blocks || !d_freq_out || !(h->packed ? (void*)h->d_codes_shard : (void*)h->d_gl_shard))
-    return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  if (h->mode != NGHMM_MODE_FAST && h->I_tot != h->I) {
-    // exact mode wants [S_own][I_tot]: re-block [rank][S_own][I] through the scratch buffer
-    set_error("exact-mode sharded est_maf is not available; use NGHMM_MODE_FAST");
-    return NGHMM_ERR_ARG;
-  }
-  if ((rc = estmaf_and_refresh(h, true, d_marg_blocks, h->S_own, h->I_tot, h->I, d_freq_out)))
-    return rc;
-  HIP_TRY(sync_stream(h));
-  return NGHMM_OK;
-}
-
-int nghmm_set_freq_dev(nghmm_t* h, const double* d_freq_all) {
-  g_last_error.clear();
-  if (!h || !d_freq_all) return NGHMM_ERR_ARG;
-  int rc;
-  if ((rc = use_device(h))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_freq, d_freq_all, h->S * sizeof(double), hipMemcpyDeviceToDevice,
-                         h->stream));
-  return emission_impl(h);
-}
-
-
-// ---------------- one process, several GPUs ----------------
-// The group functions orchestrate what ngsf-hmm_amd/distributed.py does with RCCL between
-// processes, inside one process with direct peer copies: on an MI355X node every pair of GPUs
-// has its own xGMI link, so n*(n-1) simultaneous point-to-point copies ARE the all-to-all.
-
-namespace {
-
-struct GroupHook {
-  nghmm_t** hs;
-  int n, r;
-  int rc;
-};
-
-// after rank r's E-step: its posteriors, site-major, into the send buffer; then one slice to
-// every rank's receive buffer, on the exchange stream (the objective rounds go on meanwhile)
-void group_after_estep(void* user) {
-  GroupHook* g = static_cast<GroupHook*>(user);
-  nghmm_t* h = g->hs[g->r];
-  g->rc = nghmm_pack_posteriors_dev(h, 0, h->S, h->g_send);
-  if (g->rc != NGHMM_OK) return;
-  const size_t blk = (size_t)h->S_own * h->I;
-  for (int q = 0; q < g->n; ++q) {
-    if (hipMemcpyAsync(g->hs[q]->g_recv + (size_t)g->r * blk, h->g_send + (size_t)q * blk,
-                       blk * sizeof(double), hipMemcpyDeviceToDevice, h->g_xstream) != hipSuccess) {
-      g->rc = NGHMM_ERR_HIP;
-      return;
-    }
-  }
-}
-
-int for_each_rank(int n, const std::function<int(int)>& fn) {
-  std::vector<int> rcs(n, NGHMM_OK);
-  std::vector<std::string> msgs(n);
-  if (n == 1) {
-    rcs[0] = fn(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; ++r)
-      th.emplace_back([&, r] {
-        rcs[r] = fn(r);
-        if (rcs[r] != NGHMM_OK) msgs[r] = g_last_error;  // thread-local: carry it over
-      });
-    for (auto& t : th) t.join();
-  }
-  for (int r = 0; r < n; ++r)
-    if (rcs[r] != NGHMM_OK) {
-      if (!msgs[r].empty()) g_last_error = msgs[r];
-      return rcs[r];
-    }
-  return NGHMM_OK;
-}
-
-// phases 2 and 3 of a group iteration, once every rank's posteriors have arrived: est_maf on
-// the own site range over all individuals (rank blocks = the global individual order), the
-// frequencies to everybody, and their installation (emissions follow lazily)
-int group_freq_phases(nghmm_t** hs, int n) {
-  const uint64_t S_own = hs[0]->S / n;
-  int rc = for_each_rank(n, [&](int r) -> int {
-    nghmm_t* h = hs[r];
-    int rr = nghmm_mstep_freq_sites_dev(h, h->g_recv, h->g_freq_own);
-    if (rr != NGHMM_OK) return rr;
-    for (int q = 0; q < n; ++q)
-      if (hipMemcpyAsync(hs[q]->g_freq_all + (size_t)r * S_own, h->g_freq_own, S_own * sizeof(double),
-                         hipMemcpyDeviceToDevice, h->g_xstream) != hipSuccess)
-        return NGHMM_ERR_HIP;
-    return hipStreamSynchronize(h->g_xstream) == hipSuccess ? NGHMM_OK : NGHMM_ERR_HIP;
-  });
-  if (rc != NGHMM_OK) return rc;
-  return for_each_rank(n, [&](int r) -> int { return nghmm_set_freq_dev(hs[r], hs[r]->g_freq_all); });
-}
-
-}  // namespace
-
-int nghmm_group_setup(nghmm_t** hs, int n) {
-  g_last_error.clear();
-  if (!hs || n < 1) return NGHMM_ERR_ARG;
-  nghmm_t* h0 = hs[0];
-  for (int r = 0; r < n; ++r) {
-    nghmm_t* h = hs[r];
-    if (!h || !h->loaded || (n > 1 && (h->parent || h->n_replicas.load() > 0)) ||
-        h->fast.shard.world > 1 || h->I != h0->I ||
-        h->S != h0->S || h->mode != h0->mode ||
-        h->packed != h0->packed) {
-      set_error("nghmm_group_setup: the handles must be loaded and agree in size, mode and packing");
-      return NGHMM_ERR_ARG;
-    }
-  }
-  const uint64_t I = h0->I, S = h0->S, I_tot = I * n;
-  if (S % n != 0) {
-    set_error("nghmm_group_setup: %llu sites do not divide by %d handles", (unsigned long long)S, n);
-    return NGHMM_ERR_ARG;
-  }
-  if (n > 1 && h0->mode != NGHMM_MODE_FAST) {
-    set_error("nghmm_group_setup: several handles need NGHMM_MODE_FAST");
-    return NGHMM_ERR_ARG;
-  }
-  const uint64_t S_own = S / n;
-  int rc;
-  // peer access between the devices involved (a no-op for handles that share a device)
-  for (int r = 0; r < n; ++r)
-    for (int q = 0; q < n; ++q)
-      if (hs[r]->device != hs[q]->device) {
-        int can = 0;
-        HIP_TRY(hipDeviceCanAccessPeer(&can, hs[r]->device, hs[q]->device));
-        if (!can) {
-          set_error("nghmm_group_setup: device %d cannot access device %d", hs[r]->device, hs[q]->device);
-          return NGHMM_ERR_HIP;
-        }
-        HIP_TRY(hipSetDevice(hs[r]->device));
-        const hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
-        (void)hipGetLastError();
-      }
-  for (int r = 0; r < n; ++r) {
-    nghmm_t* h = hs[r];
-    if ((rc = use_device(h))) return rc;
-    if ((rc = nghmm_shard_config(h, I_tot, (uint64_t)r * I, (uint64_t)r * S_own, S_own))) return rc;
-    h->g_n = n;
-    h->g_rank = r;
-    if (n == 1) continue;
-    void* old[] = {h->g_send, h->g_recv, h->g_freq_own, h->g_freq_all};
-    for (void* p : old)
-      if (p) (void)hipFree(p);
-    h->g_send = h->g_recv = h->g_freq_own = h->g_freq_all = nullptr;
-    if ((rc = dev_alloc(&h->g_send, (size_t)S * I))) return rc;
-    if ((rc = dev_alloc(&h->g_recv, (size_t)S * I))) return rc;
-    if ((rc = dev_alloc(&h->g_freq_own, (size_t)S_own))) return rc;
-    if ((rc = dev_alloc(&h->g_freq_all, (size_t)S))) return rc;
-    if (!h->g_xstream) HIP_TRY(hipStreamCreateWithFlags(&h->g_xstream, hipStreamNonBlocking));
-  }
-  if (n == 1) return NGHMM_OK;
-  // static site-shard copies: rank r gets the likelihoods of ALL individuals for its site range,
-  // pulled from every rank's own matrix with strided peer copies
-  for (int r = 0; r < n; ++r) {
-    nghmm_t* h = hs[r];
-    if ((rc = use_device(h))) return rc;
-    const uint64_t lo = (uint64_t)r * S_own;
-    if (!h->packed) {
-      if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
-      h->d_gl_shard = nullptr;
-      if ((rc = dev_alloc(&h->d_gl_shard, (size_t)S_own * I_tot * 3))) return rc;
-      for (int q = 0; q < n; ++q)
-        HIP_TRY(hipMemcpy2DAsync(h->d_gl_shard + (size_t)q * I * 3, I_tot * 3 * sizeof(double),
-                                 hs[q]->d_gl + lo * I * 3, I * 3 * sizeof(double),
-                                 I * 3 * sizeof(double), S_own, hipMemcpyDeviceToDevice, h->stream));
-      fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, (size_t)S_own * I_tot * 3);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(sync_stream(h));
-    } else {
-      uint8_t *bytes = nullptr, *part = nullptr;  // [S_own][I_tot] on r; [S_own][I] on q
-      if ((rc = dev_alloc(&bytes, (size_t)S_own * I_tot))) return rc;
-      for (int q = 0; q < n && rc == NGHMM_OK; ++q) {
-        hipError_t e = hipSetDevice(hs[q]->device);
-        if (e == hipSuccess) e = hipMalloc((void**)&part, (size_t)S_own * I);
-        if (e == hipSuccess) {
-          launch_codes_to_bytes(hs[q]->stream, hs[q]->d_codes, lo * I, S_own * I, part);
-          e = hipStreamSynchronize(hs[q]->stream);
-        }
-        if (e == hipSuccess) e = hipSetDevice(h->device);
-        if (e == hipSuccess)
-          e = hipMemcpy2DAsync(bytes + (size_t)q * I, I_tot, part, I, I, S_own,
-                               hipMemcpyDeviceToDevice, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (part) {
-          (void)hipSetDevice(hs[q]->device);
-          (void)hipFree(part);
-          part = nullptr;
-          (void)hipSetDevice(h->device);
-        }
-        if (e != hipSuccess) {
-          set_error("nghmm_group_setup: %s", hipGetErrorString(e));
-          rc = NGHMM_ERR_HIP;
-        }
-      }
-      if (rc == NGHMM_OK) rc = nghmm_load_geno_site_shard_dev(h, bytes);
-      (void)hipFree(bytes);
-      if (rc != NGHMM_OK) return rc;
-    }
-  }
-  return NGHMM_OK;
-}
-
-int nghmm_group_iter_em(nghmm_t** hs, int n, int freq_est, int indF_fixed, int alpha_fixed,
-                        double* ind_lkl, nghmm_mstep_stats* stats) {
-  g_last_error.clear();
-  if (!hs || n < 1 || !hs[0] || hs[0]->g_n != n) {
-    set_error("nghmm_group_iter_em: call nghmm_group_setup on these handles first");
-    return NGHMM_ERR_ARG;
-  }
-  if (n == 1) return nghmm_iter_em(hs[0], freq_est, indF_fixed, alpha_fixed, ind_lkl, stats);
-  if (freq_est & NGHMM_LD_INTENDED) {
-    set_error("the intended --freq_est 2 walks the sites in order on ONE handle: not available "
-              "for a group of several");
-    return NGHMM_ERR_ARG;
-  }
-  if (freq_est != 0 && freq_est != 1) {  // as nghmm_mstep_freq (EM.cpp:212-239)
-    set_error(freq_est == 2 ? "invalid allele frequencies" : "wrong MAF estimation method!");
-    return freq_est == 2 ? NGHMM_ERR_FREQ_EST2 : NGHMM_ERR_ARG;
-  }
-  const uint64_t I = hs[0]->I;
-  std::vector<nghmm_mstep_stats> st(n);
-  std::vector<GroupHook> hook(n);
-  // phase 1: E-step + indF/alpha M-step per rank; posteriors leave for their site owners as
-  // soon as they are final
-  int rc = for_each_rank(n, [&](int r) -> int {
-    hook[r] = GroupHook{hs, n, r, NGHMM_OK};
-    int rr = nghmm_estep_mstep(hs[r], indF_fixed, alpha_fixed, ind_lkl ? ind_lkl + (size_t)r * I : nullptr,
-                               &st[r], freq_est ? group_after_estep : nullptr, &hook[r]);
-    if (rr == NGHMM_OK) rr = hook[r].rc;
-    if (rr == NGHMM_OK && freq_est && hipStreamSynchronize(hs[r]->g_xstream) != hipSuccess)
-      rr = NGHMM_ERR_HIP;
-    return rr;
-  });
-  if (rc != NGHMM_OK) return rc;
-  if (stats) {
-    std::memset(stats, 0, sizeof *stats);
-    for (int r = 0; r < n; ++r) {
-      stats->rounds = st[r].rounds > stats->rounds ? st[r].rounds : stats->rounds;
-      stats->points += st[r].points;
-      stats->ref_forward_calls += st[r].ref_forward_calls;
-      stats->ind_rounds += st[r].ind_rounds;
-    }
-  }
-  if (!freq_est) return NGHMM_OK;
-  return group_freq_phases(hs, n);
-}
-
-// The allele-frequency step alone, from the posteriors the handles hold (all zero before the
-// first E-step: --freq e, parse_args.cpp:312-318).
-int nghmm_group_mstep_freq(nghmm_t** hs, int n, int freq_est) {
-  g_last_error.clear();
-  if (!hs || n < 1 || !hs[0] || hs[0]->g_n != n) {
-    set_error("nghmm_group_mstep_freq: call nghmm_group_setup on these handles first");
-    return NGHMM_ERR_ARG;
-  }
-  if (n == 1) return nghmm_mstep_freq(hs[0], freq_est);
-  if (freq_est == 0) return NGHMM_OK;
-  if (freq_est != 1) {
-    set_error(freq_est == 2 ? "invalid allele frequencies" : "wrong MAF estimation method!");
-    return freq_est == 2 ? NGHMM_ERR_FREQ_EST2 : NGHMM_ERR_ARG;
-  }
-  std::vector<GroupHook> hook(n);
-  int rc = for_each_rank(n, [&](int r) -> int {
-    hook[r] = GroupHook{hs, n, r, NGHMM_OK};
-    group_after_estep(&hook[r]);
-    if (hook[r].rc != NGHMM_OK) return hook[r].rc;
-    return hipStreamSynchronize(hs[r]->g_xstream) == hipSuccess ? NGHMM_OK : NGHMM_ERR_HIP;
-  });
-  if (rc != NGHMM_OK) return rc;
-  return group_freq_phases(hs, n);
-}
-
-// ---- one process, several GPUs, fast mode: a CHAIN of site shards ----
-// (include/nghmm.h; between processes ngsf-hmm_amd/distributed.py does the same over RCCL.)
-// The all-gather of nghmm_site_shard_setup among the handles of one process: every handle runs
-// on a host thread of its own; at an exchange it waits for its stream (its part of the send
-// buffers is complete), meets the others at a barrier, copies every handle's part into its own
-// receive buffer -- direct device-to-device copies, over the GPU pair's xGMI link where the
-// devices differ --, waits for the copies and meets the others again (nobody rewrites its part
-// before everyone has read it).  A handle that fails aborts the barrier for the others.
-struct ChainCtx {
-  std::vector<nghmm_t*> hs;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  uint64_t generation = 0;
-  bool aborted = false;
-  int refs = 0;
-  // false: somebody aborted
-  bool wait() {
-    std::unique_lock<std::mutex> lk(mu);
-    if (aborted) return false;
-    const uint64_t gen = generation;
-    if (++arrived == (int)hs.size()) {
-      arrived = 0;
-      ++generation;
-      cv.notify_all();
-      return true;
-    }
-    cv.wait(lk, [&] { return generation != gen || aborted; });
-    return !aborted;
-  }
-  void abort() {
-    std::lock_guard<std::mutex> lk(mu);
-    aborted = true;
-    cv.notify_all();
-  }
-  void reset() {
-    std::lock_guard<std::mutex> lk(mu);
-    aborted = false;
-    arrived = 0;
-  }
-};
-
-namespace {
-
-int chain_allgather(void* user, uint64_t n_bytes) {
-  nghmm_t* h = static_cast<nghmm_t*>(user);
-  ChainCtx* cx = h->chain;
-  if (!cx) return 1;
-  const int n = (int)cx->hs.size();
-  for (int q = 0; q < n; ++q)
-    if (!cx->hs[q]) return 1;  // (a dissolved chain: chain_release detaches every member)
-  bool ok = hipStreamSynchronize(h->stream) == hipSuccess;
-  if (!ok) cx->abort();
-  if (!cx->wait()) return 1;
-  for (int q = 0; q < n && ok; ++q) {
-    nghmm_t* o = cx->hs[q];
-    char* dst = reinterpret_cast<char*>(h->c_recv) + (size_t)q * n_bytes;
-    const hipError_t e = o->device == h->device
-                             ? hipMemcpyAsync(dst, o->c_send, n_bytes, hipMemcpyDeviceToDevice, h->stream)
-                             : hipMemcpyPeerAsync(dst, h->device, o->c_send, o->device, n_bytes, h->stream);
-    ok = e == hipSuccess;
-  }
-  if (ok) ok = hipStreamSynchronize(h->stream) == hipSuccess;
-  if (!ok) cx->abort();
-  return cx->wait() && ok ? 0 : 1;
-}
-
-void chain_release(nghmm_t* h) {
-  if (!h->chain) return;
-  // One member leaving DISSOLVES the chain (include/nghmm.h): every remaining member goes back
-  // to being a plain handle over its own sites -- no all-gather installed, no exchange buffers,
-  // no context whose barrier could never fill again.  (Leaving the survivors attached made a
-  // direct nghmm_iter_em / nghmm_estep / nghmm_lkl_batch on one of them wait in ChainCtx::wait
-  // for a member that no longer exists.)
-  ChainCtx* cx = h->chain;
-  cx->abort();
-  std::vector<nghmm_t*> members;
-  {
-    std::lock_guard<std::mutex> lk(cx->mu);
-    members = cx->hs;
-    for (auto& m : cx->hs) m = nullptr;
-  }
-  int dev_before = -1;
-  (void)hipGetDevice(&dev_before);
-  for (nghmm_t* m : members) {
-    if (!m || m->chain != cx) continue;
-    m->chain = nullptr;
-    m->fast.shard.world = 1;
-    m->fast.shard.rank = 0;
-    m->fast.shard.allgather = nullptr;
-    m->fast.shard.user = nullptr;
-    m->fast.shard.send = m->fast.shard.recv = nullptr;
-    m->fast.shard.edges_from_round = false;
-    (void)hipSetDevice(m->device);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->c_send) (void)hipFree(m->c_send);
-    if (m->c_recv) (void)hipFree(m->c_recv);
-    m->c_send = m->c_recv = nullptr;
-  }
-  if (dev_before >= 0) (void)hipSetDevice(dev_before);
-  delete cx;
-}
-
-bool is_chain(nghmm_t** hs, int n) {
-  if (!hs || n < 1 || !hs[0]) return false;
-  if (n == 1) return hs[0]->chain == nullptr || hs[0]->chain->hs.size() == 1;
-  ChainCtx* cx = hs[0]->chain;
-  if (!cx || (int)cx->hs.size() != n) return false;
-  for (int r = 0; r < n; ++r)
-    if (hs[r] != cx->hs[r]) return false;
-  return true;
-}
-
-}  // namespace
-
-int nghmm_chain_setup(nghmm_t** hs, int n) {
-  g_last_error.clear();
-  if (!hs || n < 1) return NGHMM_ERR_ARG;
-  for (int r = 0; r < n; ++r) {
-    nghmm_t* h = hs[r];
-    if (!h || h->I != hs[0]->I || h->mode != hs[0]->mode || h->packed != hs[0]->packed || h->parent ||
-        h->n_replicas.load() > 0 || h->g_n > 1 || h->I_tot != h->I) {
-      set_error("nghmm_chain_setup: plain handles of the same individuals, mode and packing are needed");
-      return NGHMM_ERR_ARG;
-    }
-  }
-  if (n > 1 && hs[0]->mode != NGHMM_MODE_FAST) {
-    set_error("nghmm_chain_setup: site shards are a fast-mode layout");
-    return NGHMM_ERR_ARG;
-  }
-  for (int r = 0; r < n; ++r) chain_release(hs[r]);
-  if (n == 1) return NGHMM_OK;
-  int rc;
-  for (int r = 0; r < n; ++r)
-    for (int q = 0; q < n; ++q)
-      if (hs[r]->device != hs[q]->device) {
-        int can = 0;
-        HIP_TRY(hipDeviceCanAccessPeer(&can, hs[r]->device, hs[q]->device));
-        if (!can) {
-          set_error("nghmm_chain_setup: device %d cannot access device %d", hs[r]->device, hs[q]->device);
-          return NGHMM_ERR_HIP;
-        }
-        HIP_TRY(hipSetDevice(hs[r]->device));
-        const hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
-        (void)hipGetLastError();
-      }
-  ChainCtx* cx = new (std::nothrow) ChainCtx;
-  if (!cx) return NGHMM_ERR_NOMEM;
-  cx->hs.assign(hs, hs + n);
-  cx->refs = n;
-  for (int r = 0; r < n; ++r) hs[r]->chain = cx;
-  for (int r = 0; r < n; ++r) {
-    nghmm_t* h = hs[r];
-    const uint64_t bytes = nghmm_site_shard_bytes(h);
-    if ((rc = use_device(h)) || (rc = dev_alloc(&h->c_send, (size_t)(bytes / sizeof(double)))) ||
-        (rc = dev_alloc(&h->c_recv, (size_t)(bytes / sizeof(double)) * n)) ||
-        (rc = nghmm_site_shard_setup(h, r, n, h->c_send, h->c_recv, bytes, chain_allgather, h))) {
-      const std::string msg = g_last_error;
-      for (int q = 0; q < n; ++q) chain_release(hs[q]);
-      g_last_error = msg;
-      return rc;
-    }
-  }
-  return NGHMM_OK;
-}
-
-int nghmm_chain_iter_em(nghmm_t** hs, int n, int freq_est, int indF_fixed, int alpha_fixed,
-                        double* ind_lkl, nghmm_mstep_stats* stats) {
-  g_last_error.clear();
-  if (!is_chain(hs, n)) {
-    set_error("nghmm_chain_iter_em: call nghmm_chain_setup on these handles first");
-    return NGHMM_ERR_ARG;
-  }
-  if (n == 1) return nghmm_iter_em(hs[0], freq_est, indF_fixed, alpha_fixed, ind_lkl, stats);
-  if (freq_est & NGHMM_LD_INTENDED) {
-    set_error("the intended --freq_est 2 walks the sites in order on ONE handle: not available "
-              "for a chain of several");
-    return NGHMM_ERR_ARG;
-  }
-  ChainCtx* cx = hs[0]->chain;
-  cx->reset();
-  std::vector<nghmm_mstep_stats> st(n);
-  const int rc = for_each_rank(n, [&](int r) -> int {
-    // every handle computes the chain's log-likelihoods: the first one's go to the caller
-    const int rr = nghmm_iter_em(hs[r], freq_est, indF_fixed, alpha_fixed, r == 0 ? ind_lkl : nullptr,
-                                 &st[r]);
-    if (rr != NGHMM_OK) cx->abort();
-    return rr;
-  });
-  if (stats) *stats = st[0];
-  return rc;
-}
-
-int nghmm_chain_mstep_freq(nghmm_t** hs, int n, int freq_est) {
-  g_last_error.clear();
-  if (!is_chain(hs, n)) {
-    set_error("nghmm_chain_mstep_freq: call nghmm_chain_setup on these handles first");
-    return NGHMM_ERR_ARG;
-  }
-  // every handle has all individuals of its own sites: nothing to exchange
-  return for_each_rank(n, [&](int r) -> int { return nghmm_mstep_freq(hs[r], freq_est); });
-}
-
-int nghmm_chain_viterbi(nghmm_t** hs, int n, uint8_t* path) {
-  g_last_error.clear();
-  if (!is_chain(hs, n) || !path) {
-    set_error("nghmm_chain_viterbi: call nghmm_chain_setup on these handles first");
-    return NGHMM_ERR_ARG;
-  }
-  if (n == 1) return nghmm_viterbi(hs[0], path);
-  const uint64_t I = hs[0]->I;
-  uint64_t S_tot = 0;
-  for (int r = 0; r < n; ++r) S_tot += hs[r]->S;
-  int rc;
-  std::vector<double> scores((size_t)I * 2);
-  for (int r = 0; r < n; ++r)
-    if ((rc = nghmm_viterbi_shard_forward(hs[r], r ? scores.data() : nullptr, scores.data()))) return rc;
-  std::vector<uint8_t> state(I), part;
-  uint64_t hi = S_tot;
-  for (int r = n - 1; r >= 0; --r) {
-    const uint64_t S = hs[r]->S, lo = hi - S;
-    part.resize((size_t)I * S);
-    if ((rc = nghmm_viterbi_shard_back(hs[r], r == n - 1 ? nullptr : state.data(), state.data(),
-                                       part.data())))
-      return rc;
-    for (uint64_t i = 0; i < I; ++i) std::memcpy(path + i * S_tot + lo, part.data() + i * S, S);
-    hi = lo;
-  }
-  return NGHMM_OK;
-}
-
 void* nghmm_alloc_host(uint64_t bytes) {
   void* p = nullptr;
   if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
@@ -2760,3 +1373,4 @@ int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches) {
 }
 
 }  // extern "C"
+

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Per-loop instruction counts of the two FP64-bound kernels from the device assembly:
 
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only \
-        ngsf-hmm_amd/csrc/kernels_fast.hip -o /tmp/kf.s
-  python tools/isa_report.py /tmp/kf.s > profiles/r03_isa_summary.txt
+  for f in walks estep estmaf; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only \
+          ngsf-hmm_amd/csrc/kernels_fast_$f.hip -o /tmp/kf_$f.s
+  done
+  cat /tmp/kf_walks.s /tmp/kf_estep.s /tmp/kf_estmaf.s > /tmp/kf.s
+  python tools/isa_report.py /tmp/kf.s > profiles/r04_isa_summary.txt
 
 For each kernel: registers / scratch / occupancy as the assembler reports them, and every
 basic block of >= 60 instructions with its opcode histogram (the loop bodies)."""
@@ -13,14 +16,16 @@ from collections import Counter
 
 KERNELS = {
     "later objective rounds: k_fast_lkl_fd<2, 2, true, false, SRC_PLAIN, 2> (8 sites per loop body)":
-        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb0ELi0ELi2EEE",
+        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb0ELi0ELi2ELb0EEE",
     "fresh forward walk: k_fast_lkl_fd<2, 2, true, true, SRC_FRESH, 2>":
-        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb1ELi1ELi2EEE",
+        "_ZN5nghmm12_GLOBAL__N_113k_fast_lkl_fdILi2ELi2ELb1ELb1ELi1ELi2ELb0EEE",
     "est_maf: k_fast_estmaf<16, 64, true> (1000 individuals per site: 16 per lane)":
         "_ZN5nghmm12_GLOBAL__N_113k_fast_estmafILi16ELi64ELb1EEE",
     "backward sweep: k_fast_bwd_recompute8 (4 waves = 8 individuals x 32 lane-chunks, LDS staging)":
         "_ZN5nghmm12_GLOBAL__N_121k_fast_bwd_recompute8",
     "est_maf interpolated passes: k_fast_estmaf_interp": "_ZN5nghmm12_GLOBAL__N_120k_fast_estmaf_interp",
+    "est_maf, called genotypes: k_fast_estmaf_called_sums<true> (one sweep over codes and posteriors)":
+        "_ZN5nghmm12_GLOBAL__N_125k_fast_estmaf_called_sumsILb1EEE",
 }
 
 
