@@ -34,6 +34,19 @@ int host_threads(uint64_t n_items) {
 }
 }  // namespace
 
+void BfgsBatch::reserve(uint64_t n_ind) {
+  if (probs_.size() != n_ind) {
+    probs_.clear();
+    probs_.resize(n_ind);
+  }
+  for (auto& p : probs_) p.solver.configure(2, 10);
+  // (the first parallel region of a process starts the OpenMP runtime: not inside an M-step)
+  int sink = 0;
+#pragma omp parallel for num_threads(host_threads(8 * 512)) reduction(+ : sink)
+  for (int i = 0; i < 64; ++i) sink += i;
+  (void)sink;
+}
+
 void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, bool F_fixed,
                       bool alpha_fixed) {
   // the problems (and their solvers' work arrays) are reused from call to call

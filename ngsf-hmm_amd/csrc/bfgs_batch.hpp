@@ -36,6 +36,9 @@ class BfgsBatch {
   // lkl[p] = forward log-likelihood of point p of the last gather() over the same range.
   void scatter(const double* lkl, uint64_t lo = 0, uint64_t hi = ~0ull);
 
+  // the solvers' storage (and the OpenMP runtime) ahead of the first M-step: a run's first
+  // iteration should not pay 15 ms for them
+  void reserve(uint64_t n_ind);
   bool done() const { return n_active_ == 0; }
   uint64_t active_in(uint64_t lo, uint64_t hi) const;
   void result(double* indF, double* alpha) const;

@@ -64,6 +64,7 @@ struct nghmm_handle {
   hipEvent_t aux_piece_ev[kAuxPieces] = {};
   bool blocking_sync = false;
   bool loaded = false;
+  bool warmed = false;   // nghmm_emission has set up what the first EM iteration needs
 
   double *d_gl = nullptr, *d_pos = nullptr, *d_freq = nullptr, *d_eprob = nullptr, *d_fw = nullptr,
          *d_marg = nullptr, *d_indF = nullptr, *d_alpha = nullptr, *d_ind_lkl = nullptr;

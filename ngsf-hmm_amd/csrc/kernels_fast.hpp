@@ -150,6 +150,7 @@ GlView fast_gl_lin(const FastState& fs);
 bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major);
 // est_maf reads the E-step's tile-major posteriors in place (else: a site-major copy first)
 bool fast_estmaf_in_place(const FastState& fs, uint64_t I_tot);
+bool fast_estmaf_reserve(FastState& fs, uint64_t S_own);
 // called genotypes: the per-pass sums in closed form (k_fast_estmaf_called_sums)
 bool fast_estmaf_called(const FastState& fs, const GlView& gl);
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_lin_sites,

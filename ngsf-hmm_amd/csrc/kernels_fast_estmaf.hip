@@ -1257,6 +1257,22 @@ bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major
   return tile_major && I_tot > 128 && I_tot <= 8192;
 }
 
+// per-site state of the frequency step (flags, status, the interpolant's node values)
+bool fast_estmaf_reserve(FastState& fs, uint64_t S_own) {
+  if (S_own <= fs.redo_cap) return true;
+  if (fs.redo) (void)hipFree(fs.redo);
+  if (fs.est_status) (void)hipFree(fs.est_status);
+  if (fs.est_state) (void)hipFree(fs.est_state);
+  fs.redo = fs.est_status = nullptr;
+  fs.est_state = nullptr;
+  fs.redo_cap = 0;
+  if (hipMalloc((void**)&fs.redo, S_own) != hipSuccess) return false;
+  if (hipMalloc((void**)&fs.est_status, S_own) != hipSuccess) return false;
+  if (hipMalloc((void**)&fs.est_state, S_own * EST_FIELDS * sizeof(double)) != hipSuccess) return false;
+  fs.redo_cap = S_own;
+  return true;
+}
+
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out, bool tile_major, uint32_t part, uint32_t n_parts) {
@@ -1280,19 +1296,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   const bool stream_all = I_tot > 8192 && !tile_major;
   const uint64_t stream_wgs = stream_all ? (S_own + 3) / 4 : (S_own + 255) / 256;
   const dim3 grid((unsigned)(stream_wgs < 65536 ? stream_wgs : 65536)), block(256);
-  if (S_own > fs.redo_cap) {
-    if (fs.redo) (void)hipFree(fs.redo);
-    if (fs.est_status) (void)hipFree(fs.est_status);
-    if (fs.est_state) (void)hipFree(fs.est_state);
-    fs.redo = fs.est_status = nullptr;
-    fs.est_state = nullptr;
-    fs.redo_cap = 0;
-    if (hipMalloc((void**)&fs.redo, S_own) != hipSuccess) return false;
-    if (hipMalloc((void**)&fs.est_status, S_own) != hipSuccess) return false;
-    if (hipMalloc((void**)&fs.est_state, S_own * EST_FIELDS * sizeof(double)) != hipSuccess)
-      return false;
-    fs.redo_cap = S_own;
-  }
+  if (!fast_estmaf_reserve(fs, S_own)) return false;
   if (fast_estmaf_called(fs, d_gl_sites)) {
     // called genotypes: the per-pass sums in closed form (k_fast_estmaf_called_sums)
     if (tile_major)

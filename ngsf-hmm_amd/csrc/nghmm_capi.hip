@@ -680,6 +680,17 @@ int nghmm_emission(nghmm_t* h) {
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
+  // init_output's place (parse_args.cpp:372-387): once per run, right before the EM loop -- also
+  // where what the first iteration would otherwise allocate on its way is set up (the metric is
+  // EM iterations per second of a run that starts here)
+  if (!h->warmed) {
+    h->warmed = true;
+    h->batch.reserve(h->I);
+    if (h->mode == NGHMM_MODE_FAST) {
+      if ((rc = lane_setup(h, 0, (size_t)h->I * 5)) || (rc = lane_setup(h, 1, (size_t)h->I * 5))) return rc;
+      if (h->I_tot == h->I && !fast_estmaf_reserve(h->fast, h->S)) return NGHMM_ERR_NOMEM;
+    }
+  }
   return emission_impl(h);
 }
 

@@ -8,13 +8,13 @@
 #                                      section HBM prescribes
 #   <tag>_pmc_summary.json           profiles/summarize_pmc.py over the three passes
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT/pmc
 export TMPDIR=/tmp
 # no warm-up: the trace then holds exactly the kernels of the timed region (plus the one-off
 # load kernels, which have names of their own), so its averages can be set against bench.py's
-BENCH="bench.py --steps 7 --warmup 0 --no_cpu_baseline"
+BENCH="bench.py --steps 7 --warmup 0 --no_cpu_baseline --no_exact_line --no_check"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $BENCH \
   > $OUT/bench_under_trace.json 2> $OUT/trace.err
@@ -24,7 +24,7 @@ python3 profiles/reconcile.py $OUT/${TAG}_c3_fast_kernel_stats.csv $OUT/${TAG}_b
   > $OUT/${TAG}_trace_vs_bench.json
 echo "trace done"
 
-PMCBENCH="bench.py --steps 2 --warmup 1 --no_cpu_baseline"
+PMCBENCH="bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_exact_line --no_check"
 filter() {  # keep the header and this library's kernels
   python3 - "$1" "$2" <<'EOF'
 import csv, sys

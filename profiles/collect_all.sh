@@ -1,17 +1,28 @@
 #!/bin/bash
 # One session on the GPU box = every number of the round from the same build:
-#   bash profiles/collect_all.sh r03
+#   bash profiles/collect_all.sh r04
 # kernel trace + PMC passes of the default workload (profiles/collect.sh), then the bench lines:
 # default (1000 x 1M), one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (both shardings),
 # configs[1] (100 x 100k) alone and with replicas, config 5's per-GPU share.
+# (a gpurun call is at most 20 minutes: `collect_all.sh r04 1` = the profiler passes and the default
+# lines, `collect_all.sh r04 2` = the other workloads; the committed profiles/<tag>_pmc_summary.json of
+# part 1 must be in place for part 2's lines to carry `traffic`)
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
+PART=${2:-all}
 OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+if [ "$PART" != 2 ]; then
 bash profiles/collect.sh $TAG
 # bench.py reads profiles/<tag>_pmc_summary.json for `traffic`: install this session's first
 cp $OUT/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json
 python3 bench.py > $OUT/${TAG}_bench_default_n1.json
+# the one-GPU result check every N > 1 line compares itself with (profiles/check_n1.json)
+python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_exact_line --write_check > /dev/null
+cp profiles/check_n1.json $OUT/check_n1.json
+fi
+if [ "$PART" = 1 ]; then ls -la $OUT; exit 0; fi
 # one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (exchanges as local copies):
 # site shards (fast mode's default) and individual shards
 # (the driver's N = 1 flags, --steps 20 --warmup 5: the first iterations of a run take more
@@ -30,4 +41,15 @@ python3 bench.py --workload c2 --no_cpu_baseline --steps 100 --warmup 10 --repli
 python3 bench.py --workload c5share --no_cpu_baseline > $OUT/${TAG}_bench_c5share_n1.json
 # config 5's share as a site shard: all 5000 individuals x 625 000 sites (one of eight ranks)
 python3 bench.py --workload c5 --emulate_ranks 8 --no_cpu_baseline > $OUT/${TAG}_bench_c5_rank_of_8_sites.json
+# the called genotypes' est_maf (k_fast_estmaf_called_sums: one sweep over codes and posteriors) on
+# config 5's rank: kernel trace + FETCH_SIZE / WRITE_SIZE passes of a two-iteration run
+C5="bench.py --workload c5 --emulate_ranks 8 --steps 2 --warmup 1 --no_cpu_baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5trace -o trace -- python3 $C5 > /dev/null 2> $OUT/c5trace.err
+cp "$(find $OUT/c5trace -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_c5_rank_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c5fetch -o fetch -- python3 $C5 > /dev/null 2> $OUT/c5fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c5write -o write -- python3 $C5 > /dev/null 2> $OUT/c5write.err
+python3 profiles/summarize_called.py $OUT/${TAG}_c5_rank_kernel_stats.csv \
+  "$(find $OUT/c5fetch -name '*counter_collection.csv' | head -1)" \
+  "$(find $OUT/c5write -name '*counter_collection.csv' | head -1)" 5000 625000 > $OUT/${TAG}_c5_estmaf_called.json
+rm -rf $OUT/c5trace $OUT/c5fetch $OUT/c5write
 ls -la $OUT

@@ -26,7 +26,8 @@ FAMILIES = {
     "forward": ("k_fast_chunk_ops", "k_fast_bounds", "k_fast_bwd_recompute",
                 "k_fast_bwd_recompute8"),
     "est_maf": ("k_fast_estmaf", "k_fast_estmaf_resume", "k_fast_estmaf_rows",
-                "k_fast_estmaf_rows_resume", "k_fast_estmaf_interp", "k_fast_estmaf_stream"),
+                "k_fast_estmaf_rows_resume", "k_fast_estmaf_interp", "k_fast_estmaf_stream",
+                "k_fast_estmaf_called_sums", "k_fast_estmaf_called_passes"),
     "emission": ("k_fast_emission", "k_fast_freq_interleave"),
 }
 
