@@ -41,10 +41,12 @@ void BfgsBatch::reserve(uint64_t n_ind) {
   }
   for (auto& p : probs_) p.solver.configure(2, 10);
   // (the first parallel region of a process starts the OpenMP runtime: not inside an M-step)
-  int sink = 0;
-#pragma omp parallel for num_threads(host_threads(8 * 512)) reduction(+ : sink)
-  for (int i = 0; i < 64; ++i) sink += i;
-  (void)sink;
+  if (max_threads_ > 1) {
+    int sink = 0;
+#pragma omp parallel for num_threads(host_threads(4 * 512)) reduction(+ : sink)
+    for (int i = 0; i < 64; ++i) sink += i;
+    (void)sink;
+  }
 }
 
 void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, bool F_fixed,
@@ -237,23 +239,21 @@ void BfgsBatch::scatter(const double* lkl, uint64_t lo, uint64_t hi) {
   if (hi > probs_.size()) hi = probs_.size();
   uint64_t ref_calls = 0, finished = 0;
   // What a machine does with its values varies by a factor of five: far from the optimum (the
-  // first EM iterations of a run) nearly every round ends a line search and starts a new
-  // L-BFGS-B iteration -- matrix updates, Cauchy point, subspace step: 0.5 us per machine, 0.5
-  // ms per round at 1000 individuals, 9 ms of a first iteration's 76 -- near it most rounds only
-  // continue one (0.1 us).  So the thread count follows the time the previous round took per
-  // machine, not only the number of machines.
+  // first EM iterations of a run: 18 and 11 rounds) nearly every round ends a line search and
+  // starts a new L-BFGS-B iteration -- matrix updates, Cauchy point, subspace step: 0.5 us per
+  // machine, 0.5 ms per round at 1000 individuals, 9 ms of a first iteration's 76 -- near it (4-5
+  // rounds) most rounds only continue one (0.1 us).  An M-step that is still going after five
+  // rounds is of the first kind: from there on a few host threads share the machines even when
+  // their number alone would not call for it.  (Never where several handles of one process run
+  // their M-steps side by side -- replicas, groups, chains: set_max_threads.)
   int nt = host_threads(n_active_);
-  if (nt == 1 && us_per_machine_ * (double)n_active_ > 150.0) nt = host_threads(8 * 512);
-  const auto t0 = std::chrono::steady_clock::now();
-  const uint64_t n_before = n_active_;
+  if (nt == 1 && max_threads_ > 1 && rounds_ > 5 && n_active_ >= 256) nt = host_threads(4 * 512);
+  if (nt > max_threads_) nt = max_threads_;
 #pragma omp parallel for schedule(static) reduction(+ : ref_calls, finished) num_threads(nt)
   for (int64_t i = (int64_t)lo; i < (int64_t)hi; ++i)
     if (probs_[i].active) consume(probs_[i], lkl, ref_calls, finished);
   ref_calls_ += ref_calls;
   n_active_ -= finished;
-  if (n_before > 0 && hi - lo == probs_.size())
-    us_per_machine_ = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() *
-                      nt / (double)n_before;
 }
 
 void BfgsBatch::result(double* indF, double* alpha) const {

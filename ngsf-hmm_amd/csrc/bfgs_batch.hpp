@@ -39,6 +39,8 @@ class BfgsBatch {
   // the solvers' storage (and the OpenMP runtime) ahead of the first M-step: a run's first
   // iteration should not pay 15 ms for them
   void reserve(uint64_t n_ind);
+  // host threads one M-step may use (1: a handle that runs next to others of its process)
+  void set_max_threads(int n) { max_threads_ = n < 1 ? 1 : n; }
   bool done() const { return n_active_ == 0; }
   uint64_t active_in(uint64_t lo, uint64_t hi) const;
   void result(double* indF, double* alpha) const;
@@ -68,7 +70,7 @@ class BfgsBatch {
   };
   std::vector<Problem> probs_;
   uint64_t n_active_ = 0;
-  double us_per_machine_ = 0;  // host time of the last whole round's scatter per active machine
+  int max_threads_ = 64;      // set_max_threads
   uint32_t rounds_ = 0;
   uint64_t points_ = 0, ref_calls_ = 0, ind_rounds_ = 0;
 

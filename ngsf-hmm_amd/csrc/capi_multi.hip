@@ -316,6 +316,8 @@ int group_freq_phases(nghmm_t** hs, int n) {
 int nghmm_group_setup(nghmm_t** hs, int n) {
   g_last_error.clear();
   if (!hs || n < 1) return NGHMM_ERR_ARG;
+  for (int r = 0; r < n; ++r)  // the members' M-steps run side by side on host threads of their own
+    if (hs[r]) hs[r]->batch.set_max_threads(n > 1 ? 1 : 64);
   nghmm_t* h0 = hs[0];
   for (int r = 0; r < n; ++r) {
     nghmm_t* h = hs[r];
@@ -626,6 +628,7 @@ int nghmm_chain_setup(nghmm_t** hs, int n) {
     set_error("nghmm_chain_setup: site shards are a fast-mode layout");
     return NGHMM_ERR_ARG;
   }
+  for (int r = 0; r < n; ++r) hs[r]->batch.set_max_threads(n > 1 ? 1 : 64);  // (as in nghmm_group_setup)
   for (int r = 0; r < n; ++r) chain_release(hs[r]);
   if (n == 1) return NGHMM_OK;
   int rc;

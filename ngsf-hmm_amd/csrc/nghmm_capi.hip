@@ -601,6 +601,10 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   h->S_own = h->S;
   h->parent = parent;
   parent->n_replicas.fetch_add(1);
+  // replicas run their EM iterations side by side from host threads of their own: each M-step
+  // keeps to its thread (R pools of OpenMP workers would fight over the cores)
+  parent->batch.set_max_threads(1);
+  h->batch.set_max_threads(1);
   h->d_gl = parent->d_gl;
   h->d_pos = parent->d_pos;
   h->d_codes = parent->d_codes;
