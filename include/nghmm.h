@@ -385,6 +385,8 @@ void nghmm_free_host(void* p);
  *                     instead of producer-consumer workgroups (kernels_exact_pc.hip): same bits
  *   estmaf_exact_lanes 1: exact-mode est_maf with a lane per site instead of a wave per site
  *                     (same bits; measured slower, kept for the comparison)
+ *   estmaf_exact_sel  1: exact-mode est_maf on the select forms of det_exp / det_log (same
+ *                     bits; measured slower since round 4's kernel, default 0)
  *   exact_bg_waves    exact mode, fused iteration: est_maf runs underneath the objective rounds
  *                     in 16 pieces capped at this many waves per SIMD (default 3; 0: uncapped;
  *                     -1: after the rounds); exact_bg_depth: pieces queued under a round (3)

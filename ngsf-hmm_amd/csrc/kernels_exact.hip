@@ -229,7 +229,7 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 // 13.5 s alone, est_maf 4.2 s against 2.4 s alone).  Claiming 512 / BG_WAVES registers caps the
 // kernel at BG_WAVES waves per SIMD and leaves the other slots to the chains, whose waves
 // raise their issue priority.
-template <int BG_WAVES>
+template <int BG_WAVES, bool SEL>
 __global__ void __launch_bounds__(256)
 k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
                uint64_t I, double* __restrict__ freq_out, uint32_t* __restrict__ passes_out) {
@@ -258,15 +258,16 @@ k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
         double g0, g1, g2;
         gl_fetch(gl, site * I + i, g0, g1, g2);
         double h0, h1, h2;
-        hwe_log(freq, F, h0, h1, h2);
+        if constexpr (SEL) hwe_log_sel(freq, F, h0, h1, h2);
+        else hwe_log(freq, F, h0, h1, h2);
         double p0 = g0 + h0, p1 = g1 + h1, p2 = g2 + h2;  // post_prob, gen_func.cpp:920-932
-        const double norm = logsum3(p0, p1, p2);
+        const double norm = SEL ? logsum3_sel(p0, p1, p2) : logsum3(p0, p1, p2);
         p0 -= norm;
         p1 -= norm;
         p2 -= norm;
-        p0 = det_exp(p0);
-        p1 = det_exp(p1);
-        p2 = det_exp(p2);
+        p0 = SEL ? det_exp_sel(p0) : det_exp(p0);
+        p1 = SEL ? det_exp_sel(p1) : det_exp(p1);
+        p2 = SEL ? det_exp_sel(p2) : det_exp(p2);
         tn = p1 + p2 * (2 - F);
         td = 2 * p1 + (p0 + p2) * (2 - F);
       }
@@ -1032,25 +1033,30 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
 
 void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out,
-                         int lanes, int bg_waves) {
+                         int lanes, int bg_waves, bool sel) {
   if (S_own == 0) return;
   // a lane per site needs enough sites to fill the chip's lanes (64 sites per wave); the few
   // sites of a small shard or of a short data set take a wave each (lanes: -1 by size, 0 / 1)
   if (lanes < 0 ? S_own >= kEstmafLanesMinSites : lanes != 0)
     hipLaunchKernelGGL(k_estmaf_exact_lanes, dim3((unsigned)((S_own + 63) / 64)), dim3(64), 0, st,
                        gl_sites, marg_sites, S_own, I_tot, freq_out, passes_out);
-  else if (bg_waves == 2)
-    hipLaunchKernelGGL(k_estmaf_exact<2>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
-                       marg_sites, S_own, I_tot, freq_out, passes_out);
-  else if (bg_waves == 3)
-    hipLaunchKernelGGL(k_estmaf_exact<3>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
-                       marg_sites, S_own, I_tot, freq_out, passes_out);
-  else if (bg_waves == 4)
-    hipLaunchKernelGGL(k_estmaf_exact<4>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
-                       marg_sites, S_own, I_tot, freq_out, passes_out);
-  else
-    hipLaunchKernelGGL(k_estmaf_exact<0>, dim3((unsigned)((S_own + 3) / 4)), dim3(256), 0, st, gl_sites,
-                       marg_sites, S_own, I_tot, freq_out, passes_out);
+  else {
+    const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
+#define ESTMAF_EXACT(BG)                                                                          \
+  do {                                                                                            \
+    if (sel)                                                                                      \
+      hipLaunchKernelGGL((k_estmaf_exact<BG, true>), grid, block, 0, st, gl_sites, marg_sites,    \
+                         S_own, I_tot, freq_out, passes_out);                                     \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_estmaf_exact<BG, false>), grid, block, 0, st, gl_sites, marg_sites,   \
+                         S_own, I_tot, freq_out, passes_out);                                     \
+  } while (0)
+    if (bg_waves == 2) ESTMAF_EXACT(2);
+    else if (bg_waves == 3) ESTMAF_EXACT(3);
+    else if (bg_waves == 4) ESTMAF_EXACT(4);
+    else ESTMAF_EXACT(0);
+#undef ESTMAF_EXACT
+  }
 }
 
 void launch_viterbi_fwd_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,

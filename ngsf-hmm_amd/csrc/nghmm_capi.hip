@@ -1102,7 +1102,7 @@ int capi::estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_blocks
                       : h->packed ? gl_packed(h->d_codes_shard, h->d_cls_log)
                                   : gl_dense(h->d_gl_shard);
     launch_estmaf_exact(h->stream, lg, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr,
-                        h->fast.sw.estmaf_exact_lanes);
+                        h->fast.sw.estmaf_exact_lanes, 0, h->fast.sw.estmaf_exact_sel != 0);
   }
   if ((rc = toc(h, SLOT_ESTMAF, false))) return rc;
   HIP_TRY(hipGetLastError());
@@ -1143,7 +1143,7 @@ static int mstep_freq_ld_impl(nghmm_t* h, int freq_est, int e_prob) {
   tic(h);
   if (exact) {
     launch_estmaf_exact(h->stream, own_gl(h), h->d_marg, n_est, h->I, h->d_freq_new, nullptr,
-                        h->fast.sw.estmaf_exact_lanes);
+                        h->fast.sw.estmaf_exact_lanes, 0, h->fast.sw.estmaf_exact_sel != 0);
   } else if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast), h->d_marg, n_est, h->I, h->I,
                           h->d_freq_new, false)) {
     return NGHMM_ERR_HIP;
@@ -1273,7 +1273,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
       GlView gl = own_gl(h);
       gl.cell0 += s0 * h->I;
       launch_estmaf_exact(h->aux_stream, gl, h->d_marg + s0 * h->I, s1 - s0, h->I, h->d_freq + s0, nullptr,
-                          h->fast.sw.estmaf_exact_lanes, bg_waves);
+                          h->fast.sw.estmaf_exact_lanes, bg_waves, h->fast.sw.estmaf_exact_sel != 0);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(h->aux_piece_ev[next], h->aux_stream));
       ++next;

@@ -20,15 +20,16 @@ with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT) as h:
     h.init_emission()
     h.estep()
     res = {}
-    for lanes in (0, 1, 0, 1):
+    for lanes, sel in ((0, 0), (0, 1), (1, 0), (0, 0), (0, 1)):
         h.set_switch("estmaf_exact_lanes", lanes)
+        h.set_switch("estmaf_exact_sel", sel)
         h.set_params(None, None, 0.1)
         h.mstep_freq(1)
         ms = h.kernel_ms("est_maf")[0]
         f = h.freq
-        print(f"{I} x {S}: lanes={lanes}: est_maf {ms:.1f} ms (+ emission refresh {h.kernel_ms('emission')[0]:.1f} ms)", flush=True)
-        if lanes in res:
-            assert np.array_equal(res[lanes], f)
-        res[lanes] = f
-    assert np.array_equal(res[0], res[1])
+        print(f"{I} x {S}: lanes={lanes} select forms={sel}: est_maf {ms:.1f} ms", flush=True)
+        if (lanes, sel) in res:
+            assert np.array_equal(res[(lanes, sel)], f)
+        res[(lanes, sel)] = f
+    assert all(np.array_equal(res[(0, 0)], v) for v in res.values())
     print("frequencies bit-identical")
