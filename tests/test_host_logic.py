@@ -5,6 +5,7 @@ reference's blocking findmax_bfgs does with the same objective -- same final
 simulator must produce well-formed inputs."""
 import ctypes as C
 import importlib
+import json
 import math
 
 import numpy as np
@@ -106,3 +107,54 @@ def test_simulator_shapes_and_model(pkg):
     # same seed, same data
     d2 = sim.simulate(7, 500, seed=3, n_chrom=3, missing_rate=0.1)
     assert np.array_equal(d.gl, d2.gl) and np.array_equal(d.path, d2.path)
+
+
+def test_indexed_simulator_slices_are_slices_of_the_whole(pkg):
+    """simulate.IndexedSim (what bench.py generates its data with): every random field is a hash
+    of the GLOBAL (individual, site) indices and the IBD chain is resumed exactly by looking back
+    to its last redraw site, so any (individual range) x (site range) slice, generated in chunks
+    of any size, is bit for bit the slice of the whole data set -- the N-rank benchmark job holds
+    pieces of the one-GPU job's data whatever the sharding (EM.cpp:151-161: results do not depend
+    on the number of workers).  On the CPU device here; element-wise torch operations only."""
+    import torch
+    dev = torch.device("cpu")
+    I, S = 18, 3000
+    for kw in (dict(n_chrom=3), dict(n_chrom=1, freq="r", indF="r", alpha="r"), dict(alpha=1e-4)):
+        whole = pkg.simulate.IndexedSim(I, S, dev, seed=77, **kw)
+        full, pd = whole.gl(chunk_sites=1111), whole.pos_dist(0, S)
+        assert full.shape == (S, I, 3) and torch.isfinite(full).all()
+        assert torch.allclose(torch.exp(full).sum(-1), torch.ones(S, I, dtype=torch.float64), atol=1e-12)
+        assert int(torch.isinf(pd).sum()) == kw.get("n_chrom", 1) - 1
+        for i0, i1, s0, s1, cs in ((0, I, 0, S, S), (0, I, 1024, 2048, 333), (5, 11, 0, S, 777),
+                                   (12, 18, 1776, S, 100), (3, 4, S - 1, S, 7), (0, 9, 16, 17, 1)):
+            part = pkg.simulate.IndexedSim(I, S, dev, seed=77, **kw)
+            part.LOOKBACK = 32          # the look-back recursion itself (alpha = 1e-4: long tracts)
+            sl = part.gl((i0, i1), (s0, s1), chunk_sites=cs)
+            assert torch.equal(sl, full[s0:s1, i0:i1]), (kw, i0, i1, s0, s1)
+            assert torch.equal(part.pos_dist(s0, s1), pd[s0:s1])
+    other = pkg.simulate.IndexedSim(I, S, dev, seed=78, n_chrom=3).gl()
+    assert not torch.equal(other, pkg.simulate.IndexedSim(I, S, dev, seed=77, n_chrom=3).gl())
+    # the data model: depth ~ Poisson(2) (13.5 % uniform cells), allele frequency 0.2
+    big = torch.exp(pkg.simulate.IndexedSim(200, 20000, dev, seed=5).gl())
+    uniform = ((big - 1.0 / 3).abs().amax(-1) < 1e-6).double().mean().item()
+    assert abs(uniform - math.exp(-2.0)) < 2e-3
+    assert abs(big[..., 0].mean().item() - 0.561) < 5e-3
+
+
+def test_bench_check_comparison():
+    """bench.compare_checks: what decides that an N-rank line reproduces the one-GPU line."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    a = {"tot_lkl": [-9.0e8, -8.5e8], "rounds": [18, 11], "freq_probes": [0.2, 0.19], "freq_sum": 2e5,
+         "freq_weighted_sum": 1e5, "indF_sum": 499.0, "alpha_sum": 10.0}
+    assert bench.compare_checks(a, a)["ok"] is True
+    b = dict(a, tot_lkl=[-9.0e8 * (1 + 5e-13), -8.5e8])
+    assert bench.compare_checks(b, a)["ok"] is True            # 1e-12 on the log-likelihoods
+    assert bench.compare_checks(dict(a, tot_lkl=[-9.0e8 * (1 + 5e-12), -8.5e8]), a)["ok"] is False
+    assert bench.compare_checks(dict(a, freq_probes=[0.2 * (1 + 5e-9), 0.19]), a)["ok"] is False
+    assert bench.compare_checks(dict(a, rounds=[18, 12]), a)["ok"] is False
+    ref = json.load(open(bench.CHECK_REF))                     # the committed one-GPU reference
+    key = "c3:fast:1000x1000000:gl"
+    assert key in ref and ref[key]["iterations"] == 2 and len(ref[key]["freq_probes"]) == 16
