@@ -29,7 +29,14 @@ int host_threads(uint64_t n_items) {
   }();
   // measured: at 1000 problems a round's host work (~0.1 ms) is not worth waking threads
   // for; at 8000 it is 5 ms -> 1 ms on 8 threads
-  const uint64_t by_work = n_items / 512;
+  static const uint64_t per_thread = [] {
+    if (const char* env = std::getenv("NGHMM_HOST_WORK")) {
+      const long v = std::atol(env);
+      if (v >= 1) return (uint64_t)v;
+    }
+    return (uint64_t)512;
+  }();
+  const uint64_t by_work = n_items / per_thread;
   return (int)(by_work < 1 ? 1 : (by_work < (uint64_t)cap ? by_work : (uint64_t)cap));
 }
 }  // namespace
