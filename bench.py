@@ -405,6 +405,11 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
 
     for _ in range(warmup):
         one()
+    if os.environ.get("NGHMM_BENCH_FAIL_RANK") == str(ctx.rank) and ctx.world > 1:
+        # (tests: one rank hits a fatal of the reference between two collectives -- the others
+        # must end with its message, not wait in their next all-gather)
+        with em.beacon.guard():
+            raise ctx.pkg.NgsFHMMError(-3, "invalid MAF! (injected by NGHMM_BENCH_FAIL_RANK)")
     em.reset_timing()
     fam = {k: 0.0 for k in FAMILIES}
     launches = dict.fromkeys(fam, 0)

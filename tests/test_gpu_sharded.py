@@ -144,6 +144,32 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert bad.returncode != 0 and "WORLD_SIZE is 1" in bad.stderr
 
 
+def test_bench_a_failing_rank_ends_the_job_with_its_message(pkg):
+    """One rank of `bench.py --gpus 2` hits a fatal (injected after the warm-up: `invalid MAF!` is
+    reachable from user data on ONE rank's site range) while the other goes on into its next
+    all-gather: the job must end non-zero within seconds, the healthy rank with the failing
+    rank's message (distributed.FailureBeacon), not after the process group's timeout."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--workload", "tiny", "--no_cpu_baseline", "--no_alt",
+                        "--timeout_s", "300"],
+                       env=dict(env, NGHMM_BENCH_FAIL_RANK="1"), capture_output=True, text=True,
+                       timeout=280, cwd=root)
+    dt = time.time() - t0
+    assert r.returncode != 0
+    assert "invalid MAF! (injected" in r.stderr
+    assert "a peer failed -- rank 1: NgsFHMMError" in r.stderr, r.stderr[-1500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # no line from a broken job
+    assert dt < 120, dt
+
+
 @pytest.mark.parametrize("I", [40, 100, 200, 400, 600, 700, 1024, 1100, 1700, 2100, 3500, 4100, 7000, 8200])
 def test_est_maf_register_and_stream_variants(pkg, I):
     """est_maf picks a kernel by the number of individuals (one wave per site with 1..16
