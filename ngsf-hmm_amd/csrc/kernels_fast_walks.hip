@@ -134,6 +134,78 @@ __device__ __forceinline__ void lkl_store_wave_op(Op r, int lane, double* __rest
   }
 }
 
+// The same ordered products for the NP points of a finite-difference group AT ONCE.  A shuffle
+// tree per point keeps 2^-k of the lanes busy at level k and does that NP times: 6 op_mul levels
+// x 5 points = 30 per lane, ~900 instructions per wave -- a dozen sites' worth, 2 % of a wave at
+// 320 sites per lane and 20 % at the 40 sites per lane of an eight-GPU site shard (or of 100 x
+// 100k).  Here the first level runs on shuffles for all points, the 32 products per point go to
+// LDS, and every further level takes ALL points' pairs side by side, one pair per lane: 80, 40,
+// 20, 10, 5 products in 2 + 1 + 1 + 1 + 1 passes -- 5 + 6 op_mul per lane instead of 30.  The
+// pairs and their order are the shuffle tree's (level k multiplies the products of lanes
+// 2^k m .. and 2^k m + 2^(k-1) ..), so every result has the same bits.  One wave per workgroup:
+// in-place updates are safe (a wave's LDS reads are issued before its writes), passes of one
+// level touch different points.
+struct TreeLds {
+  double v[MAXP * 32][6];   // a00, a01, a10, a11, (double) ex, pad: 48 B per operator
+};
+
+__device__ __forceinline__ Op tree_load(const TreeLds& L, int idx) {
+  const double2* q = reinterpret_cast<const double2*>(L.v[idx]);
+  const double2 x = q[0], y = q[1], z = q[2];
+  return Op{x.x, x.y, y.x, y.y, (int)z.x};
+}
+
+__device__ __forceinline__ void tree_store(TreeLds& L, int idx, const Op& m) {
+  double2* q = reinterpret_cast<double2*>(L.v[idx]);
+  q[0] = double2{m.a00, m.a01};
+  q[1] = double2{m.a10, m.a11};
+  q[2] = double2{(double)m.ex, 0.0};
+}
+
+template <int NP>
+__device__ __forceinline__ void lkl_store_wave_ops(Op (&R)[MAXP], int lane, double* __restrict__ out,
+                                                   TreeLds& L) {
+  static_assert(NP >= 1 && NP <= MAXP, "points of one group");
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {  // level 1, as lkl_store_wave_op does it
+    renorm(R[p]);
+    const Op o = op_shfl_down(R[p], 1);
+    if ((lane & 1) == 0) {
+      R[p] = op_mul(R[p], o);
+      tree_store(L, p * 32 + (lane >> 1), R[p]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int lg = 4; lg >= 0; --lg) {  // n = 2^lg products per point at this level
+    const int n = 1 << lg;
+    const int items = NP * n;
+#pragma unroll
+    for (int t0 = 0; t0 < NP * 16; t0 += 64) {
+      if (t0 < items) {
+        const int t = t0 + lane;
+        const bool on = t < items;
+        const int tt = on ? t : 0;
+        const int p = tt >> lg, k = tt & (n - 1);
+        const int src = p * 32 + 2 * k;
+        const Op m = op_mul(tree_load(L, src), tree_load(L, src + 1));
+        __syncthreads();  // (single wave: orders this pass's reads before its writes for the compiler)
+        if (on) tree_store(L, p * 32 + k, m);
+        __syncthreads();
+      }
+    }
+  }
+  if (lane < NP) {
+    const Op m = tree_load(L, lane * 32);
+    double* o = out + lane * 5;
+    o[0] = m.a00;
+    o[1] = m.a01;
+    o[2] = m.a10;
+    o[3] = m.a11;
+    o[4] = (double)m.ex;
+  }
+}
+
 // One kernel per loop-body version (each gets its own register allocation); the host
 // sorts the groups of a round by mode and launches every version on its range
 // [g_begin, g_begin + gridDim.x / C).
@@ -168,9 +240,14 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
     renorm(r0);
     emit_lane_op(emit.lane_ops, i * C + c, lane, r0);
   }
+#ifdef NGHMM_TREE_SHFL  // (A/B builds: a shuffle tree per point)
 #pragma unroll
   for (int p = 0; p < 1 + NF + NA; ++p)
     lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
+#else
+  __shared__ TreeLds tree;
+  lkl_store_wave_ops<1 + NF + NA>(R, lane, part + ((uint64_t)g * C + c) * MAXP * 5, tree);
+#endif
 }
 
 template <int NP_MAX, int SRC>

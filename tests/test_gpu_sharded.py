@@ -128,6 +128,10 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert alt["sharding"] == "individuals" and alt["n_ind_per_gpu"] == 32 and alt["ms_per_step"] > 0
     same(alt["check"], one["check"])
     assert alt["vs_main_sharding"]["ok"] is True
+    # a layout that does not fit the job (63 individuals over two ranks) costs the line its
+    # `alt_sharding` object, not the run
+    odd = run("--gpus", "2", "--n_ind", "63")
+    assert odd["value"] > 0 and "do not divide" in odd["alt_sharding"]["skipped"]
     sw = run("--gpus", "2", "--scaling", "weak")
     assert sw["config"]["n_sites"] == 2 * one["config"]["n_sites"] and sw["config"]["n_ind_total"] == 64
     # BASELINE configs[4]'s path at smoke size: --call_geno, 2-bit packed handles, the site
@@ -165,9 +169,14 @@ def test_bench_a_failing_rank_ends_the_job_with_its_message(pkg):
     dt = time.time() - t0
     assert r.returncode != 0
     assert "invalid MAF! (injected" in r.stderr
-    assert "a peer failed -- rank 1: NgsFHMMError" in r.stderr, r.stderr[-1500:]
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # no line from a broken job
     assert dt < 120, dt
+    # who ended the healthy rank: the beacon (its message is then on stderr) or torchrun's agent,
+    # which also terminates the other workers when one fails -- whichever came first; a launcher
+    # without that (mpirun, srun) leaves it to the beacon alone (tests/test_distributed_cpu.py
+    # covers the beacon by itself)
+    print("healthy rank ended by:", "the failure beacon" if "a peer failed -- rank 1" in r.stderr
+          else "the launcher", f"after {dt:.1f} s")
 
 
 @pytest.mark.parametrize("I", [40, 100, 200, 400, 600, 700, 1024, 1100, 1700, 2100, 3500, 4100, 7000, 8200])
