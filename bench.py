@@ -312,30 +312,46 @@ def shard_shapes(ctx, shard):
     return sh
 
 
-def build_run(ctx, shard):
+def build_run(ctx, shard, agree=None):
     """Create the rank's handle(s) for `shard` and load its slice of the synthetic data set,
     generated on the device (same data model as scripts/ngsF-HMMsim.R, every element a hash of
-    its global indices: simulate.IndexedSim)."""
+    its global indices: simulate.IndexedSim).  agree(error_or_None) -> bool: called once, between
+    the rank-local part (handle, exchange buffers, the generated likelihoods: where memory runs
+    out if it does) and the part that contains collectives (individual shards exchange their site
+    shards while loading); the ranks go on only if it returns True."""
     torch, pkg, dd, args = ctx.torch, ctx.pkg, ctx.dd, ctx.args
     sh = shard_shapes(ctx, shard)
     V = args.emulate_ranks
-    if sh["by_sites"]:
-        em = dd.SiteShardedEM(pkg, sh["I"], sh["S_job"], device_index=ctx.local_rank, mode=ctx.mode,
-                              rank=ctx.rank, world=ctx.world, emulate_ranks=V,
-                              emulate_through_group=args.emulate_rccl)
-        assert em.S_own == sh["S"]
-    else:
-        em = dd.ShardedEM(pkg, sh["I"], sh["S"], device_index=ctx.local_rank, mode=ctx.mode,
-                          rank=ctx.rank, world=ctx.world, emulate_ranks=V)
-    sim = pkg.simulate.IndexedSim(sh["I_tot"], sh["S_job"], ctx.device, seed=12345,
-                                  n_chrom=ctx.wl.get("n_chrom", 1))
-    pos = sim.pos_dist(*sh["site_range"])
+    em, gl, sim, pos, err = None, None, None, None, None
+    try:
+        if sh["by_sites"]:
+            em = dd.SiteShardedEM(pkg, sh["I"], sh["S_job"], device_index=ctx.local_rank, mode=ctx.mode,
+                                  rank=ctx.rank, world=ctx.world, emulate_ranks=V,
+                                  emulate_through_group=args.emulate_rccl)
+            assert em.S_own == sh["S"]
+        else:
+            em = dd.ShardedEM(pkg, sh["I"], sh["S"], device_index=ctx.local_rank, mode=ctx.mode,
+                              rank=ctx.rank, world=ctx.world, emulate_ranks=V)
+        sim = pkg.simulate.IndexedSim(sh["I_tot"], sh["S_job"], ctx.device, seed=12345,
+                                      n_chrom=ctx.wl.get("n_chrom", 1))
+        pos = sim.pos_dist(*sh["site_range"])
+        if not ctx.call_geno:
+            gl = sim.gl(sh["ind_range"], sh["site_range"])
+            torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001
+        if agree is None:
+            raise
+        err = f"{type(e).__name__}: {e}"
+    if agree is not None and not agree(err):
+        if em is not None:
+            em.close()
+        del gl, sim, pos
+        torch.cuda.empty_cache()
+        raise RuntimeError(err or "another rank could not set up its shard")
     if ctx.call_geno:   # a block of sites at a time, called and packed on the way in
         em.load_chunks_device(pos, sim.chunks(sh["ind_range"], sh["site_range"], chunk_sites=50_000),
                               space=0, call_geno=True)
     else:
-        gl = sim.gl(sh["ind_range"], sh["site_range"])
-        torch.cuda.synchronize()
         em.load_device(gl, pos)
         del gl
     del sim, pos
@@ -1033,20 +1049,19 @@ def alt_sharding(ctx, steps, warmup, main_check):
     does not fit (or fails) costs the line this object, not the run."""
     dist, torch = ctx.dist, ctx.torch
     out = {"sharding": "individuals", "steps": steps, "warmup": warmup}
-    err, run = None, None
+    # every rank says whether the rank-local part of the set-up worked BEFORE any of them enters
+    # the collectives of the load: a layout that does not fit this job (a size that does not
+    # divide, memory) costs the line this object, not the run
+    def agree(err):
+        return allreduce(ctx, [1.0 if err else 0.0], "max")[0] == 0.0
+    run = None
     try:
-        run = build_run(ctx, "individuals")
+        run = build_run(ctx, "individuals", agree)
         reset_params(run["em"])
-    except Exception as e:   # noqa: BLE001
-        err = f"{type(e).__name__}: {e}"
-    # (building a shard ends in collectives of its own: a rank that failed before them has made
-    # the others time out -- what is caught here is a layout EVERY rank refuses, e.g. a size
-    # that does not divide)
-    bad = allreduce(ctx, [1.0 if err else 0.0], "max")[0]
-    if bad:
-        if run:
-            run["em"].close()
-        out["skipped"] = err or "another rank could not build its individual shard"
+    except (ValueError, RuntimeError) as e:
+        if isinstance(e, ValueError):   # refused before any allocation, on every rank alike
+            agree(str(e))
+        out["skipped"] = f"{type(e).__name__}: {e}"
         return out
     em = run["em"]
     tl = timed_loop(ctx, run, steps, warmup)

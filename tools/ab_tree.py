@@ -2,7 +2,7 @@
 """A/B of the objective kernels' operator tree: the LDS-packed tree over all points of a group
 (default build) against a shuffle tree per point (ngsf-hmm_amd/libnghmm_shfl.so, built with
 -DNGHMM_TREE_SHFL): the same bits, and the round's kernel time at several shapes.
-   python tools/ab_tree.py        (needs an MI355X and both libraries)"""
+   make -C ngsf-hmm_amd/csrc ../libnghmm_shfl.so && python tools/ab_tree.py     (needs an MI355X)"""
 import importlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
