@@ -390,6 +390,8 @@ void nghmm_free_host(void* p);
  *   exact_bg_waves    exact mode, fused iteration: est_maf runs underneath the objective rounds
  *                     in 16 pieces capped at this many waves per SIMD (default 3; 0: uncapped;
  *                     -1: after the rounds); exact_bg_depth: pieces queued under a round (3)
+ *   exact_estep_overlap 0: exact mode's fused iteration runs its E-step before the objective
+ *                     rounds instead of next to the first of them (default 1)
  *   timing            1: host-side phase times of every M-step on stderr
  *   debug_modes       1: kernel versions of every objective round on stderr
  * Fixed at creation (environment only): fast_c (waves per individual), spin_sync (replicas

@@ -62,6 +62,8 @@ struct nghmm_handle {
   hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr;
   static constexpr uint32_t kAuxPieces = 16;   // exact mode: est_maf underneath the rounds, in pieces
   hipEvent_t aux_piece_ev[kAuxPieces] = {};
+  hipEvent_t aux_estep_ev[3] = {};             // ... the E-step next to the first rounds: its timing
+  double* d_aux_params = nullptr;              // ... and its own copies of indF / alpha [2][I]
   bool blocking_sync = false;
   bool loaded = false;
   bool warmed = false;   // nghmm_emission has set up what the first EM iteration needs

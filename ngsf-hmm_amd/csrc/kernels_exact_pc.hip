@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "detmath.h"
 #include "glview.hpp"
@@ -346,16 +347,43 @@ k_backward_exact_pc(const double* __restrict__ eprob, const double* __restrict__
 
 }  // namespace
 
+// Dynamic LDS on top of the 60 KB ring, so that a workgroup has its CU (160 KB) to itself when the
+// launch is small enough for every workgroup to get one: two chain workgroups on one CU share its
+// SIMDs between their producer waves and the consumers that are the critical path -- measured at
+// 1000 x 1M with the E-step's 32 workgroups next to a round's 157: forward 0.50 instead of 0.35 s,
+// the round 0.39 instead of 0.31 s; with 24 KB of padding neither notices the other.  A launch of
+// more workgroups than that (cohorts beyond ~1250 individuals) keeps two per CU: there the idle
+// issue slots of one consumer are the other's throughput.  NGHMM_PC_PAD_KB overrides (0: never).
+static unsigned pc_pad_bytes(unsigned n_workgroups) {
+  static const unsigned pad = [] {
+    unsigned kb = 24;
+    if (const char* env = std::getenv("NGHMM_PC_PAD_KB")) kb = (unsigned)std::atoi(env);
+    if (kb > 96) kb = 96;
+    const unsigned bytes = kb * 1024u;
+    if (bytes) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_exact_pc<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_exact_pc<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_backward_exact_pc),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      (void)hipGetLastError();
+    }
+    return bytes;
+  }();
+  return n_workgroups <= 200 ? pad : 0u;
+}
+
 void launch_forward_exact_pc(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
                              uint64_t I, uint32_t n_pts, const uint32_t* ind, const double* F,
                              const double* alpha, double* lkl_out, double* fw, int* flags) {
   if (n_pts == 0 || S == 0) return;
   const dim3 grid((n_pts + PC_CH - 1) / PC_CH), block(PC_THREADS);
   if (fw)
-    hipLaunchKernelGGL(k_forward_exact_pc<true>, grid, block, 0, st, eprob, pos, S, I, n_pts, ind,
+    hipLaunchKernelGGL(k_forward_exact_pc<true>, grid, block, pc_pad_bytes(grid.x), st, eprob, pos, S, I, n_pts, ind,
                        F, alpha, lkl_out, fw, flags);
   else
-    hipLaunchKernelGGL(k_forward_exact_pc<false>, grid, block, 0, st, eprob, pos, S, I, n_pts, ind,
+    hipLaunchKernelGGL(k_forward_exact_pc<false>, grid, block, pc_pad_bytes(grid.x), st, eprob, pos, S, I, n_pts, ind,
                        F, alpha, lkl_out, fw, flags);
 }
 
@@ -365,7 +393,7 @@ void launch_backward_exact_pc(hipStream_t st, const double* eprob, const double*
                               int* flags) {
   if (I == 0 || S == 0) return;
   hipLaunchKernelGGL(k_backward_exact_pc, dim3((unsigned)((I + PC_CH - 1) / PC_CH)),
-                     dim3(PC_THREADS), 0, st, eprob, pos, fw, S, I, indF, alpha, ind_lkl, marg,
+                     dim3(PC_THREADS), pc_pad_bytes((unsigned)((I + PC_CH - 1) / PC_CH)), st, eprob, pos, fw, S, I, indF, alpha, ind_lkl, marg,
                      flags);
 }
 

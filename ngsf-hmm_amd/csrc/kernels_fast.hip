@@ -260,6 +260,7 @@ const SwitchName kSwitches[] = {
     {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
     {"estmaf_exact_lanes", &Switches::estmaf_exact_lanes}, {"exact_bg_waves", &Switches::exact_bg_waves},
     {"exact_bg_depth", &Switches::exact_bg_depth}, {"estmaf_exact_sel", &Switches::estmaf_exact_sel},
+    {"exact_estep_overlap", &Switches::exact_estep_overlap},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}};
 

@@ -30,6 +30,7 @@ struct Switches {
   int estmaf_exact_lanes = 0;   // exact est_maf with a lane per site (measured slower: 4.05 vs 2.38 s): 0 off, 1 on
   int exact_bg_waves = 3;     // exact est_maf underneath the rounds: waves per SIMD (0: all; -1: after them)
   int estmaf_exact_sel = 0;   // exact est_maf on the select forms of det_exp / det_log (same bits; measured 2.62 vs 2.38 s)
+  int exact_estep_overlap = 1;  // exact mode, fused iteration: the E-step next to the first objective rounds
   int exact_bg_depth = 3;     // ... pieces of it queued underneath a round at most
   int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
   int timing = 0;             // host-side phase times of every M-step on stderr

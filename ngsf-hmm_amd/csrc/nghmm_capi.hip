@@ -568,6 +568,9 @@ int nghmm_destroy(nghmm_t* h) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->aux_piece_ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->aux_estep_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->d_aux_params) (void)hipFree(h->d_aux_params);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1247,13 +1250,24 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     // their issue priority, then lose ~8 % -- and whatever is left when the rounds are over
     // runs uncapped on the whole chip.  The emissions are refreshed when both are done.  Same
     // kernels, same data, same bits.
-    if ((rc = nghmm_estep(h, ind_lkl))) return rc;
+    // The E-step, too, is latency-bound chains (one per individual: 32 workgroups), and the
+    // objective rounds need nothing from it -- both read the emissions of the old frequencies
+    // and the current (indF, alpha).  It runs on the second stream NEXT TO the first rounds
+    // (switch exact_estep_overlap; its own copies of indF / alpha, since the M-step uploads the
+    // new ones when it ends; its own error flags and events), est_maf's pieces queue up behind
+    // it, and its fatal conditions are looked at first when everything is done -- the
+    // reference's E-step comes before its M-step (EM.cpp:147-201).
+    const bool overlap_estep = h->fast.sw.exact_estep_overlap != 0;
+    if (!overlap_estep && (rc = nghmm_estep(h, ind_lkl))) return rc;
     if (!h->aux_stream) {
       HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreate(&h->aux_ev0));
       HIP_TRY(hipEventCreate(&h->aux_ev1));
       HIP_TRY(hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
       for (auto& e : h->aux_piece_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (auto& e : h->aux_estep_ev) HIP_TRY(hipEventCreate(&e));
+      if ((rc = dev_alloc(&h->d_aux_params, (size_t)h->I * 2))) return rc;
+      if (!h->d_flags_bg && (rc = dev_alloc(&h->d_flags_bg, (size_t)NFLAGS))) return rc;
     }
     // whatever happens from here on, nothing may be left running on the second stream when
     // this call returns (the caller may destroy the handle or load other data next)
@@ -1263,6 +1277,23 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     } drain{h->aux_stream};
     HIP_TRY(hipEventRecord(h->aux_go, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
+    if (overlap_estep) {
+      hipStream_t as = h->aux_stream;
+      double *aF = h->d_aux_params, *aA = h->d_aux_params + h->I;
+      HIP_TRY(hipMemsetAsync(h->d_flags_bg, 0, NFLAGS * sizeof(int), as));
+      HIP_TRY(hipMemcpyAsync(aF, h->d_indF, h->I * sizeof(double), hipMemcpyDeviceToDevice, as));
+      HIP_TRY(hipMemcpyAsync(aA, h->d_alpha, h->I * sizeof(double), hipMemcpyDeviceToDevice, as));
+      HIP_TRY(hipEventRecord(h->aux_estep_ev[0], as));
+      (h->fast.sw.exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
+          as, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr, aF, aA, h->d_ind_lkl, h->d_fw,
+          h->d_flags_bg);
+      HIP_TRY(hipEventRecord(h->aux_estep_ev[1], as));
+      h->tmp_is_posteriors = false;
+      (h->fast.sw.exact_serial ? launch_backward_exact : launch_backward_exact_pc)(
+          as, h->d_eprob, h->d_pos, h->d_fw, h->S, h->I, aF, aA, h->d_ind_lkl, h->d_marg, h->d_flags_bg);
+      HIP_TRY(hipEventRecord(h->aux_estep_ev[2], as));
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(h->aux_ev0, h->aux_stream));
     constexpr uint32_t kPieces = nghmm_t::kAuxPieces;
     const uint32_t n_pieces = h->S >= 64 * kPieces ? kPieces : 1;
@@ -1294,6 +1325,19 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     HIP_TRY(hipEventElapsedTime(&ms, h->aux_ev0, h->aux_ev1));
     h->ms[SLOT_ESTMAF] = ms;
     h->launches[SLOT_ESTMAF] = 1;
+    if (overlap_estep) {  // the E-step's outcome first, as in the reference's order
+      HIP_TRY(hipEventElapsedTime(&ms, h->aux_estep_ev[0], h->aux_estep_ev[1]));
+      h->ms[SLOT_FORWARD] = ms;
+      h->launches[SLOT_FORWARD] = 1;
+      HIP_TRY(hipEventElapsedTime(&ms, h->aux_estep_ev[1], h->aux_estep_ev[2]));
+      h->ms[SLOT_BACKWARD] = ms;
+      h->launches[SLOT_BACKWARD] = 1;
+      if (ind_lkl)
+        HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                               h->stream));
+      const int rc_e = check_flags(h, h->d_flags_bg);  // synchronises the stream
+      if (rc_e != NGHMM_OK) return rc_e;
+    }
     if (rc != NGHMM_OK) return rc;
     return emission_impl(h);
   }
