@@ -117,6 +117,38 @@ def test_mstep_freq_lane_per_site_kernel_bitwise(pkg, orc_det, shape, packed):
         assert np.array_equal(hmm.freq, em.freq) and np.array_equal(hmm.indF, em.indF)
 
 
+def test_fused_exact_iteration_schedules_give_the_same_bits(pkg, orc_det):
+    """Exact mode's fused iteration (nghmm_iter_em) runs its E-step on a second stream next to the
+    first objective rounds and est_maf underneath the rest in capped pieces; every schedule --
+    E-step first (exact_estep_overlap 0), est_maf after the rounds (exact_bg_waves -1), uncapped
+    (0), other caps and depths -- is the same kernels on the same data: three iterations of each
+    are bit-identical to the oracle's.  Sites enough for the 16 pieces to exist (>= 1024)."""
+    import orclib
+    I, S = 45, 1500
+    d = pkg.simulate.simulate(I, S, seed=61, n_chrom=3, missing_rate=0.05, indF="r")
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    em = orclib.OracleEM(orc_det, gl, d.pos_dist_mb)
+    em.set_params(0.1, 0.2, 0.1)
+    em.init_emission()
+    want = []
+    for _ in range(3):
+        assert em.iterate() == 0
+        want.append((em.ind_lkl.copy(), em.indF.copy(), em.alpha.copy(), em.freq.copy(), em.marg.copy()))
+    for sw in ({}, {"exact_estep_overlap": 0}, {"exact_bg_waves": -1}, {"exact_bg_waves": 0},
+               {"exact_bg_waves": 2, "exact_bg_depth": 1}, {"exact_bg_waves": 4, "exact_bg_depth": 16}):
+        with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT) as hmm:
+            for k, v in sw.items():
+                hmm.set_switch(k, v)
+            hmm.load(gl, d.pos_dist_mb)
+            hmm.set_params(0.1, 0.2, 0.1)
+            hmm.init_emission()
+            for it in range(3):
+                hmm.iter_EM()
+                got = (hmm.ind_lkl, hmm.indF, hmm.alpha, hmm.freq, hmm.marg_prob)
+                for a, b in zip(got, want[it]):
+                    assert np.array_equal(a, b), (sw, it)
+
+
 @pytest.mark.parametrize("fixed", [(False, False), (True, False), (False, True), (True, True)])
 def test_mstep_indf_bitwise(pkg, orc_det, small_sim, fixed):
     d, gl = small_sim
