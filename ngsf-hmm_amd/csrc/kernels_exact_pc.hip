@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 
@@ -358,20 +359,25 @@ static unsigned pc_pad_bytes(unsigned n_workgroups) {
   static const unsigned pad = [] {
     unsigned kb = 24;
     if (const char* env = std::getenv("NGHMM_PC_PAD_KB")) kb = (unsigned)std::atoi(env);
-    if (kb > 96) kb = 96;
-    const unsigned bytes = kb * 1024u;
-    if (bytes) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_exact_pc<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_exact_pc<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_backward_exact_pc),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      (void)hipGetLastError();
-    }
-    return bytes;
+    return (kb > 96 ? 96u : kb) * 1024u;
   }();
-  return n_workgroups <= 200 ? pad : 0u;
+  if (pad == 0 || n_workgroups > 200) return 0u;
+  // more than 64 KB of LDS per workgroup must be allowed per kernel AND per device (a process may
+  // drive several: nghmm_group_*)
+  static std::atomic<uint64_t> allowed{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0u;
+  if (!(allowed.load() >> dev & 1)) {
+    bool ok = true;
+    for (const void* f : {reinterpret_cast<const void*>(k_forward_exact_pc<true>),
+                          reinterpret_cast<const void*>(k_forward_exact_pc<false>),
+                          reinterpret_cast<const void*>(k_backward_exact_pc)})
+      ok = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) == hipSuccess && ok;
+    (void)hipGetLastError();
+    if (!ok) return 0u;
+    allowed.fetch_or(1ull << dev);
+  }
+  return pad;
 }
 
 void launch_forward_exact_pc(hipStream_t st, const double* eprob, const double* pos, uint64_t S,
