@@ -224,60 +224,64 @@ k_forward_exact_pc(const double* __restrict__ eprob, const double* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // backward + posteriors + Fw/Bw check (shared/HMM.cpp:33-60, EM.cpp:166-185), one chain per
 // individual.  Block b of the ring holds the reference sites s = S - (b PC_B + u), u = 0 ..
+// LDS of the backward kernel: the consumer's two inputs per site and lane, and the Bw values it
+// leaves behind for the posteriors (2 x 20 x (2 + 1) x 64 doubles = 60 KB, as before)
+struct BwRing {
+  double in[2][PC_B][2][64];
+  double out[2][PC_B][64];
+};
+
 __global__ void __launch_bounds__(PC_THREADS)
 k_backward_exact_pc(const double* __restrict__ eprob, const double* __restrict__ pos,
                     const double* __restrict__ fw, uint64_t S, uint64_t I,
                     const double* __restrict__ indF, const double* __restrict__ alpha,
                     const double* __restrict__ ind_lkl, double* __restrict__ marg,
                     int* __restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) Ring ring;
+  __shared__ __attribute__((aligned(16))) BwRing ring;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const uint64_t nblk = (S + PC_B - 1) / PC_B;
   const double2* e2 = reinterpret_cast<const double2*>(eprob);
   const double2* f2 = reinterpret_cast<const double2*>(fw);
 
+  // Three roles over the steps 0 .. nblk + 1 (one barrier per step): the producers fill block
+  // `step`, the consumer walks block step - 1, and the producers -- who have time to spare --
+  // turn the Bw values the consumer left of block step - 2 into posteriors.  (Round 3's consumer
+  // formed the posterior itself: a det_exp that is not on the recursion's dependency chain but
+  // shares the one wave's issue slots with it: 0.60 us per site against the forward sweep's 0.34.)
   if (tid < 64) {
     // ---- consumer: lane 2c + k is state k of individual c's Bw ----
     __builtin_amdgcn_s_setprio(3);
     const int k = lane & 1;
     uint64_t i = (uint64_t)blockIdx.x * PC_CH + (lane >> 1);
-    const bool valid = i < I;
-    if (!valid) i = I - 1;
+    if (i >= I) i = I - 1;
     const double f = indF[i];
-    const double lkl = ind_lkl[i];
     double own = det_log(1.0), oth = det_log(1.0);  // Bw[S][k], Bw[S][1 - k]   (HMM.cpp:37)
     int bad = 0;
-    bool nanflag = false;
-    double A, B, Fk;  // the site's ring entries, read one site ahead
-    auto site = [&](const double* rn, uint64_t s) {  // s: reference site number
-      const double a = A, b = B, fk = Fk;
+    double A, B;  // the site's ring entries, read one site ahead
+    auto site = [&](const double* rn, double* wo) {
+      const double a = A, b = B;
       A = rn[0];
       B = rn[64];
-      Fk = rn[128];
-      // posterior of state k at site s (EM.cpp:184); k = 0 only for its NaN check
-      const double m = check_interv(det_exp_sel(own + fk - lkl), nanflag);
-      if (valid && k == 1) marg[(s - 1) * I + i] = m;
+      *wo = own;  // Bw[s][k]: the posterior of site s is the producers' (EM.cpp:184)
       // Bw[s-1][k] = logsum_l(log T_s(k, l) + e[s][l] + Bw[s][l])   (HMM.cpp:40-52)
       const double nb = chain_logsum(a + own, b + oth, k, bad);
       own = nb;
       oth = pair_swap(nb);
     };
-    for (uint64_t step = 0; step <= nblk; ++step) {
-      if (step >= 1) {
+    for (uint64_t step = 0; step <= nblk + 1; ++step) {
+      if (step >= 1 && step <= nblk) {
         const uint64_t r0 = (step - 1) * PC_B;
-        const double* rb = &ring[(step - 1) & 1][0][0][lane];
+        const double* rb = &ring.in[(step - 1) & 1][0][0][lane];
+        double* wb = &ring.out[(step - 1) & 1][0][lane];
         A = rb[0];
         B = rb[64];
-        Fk = rb[128];
         if (S - r0 >= (uint64_t)PC_B) {
 #pragma unroll 4
-          for (int u = 0; u < PC_B; ++u)
-            site(rb + (u + 1 < PC_B ? u + 1 : u) * (PC_PLANES * 64), S - (r0 + u));
+          for (int u = 0; u < PC_B; ++u) site(rb + (u + 1 < PC_B ? u + 1 : u) * (2 * 64), wb + u * 64);
         } else {
           const int ns = (int)(S - r0);
-          for (int u = 0; u < ns; ++u)
-            site(rb + (u + 1 < ns ? u + 1 : u) * (PC_PLANES * 64), S - (r0 + u));
+          for (int u = 0; u < ns; ++u) site(rb + (u + 1 < ns ? u + 1 : u) * (2 * 64), wb + u * 64);
         }
       }
       __syncthreads();
@@ -292,17 +296,19 @@ k_backward_exact_pc(const double* __restrict__ eprob, const double* __restrict__
     const double adiff = (diff >= 0) ? diff : -diff;  // the reference's abs macro
     if (adiff > 0.001) flags[FLAG_FW_BW] = 1;         // EM.cpp:167
     if (bad) flags[FLAG_INVALID_LKL] = 1;
-    if (nanflag) flags[FLAG_NAN] = 1;
   } else {
     // ---- producers ----
     const int pl = tid - 64;
     const int c = pl % PC_CH, so = pl / PC_CH;
     uint64_t i = (uint64_t)blockIdx.x * PC_CH + c;
-    if (i >= I) i = I - 1;
-    const double f = indF[i], a = alpha[i];
+    const bool vi = i < I;
+    if (!vi) i = I - 1;
+    const double f = indF[i], a = alpha[i], lkl = ind_lkl[i];
     const double q0 = 1 - f, q1 = f;
     double dn[PC_ITEMS];
     double2 en[PC_ITEMS], fn[PC_ITEMS];
+    double2 fh[2][PC_ITEMS];  // Fw of the items of the last two blocks produced (by step parity)
+    bool nanflag = false;
     auto fetch = [&](uint64_t blk) {
 #pragma unroll
       for (int k = 0; k < PC_ITEMS; ++k) {
@@ -314,16 +320,38 @@ k_backward_exact_pc(const double* __restrict__ eprob, const double* __restrict__
         fn[k] = v ? f2[s * I + i] : double2{0, 0};
       }
     };
+    // posteriors of block `blk` (produced two steps ago: its Fw values are in fh[blk & 1])
+    auto finish = [&](uint64_t blk, const double2 (&fw_of)[PC_ITEMS]) {
+#pragma unroll
+      for (int k = 0; k < PC_ITEMS; ++k) {
+        const int u = so + k * PC_SSTRIDE;
+        const uint64_t r = blk * PC_B + u;
+        if (r < S) {
+          const uint64_t s = S - r;
+          const double2 bw = *reinterpret_cast<const double2*>(&ring.out[blk & 1][u][2 * c]);
+          // marg_prob[i][s][k] = check_interv(exp(Fw + Bw - lkl)) (EM.cpp:184); state 0 only
+          // for its NaN check
+          (void)check_interv(det_exp_sel(bw.x + fw_of[k].x - lkl), nanflag);
+          const double m1 = check_interv(det_exp_sel(bw.y + fw_of[k].y - lkl), nanflag);
+          if (vi) marg[(s - 1) * I + i] = m1;
+        }
+      }
+    };
     fetch(0);
-    for (uint64_t step = 0; step <= nblk; ++step) {
+    for (uint64_t step = 0; step <= nblk + 1; ++step) {
+      if (step >= 2) {
+        if (step & 1) finish(step - 2, fh[1]);
+        else finish(step - 2, fh[0]);
+      }
       if (step < nblk) {
         double dc[PC_ITEMS];
-        double2 ec[PC_ITEMS], fc[PC_ITEMS];
+        double2 ec[PC_ITEMS];
 #pragma unroll
         for (int k = 0; k < PC_ITEMS; ++k) {
           dc[k] = dn[k];
           ec[k] = en[k];
-          fc[k] = fn[k];
+          if (step & 1) fh[1][k] = fn[k];
+          else fh[0][k] = fn[k];
         }
         if (step + 1 < nblk) fetch(step + 1);
 #pragma unroll
@@ -331,18 +359,18 @@ k_backward_exact_pc(const double* __restrict__ eprob, const double* __restrict__
           const int u = so + k * PC_SSTRIDE;
           if (step * PC_B + u < S) {
             const Trans t = calc_trans_sel(q0, q1, a, dc[k]);
-            double* w = &ring[step & 1][u][0][2 * c];
+            double* w = &ring.in[step & 1][u][0][2 * c];
             // lane k's term through its own state, t[k][k] + e_k, and through the other one,
             // t[k][1-k] + e_(1-k) (HMM.cpp:44-45: the reference adds the transition and the
             // emission first, then Bw)
             *reinterpret_cast<double2*>(w) = double2{t.t00 + ec[k].x, t.t11 + ec[k].y};
             *reinterpret_cast<double2*>(w + 64) = double2{t.t01 + ec[k].y, t.t10 + ec[k].x};
-            *reinterpret_cast<double2*>(w + 128) = fc[k];
           }
         }
       }
       __syncthreads();
     }
+    if (nanflag) flags[FLAG_NAN] = 1;
   }
 }
 
