@@ -323,3 +323,32 @@ def test_bench_four_ranks_on_the_full_workload_reproduce_the_one_gpu_job(pkg):
     assert out["value"] > 0 and out["parity"]["per_call"].startswith("1e-9")
     print(json.dumps({k: out[k] for k in ("value", "ms_per_step", "exchange_ms", "collectives")}),
           json.dumps({k: alt[k] for k in ("value", "ms_per_step", "exchange_ms")}))
+
+
+def test_bench_config5_shape_two_ranks_reproduce_the_one_gpu_job(pkg):
+    """BASELINE configs[4]'s shape through bench.py -- 5000 individuals, 25 chromosomes, --call_geno
+    (2-bit packed handles, the called genotypes' closed-form frequency step over all 5000) -- at
+    200 000 sites: two ranks (gloo on one GPU) as site shards and, embedded, as individual shards
+    (genotype codes exchanged once, posteriors every iteration) give the one-GPU line's `check`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
+
+    def run(*extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--n_sites", "200000",
+               "--steps", "2", "--warmup", "1", "--no_cpu_baseline", *extra]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    one, two = run(), run("--gpus", "2")
+    assert "packed" in one["config"]["workload"] and one["config"]["n_ind_total"] == 5000
+    assert two["config"]["n_sites_per_gpu"] == 100_000 and two["config"]["sharding"].startswith("sites:")
+    alt = two["alt_sharding"]
+    assert alt["sharding"] == "individuals" and alt["n_ind_per_gpu"] == 2500 and "skipped" not in alt
+    for name, chk in (("site shards", two["check"]), ("individual shards", alt["check"])):
+        d = bench.compare_checks(chk, one["check"])
+        print(name, "vs N=1:", json.dumps(d))
+        assert d["tot_lkl_max_rel_diff"] <= 1e-12 and d["freq_probe_max_rel_diff"] <= 1e-9
+        assert d["freq_weighted_sum_rel_diff"] <= 1e-9 and d["rounds_equal"], d
