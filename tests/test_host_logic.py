@@ -158,3 +158,55 @@ def test_bench_check_comparison():
     ref = json.load(open(bench.CHECK_REF))                     # the committed one-GPU reference
     key = "c3:fast:1000x1000000:gl"
     assert key in ref and ref[key]["iterations"] == 2 and len(ref[key]["freq_probes"]) == 16
+
+
+def test_bench_shard_shapes_cover_the_job_exactly_once(pkg):
+    """bench.shard_shapes: what every rank of an N-rank job holds under either layout -- the
+    ranks' slices of IndexedSim(I_tot, S_job) tile the one-GPU job's data set exactly (strong
+    scaling), or N times the workload (weak), and a size that does not divide is refused."""
+    import importlib
+    import os
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dd = importlib.import_module("ngsf-hmm_amd.distributed")
+
+    def shapes(world, shard, scaling="strong", I=1000, S=1_000_000, V=1, call_geno=False):
+        out = []
+        for rank in range(world):
+            ctx = types.SimpleNamespace(
+                args=types.SimpleNamespace(emulate_ranks=V, scaling=scaling, workload="c3"),
+                wl=dict(n_ind=I, n_sites=S), world=world, rank=rank, dd=dd, call_geno=call_geno)
+            out.append(bench.shard_shapes(ctx, shard))
+        return out
+
+    for world in (1, 2, 4, 8):
+        for shard in ("sites", "individuals"):
+            sh = shapes(world, shard if world > 1 else None)
+            assert all(s["I_tot"] == 1000 and s["S_job"] == 1_000_000 for s in sh)
+            for s in sh:
+                (i0, i1), (s0, s1) = s["ind_range"], s["site_range"]
+                assert s["I"] == i1 - i0 and s["S"] == s1 - s0 and s["I"] > 0 and s["S"] > 0
+            if shard == "sites" and world > 1:      # contiguous site ranges, all individuals each
+                assert [s["ind_range"] for s in sh] == [(0, 1000)] * world
+                cuts = [s["site_range"] for s in sh]
+                assert cuts[0][0] == 0 and cuts[-1][1] == 1_000_000
+                assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+            else:                                   # contiguous individual ranges, all sites each
+                assert [s["site_range"] for s in sh] == [(0, 1_000_000)] * world
+                cuts = [s["ind_range"] for s in sh]
+                assert cuts[0][0] == 0 and cuts[-1][1] == 1000
+                assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+    weak = shapes(4, "sites", "weak")
+    assert weak[0]["S_job"] == 4_000_000 and weak[3]["site_range"][1] == 4_000_000 and weak[0]["I"] == 1000
+    weak = shapes(4, "individuals", "weak")
+    assert weak[0]["I_tot"] == 4000 and weak[3]["ind_range"] == (3000, 4000) and weak[0]["S"] == 1_000_000
+    with pytest.raises(ValueError):
+        shapes(2, "individuals", I=63, S=20_000)
+    with pytest.raises(ValueError):                          # 5000 x 5M unpacked does not fit one GPU
+        shapes(1, None, I=5000, S=5_000_000)
+    assert shapes(8, "sites", I=5000, S=5_000_000, call_geno=True)[0]["S"] == 625_000
+    # an emulated rank of eight: the first range of eight, not an eighth of one rank's
+    em = shapes(1, "sites", V=8)[0]
+    assert em["site_range"][0] == 0 and abs(em["S"] - 125_000) <= 16 and em["S_job"] == 1_000_000
