@@ -206,7 +206,7 @@ def test_bench_shard_shapes_cover_the_job_exactly_once(pkg):
         shapes(2, "individuals", I=63, S=20_000)
     with pytest.raises(ValueError):                          # 5000 x 5M unpacked does not fit one GPU
         shapes(1, None, I=5000, S=5_000_000)
-    assert shapes(8, "sites", I=5000, S=5_000_000, call_geno=True)[0]["S"] == 625_000
+    assert abs(shapes(8, "sites", I=5000, S=5_000_000, call_geno=True)[0]["S"] - 625_000) <= 16
     # an emulated rank of eight: the first range of eight, not an eighth of one rank's
     em = shapes(1, "sites", V=8)[0]
     assert em["site_range"][0] == 0 and abs(em["S"] - 125_000) <= 16 and em["S_job"] == 1_000_000
