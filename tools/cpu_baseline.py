@@ -5,7 +5,7 @@ BASELINE.json configs[1] in full (100 x 100k) and on a 1000 x 10k slice of confi
 linear in individuals x sites), with the per-individual phases on all cores and on one thread
 -- the allele-frequency loop is serial in the reference (EM.cpp:224) and stays serial -- and,
 labelled as such, the "improved CPU" with that loop threaded over sites too.  Timed region: EM
-iterations only.  Prints one JSON object (committed as profiles/r03_cpu_baseline.json, which
+iterations only.  Prints one JSON object (committed as profiles/r04_cpu_baseline.json, which
 bench.py's cpu_baseline cites).
 
   python tools/cpu_baseline.py [--quick]        (about four minutes on a 256-thread host)
