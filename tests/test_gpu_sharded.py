@@ -110,8 +110,6 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["scaling"] == "strong"
     assert two["config"]["n_ind_total"] == 64 and two["config"]["n_ind_per_gpu"] == 32
     assert "gloo" in two["collectives"] and two["value"] > 0
-    weak = run("--gpus", "2", "--scaling", "weak", "--shard", "individuals")
-    assert weak["config"]["n_ind_total"] == 128 and weak["scaling"] == "weak"
     # the default in fast mode: SITE shards -- every rank all 64 individuals for half the sites,
     # one small all-gather per E-step and per objective round, nothing for the frequency step
     st = run("--gpus", "2")
@@ -136,10 +134,9 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert sw["config"]["n_sites"] == 2 * one["config"]["n_sites"] and sw["config"]["n_ind_total"] == 64
     # BASELINE configs[4]'s path at smoke size: --call_geno, 2-bit packed handles, the site
     # shards built from exchanged genotype codes
-    cg = run("--gpus", "2", "--shard", "individuals", workload="tinycg")
-    assert cg["n_gpus"] == 2 and cg["value"] > 0 and "packed" in cg["config"]["workload"]
-    cg = run("--gpus", "2", workload="tinycg")           # ... and as site shards
+    cg = run("--gpus", "2", workload="tinycg")           # site shards, and individual shards as `alt_sharding`
     assert cg["n_gpus"] == 2 and cg["value"] > 0 and cg["config"]["sharding"].startswith("sites:")
+    assert "packed" in cg["config"]["workload"] and cg["alt_sharding"]["vs_main_sharding"]["ok"] is True
     # a rank count that does not match --gpus is an error, not a silent N = 1 run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
                           "--workload", "tiny", "--no_cpu_baseline"],
