@@ -186,6 +186,13 @@ typedef double (*nghmm_objective_fn)(uint32_t ind, double F, double alpha, void*
 int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
                           int alpha_fixed, nghmm_objective_fn fn, void* user,
                           nghmm_mstep_stats* stats);
+/* The same with flags: 1 = the finite-difference step eh = (1e-8 (|x| + 1))^0.67
+ * (shared/bfgs.cpp:33) by the library's own exp / log instead of libm's pow (what fast mode
+ * uses: host and device then agree bit for bit); 2 = run the solver type the device runs
+ * (kernels_bfgs.hip), one problem after the other.  Test hook: both give identical bits. */
+int nghmm_bfgs_batch_host2(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
+                           int alpha_fixed, nghmm_objective_fn fn, void* user,
+                           nghmm_mstep_stats* stats, int flags);
 
 /* Allele-frequency M-step + emission refresh (EM.cpp:210-272; est_maf,
  * shared/gen_func.cpp:974-1009).  freq_est 0 = keep, 1 = per-site EM,
@@ -410,7 +417,9 @@ int nghmm_synchronize(nghmm_t* h);
  * 0 emission, 1 forward(store), 2 backward+posterior, 3 lkl_batch (sum over rounds of
  * the last mstep_indf or the last lkl_batch call), 4 est_maf+emission, 5 viterbi, 6 the
  * part of slot 3 spent in the round that doubled as the E-step's forward walk
- * (nghmm_estep_mstep).  Also the launch count behind each slot. */
+ * (nghmm_estep_mstep), 7 the kernels that advance the L-BFGS-B machines on the device between
+ * two rounds (fast mode; 0 where the host advances them).  Also the launch count behind each
+ * slot. */
 int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches);
 
 #ifdef __cplusplus

@@ -12,9 +12,6 @@
 namespace nghmm {
 
 namespace {
-constexpr double kINF = 1e15;  // shared/gen_func.hpp:15
-inline bool same_bits(const double* a, const double* b) { return std::memcmp(a, b, 16) == 0; }
-inline bool nonfinite(double v) { return std::isnan(v) || std::isinf(v); }
 
 // Host threads for the per-individual state machines (independent problems).  Bounded:
 // an 8-GPU node runs eight of these processes side by side.  NGHMM_HOST_THREADS overrides.
@@ -71,72 +68,20 @@ void BfgsBatch::begin(uint64_t n_ind, const double* indF, const double* alpha, b
   for (uint64_t i = 0; i < n_ind; ++i) {
     Problem& p = probs_[i];
     p.solver.configure(2, 10);  // MVAL, shared/bfgs.h:23; start() zeroes the work arrays
-    p.x[0] = indF[i];
-    p.x[1] = alpha[i];
-    // EM.cpp:424-436
-    p.lb[0] = 1 / kINF;
-    p.lb[1] = 1 / kINF;
-    p.ub[0] = 1 - p.lb[0];
-    p.ub[1] = 10;
-    if (F_fixed) p.lb[0] = p.ub[0] = indF[i];
-    if (alpha_fixed) p.lb[1] = p.ub[1] = alpha[i];
-    p.like = 0;
-    p.n_rounds = 0;
-    p.grad[0] = p.grad[1] = 0;
-    p.have_eval = false;
-    p.started = false;
-    p.active = true;
+    bfgs_problem_begin(p.p, indF[i], alpha[i], F_fixed, alpha_fixed);
   }
 }
 
 // The points one objective + gradient evaluation needs (bfgs.cpp:22-43,54).
 void BfgsBatch::plan(Problem& p) {
-  for (int k = 0; k < 5; ++k) p.slot_used[k] = false;
-  p.pt[0][0] = p.x[0];
-  p.pt[0][1] = p.x[1];
-  p.slot_used[0] = true;
-  for (int i = 0; i < 2; ++i) {
-    const int sa = 1 + 2 * i, sb = 2 + 2 * i;
-    if (p.lb[i] == p.ub[i]) {
-      // Fixed parameter: the reference still spends one probe on it, but the
-      // bound check (bfgs.cpp:58-63) then forces the component to zero.
-      p.probe_kind[i] = 3;
-      continue;
-    }
-    const double eh = std::pow(1.e-8 * (std::fabs(p.x[i]) + 1), 0.67);
-    p.eh[i] = eh;
-    double x0 = p.x[i], x1 = p.x[i];
-    x0 -= eh;
-    x1 += eh;
-    for (int k = sa; k <= sb; ++k) {
-      p.pt[k][0] = p.x[0];
-      p.pt[k][1] = p.x[1];
-    }
-    if (x0 < p.lb[i]) {
-      x1 += eh;
-      p.probe_kind[i] = 1;
-      p.pt[sa][i] = x1;
-      p.slot_used[sa] = true;
-    } else if (x1 > p.ub[i]) {
-      x0 -= eh;
-      p.probe_kind[i] = 2;
-      p.pt[sa][i] = x0;
-      p.slot_used[sa] = true;
-    } else {
-      p.probe_kind[i] = 0;
-      p.pt[sa][i] = x1;
-      p.pt[sb][i] = x0;
-      p.slot_used[sa] = p.slot_used[sb] = true;
-    }
-  }
-  for (int k = 0; k < 5; ++k)
-    p.slot_nonfinite[k] = p.slot_used[k] && (nonfinite(p.pt[k][0]) || nonfinite(p.pt[k][1]));
+  if (det_pow_) bfgs_plan<DetPow>(p.p);
+  else bfgs_plan<LibmPow>(p.p);
 }
 
 uint64_t BfgsBatch::active_in(uint64_t lo, uint64_t hi) const {
   if (hi > probs_.size()) hi = probs_.size();
   uint64_t n = 0;
-  for (uint64_t i = lo; i < hi; ++i) n += probs_[i].active ? 1 : 0;
+  for (uint64_t i = lo; i < hi; ++i) n += probs_[i].p.active ? 1 : 0;
   return n;
 }
 
@@ -152,10 +97,10 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
   if (n_act == 0) return 0;
 #pragma omp parallel for schedule(static) num_threads(host_threads(n_act))
   for (int64_t i = (int64_t)lo; i < (int64_t)hi; ++i)
-    if (probs_[i].active) plan(probs_[i]);
+    if (probs_[i].p.active) plan(probs_[i]);
   for (int k = 0; k < 5; ++k) {
     for (size_t i = lo; i < hi; ++i) {
-      Problem& p = probs_[i];
+      BfgsProblem& p = probs_[i].p;
       if (!p.active || !p.slot_used[k] || p.slot_nonfinite[k]) continue;
       p.slot_pos[k] = (uint32_t)ind.size();
       ind.push_back((uint32_t)i);
@@ -167,7 +112,7 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
   // lock-step rounds when every gather covers everybody, and the same figure when the
   // individuals are gathered in parts (two-lane M-step), whatever the number of launches
   for (size_t i = lo; i < hi; ++i) {
-    Problem& p = probs_[i];
+    BfgsProblem& p = probs_[i].p;
     if (!p.active) continue;
     if (++p.n_rounds > rounds_) rounds_ = p.n_rounds;
   }
@@ -177,69 +122,14 @@ size_t BfgsBatch::gather(std::vector<uint32_t>& ind, std::vector<double>& F,
 }
 
 void BfgsBatch::consume(Problem& p, const double* lkl, uint64_t& ref_calls, uint64_t& finished) {
-  // objective = -forward log-likelihood; non-finite parameters give -INF... i.e.
-  // lkl = INF and the function returns -lkl (EM.cpp:454-463)
-  double fv[5] = {0, 0, 0, 0, 0};
-  for (int k = 0; k < 5; ++k) {
-    if (!p.slot_used[k]) continue;
-    fv[k] = p.slot_nonfinite[k] ? -kINF : -lkl[p.slot_pos[k]];
-  }
-  const double f0 = fv[0];
-  p.like = fv[0];
-  uint64_t calls = 2;  // fun(x) in findmax_bfgs + fun(x) again inside getgradient
-  for (int i = 0; i < 2; ++i) {
-    const int sa = 1 + 2 * i, sb = 2 + 2 * i;
-    double g;
-    switch (p.probe_kind[i]) {
-      case 0:
-        g = (fv[sa] - fv[sb]) / (p.eh[i] * 2.0);
-        calls += 2;
-        break;
-      case 1:
-        g = (fv[sa] - f0) / (p.eh[i] * 2.0);
-        calls += 1;
-        break;
-      case 2:
-        g = (f0 - fv[sa]) / (p.eh[i] * 2.0);
-        calls += 1;
-        break;
-      default:
-        g = 0.0;
-        calls += 1;
-        break;
-    }
-    if (p.x[i] <= p.lb[i] && g > 0.0) g = 0.0;  // bfgs.cpp:58-63
-    if (p.x[i] >= p.ub[i] && g < 0.0) g = 0.0;
-    p.grad[i] = g;
-  }
-  ref_calls += calls;
-  p.eval_x[0] = p.x[0];
-  p.eval_x[1] = p.x[1];
-  p.have_eval = true;
-
-  if (!p.started) {
+  double lklv[5] = {0, 0, 0, 0, 0};
+  for (int k = 0; k < 5; ++k)
+    if (p.p.slot_used[k] && !p.p.slot_nonfinite[k]) lklv[k] = lkl[p.p.slot_pos[k]];
+  const bool again = bfgs_consume(p.p, p.solver, lklv, ref_calls, [&](BfgsProblem& q) {
     const int nbd[2] = {2, 2};
-    p.solver.start(p.x, p.lb, p.ub, nbd, 1.0e6, 1.0e-3);  // FACTR, PGTOL: bfgs.h:24-25
-    p.started = true;
-  }
-  for (;;) {
-    const Lbfgsb::Task task = p.solver.advance(&p.like, p.grad);
-    p.x[0] = p.solver.x()[0];
-    p.x[1] = p.solver.x()[1];
-    if (task == Lbfgsb::Task::EvalFG) {
-      if (p.have_eval && same_bits(p.x, p.eval_x)) {
-        // the START call asks for f and g at the point just evaluated
-        // (bfgs.cpp:901,114-121): same x, same values.
-        ref_calls += calls;
-        continue;
-      }
-      return;  // wants a new round
-    }
-    if (task == Lbfgsb::Task::NewX) continue;
-    p.active = false;
-    ++finished;
-    return;
-  }
+    p.solver.start(q.x, q.lb, q.ub, nbd, 1.0e6, 1.0e-3);  // FACTR, PGTOL: bfgs.h:24-25
+  });
+  if (!again) ++finished;
 }
 
 void BfgsBatch::scatter(const double* lkl, uint64_t lo, uint64_t hi) {
@@ -258,15 +148,15 @@ void BfgsBatch::scatter(const double* lkl, uint64_t lo, uint64_t hi) {
   if (nt > max_threads_) nt = max_threads_;
 #pragma omp parallel for schedule(static) reduction(+ : ref_calls, finished) num_threads(nt)
   for (int64_t i = (int64_t)lo; i < (int64_t)hi; ++i)
-    if (probs_[i].active) consume(probs_[i], lkl, ref_calls, finished);
+    if (probs_[i].p.active) consume(probs_[i], lkl, ref_calls, finished);
   ref_calls_ += ref_calls;
   n_active_ -= finished;
 }
 
 void BfgsBatch::result(double* indF, double* alpha) const {
   for (size_t i = 0; i < probs_.size(); ++i) {
-    indF[i] = probs_[i].x[0];
-    alpha[i] = probs_[i].x[1];
+    indF[i] = probs_[i].p.x[0];
+    alpha[i] = probs_[i].p.x[1];
   }
 }
 

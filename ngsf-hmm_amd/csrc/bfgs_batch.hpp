@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "bfgs_problem.hpp"
 #include "lbfgsb.hpp"
 
 namespace nghmm {
@@ -41,6 +42,9 @@ class BfgsBatch {
   void reserve(uint64_t n_ind);
   // host threads one M-step may use (1: a handle that runs next to others of its process)
   void set_max_threads(int n) { max_threads_ = n < 1 ? 1 : n; }
+  // getgradient's step size by detmath's exp / log instead of libm's pow (bfgs_problem.hpp):
+  // fast mode, where the device advances the same machines (kernels_bfgs.hip)
+  void set_det_pow(bool on) { det_pow_ = on; }
   bool done() const { return n_active_ == 0; }
   uint64_t active_in(uint64_t lo, uint64_t hi) const;
   void result(double* indF, double* alpha) const;
@@ -53,24 +57,12 @@ class BfgsBatch {
  private:
   struct Problem {
     Lbfgsb solver;
-    double x[2], lb[2], ub[2];
-    double like, grad[2];
-    double eval_x[2];   // where (like, grad) were last evaluated
-    bool have_eval = false;
-    bool started = false;
-    bool active = true;
-    uint32_t n_rounds = 0;  // rounds this problem has had points in
-    // plan of the current round
-    int probe_kind[2];  // 0 central, 1 forward (x + 2eh), 2 backward (x - 2eh), 3 fixed (skipped)
-    double eh[2];
-    double pt[5][2];    // slot 0 = x; slots 1,2 = param 0 probes; 3,4 = param 1 probes
-    bool slot_used[5];
-    bool slot_nonfinite[5];
-    uint32_t slot_pos[5];
+    BfgsProblem p;   // bfgs_problem.hpp: the part the device runs too
   };
   std::vector<Problem> probs_;
   uint64_t n_active_ = 0;
   int max_threads_ = 64;      // set_max_threads
+  bool det_pow_ = false;      // set_det_pow
   uint32_t rounds_ = 0;
   uint64_t points_ = 0, ref_calls_ = 0, ind_rounds_ = 0;
 

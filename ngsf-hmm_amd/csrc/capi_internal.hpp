@@ -45,7 +45,7 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 enum Slot { SLOT_EMISSION = 0, SLOT_FORWARD = 1, SLOT_BACKWARD = 2, SLOT_LKL = 3, SLOT_ESTMAF = 4,
-            SLOT_VITERBI = 5, SLOT_LKL_FIRST = 6, NSLOTS = 7 };
+            SLOT_VITERBI = 5, SLOT_LKL_FIRST = 6, SLOT_BFGS = 7, NSLOTS = 8 };
 
 }  // namespace capi
 
@@ -159,8 +159,8 @@ struct nghmm_handle {
   bool marg_valid = false;
 
   std::vector<double> h_indF, h_alpha;
-  double ms[NSLOTS] = {0, 0, 0, 0, 0, 0, 0};
-  uint32_t launches[NSLOTS] = {0, 0, 0, 0, 0, 0, 0};
+  double ms[NSLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t launches[NSLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace capi {

@@ -26,7 +26,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define NGH_HD __host__ __device__ __forceinline__
+#define NGH_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define NGH_HD static inline
 #endif

@@ -225,6 +225,55 @@ __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small, bool 
          (uint32_t)na;
 }
 
+// Recognise the finite-difference pattern of one objective + gradient evaluation
+// (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
+// close enough for exp_small<4> (or <2>) on every finite distance of this data set.
+__host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits,
+                           bool allow_xdeg2) {
+  if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
+  int nf = 0, na = 0;
+  bool ownex = false;
+  double xmax = 0;  // largest |alpha_0 - alpha_probe| d over the data's finite distances
+  for (uint32_t p = 1; p < G.np; ++p) {
+    if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
+      if (na) return 0;  // F probes come first
+      // The pattern kernel rescales all points by point 0's exponent.  A site that forces
+      // the non-IBD state (a called heterozygote: e1 = 0) multiplies an F probe's operator by
+      // rho0 = (1 - F_p) / (1 - F_0) relative to point 0's; with F_0 at its upper bound that
+      // is ~1e10 per such site and would overflow within a lane-chunk.  For called genotypes
+      // (packed handles: such sites exist by construction) keep rho0^T inside the double
+      // range, else the general kernel (an exponent per point) takes the group.  Likelihood
+      // data have no forced visits; should a probe overflow there all the same, its value
+      // comes back non-finite and the host re-evaluates it with the general kernel.
+      const double rho0 = (1 - G.F[p]) / (1 - G.F[0]);
+      if (forced_visits && !(fabs(log(rho0)) * (double)T <= 600.0)) {
+        // ... or, where the probe stays in range over the eight sites between two rescales
+        // (always, with F inside [1e-15, 1 - 1e-15]), the pattern kernel with an exponent per
+        // point: the shared transition terms are still formed once per site
+        if (!(fabs(log(rho0)) * 8.0 <= 600.0)) return 0;
+        ownex = true;
+      }
+      ++nf;
+    } else if (G.F[p] == G.F[0] && fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
+      ++na;
+      xmax = fmax(xmax, fabs(G.A[p] - G.A[0]) * dmax);
+    } else {
+      return 0;
+    }
+  }
+  const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
+                  (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
+  if (!ok) return 0;
+  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625, allow_xdeg2 && na > 0 && xmax <= 1e-5) |
+         (ownex ? FD_OWNEX : 0u);
+}
+
+// compact index of a mode (0 = general): the device-planned rounds keep one worklist per mode
+constexpr uint32_t kModeSlots = 1 + 8 * 16;
+__host__ __device__ constexpr uint32_t mode_slot(uint32_t mode) {
+  return mode == 0 ? 0u : 1u + ((mode >> 9) & 7u) * 16u + (mode & 15u);
+}
+
 // Where a forward walk gets its per-site inputs from.  Plain: the materialised emission
 // ratios e_il.  Fresh: the first walk after an allele-frequency update computes the
 // emissions itself from the interleaved linear genotype likelihoods and the new

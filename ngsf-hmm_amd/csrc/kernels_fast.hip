@@ -262,7 +262,7 @@ const SwitchName kSwitches[] = {
     {"exact_bg_depth", &Switches::exact_bg_depth}, {"estmaf_exact_sel", &Switches::estmaf_exact_sel},
     {"exact_estep_overlap", &Switches::exact_estep_overlap},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
-    {"debug_modes", &Switches::debug_modes}};
+    {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs}};
 
 }  // namespace
 
@@ -393,6 +393,7 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
 }
 
 void fast_destroy(FastState& fs) {
+  dbfgs_destroy(fs);
   void* run[] = {fs.e_il, fs.base_c, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.lanes[0].part,
                  fs.lanes[0].grp_dev, fs.lanes[1].part, fs.lanes[1].grp_dev, fs.redo, fs.est_status,
                  fs.est_state, fs.shard.edges};

@@ -35,6 +35,7 @@ struct Switches {
   int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
   int timing = 0;             // host-side phase times of every M-step on stderr
   int debug_modes = 0;        // kernel versions of every objective round on stderr
+  int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
   static Switches from_env();
   // false: no switch of that name
   bool set(const char* name, long value);
@@ -105,6 +106,34 @@ struct FastState {
   LklLane lanes[2];
   int cur_lane = 0;
 
+  // indF / alpha M-step advanced on the device (kernels_bfgs.hip): the per-individual problems
+  // and solvers, the group descriptors of the round being planned (by individual), one worklist
+  // per loop-body version + one of everybody, the objective values at [individual * 5 + slot].
+  // The kernel that plans a round publishes (round, number of active individuals, modes and
+  // their counts) in pinned host memory, which the host polls -- no copy, no event.
+  struct DevBfgs {
+    static constexpr uint32_t kRing = 4;           // control slots, by round % kRing
+    static constexpr uint32_t kTableWords = 4 + 2 * 129;
+    uint64_t cap_I = 0;
+    void* prob = nullptr;        // BfgsProblem [I]
+    void* solver = nullptr;      // LbfgsbT<PtrStore> [I]: the saved scalars
+    double* arrays = nullptr;    // [I][LbfgsbPtrs::doubles(2, 10)]: the solvers' work arrays
+    void* groups = nullptr;      // GroupDesc [I], by individual
+    uint32_t* last_mode = nullptr;   // [I]: the mode an individual's points were last evaluated by
+    uint32_t* worklists = nullptr;   // [kRing % 2 ... ][kModeSlots][I]: two sets, by round parity
+    uint32_t* all = nullptr;         // [2][I]
+    uint32_t* counts = nullptr;      // [kRing][kModeSlots + 3]: per-mode counts, all, tickets
+    unsigned long long* stats = nullptr;  // points, ref_calls, ind_rounds, rounds
+    double* lkl = nullptr;           // [5 I]
+    double* part = nullptr;          // [I][C][MAXP][5]
+    double *new_F = nullptr, *new_A = nullptr;  // [I]: results (the E-step still reads the old ones)
+    int* flags = nullptr;            // [NFLAGS]
+    volatile uint32_t* h_table = nullptr;  // pinned, [kRing][kTableWords]: seq, n_active, n_modes, pad, (mode, count)...
+    unsigned long long* h_stats = nullptr;  // pinned [4]
+    int* h_flags = nullptr;          // pinned [NFLAGS]
+    uint32_t seq_base = 0;           // rounds of earlier M-steps (the published sequence numbers go on)
+  } dev;
+
   double dmax_finite = 0;         // largest finite distance of the loaded data
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;
@@ -134,6 +163,33 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
 bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
                      bool emit_estep = false);
 bool fast_lkl_covers_everyone(const FastState& fs);
+// ---- the M-step's rounds planned on the device (kernels_bfgs.hip) ----
+// whether this handle's data admit them (every finite-difference probe inside the pattern
+// kernels' range: else all groups would take the general kernel one point at a time)
+bool dbfgs_available(const FastState& fs);
+bool dbfgs_reserve(FastState& fs);
+void dbfgs_destroy(FastState& fs);
+// plan round 1 from the current parameters; nothing waits
+bool dbfgs_begin(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
+                 bool F_fixed, bool alpha_fixed);
+// the values of round `round` into the machines, round + 1 planned; nothing waits
+// (n_in = the active individuals of that round, as dbfgs_wait_plan reported them)
+bool dbfgs_advance(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_in);
+// wait (polling pinned memory) for the plan of round `round`: active individuals and the modes
+// present; false: the stream ran dry without publishing it
+// (yield: give the core up between looks -- handles that run next to others from host threads)
+bool dbfgs_wait_plan(FastState& fs, hipStream_t st, uint32_t round, uint32_t* n_active,
+                     std::vector<FastState::ModeRange>* ranges, bool yield = false);
+// launch the planned round
+bool dbfgs_launch_round(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_active,
+                        const std::vector<FastState::ModeRange>& ranges, bool emit_estep);
+// results into d_indF / d_alpha, stats + flags to their pinned mirrors (valid after a sync);
+// rounds_used = the last round planned (the sequence numbers of the next M-step go on from there)
+bool dbfgs_end(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, uint32_t rounds_used);
+bool fast_lkl_launch_planned(FastState& fs, hipStream_t st, const void* d_groups_by_ind,
+                             const std::vector<FastState::ModeRange>& ranges, uint32_t n_active,
+                             const uint32_t* d_worklists, const uint32_t* d_all, double* part,
+                             double* d_lkl, bool emit_estep);
 // forward checkpoints (unless a preceding fast_lkl_launch(emit_estep) left them), boundary
 // vectors, backward sweep with posteriors into fs.post (tile-major)
 bool fast_estep(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,

@@ -212,12 +212,15 @@ __device__ __forceinline__ void lkl_store_wave_ops(Op (&R)[MAXP], int lane, doub
 template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG, bool OWNEX = false>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
-              uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
+              uint32_t g_begin, double* __restrict__ part, EmitPtrs emit,
+              const uint32_t* __restrict__ worklist = nullptr) {
   static_assert(EMIT || SRC == SRC_PLAIN, "the fresh walk is the first round of an M-step");
   // chunk-major: the waves resident at a time walk the same few slices of the shared
   // distance / frequency tables, which then stay in L2
   const uint32_t n_g = gridDim.x / C;
-  const uint32_t g = g_begin + blockIdx.x % n_g;
+  // (rounds planned on the device, kernels_bfgs.hip: the mode's worklist names the groups,
+  // which lie -- descriptors and partial operators -- by individual)
+  const uint32_t g = worklist ? worklist[blockIdx.x % n_g] : g_begin + blockIdx.x % n_g;
   const uint32_t c = blockIdx.x / n_g;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
@@ -253,11 +256,12 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
 template <int NP_MAX, int SRC>
 __global__ void __launch_bounds__(64)
 k_fast_lkl_chunks(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
-                  uint32_t g_begin, double* __restrict__ part, EmitPtrs emit) {
+                  uint32_t g_begin, double* __restrict__ part, EmitPtrs emit,
+                  const uint32_t* __restrict__ worklist = nullptr) {
   // chunk-major: the waves resident at a time walk the same few slices of the shared
   // distance / frequency tables, which then stay in L2
   const uint32_t n_g = gridDim.x / C;
-  const uint32_t g = g_begin + blockIdx.x % n_g;
+  const uint32_t g = worklist ? worklist[blockIdx.x % n_g] : g_begin + blockIdx.x % n_g;
   const uint32_t c = blockIdx.x / n_g;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
@@ -335,8 +339,9 @@ template <bool SHARD>
 __global__ void __launch_bounds__(64 * MAXP)
 k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint32_t C,
                   const double* __restrict__ part, const double* __restrict__ base_c,
-                  double* __restrict__ lkl_out, int* __restrict__ flags) {
-  const uint32_t g = blockIdx.x;
+                  double* __restrict__ lkl_out, int* __restrict__ flags,
+                  const uint32_t* __restrict__ worklist = nullptr) {
+  const uint32_t g = worklist ? worklist[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x & 63;
   const GroupDesc& G = groups[g];
   const uint32_t p = threadIdx.x >> 6;
@@ -371,7 +376,8 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
         lkl_out[G.out_idx[p]] = l;
         // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
         // in linear space; the host re-evaluates such points with the general kernel
-        if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
+        // (device-planned rounds pass no flags: k_bfgs_advance looks at the values itself)
+        if (flags && !(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
       }
     }
   }
@@ -463,49 +469,6 @@ k_fast_shard_edges_from_round(const GroupDesc* __restrict__ groups, uint32_t n_g
 }  // namespace
 
 
-// Recognise the finite-difference pattern of one objective + gradient evaluation
-// (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
-// close enough for exp_small<4> (or <2>) on every finite distance of this data set.
-static uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits,
-                           bool allow_xdeg2) {
-  if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
-  int nf = 0, na = 0;
-  bool ownex = false;
-  double xmax = 0;  // largest |alpha_0 - alpha_probe| d over the data's finite distances
-  for (uint32_t p = 1; p < G.np; ++p) {
-    if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
-      if (na) return 0;  // F probes come first
-      // The pattern kernel rescales all points by point 0's exponent.  A site that forces
-      // the non-IBD state (a called heterozygote: e1 = 0) multiplies an F probe's operator by
-      // rho0 = (1 - F_p) / (1 - F_0) relative to point 0's; with F_0 at its upper bound that
-      // is ~1e10 per such site and would overflow within a lane-chunk.  For called genotypes
-      // (packed handles: such sites exist by construction) keep rho0^T inside the double
-      // range, else the general kernel (an exponent per point) takes the group.  Likelihood
-      // data have no forced visits; should a probe overflow there all the same, its value
-      // comes back non-finite and the host re-evaluates it with the general kernel.
-      const double rho0 = (1 - G.F[p]) / (1 - G.F[0]);
-      if (forced_visits && !(std::fabs(std::log(rho0)) * (double)T <= 600.0)) {
-        // ... or, where the probe stays in range over the eight sites between two rescales
-        // (always, with F inside [1e-15, 1 - 1e-15]), the pattern kernel with an exponent per
-        // point: the shared transition terms are still formed once per site
-        if (!(std::fabs(std::log(rho0)) * 8.0 <= 600.0)) return 0;
-        ownex = true;
-      }
-      ++nf;
-    } else if (G.F[p] == G.F[0] && std::fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
-      ++na;
-      xmax = std::fmax(xmax, std::fabs(G.A[p] - G.A[0]) * dmax);
-    } else {
-      return 0;
-    }
-  }
-  const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
-                  (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
-  if (!ok) return 0;
-  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625, allow_xdeg2 && na > 0 && xmax <= 1e-5) |
-         (ownex ? FD_OWNEX : 0u);
-}
-
 bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint32_t* h_ind,
                       const double* h_F, const double* h_A, bool force_general) {
   FastState::LklLane& L = fs.lanes[fs.cur_lane];
@@ -588,11 +551,16 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
   return true;
 }
 
-bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags, bool emit_estep) {
-  FastState::LklLane& L = fs.lanes[fs.cur_lane];
-  const uint32_t ng = L.n_groups;
+// One round: every loop-body version on its range of the sorted descriptors, then the finish.
+// Device-planned rounds (d_worklists != null, kernels_bfgs.hip): the descriptors lie by
+// individual, range r = the first r.count entries of mode r.mode's worklist
+// (d_worklists + mode_slot(mode) * wl_stride), d_all = the ng groups of the round in one list.
+static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg,
+                              const std::vector<FastState::ModeRange>& mode_ranges, uint32_t ng,
+                              uint32_t n_pts, double* part, double* d_lkl, int* d_flags,
+                              bool emit_estep, const uint32_t* d_worklists = nullptr,
+                              uint64_t wl_stride = 0, const uint32_t* d_all = nullptr) {
   if (ng == 0) return true;
-  const GroupDesc* dg = reinterpret_cast<const GroupDesc*>(L.grp_dev);
   const LklArrays arr = lkl_arrays(fs);
   // first round of an M-step inside nghmm_estep_mstep: point 0 of every individual is the
   // E-step's forward walk, whose lane operators and checkpoints it leaves behind; if the
@@ -604,15 +572,16 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
   // (the kernel versions of one round side by side on helper streams, so that they share one
   // partly filled last wave batch: measured, no gain -- 26.6-26.9 vs 27.0-27.1 ms per iteration
   // at 1000 x 1M)
-  for (const auto& r : L.mode_ranges) {
+  for (const auto& r : mode_ranges) {
     const dim3 grid(r.count * fs.C), block(64);
+    const uint32_t* wl = d_worklists ? d_worklists + (uint64_t)mode_slot(r.mode) * wl_stride : nullptr;
     // a group that needs an exponent per point (FD_OWNEX) in a round that also emits the
     // E-step's by-products goes to the general kernel as before
     const uint32_t mode = ((r.mode & FD_OWNEX) && emit_estep) ? 0u : r.mode;
     switch (mode) {
 #define FD_LAUNCH(NF, NA, SM, EM, FR, XD)                                                    \
   hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, EM, FR, XD>), grid, block, 0, st, arr, fs.T,    \
-                     fs.C, dg, r.begin, L.part, emit)
+                     fs.C, dg, r.begin, part, emit, wl)
 #define FD_CASE1(NF, NA, SM, XD)                                              \
   case fd_mode(NF, NA, SM, XD == 2):                                          \
     if (fresh && fs.packed) FD_LAUNCH(NF, NA, SM, true, SRC_FRESH_PACKED, XD); \
@@ -622,7 +591,7 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
     break;                                                                    \
   case fd_mode(NF, NA, SM, XD == 2) | FD_OWNEX:                               \
     hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, false, SRC_PLAIN, XD, true>), grid, block, 0, st, arr, \
-                       fs.T, fs.C, dg, r.begin, L.part, emit);                \
+                       fs.T, fs.C, dg, r.begin, part, emit, wl);                \
     break;
 #define FD_CASE(NF, NA)       \
   FD_CASE1(NF, NA, false, 4)  \
@@ -642,40 +611,58 @@ bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags,
       default:
         if (fresh && fs.packed)
           hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_FRESH_PACKED>), grid, block, 0, st, arr,
-                             fs.T, fs.C, dg, r.begin, L.part, emit);
+                             fs.T, fs.C, dg, r.begin, part, emit, wl);
         else if (fresh)
           hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_FRESH>), grid, block, 0, st, arr, fs.T,
-                             fs.C, dg, r.begin, L.part, emit);
+                             fs.C, dg, r.begin, part, emit, wl);
         else
           hipLaunchKernelGGL((k_fast_lkl_chunks<MAXP, SRC_PLAIN>), grid, block, 0, st, arr, fs.T,
-                             fs.C, dg, r.begin, L.part, emit);
+                             fs.C, dg, r.begin, part, emit, wl);
     }
   }
   if (fresh) fs.e_stale = false;
   if (fs.shard.world > 1) {
     // this handle's sites are a range of the data set's: its operators to everybody, theirs back
     SiteShard& sh = fs.shard;
-    if ((uint64_t)L.n_pts * 6 > sh.cap) return false;
-    hipLaunchKernelGGL(k_fast_lkl_finish<true>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part,
+    if ((uint64_t)n_pts * 6 > sh.cap) return false;
+    hipLaunchKernelGGL(k_fast_lkl_finish<true>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, part,
                        fs.base_c, sh.send, d_flags);
     if (hipGetLastError() != hipSuccess) return false;
-    if (sh.allgather(sh.user, (uint64_t)L.n_pts * 6 * sizeof(double)) != 0) return false;
+    if (sh.allgather(sh.user, (uint64_t)n_pts * 6 * sizeof(double)) != 0) return false;
     ++sh.n_gathers;
     hipLaunchKernelGGL(k_fast_shard_combine, dim3(((unsigned)ng * MAXP + 255) / 256), dim3(256), 0, st, dg,
-                       ng, sh.recv, sh.world, (uint64_t)L.n_pts, d_lkl, d_flags);
+                       ng, sh.recv, sh.world, (uint64_t)n_pts, d_lkl, d_flags);
     sh.edges_from_round = false;
 #ifndef NGHMM_NO_EDGE_MERGE  // (A/B builds: the E-step with an all-gather of its own)
     if (emit_estep && !fs.sw.no_fuse) {  // every individual is in the batch: the E-step's edges too
       hipLaunchKernelGGL(k_fast_shard_edges_from_round, dim3((ng + 255) / 256), dim3(256), 0, st, dg, ng,
-                         sh.recv, sh.world, sh.rank, (uint64_t)L.n_pts, sh.edges);
+                         sh.recv, sh.world, sh.rank, (uint64_t)n_pts, sh.edges);
       sh.edges_from_round = true;
     }
 #endif
     return hipGetLastError() == hipSuccess;
   }
-  hipLaunchKernelGGL(k_fast_lkl_finish<false>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, L.part,
-                     fs.base_c, d_lkl, d_flags);
+  hipLaunchKernelGGL(k_fast_lkl_finish<false>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, part,
+                     fs.base_c, d_lkl, d_flags, d_all);
   return hipGetLastError() == hipSuccess;
+}
+
+bool fast_lkl_launch(FastState& fs, hipStream_t st, double* d_lkl, int* d_flags, bool emit_estep) {
+  FastState::LklLane& L = fs.lanes[fs.cur_lane];
+  return lkl_launch_groups(fs, st, reinterpret_cast<const GroupDesc*>(L.grp_dev), L.mode_ranges,
+                           L.n_groups, L.n_pts, L.part, d_lkl, d_flags, emit_estep);
+}
+
+// a round planned on the device (kernels_bfgs.hip): `ranges` = the modes present and their
+// counts (begin unused), values to d_lkl[individual * 5 + slot]
+bool fast_lkl_launch_planned(FastState& fs, hipStream_t st, const void* d_groups_by_ind,
+                             const std::vector<FastState::ModeRange>& ranges, uint32_t n_active,
+                             const uint32_t* d_worklists, const uint32_t* d_all, double* part,
+                             double* d_lkl, bool emit_estep) {
+  if (fs.shard.world > 1) return false;  // (site shards keep the host-planned rounds)
+  return lkl_launch_groups(fs, st, reinterpret_cast<const GroupDesc*>(d_groups_by_ind), ranges,
+                           n_active, n_active * (uint32_t)MAXP, part, d_lkl, nullptr, emit_estep,
+                           d_worklists, fs.I, d_all);
 }
 
 bool fast_lkl_covers_everyone(const FastState& fs) {

@@ -89,6 +89,12 @@ struct LbfgsbPtrs {
   }
 };
 
+// pointers into a block the caller owns (device: LDS; host tests: a plain buffer)
+struct PtrStore : LbfgsbPtrs {
+  // dpmeps (bfgs.cpp:5166) evaluates to 2^-52 on IEEE binary64 with round-to-nearest
+  NGHMM_HD static double machine_eps() { return 2.220446049250313080847263336181640625e-16; }
+};
+
 namespace lbfgsb_detail {
 
 NGHMM_HD inline double absd(double v) { return v >= 0 ? v : -v; }        // bfgs.cpp:147 macro
@@ -258,6 +264,28 @@ struct LbfgsbT {
     fold_ = tol_ = dnorm_ = epsmch_ = gd_ = stpmx_ = sbgnrm_ = stp_ = gdold_ = dtd_ = xstep_ = 0;
     ls_task_ = LbfgsbLs::Start;
     ls_ = LbfgsbLsState();
+  }
+
+  NGHMM_HD const double* x() const { return st_.x; }
+
+  // Begin a minimisation of size (n, m) on a store whose pointers are bound: the work arrays
+  // zeroed as the reference calloc()s them per findmax_bfgs call (bfgs.cpp:103-105), x0 and
+  // the bounds copied in (nbd[i] = 0 none, 1 lower, 2 both, 3 upper: bfgs.h:27-33).
+  NGHMM_HD void start_bound(int n, int m, const double* x0, const double* l, const double* u,
+                            const int* nbd, double factr, double pgtol) {
+    clear_scalars();
+    n_ = n;
+    m_ = m;
+    const size_t nd = LbfgsbPtrs::doubles(n, m);
+    for (size_t k = 0; k < nd; ++k) st_.x[k] = 0.0;  // one block from x on (LbfgsbPtrs::bind)
+    for (int i = 0; i < n; ++i) {
+      st_.x[i] = x0[i];
+      st_.l[i] = l[i];
+      st_.u[i] = u[i];
+      st_.nbd[i] = nbd ? nbd[i] : 2;
+    }
+    factr_ = factr;
+    pgtol_ = pgtol;
   }
 
   // One call of the reference's setulb_.  `f` and `g[n]` are read when the previous task was

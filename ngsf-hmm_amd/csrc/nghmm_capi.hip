@@ -696,6 +696,7 @@ int nghmm_emission(nghmm_t* h) {
     if (h->mode == NGHMM_MODE_FAST) {
       if ((rc = lane_setup(h, 0, (size_t)h->I * 5)) || (rc = lane_setup(h, 1, (size_t)h->I * 5))) return rc;
       if (h->I_tot == h->I && !fast_estmaf_reserve(h->fast, h->S)) return NGHMM_ERR_NOMEM;
+      if (!h->fast.sw.no_dev_bfgs && dbfgs_available(h->fast) && !dbfgs_reserve(h->fast)) return NGHMM_ERR_NOMEM;
     }
   }
   return emission_impl(h);
@@ -781,6 +782,7 @@ struct MstepRun {
   std::function<int()> before_round;
   bool estep_pending = false;
   bool bg_active = false;
+  bool bg_begun = false;        // the iteration's timing spans and background flags are set up
   bool tile_major = false;      // est_maf reads the tile-major posteriors in place
   uint32_t bg_parts = 0, bg_next = 0;  // est_maf parts queued / already on the stream
   // host-side wall time of the phases (switch `timing`)
@@ -825,7 +827,8 @@ struct MstepRun {
   int start_background(bool have_walk) {
     int r;
     if (!have_walk && (r = ensure_emissions(h))) return r;
-    if ((r = bg_begin(h))) return r;
+    if (!bg_begun && (r = bg_begin(h))) return r;
+    bg_begun = true;
     if ((r = bg_open(h, SLOT_FORWARD))) return r;
     if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_flags_bg,
                     have_walk))
@@ -956,6 +959,121 @@ struct MstepRun {
     return NGHMM_OK;
   }
 
+  // ---- the rounds planned on the device (kernels_bfgs.hip) ----
+  // Fast mode, a handle that holds whole chains (no site shard): the L-BFGS-B machines live in
+  // device memory, k_bfgs_advance turns a round's values into the next round's points, and the
+  // host only learns HOW MANY groups of which loop-body version the next round has -- by polling
+  // a word of pinned memory the planning kernel's last workgroup writes -- and launches them.
+  // No copy, no event wait, no host arithmetic between two rounds.
+  bool wants_device() const {
+    return h->mode == NGHMM_MODE_FAST && !before_round && !h->chain && h->g_n <= 1 &&
+           !h->fast.sw.no_dev_bfgs && dbfgs_available(h->fast);
+  }
+
+  int run_device(nghmm_mstep_stats* stats, bool* freq_done) {
+    FastState& fs = h->fast;
+    int rc;
+    if (!dbfgs_reserve(fs)) {
+      set_error("out of device memory (device-side L-BFGS-B state)");
+      return NGHMM_ERR_NOMEM;
+    }
+    if ((rc = bg_begin(h))) return rc;  // timing spans of the rounds; flags of the background work
+    bg_begun = true;
+    h->ms[SLOT_BFGS] = 0;
+    h->launches[SLOT_BFGS] = 0;
+    estep_pending = fuse_estep;
+    auto t0 = clock::now();
+    if ((rc = bg_open(h, SLOT_BFGS))) return rc;
+    if (!dbfgs_begin(fs, h->stream, h->d_indF, h->d_alpha, indF_fixed != 0, alpha_fixed != 0)) {
+      set_error("dbfgs_begin failed: %s", hipGetErrorString(hipGetLastError()));
+      return NGHMM_ERR_HIP;
+    }
+    if ((rc = bg_close(h))) return rc;
+    uint32_t round = 1, n_active = 0;
+    std::vector<FastState::ModeRange> ranges;
+    const bool yield = h->blocking_sync;
+    for (;;) {
+      if (!dbfgs_wait_plan(fs, h->stream, round, &n_active, &ranges, yield)) {
+        set_error("the device-side M-step did not publish round %u: %s", round,
+                  hipGetErrorString(hipGetLastError()));
+        return NGHMM_ERR_HIP;
+      }
+      if (n_active == 0) break;
+      if (fs.sw.debug_modes) {
+        std::fprintf(stderr, "[nghmm modes] round %u, %u active:", round, n_active);
+        for (const auto& r : ranges)
+          if (r.mode)
+            std::fprintf(stderr, " %uF%uA%s%s%s x%u", (r.mode >> 2) & 3, r.mode & 3, (r.mode & 0x200) ? "s" : "",
+                         (r.mode & 0x400) ? "2" : "", (r.mode & 0x800) ? "e" : "", r.count);
+          else
+            std::fprintf(stderr, " general x%u", r.count);
+        std::fprintf(stderr, "\n");
+      }
+      bool emit = false;
+      if (round == 1) {
+        emit = estep_pending && n_active == h->I;
+        if (!emit && (rc = ensure_emissions(h))) return rc;
+      }
+      if ((rc = bg_open(h, round == 1 ? SLOT_LKL_FIRST : SLOT_LKL))) return rc;
+      if (!dbfgs_launch_round(fs, h->stream, round, n_active, ranges, emit)) {
+        set_error("objective round %u failed to launch: %s", round, hipGetErrorString(hipGetLastError()));
+        return NGHMM_ERR_HIP;
+      }
+      if ((rc = bg_close(h))) return rc;
+      if ((rc = bg_open(h, SLOT_BFGS))) return rc;
+      if (!dbfgs_advance(fs, h->stream, round, n_active)) {
+        set_error("k_bfgs_advance failed to launch: %s", hipGetErrorString(hipGetLastError()));
+        return NGHMM_ERR_HIP;
+      }
+      if ((rc = bg_close(h))) return rc;
+      // behind the round and its planning kernel: the E-step's backward sweep (round 1), est_maf
+      // in parts (rounds 2, 3, ...) -- the GPU works on them while the plan travels to the host
+      if (estep_pending) {
+        if ((rc = wants_background() ? start_background(emit) : estep_then_hook(emit))) return rc;
+        estep_pending = false;
+      } else if (bg_active) {
+        if ((rc = push_background_piece())) return rc;
+      }
+      ++round;
+    }
+    t_lkl += since(t0);
+    if (fs.sw.timing)
+      std::fprintf(stderr, "[nghmm timing] mstep (device-planned): %.3f ms for %u rounds\n", t_lkl, round - 1);
+    if (estep_pending && (rc = estep_then_hook(false))) return rc;
+    if (bg_active) {  // what is left of the background work, then the frequency table
+      while (bg_next < bg_parts)
+        if ((rc = push_background_piece())) return rc;
+      if ((rc = bg_open(h, SLOT_EMISSION))) return rc;
+      if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
+      if ((rc = bg_close(h))) return rc;
+    }
+    if (!dbfgs_end(fs, h->stream, h->d_indF, h->d_alpha, round)) return NGHMM_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(h->h_indF.data(), h->d_indF, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_alpha.data(), h->d_alpha, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    if (bg_active && ind_lkl)
+      HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                             h->stream));
+    rc = bg_finish(h);  // waits for the stream; the spans' times; the background work's flags
+    h->ms[SLOT_LKL] += h->ms[SLOT_LKL_FIRST];
+    h->launches[SLOT_LKL] = round - 1;
+    if (rc) return rc;
+    if (bg_active && freq_done) *freq_done = true;
+    if (fs.dev.h_flags[FLAG_INVALID_LKL]) {
+      set_error("invalid Lkl found!");
+      return NGHMM_ERR_INVALID_LKL;
+    }
+    h->lkl_redone += fs.dev.h_stats[4];
+    if (stats) {
+      stats->points = fs.dev.h_stats[0];
+      stats->ref_forward_calls = fs.dev.h_stats[1];
+      stats->ind_rounds = fs.dev.h_stats[2];
+      stats->rounds = (uint32_t)fs.dev.h_stats[3];
+    }
+    return NGHMM_OK;
+  }
+
   // *freq_done tells the caller that the frequency step (and the frequency-table refresh of
   // nghmm_init_emission) has been done here.
   int run(nghmm_mstep_stats* stats, bool* freq_done) {
@@ -969,7 +1087,11 @@ struct MstepRun {
     if (indF_fixed && alpha_fixed)  // EM.cpp:191-193
       return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
 
+    if (wants_device()) return run_device(stats, freq_done);
+
     auto t0 = clock::now();
+    // (fast mode: getgradient's step by detmath on host and device alike, bfgs_problem.hpp)
+    batch.set_det_pow(h->mode == NGHMM_MODE_FAST);
     batch.begin(h->I, h->h_indF.data(), h->h_alpha.data(), indF_fixed != 0, alpha_fixed != 0);
     t_gather += since(t0);
     estep_pending = fuse_estep;
@@ -1064,6 +1186,79 @@ int nghmm_bfgs_batch_host(uint64_t n_ind, double* indF, double* alpha, int indF_
     stats->points = batch.points();
     stats->ref_forward_calls = batch.ref_forward_calls();
     stats->ind_rounds = batch.ind_rounds();
+  }
+  return NGHMM_OK;
+}
+
+// flags: 1 = getgradient's step size by detmath (fast mode's, bfgs_problem.hpp: DetPow);
+// 2 = the solver type the DEVICE runs (LbfgsbT<PtrStore> over a plain block of memory, the
+// problems one after the other) instead of class Lbfgsb in lock-step rounds.  Same code path
+// per problem either way (bfgs_problem.hpp): the CPU test-suite checks that both give the same
+// bits, the GPU suite that k_bfgs_advance does.
+int nghmm_bfgs_batch_host2(uint64_t n_ind, double* indF, double* alpha, int indF_fixed,
+                           int alpha_fixed, nghmm_objective_fn fn, void* user,
+                           nghmm_mstep_stats* stats, int flags) {
+  g_last_error.clear();
+  if (!indF || !alpha || !fn) return NGHMM_ERR_ARG;
+  if (stats) std::memset(stats, 0, sizeof *stats);
+  if (indF_fixed && alpha_fixed) return NGHMM_OK;
+  const bool det = (flags & 1) != 0;
+  if (!(flags & 2)) {
+    BfgsBatch batch;
+    batch.set_det_pow(det);
+    batch.set_max_threads(1);
+    batch.begin(n_ind, indF, alpha, indF_fixed != 0, alpha_fixed != 0);
+    std::vector<uint32_t> ind;
+    std::vector<double> F, A, lkl;
+    while (!batch.done()) {
+      const size_t n = batch.gather(ind, F, A);
+      lkl.resize(n);
+      for (size_t p = 0; p < n; ++p) lkl[p] = fn(ind[p], F[p], A[p], user);
+      batch.scatter(lkl.data());
+    }
+    batch.result(indF, alpha);
+    if (stats) {
+      stats->rounds = batch.rounds();
+      stats->points = batch.points();
+      stats->ref_forward_calls = batch.ref_forward_calls();
+      stats->ind_rounds = batch.ind_rounds();
+    }
+    return NGHMM_OK;
+  }
+  std::vector<double> block(LbfgsbPtrs::doubles(2, 10));
+  uint64_t points = 0, ref_calls = 0, ind_rounds = 0;
+  uint32_t rounds = 0;
+  for (uint64_t i = 0; i < n_ind; ++i) {
+    BfgsProblem p;
+    bfgs_problem_begin(p, indF[i], alpha[i], indF_fixed != 0, alpha_fixed != 0);
+    LbfgsbT<PtrStore> solver;
+    solver.st_.bind(block.data(), 2, 10);
+    for (;;) {
+      if (det) bfgs_plan<DetPow>(p);
+      else bfgs_plan<LibmPow>(p);
+      ++p.n_rounds;
+      ++ind_rounds;
+      double lklv[5] = {0, 0, 0, 0, 0};
+      for (int k = 0; k < 5; ++k)
+        if (p.slot_used[k] && !p.slot_nonfinite[k]) {
+          lklv[k] = fn((uint32_t)i, p.pt[k][0], p.pt[k][1], user);
+          ++points;
+        }
+      const bool again = bfgs_consume(p, solver, lklv, ref_calls, [&](BfgsProblem& q) {
+        const int nbd[2] = {2, 2};
+        solver.start_bound(2, 10, q.x, q.lb, q.ub, nbd, 1.0e6, 1.0e-3);
+      });
+      if (!again) break;
+    }
+    if (p.n_rounds > rounds) rounds = p.n_rounds;
+    indF[i] = p.x[0];
+    alpha[i] = p.x[1];
+  }
+  if (stats) {
+    stats->rounds = rounds;
+    stats->points = points;
+    stats->ref_forward_calls = ref_calls;
+    stats->ind_rounds = ind_rounds;
   }
   return NGHMM_OK;
 }

@@ -103,6 +103,7 @@ def load_library():
         "nghmm_lkl_batch": (i32, [vp, u32, C.POINTER(u32), dp, dp, dp]),
         "nghmm_mstep_indf": (i32, [vp, i32, i32, C.POINTER(MstepStats)]),
         "nghmm_bfgs_batch_host": (i32, [u64, dp, dp, i32, i32, vp, vp, C.POINTER(MstepStats)]),
+        "nghmm_bfgs_batch_host2": (i32, [u64, dp, dp, i32, i32, vp, vp, C.POINTER(MstepStats), i32]),
         "nghmm_mstep_freq": (i32, [vp, i32]),
         "nghmm_estep_mstep": (i32, [vp, i32, i32, dp, C.POINTER(MstepStats), HOOK_FN, vp]),
         "nghmm_iter_em": (i32, [vp, i32, i32, i32, dp, C.POINTER(MstepStats)]),
@@ -157,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "nghmm_get_geno_codes_dev", "nghmm_load_geno_site_shard_dev",
     "nghmm_set_params", "nghmm_get_params",
     "nghmm_emission", "nghmm_estep", "nghmm_lkl_batch", "nghmm_mstep_indf",
-    "nghmm_bfgs_batch_host", "nghmm_mstep_freq", "nghmm_estep_mstep",
+    "nghmm_bfgs_batch_host", "nghmm_bfgs_batch_host2", "nghmm_mstep_freq", "nghmm_estep_mstep",
     "nghmm_iter_em", "nghmm_viterbi", "nghmm_get_posteriors", "nghmm_get_emissions",
     "nghmm_shard_config", "nghmm_load_gl_site_shard", "nghmm_load_gl_site_shard_dev",
     "nghmm_pack_posteriors_dev",
@@ -174,24 +175,32 @@ EXPORTED_SYMBOLS = [
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_void_p)
 
 
-def bfgs_batch_host(indF, alpha, objective, indF_fixed=False, alpha_fixed=False):
+def bfgs_batch_host(indF, alpha, objective, indF_fixed=False, alpha_fixed=False, det_pow=None,
+                    device_solver=False):
     """Lock-step batched L-BFGS-B (the indF/alpha M-step's host half) with a Python
     objective ``objective(ind, F, alpha) -> forward log-likelihood``.  Returns
-    (indF, alpha, stats)."""
+    (indF, alpha, stats).  det_pow: the finite-difference step by the library's own exp / log
+    (fast mode's) instead of libm's pow; device_solver: the solver type k_bfgs_advance runs on
+    the GPU, on the host (nghmm_bfgs_batch_host2)."""
     L = load_library()
     F = np.array(indF, dtype=np.float64)
     A = np.array(alpha, dtype=np.float64)
     st = MstepStats()
     cb = OBJECTIVE_FN(lambda i, f, a, _u: float(objective(i, f, a)))
-    rc = L.nghmm_bfgs_batch_host(len(F), _dp(F), _dp(A), int(indF_fixed), int(alpha_fixed),
-                                 C.cast(cb, C.c_void_p), None, C.byref(st))
+    if det_pow is None and not device_solver:
+        rc = L.nghmm_bfgs_batch_host(len(F), _dp(F), _dp(A), int(indF_fixed), int(alpha_fixed),
+                                     C.cast(cb, C.c_void_p), None, C.byref(st))
+    else:
+        rc = L.nghmm_bfgs_batch_host2(len(F), _dp(F), _dp(A), int(indF_fixed), int(alpha_fixed),
+                                      C.cast(cb, C.c_void_p), None, C.byref(st),
+                                      (1 if det_pow else 0) | (2 if device_solver else 0))
     if rc != 0:
         raise NgsFHMMError(rc, L.nghmm_strerror(rc).decode())
     return F, A, st
 
 
 KERNEL_SLOTS = {"emission": 0, "forward": 1, "backward": 2, "lkl_batch": 3, "est_maf": 4,
-                "viterbi": 5, "lkl_first": 6}
+                "viterbi": 5, "lkl_first": 6, "bfgs": 7}
 
 
 class NgsFHMM:

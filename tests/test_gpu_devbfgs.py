@@ -1,0 +1,109 @@
+"""The indF / alpha M-step's L-BFGS-B machines ON THE DEVICE (kernels_bfgs.hip) against the
+same machines on the host (bfgs_batch.cpp, the round-1..4 path, still there behind the switch
+`no_dev_bfgs`): the reference's per-individual optimizer (EM.cpp:198-201,423-440;
+shared/bfgs.cpp:22-138) has no barrier between individuals, so WHO advances the machines between
+two objective rounds must not show in any result.  Same handle, same data, same starting
+values; the objective kernels are the same either way, so every array must agree bit for bit
+and the optimizer's accounting (rounds, points, the reference's forward-pass count) too."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def _stats(st):
+    return (st.rounds, st.points, st.ref_forward_calls, st.ind_rounds)
+
+
+def _two_paths(h, fn):
+    out = []
+    for host in (1, 0):
+        h.set_switch("no_dev_bfgs", host)
+        out.append(fn(h))
+    return out
+
+
+CASES = [
+    # I, S, chromosomes, missing, call_geno, seed
+    (7, 900, 1, 0.0, False, 1),
+    (100, 20_000, 3, 0.03, False, 2),
+    (333, 6_000, 2, 0.1, False, 3),
+    (1000, 4_000, 1, 0.0, False, 4),
+    (64, 12_000, 4, 0.05, True, 5),     # called genotypes: probes at F's upper bound, own exponents
+    (13, 257, 1, 0.0, False, 6),
+]
+
+
+@pytest.mark.parametrize("I,S,nchr,miss,call,seed", CASES)
+def test_mstep_on_the_device_equals_the_host_machines(pkg, I, S, nchr, miss, call, seed):
+    d = pkg.simulate.simulate(I, S, seed=seed, n_chrom=nchr, missing_rate=miss, indF="r", freq="r", alpha=0.4)
+    rng = np.random.default_rng(seed)
+    F0, A0 = rng.uniform(0.02, 0.9, I), 10 ** rng.uniform(-2, 0.7, I)
+    f0 = rng.uniform(0.05, 0.5, S)
+    mode = pkg.MODE_FAST | (pkg.GENO_PACKED if call else 0)
+    with pkg.NgsFHMM(I, S, mode=mode) as h:
+        h.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=call)
+        for fixed in ((False, False), (True, False), (False, True)):
+            def run(h):
+                h.set_params(F0, A0, f0)
+                h.init_emission()
+                st = h.mstep_indf(*fixed)
+                return h.indF.copy(), h.alpha.copy(), _stats(st)
+            (Fh, Ah, sh), (Fd, Ad, sd) = _two_paths(h, run)
+            assert np.array_equal(Fh, Fd), (fixed, np.abs(Fh - Fd).max())
+            assert np.array_equal(Ah, Ad), (fixed, np.abs(Ah - Ad).max())
+            assert sh == sd, (fixed, sh, sd)
+            assert sd[0] >= 2 and np.all(np.isfinite(Fd)) and np.all(np.isfinite(Ad))
+            if fixed[0]:
+                assert np.array_equal(Fd, F0)
+            if fixed[1]:
+                assert np.array_equal(Ad, A0)
+
+
+@pytest.mark.parametrize("I,S,nchr,call", [(100, 30_000, 2, False), (1000, 5_000, 1, False), (96, 16_000, 4, True)])
+def test_whole_iterations_on_the_device_equal_the_host_machines(pkg, I, S, nchr, call):
+    """Six fused EM iterations (E-step sharing the first round's walk, frequency step behind the
+    rounds) from test.sh's starting values: every array after every iteration."""
+    d = pkg.simulate.simulate(I, S, seed=77, n_chrom=nchr, missing_rate=0.02, indF="r", freq="r", alpha=0.3)
+    mode = pkg.MODE_FAST | (pkg.GENO_PACKED if call else 0)
+    with pkg.NgsFHMM(I, S, mode=mode) as h:
+        h.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=call)
+
+        def run(h):
+            h.set_params(0.1, 0.2, 0.1)
+            h.init_emission()
+            out = []
+            for _ in range(6):
+                st = h.iter_EM()
+                out.append((h.ind_lkl.copy(), h.indF.copy(), h.alpha.copy(), h.freq.copy(), _stats(st)))
+            out.append(h.marg_prob)
+            return out
+        host, dev = _two_paths(h, run)
+        for it, (a, b) in enumerate(zip(host[:-1], dev[:-1])):
+            for name, x, y in zip(("ind_lkl", "indF", "alpha", "freq"), a, b):
+                assert np.array_equal(x, y), (it, name, np.abs(x - y).max())
+            assert a[4] == b[4], (it, a[4], b[4])
+        assert np.array_equal(host[-1], dev[-1])
+        assert dev[0][4][0] > dev[-2][4][0]        # the first iteration needs more rounds than the sixth
+        bf, n = h.kernel_ms("bfgs")
+        assert bf > 0                              # the device's planning kernels ran (slot 7)
+
+
+def test_device_mstep_of_a_replica_and_stats_of_the_reference(pkg):
+    """A replica (multi-start, nghmm_create_replica) has machines of its own on the device; and
+    the count of forward passes the reference would have spent is reported as before."""
+    I, S = 50, 8_000
+    d = pkg.simulate.simulate(I, S, seed=9, n_chrom=2, indF="r", freq=0.2, alpha=0.1)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as h:
+        h.load(gl, d.pos_dist_mb)
+        with h.replica() as r:
+            for x in (h, r):
+                x.set_params(0.1, 0.2, 0.1)
+                x.init_emission()
+            sa, sb = h.iter_EM(), r.iter_EM()
+            assert _stats(sa) == _stats(sb)
+            assert np.array_equal(h.indF, r.indF) and np.array_equal(h.freq, r.freq)
+            assert sa.ref_forward_calls > sa.points > 0

@@ -71,6 +71,47 @@ def test_batched_bfgs_against_reference_object(pkg, orc_libm, ref_bfgs, small_si
         assert x[0] == F[i] and x[1] == A[i]
 
 
+@pytest.mark.parametrize("fixed", [(False, False), (True, False), (False, True)])
+def test_device_solver_type_takes_the_host_machines_steps(pkg, orc_libm, small_sim, fixed):
+    """The solver the GPU runs between two objective rounds (kernels_bfgs.hip: LbfgsbT<PtrStore>,
+    lbfgsb_core.hpp, around bfgs_problem.hpp's plan / consume) is the same code as the host's
+    class Lbfgsb over other storage.  Here both on the CPU, on the real objective and on a
+    rough one that drives the line search into its safeguards and the memory around its ring:
+    same final (indF, alpha) to the last bit, same number of rounds, points and reference
+    forward calls -- with libm's pow (exact mode's) and with detmath's (fast mode's)."""
+    hm = importlib.import_module("ngsf-hmm_amd.hmm")
+    d, gl = small_sim
+    em = orclib.OracleEM(orc_libm, gl, d.pos_dist_mb)
+    em.set_params(0.1, 0.2, 0.1)
+    em.init_emission()
+    e = em.e_prob
+    pos = np.ascontiguousarray(d.pos_dist_mb)
+    x0F = np.linspace(0.05, 0.9, d.n_ind)
+    x0A = np.linspace(0.01, 2.0, d.n_ind)
+
+    def real(i, F, a):
+        return -orc_libm.lkl([F, a], e[i], pos)
+
+    def rough(i, F, a):     # many iterations: a curved valley with a ripple on it
+        return -(100.0 * (a - 3.0 * F * F) ** 2 + (0.7 - F) ** 2 + 1e-3 * math.sin(40.0 * F + i))
+
+    for objective in (real, rough):
+        for det in (False, True):
+            Fh, Ah, sh = hm.bfgs_batch_host(x0F, x0A, objective, fixed[0], fixed[1], det_pow=det)
+            Fd, Ad, sd = hm.bfgs_batch_host(x0F, x0A, objective, fixed[0], fixed[1], det_pow=det,
+                                            device_solver=True)
+            assert np.array_equal(Fh, Fd) and np.array_equal(Ah, Ad)
+            assert (sh.rounds, sh.points, sh.ref_forward_calls, sh.ind_rounds) == \
+                   (sd.rounds, sd.points, sd.ref_forward_calls, sd.ind_rounds)
+        # libm's pow and detmath's differ by at most a few ulp in the step: the same optimum
+        Fl, Al, _ = hm.bfgs_batch_host(x0F, x0A, objective, fixed[0], fixed[1], det_pow=False)
+        np.testing.assert_allclose(Fd, Fl, atol=2e-4)
+    # and without flags the entry point is the round-1..4 one
+    F0, A0, s0 = hm.bfgs_batch_host(x0F, x0A, rough, fixed[0], fixed[1])
+    assert np.array_equal(F0, Fl) and np.array_equal(A0, Al)
+    assert sd.rounds >= 10 if not any(fixed) else sd.rounds >= 2
+
+
 def test_nonfinite_parameters_take_the_reference_branch(pkg):
     """EM.cpp:454-456: NaN/Inf parameters make the objective -1e15 without a forward pass."""
     hm = importlib.import_module("ngsf-hmm_amd.hmm")
