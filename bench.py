@@ -388,7 +388,7 @@ def allreduce(ctx, values, op="sum"):
     return t.cpu().numpy()
 
 
-FAMILIES = ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first")
+FAMILIES = ("emission", "forward", "backward", "lkl_batch", "est_maf", "lkl_first", "bfgs")
 
 
 def timed_loop(ctx, run, steps, warmup, replicas=()):

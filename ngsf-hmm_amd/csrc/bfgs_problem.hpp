@@ -32,6 +32,12 @@ struct BfgsProblem {
   double pt[5][2];   // slot 0 = x; slots 1,2 = param 0 probes; 3,4 = param 1 probes
   uint32_t slot_pos[5];
   uint32_t n_rounds;  // rounds this problem has had points in
+  // accounting of this M-step (the device sums these over the individuals when the M-step ends;
+  // the host's BfgsBatch keeps totals of its own)
+  uint32_t acc_points;      // points evaluated
+  uint32_t acc_ref_calls;   // forward passes the reference would have spent (bfgs.cpp:54,114-121)
+  uint32_t acc_redone;      // rounds repeated by the general kernel
+  uint32_t acc_invalid;     // "invalid Lkl found!"
   // plan of the current round
   int8_t probe_kind[2];  // 0 central, 1 forward (x + 2eh), 2 backward (x - 2eh), 3 fixed (skipped)
   uint8_t slot_used[5];
@@ -60,6 +66,7 @@ NGHMM_HD inline void bfgs_problem_begin(BfgsProblem& p, double F, double alpha, 
   if (alpha_fixed) p.lb[1] = p.ub[1] = alpha;
   p.like = 0;
   p.n_rounds = 0;
+  p.acc_points = p.acc_ref_calls = p.acc_redone = p.acc_invalid = 0;
   p.grad[0] = p.grad[1] = 0;
   p.eval_x[0] = p.eval_x[1] = 0;
   p.have_eval = 0;

@@ -59,7 +59,7 @@ struct nghmm_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
   // exact mode, fused iteration: est_maf on a second stream underneath the objective rounds
   hipStream_t aux_stream = nullptr;
-  hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr;
+  hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr, aux_done = nullptr;
   static constexpr uint32_t kAuxPieces = 16;   // exact mode: est_maf underneath the rounds, in pieces
   hipEvent_t aux_piece_ev[kAuxPieces] = {};
   hipEvent_t aux_estep_ev[3] = {};             // ... the E-step next to the first rounds: its timing
@@ -185,8 +185,8 @@ int lkl_submit(nghmm_t* h, int k);
 int lkl_wait(nghmm_t* h, int k);
 int emission_impl(nghmm_t* h);
 int bg_begin(nghmm_t* h);
-int bg_open(nghmm_t* h, int slot);
-int bg_close(nghmm_t* h);
+int bg_open(nghmm_t* h, int slot, hipStream_t st = nullptr);   // (st: where the piece runs; default the handle's stream)
+int bg_close(nghmm_t* h, hipStream_t st = nullptr);
 int bg_finish(nghmm_t* h);
 int ensure_emissions(nghmm_t* h);
 

@@ -44,13 +44,15 @@ namespace {
 
 constexpr int kN = 2, kM = 10;                                   // MVAL, shared/bfgs.h:23
 constexpr int kArr = (int)LbfgsbPtrs::doubles(kN, kM);           // 1238 doubles per individual
-constexpr int kArrPad = kArr + 3;                                // LDS stride: no two lanes on a bank pair
-constexpr int kPerWg = 6;                                        // individuals per workgroup (59.6 KB LDS)
+constexpr int kStage = (kArr + 63) / 64;                         // ... = 20 per lane
 using DevSolver = LbfgsbT<PtrStore>;
 using DevBfgs = FastState::DevBfgs;
 constexpr uint32_t kCntAll = kModeSlots, kCntTicket = kModeSlots + 1, kCntStride = kModeSlots + 3;
-static_assert(DevBfgs::kTableWords >= 4 + 2 * kModeSlots, "a pair per mode");
-static_assert(kPerWg * kArrPad * sizeof(double) <= 65536, "one workgroup's LDS");
+constexpr uint32_t kTblStats = 4 + 2 * kModeSlots;               // table: 6 x u64 of statistics behind the pairs
+static_assert(DevBfgs::kTableWords >= kTblStats + 12, "pairs + statistics");
+// statistics published with an M-step's last (empty) plan: 0 points, 1 the reference's forward
+// passes, 2 individual-rounds, 3 rounds, 4 rounds repeated by the general kernel, 5 "invalid Lkl
+// found!"
 
 struct DevPtrs {
   BfgsProblem* prob;
@@ -61,13 +63,12 @@ struct DevPtrs {
   uint32_t* worklists;
   uint32_t* all;
   uint32_t* counts;
-  unsigned long long* stats;
   const double* lkl;
-  double *new_F, *new_A;
-  int* flags;
+  double *d_F, *d_A;              // the handle's parameters: a finished individual's go there ...
+  double *h_F, *h_A;              // ... and to their pinned host mirror
+  double *snap_F, *snap_A;        // the parameters the M-step started from (the E-step's, which runs next to it)
   uint32_t* h_table;
   uint32_t I;
-  uint32_t seq_base;
   // fd_pattern's view of the data
   double dmax;
   uint64_t T;
@@ -86,11 +87,13 @@ __device__ inline void build_group(const BfgsProblem& p, uint32_t i, const DevPt
   G.pad = 0;
   G.pad2 = 0;
   uint32_t np = 0;
+#pragma unroll
   for (int k = 0; k < 5; ++k) {
     G.F[k] = 0;
     G.A[k] = 0;
     G.out_idx[k] = 0;
   }
+#pragma unroll
   for (int k = 0; k < 5; ++k) {
     if (!p.slot_used[k] || p.slot_nonfinite[k]) continue;
     G.F[np] = p.pt[k][0];
@@ -102,70 +105,97 @@ __device__ inline void build_group(const BfgsProblem& p, uint32_t i, const DevPt
   G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.allow_xdeg2 != 0);
 }
 
-// individual i into the plan of round p_next
-__device__ inline void enlist(const DevPtrs& D, uint32_t p_next, uint32_t i, uint32_t mode) {
-  uint32_t* cnt = D.counts + (p_next % DevBfgs::kRing) * kCntStride;
-  const uint32_t par = p_next & 1u, slot = mode_slot(mode);
+// individual i into plan P
+__device__ inline void enlist(const DevPtrs& D, uint32_t P, uint32_t i, uint32_t mode) {
+  uint32_t* cnt = D.counts + (P % DevBfgs::kRing) * kCntStride;
+  const uint32_t par = P & 1u, slot = mode_slot(mode);
   const uint32_t pos = atomicAdd(&cnt[slot], 1u);
   D.worklists[((uint64_t)par * kModeSlots + slot) * D.I + pos] = i;
   const uint32_t pa = atomicAdd(&cnt[kCntAll], 1u);
   D.all[(uint64_t)par * D.I + pa] = i;
 }
 
-// FIRST: plan round 1 from the current parameters (no values yet); else: the values of round
-// `round` into the machines of the n_in individuals of that round, round + 1 planned.
+// One individual per workgroup (= one wave): the machines of different individuals are at
+// different places of the algorithm, lanes of one wave would take their branches one after the
+// other.  Lane 0 walks; all 64 lanes move the individual's work arrays between memory and LDS.
+//
+// FIRST: plan P_out from the current parameters of individual blockIdx.x (no values yet).
+// Else: the values of plan P_out - 1 into the machine of the blockIdx.x-th individual of that
+// plan, P_out planned.  Plans are numbered through the handle's life (slot = P mod kRing,
+// worklists by parity), so every kernel finds its counters zeroed by the one two before it.
+#ifdef NGHMM_BFGS_TIMING   // phase times of the slowest workgroup (tools/bfgs_phase_timing.py)
+__device__ unsigned long long g_bfgs_phase[8];
+#define PHASE(k)                                                                      \
+  if (lane == 0) {                                                                    \
+    const unsigned long long now = wall_clock64();                                    \
+    atomicMax(&g_bfgs_phase[k], now - t_phase);                                       \
+    t_phase = now;                                                                    \
+  }
+#else
+#define PHASE(k)
+#endif
+
 template <bool FIRST>
 __global__ void __launch_bounds__(64)
-k_bfgs_advance(DevPtrs D, uint32_t round, uint32_t n_in, const double* __restrict__ indF,
-               const double* __restrict__ alpha, int F_fixed, int alpha_fixed) {
-  __shared__ double lds[kPerWg * kArrPad];
+k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_fixed, int alpha_fixed) {
+#ifdef NGHMM_BFGS_TIMING
+  unsigned long long t_phase = wall_clock64();
+#endif
+  __shared__ double lds[kArr];
+  __shared__ BfgsProblem p_lds;
+  __shared__ GroupDesc g_lds;
   const int lane = threadIdx.x;
-  const uint32_t p_next = round + 1;
-  uint32_t* cnt_next = D.counts + (p_next % DevBfgs::kRing) * kCntStride;
-  if (blockIdx.x == 0)  // the slot after next is nobody's at the moment
+  uint32_t* cnt_out = D.counts + (P_out % DevBfgs::kRing) * kCntStride;
+  if (blockIdx.x == 0) {  // the slot after next is nobody's at the moment
     for (uint32_t k = lane; k < kCntStride; k += 64)
-      D.counts[((p_next + 1) % DevBfgs::kRing) * kCntStride + k] = 0;
-
-  const uint32_t base = blockIdx.x * kPerWg;
-  uint32_t my_i = ~0u;
-  if (lane < kPerWg && base + lane < n_in)
-    my_i = FIRST ? base + lane : D.all[(uint64_t)(round & 1u) * D.I + base + lane];
-
-  if constexpr (!FIRST) {  // the started solvers' work arrays into LDS, by everybody
-    for (int k = 0; k < kPerWg; ++k) {
-      const uint32_t ik = __shfl(my_i, k);
-      if (ik == ~0u) continue;
-      if (!D.prob[ik].started) continue;  // (start_bound zeroes its block)
-      const double* src = D.arrays + (uint64_t)ik * kArr;
-      double* dst = lds + k * kArrPad;
-      for (int j = lane; j < kArr; j += 64) dst[j] = src[j];
+      D.counts[((P_out + 1) % DevBfgs::kRing) * kCntStride + k] = 0;
+  }
+  const uint32_t i = FIRST ? blockIdx.x : D.all[(uint64_t)((P_out - 1) & 1u) * D.I + blockIdx.x];
+  BfgsProblem& p = p_lds;
+  GroupDesc& G = g_lds;
+  bool started = false;
+  if constexpr (!FIRST) {
+    if (lane == 0) p = D.prob[i];
+    __syncthreads();
+    started = p.started != 0;
+    if (started) {  // (else start_bound zeroes the block)
+      // (every load of the block in flight at once: 20 per lane)
+      const double* src = D.arrays + (uint64_t)i * kArr;
+      double v[kStage];
+#pragma unroll
+      for (int t = 0; t < kStage; ++t) {
+        const int j = lane + 64 * t;
+        v[t] = j < kArr ? src[j] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < kStage; ++t) {
+        const int j = lane + 64 * t;
+        if (j < kArr) lds[j] = v[t];
+      }
     }
     __syncthreads();
   }
 
-  bool keep = false;  // the solver's arrays go back to memory
-  if (my_i != ~0u) {
-    const uint32_t i = my_i;
-    BfgsProblem p;
+  PHASE(0)  // problem + work arrays in LDS
+  bool keep = false;        // the solver's arrays go back to memory
+  bool wrote_host = false;  // a finished individual's parameters went to pinned host memory
+  if (lane == 0) {
     if constexpr (FIRST) {
-      bfgs_problem_begin(p, indF[i], alpha[i], F_fixed != 0, alpha_fixed != 0);
-      D.new_F[i] = p.x[0];
-      D.new_A[i] = p.x[1];
+      bfgs_problem_begin(p, D.d_F[i], D.d_A[i], F_fixed != 0, alpha_fixed != 0);
+      D.snap_F[i] = p.x[0];
+      D.snap_A[i] = p.x[1];
       bfgs_plan<DetPow>(p);
       p.n_rounds = 1;
-      GroupDesc G;
       build_group(p, i, D, G);
       D.groups[i] = G;
       D.last_mode[i] = G.mode;
+      p.acc_points = G.np;
       D.prob[i] = p;
-      enlist(D, p_next, i, G.mode);
-      atomicAdd(&D.stats[0], (unsigned long long)G.np);
-      atomicAdd(&D.stats[2], 1ull);
-      atomicMax(&D.stats[3], 1ull);
+      enlist(D, P_out, i, G.mode);
     } else {
-      p = D.prob[i];
       double lklv[5] = {0, 0, 0, 0, 0};
       bool bad = false;
+#pragma unroll
       for (int k = 0; k < 5; ++k)
         if (p.slot_used[k] && !p.slot_nonfinite[k]) {
           lklv[k] = D.lkl[(uint64_t)i * 5 + k];
@@ -175,87 +205,128 @@ k_bfgs_advance(DevPtrs D, uint32_t round, uint32_t n_in, const double* __restric
         // a probe left the pattern kernel's shared scale: the same points by the general kernel
         D.groups[i].mode = 0;
         D.last_mode[i] = 0;
-        enlist(D, p_next, i, 0);
-        atomicAdd(&D.stats[4], 1ull);
-      } else if (bad) {
-        D.flags[FLAG_INVALID_LKL] = 1;  // EM.cpp:400-410: "invalid Lkl found!"
-        p.active = 0;
+        enlist(D, P_out, i, 0);
+        ++p.acc_redone;  // (not a round of the optimizer's: n_rounds counts evaluations it asked for)
         D.prob[i] = p;
+      } else if (bad) {
+        p.acc_invalid = 1;  // EM.cpp:400-410: "invalid Lkl found!"
+        p.active = 0;
+        wrote_host = true;
+        D.prob[i] = p;
+        D.h_F[i] = p.x[0];
+        D.h_A[i] = p.x[1];
       } else {
         DevSolver s;
-        if (p.started) s = D.solver[i];
-        s.st_.bind(lds + lane * kArrPad, kN, kM);
-        unsigned long long ref_calls = 0;
+        if (started) s = D.solver[i];
+        s.st_.bind(lds, kN, kM);
         uint64_t rc = 0;
         const bool again = bfgs_consume(p, s, lklv, rc, [&](BfgsProblem& q) {
           const int nbd[2] = {2, 2};
           s.start_bound(kN, kM, q.x, q.lb, q.ub, nbd, 1.0e6, 1.0e-3);  // FACTR, PGTOL: bfgs.h:24-25
         });
-        ref_calls = rc;
-        atomicAdd(&D.stats[1], ref_calls);
+        p.acc_ref_calls += (uint32_t)rc;
+        PHASE(1)  // solver scalars in, gradient, setulb calls
         if (again) {
           bfgs_plan<DetPow>(p);
           ++p.n_rounds;
-          GroupDesc G;
           build_group(p, i, D, G);
           D.groups[i] = G;
           D.last_mode[i] = G.mode;
-          enlist(D, p_next, i, G.mode);
-          atomicAdd(&D.stats[0], (unsigned long long)G.np);
-          atomicAdd(&D.stats[2], 1ull);
-          atomicMax(&D.stats[3], (unsigned long long)p.n_rounds);
+          p.acc_points += G.np;
+          enlist(D, P_out, i, G.mode);
           D.solver[i] = s;
           keep = true;
         } else {
-          D.new_F[i] = p.x[0];
-          D.new_A[i] = p.x[1];
+          wrote_host = true;
+          D.d_F[i] = p.x[0];
+          D.d_A[i] = p.x[1];
+          D.h_F[i] = p.x[0];
+          D.h_A[i] = p.x[1];
         }
         D.prob[i] = p;
+        PHASE(2)  // plan, descriptor, worklists, state out
       }
     }
   }
 
   if constexpr (!FIRST) {
     __syncthreads();
-    for (int k = 0; k < kPerWg; ++k) {
-      const uint32_t ik = __shfl(my_i, k);
-      const int kk = __shfl((int)keep, k);
-      if (ik == ~0u || !kk) continue;
-      double* dst = D.arrays + (uint64_t)ik * kArr;
-      const double* src = lds + k * kArrPad;
-      for (int j = lane; j < kArr; j += 64) dst[j] = src[j];
+    if (__shfl((int)keep, 0)) {
+      double* dst = D.arrays + (uint64_t)i * kArr;
+#pragma unroll 4
+      for (int j = lane; j < kArr; j += 64) dst[j] = lds[j];
     }
   }
 
-  // the last workgroup publishes the plan of round p_next to the host
-  __threadfence();
+  PHASE(3)  // work arrays back
+  // The last workgroup publishes plan P_out to the host: the modes present and their counts
+  // (all lanes read the counters, a ballot compacts them) -- and, when the plan is empty, i.e.
+  // the M-step is over, the accounting summed over the individuals.
+  if (__shfl((int)wrote_host, 0)) __threadfence_system();
+  else __threadfence();
   __shared__ int is_last;
-  if (lane == 0) is_last = atomicAdd(&cnt_next[kCntTicket], 1u) == gridDim.x - 1;
+  if (lane == 0) is_last = atomicAdd(&cnt_out[kCntTicket], 1u) == gridDim.x - 1;
   __syncthreads();
-  if (is_last && lane == 0) {
+  if (is_last) {
     __threadfence();
-    uint32_t* t = D.h_table + (p_next % DevBfgs::kRing) * DevBfgs::kTableWords;
-    const uint32_t n_all = __hip_atomic_load(&cnt_next[kCntAll], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* t = D.h_table + (P_out % DevBfgs::kRing) * DevBfgs::kTableWords;
+    const uint32_t n_all = __hip_atomic_load(&cnt_out[kCntAll], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t n_modes = 0;
-    for (uint32_t sl = 0; sl < kModeSlots; ++sl) {
-      const uint32_t c = __hip_atomic_load(&cnt_next[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (c == 0) continue;
-      t[4 + 2 * n_modes] = slot_mode(sl);
-      t[5 + 2 * n_modes] = c;
-      ++n_modes;
+    for (uint32_t s0 = 0; s0 < kModeSlots; s0 += 64) {
+      const uint32_t sl = s0 + lane;
+      const uint32_t c = sl < kModeSlots
+                             ? __hip_atomic_load(&cnt_out[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : 0u;
+      const uint64_t have = __ballot(c != 0);
+      if (c != 0) {
+        const uint32_t k = n_modes + (uint32_t)__popcll(have & ((1ull << lane) - 1));
+        t[4 + 2 * k] = slot_mode(sl);
+        t[5 + 2 * k] = c;
+      }
+      n_modes += (uint32_t)__popcll(have);
     }
-    t[1] = n_all;
-    t[2] = n_modes;
-    t[3] = 0;
+    if (n_all == 0) {  // the M-step's accounting
+      unsigned long long pts = 0, calls = 0, indr = 0, redone = 0, invalid = 0;
+      uint32_t rmax = 0;
+      for (uint32_t k = lane; k < D.I; k += 64) {
+        const BfgsProblem& q = D.prob[k];
+        pts += q.acc_points;
+        calls += q.acc_ref_calls;
+        indr += q.n_rounds;
+        redone += q.acc_redone;
+        invalid += q.acc_invalid;
+        rmax = q.n_rounds > rmax ? q.n_rounds : rmax;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        pts += __shfl_down(pts, off);
+        calls += __shfl_down(calls, off);
+        indr += __shfl_down(indr, off);
+        redone += __shfl_down(redone, off);
+        invalid += __shfl_down(invalid, off);
+        const uint32_t o = __shfl_down(rmax, off);
+        rmax = o > rmax ? o : rmax;
+      }
+      if (lane == 0) {
+        const unsigned long long v[6] = {pts, calls, indr, rmax, redone, invalid};
+        for (int k = 0; k < 6; ++k) {
+          t[kTblStats + 2 * k] = (uint32_t)v[k];
+          t[kTblStats + 2 * k + 1] = (uint32_t)(v[k] >> 32);
+        }
+      }
+    }
+    if (lane == 0) {
+      t[1] = n_all;
+      t[2] = n_modes;
+      t[3] = round;
+    }
     __threadfence_system();
-    __hip_atomic_store(&t[0], D.seq_base + p_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&t[0], P_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  PHASE(4)  // fence, ticket, publication
 }
 
-// nothing left to do, but the host waits for a plan: an M-step whose round came out empty
-// never happens (advance is launched with n_in >= 1); begin with I = 0 is refused on the host.
-
-DevPtrs dev_ptrs(const FastState& fs) {
+DevPtrs dev_ptrs(const FastState& fs, double* d_F, double* d_A) {
   const DevBfgs& d = fs.dev;
   DevPtrs D;
   D.prob = reinterpret_cast<BfgsProblem*>(d.prob);
@@ -266,14 +337,15 @@ DevPtrs dev_ptrs(const FastState& fs) {
   D.worklists = d.worklists;
   D.all = d.all;
   D.counts = d.counts;
-  D.stats = d.stats;
   D.lkl = d.lkl;
-  D.new_F = d.new_F;
-  D.new_A = d.new_A;
-  D.flags = d.flags;
+  D.d_F = d_F;
+  D.d_A = d_A;
+  D.h_F = d.h_F;
+  D.h_A = d.h_A;
+  D.snap_F = d.snap_F;
+  D.snap_A = d.snap_A;
   D.h_table = const_cast<uint32_t*>(d.h_table);
   D.I = (uint32_t)fs.I;
-  D.seq_base = d.seq_base;
   D.dmax = fs.dmax_finite;
   D.T = fs.T;
   D.packed = fs.packed ? 1 : 0;
@@ -288,8 +360,19 @@ bool dmalloc(T** p, size_t n) {
 
 }  // namespace
 
+#ifdef NGHMM_BFGS_TIMING
+extern "C" void nghmm_debug_bfgs_phases(unsigned long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfgs_phase), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bfgs_phase), z, sizeof z);
+  }
+}
+#endif
+
 bool dbfgs_available(const FastState& fs) {
-  if (fs.shard.world > 1 || fs.I == 0 || fs.I > 0x0fffffffu) return false;
+  if (fs.I == 0 || fs.I > 0x0fffffffu) return false;
   // the largest step of an alpha probe (alpha <= 10, EM.cpp:427) inside exp_small's range on
   // every finite distance: else every group is a general one
   return DetPow::eh(10.0) * fs.dmax_finite <= 1e-3;
@@ -306,21 +389,21 @@ bool dbfgs_reserve(FastState& fs) {
   bool ok = dmalloc(&prob, I) && dmalloc(&solver, I) && dmalloc(&d.arrays, I * kArr) &&
             dmalloc(&groups, I) && dmalloc(&d.last_mode, I) &&
             dmalloc(&d.worklists, (size_t)2 * kModeSlots * I) && dmalloc(&d.all, 2 * I) &&
-            dmalloc(&d.counts, (size_t)DevBfgs::kRing * kCntStride) && dmalloc(&d.stats, (size_t)8) &&
-            dmalloc(&d.lkl, 5 * I) && dmalloc(&d.part, I * fs.C * MAXP * 5) && dmalloc(&d.new_F, I) &&
-            dmalloc(&d.new_A, I) && dmalloc(&d.flags, (size_t)NFLAGS);
+            dmalloc(&d.counts, (size_t)DevBfgs::kRing * kCntStride) &&
+            dmalloc(&d.lkl, 5 * I) && dmalloc(&d.part, I * fs.C * MAXP * 5) && dmalloc(&d.snap_F, I) &&
+            dmalloc(&d.snap_A, I);
   d.prob = prob;
   d.solver = solver;
   d.groups = groups;
-  void *t = nullptr, *hs = nullptr, *hf = nullptr;
-  ok = ok &&
-       hipHostMalloc(&t, DevBfgs::kRing * DevBfgs::kTableWords * sizeof(uint32_t),
-                     hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
-       hipHostMalloc(&hs, 8 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
-       hipHostMalloc(&hf, NFLAGS * sizeof(int), hipHostMallocDefault) == hipSuccess;
+  void *t = nullptr, *hf = nullptr, *ha = nullptr;
+  const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
+  ok = ok && hipHostMalloc(&t, DevBfgs::kRing * DevBfgs::kTableWords * sizeof(uint32_t), flags) == hipSuccess &&
+       hipHostMalloc(&hf, I * sizeof(double), flags) == hipSuccess &&
+       hipHostMalloc(&ha, I * sizeof(double), flags) == hipSuccess;
   d.h_table = static_cast<volatile uint32_t*>(t);
-  d.h_stats = static_cast<unsigned long long*>(hs);
-  d.h_flags = static_cast<int*>(hf);
+  d.h_F = static_cast<double*>(hf);
+  d.h_A = static_cast<double*>(ha);
+  ok = ok && hipMemset(d.counts, 0, (size_t)DevBfgs::kRing * kCntStride * sizeof(uint32_t)) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     dbfgs_destroy(fs);
@@ -328,6 +411,7 @@ bool dbfgs_reserve(FastState& fs) {
   }
   std::memset(t, 0, DevBfgs::kRing * DevBfgs::kTableWords * sizeof(uint32_t));
   d.seq_base = 0;
+  d.mstep_no = 0;
   d.cap_I = I;
   return true;
 }
@@ -335,47 +419,46 @@ bool dbfgs_reserve(FastState& fs) {
 void dbfgs_destroy(FastState& fs) {
   DevBfgs& d = fs.dev;
   void* dev[] = {d.prob, d.solver, d.arrays, d.groups, d.last_mode, d.worklists, d.all, d.counts,
-                 d.stats, d.lkl, d.part, d.new_F, d.new_A, d.flags};
+                 d.lkl, d.part, d.snap_F, d.snap_A};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (d.h_table) (void)hipHostFree(const_cast<uint32_t*>(d.h_table));
-  if (d.h_stats) (void)hipHostFree(d.h_stats);
-  if (d.h_flags) (void)hipHostFree(d.h_flags);
+  if (d.h_F) (void)hipHostFree(d.h_F);
+  if (d.h_A) (void)hipHostFree(d.h_A);
   d = DevBfgs();
 }
 
-bool dbfgs_begin(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
-                 bool F_fixed, bool alpha_fixed) {
+bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, bool F_fixed,
+                 bool alpha_fixed) {
   DevBfgs& d = fs.dev;
   if (d.cap_I != fs.I || fs.I == 0) return false;
-  if (hipMemsetAsync(d.counts, 0, (size_t)DevBfgs::kRing * kCntStride * sizeof(uint32_t), st) != hipSuccess ||
-      hipMemsetAsync(d.stats, 0, 8 * sizeof(unsigned long long), st) != hipSuccess ||
-      hipMemsetAsync(d.flags, 0, NFLAGS * sizeof(int), st) != hipSuccess)
-    return false;
   const uint32_t n = (uint32_t)fs.I;
-  hipLaunchKernelGGL(k_bfgs_advance<true>, dim3((n + kPerWg - 1) / kPerWg), dim3(64), 0, st, dev_ptrs(fs),
-                     0u, n, d_indF, d_alpha, F_fixed ? 1 : 0, alpha_fixed ? 1 : 0);
+  d.d_F = d_indF;
+  d.d_A = d_alpha;
+  hipLaunchKernelGGL(k_bfgs_advance<true>, dim3(n), dim3(64), 0, st, dev_ptrs(fs, d_indF, d_alpha),
+                     d.seq_base + 1, n, 1u, F_fixed ? 1 : 0, alpha_fixed ? 1 : 0);
   return hipGetLastError() == hipSuccess;
 }
 
 bool dbfgs_advance(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_in) {
+  DevBfgs& d = fs.dev;
   if (n_in == 0) return false;
-  hipLaunchKernelGGL(k_bfgs_advance<false>, dim3((n_in + kPerWg - 1) / kPerWg), dim3(64), 0, st,
-                     dev_ptrs(fs), round, n_in, (const double*)nullptr, (const double*)nullptr, 0, 0);
+  hipLaunchKernelGGL(k_bfgs_advance<false>, dim3(n_in), dim3(64), 0, st, dev_ptrs(fs, d.d_F, d.d_A),
+                     d.seq_base + round + 1, n_in, round + 1, 0, 0);
   return hipGetLastError() == hipSuccess;
 }
 
 bool dbfgs_wait_plan(FastState& fs, hipStream_t st, uint32_t round, uint32_t* n_active,
                      std::vector<FastState::ModeRange>* ranges, bool yield) {
   DevBfgs& d = fs.dev;
-  const volatile uint32_t* t = d.h_table + (round % DevBfgs::kRing) * DevBfgs::kTableWords;
-  const uint32_t want = d.seq_base + round;
-  // the planning kernel is on the stream: its last workgroup stores the sequence number with
+  const uint32_t P = d.seq_base + round;
+  const volatile uint32_t* t = d.h_table + (P % DevBfgs::kRing) * DevBfgs::kTableWords;
+  // the planning kernel is on the stream: its last workgroup stores the plan's number with
   // system scope.  Should the stream run dry without it (a failed launch), give up.
   uint32_t spins = 0;
   bool drained = false;
   for (;;) {
-    if (__atomic_load_n(const_cast<const uint32_t*>(t), __ATOMIC_ACQUIRE) == want) break;
+    if (__atomic_load_n(const_cast<const uint32_t*>(t), __ATOMIC_ACQUIRE) == P) break;
     if (yield && (spins & 0x3fu) == 0x3fu) std::this_thread::yield();
     if ((++spins & 0x3fffu) == 0) {
       if (drained) return false;
@@ -393,26 +476,26 @@ bool dbfgs_wait_plan(FastState& fs, hipStream_t st, uint32_t round, uint32_t* n_
     ranges->push_back({t[4 + 2 * k], begin, t[5 + 2 * k]});
     begin += t[5 + 2 * k];
   }
+  for (int k = 0; k < 6; ++k)
+    d.stats_host[k] = (unsigned long long)t[kTblStats + 2 * k] | ((unsigned long long)t[kTblStats + 2 * k + 1] << 32);
   return begin == *n_active;
 }
 
 bool dbfgs_launch_round(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_active,
                         const std::vector<FastState::ModeRange>& ranges, bool emit_estep) {
   DevBfgs& d = fs.dev;
-  const uint32_t par = round & 1u;
+  const uint32_t par = (d.seq_base + round) & 1u;
   return fast_lkl_launch_planned(fs, st, d.groups, ranges, n_active,
                                  d.worklists + (uint64_t)par * kModeSlots * fs.I, d.all + (uint64_t)par * fs.I,
                                  d.part, d.lkl, emit_estep);
 }
 
-bool dbfgs_end(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, uint32_t rounds_used) {
+// the M-step is over (the plan of round `last_round` came out empty): the parameters of every
+// individual are in d.h_F / d.h_A (and on the device), the statistics in d.stats_host
+void dbfgs_end(FastState& fs, uint32_t last_round) {
   DevBfgs& d = fs.dev;
-  d.seq_base += rounds_used + 1;
-  return hipMemcpyAsync(d_indF, d.new_F, fs.I * sizeof(double), hipMemcpyDeviceToDevice, st) == hipSuccess &&
-         hipMemcpyAsync(d_alpha, d.new_A, fs.I * sizeof(double), hipMemcpyDeviceToDevice, st) == hipSuccess &&
-         hipMemcpyAsync(d.h_stats, d.stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) ==
-             hipSuccess &&
-         hipMemcpyAsync(d.h_flags, d.flags, NFLAGS * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+  d.seq_base += last_round;
+  ++d.mstep_no;
 }
 
 }  // namespace nghmm

@@ -36,6 +36,7 @@ struct Switches {
   int timing = 0;             // host-side phase times of every M-step on stderr
   int debug_modes = 0;        // kernel versions of every objective round on stderr
   int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
+  int no_bg_stream = 0;       // device-planned rounds: backward sweep and est_maf between the rounds on the one stream, not next to them on a second
   static Switches from_env();
   // false: no switch of that name
   bool set(const char* name, long value);
@@ -112,26 +113,28 @@ struct FastState {
   // The kernel that plans a round publishes (round, number of active individuals, modes and
   // their counts) in pinned host memory, which the host polls -- no copy, no event.
   struct DevBfgs {
-    static constexpr uint32_t kRing = 4;           // control slots, by round % kRing
-    static constexpr uint32_t kTableWords = 4 + 2 * 129;
+    static constexpr uint32_t kRing = 4;           // control slots, by plan number % kRing
+    static constexpr uint32_t kTableWords = 4 + 2 * 129 + 12;
     uint64_t cap_I = 0;
     void* prob = nullptr;        // BfgsProblem [I]
     void* solver = nullptr;      // LbfgsbT<PtrStore> [I]: the saved scalars
     double* arrays = nullptr;    // [I][LbfgsbPtrs::doubles(2, 10)]: the solvers' work arrays
     void* groups = nullptr;      // GroupDesc [I], by individual
     uint32_t* last_mode = nullptr;   // [I]: the mode an individual's points were last evaluated by
-    uint32_t* worklists = nullptr;   // [kRing % 2 ... ][kModeSlots][I]: two sets, by round parity
+    uint32_t* worklists = nullptr;   // [2][kModeSlots][I]: two sets, by plan parity
     uint32_t* all = nullptr;         // [2][I]
-    uint32_t* counts = nullptr;      // [kRing][kModeSlots + 3]: per-mode counts, all, tickets
-    unsigned long long* stats = nullptr;  // points, ref_calls, ind_rounds, rounds
+    uint32_t* counts = nullptr;      // [kRing][kModeSlots + 3]: per-mode counts, everybody, ticket
     double* lkl = nullptr;           // [5 I]
     double* part = nullptr;          // [I][C][MAXP][5]
-    double *new_F = nullptr, *new_A = nullptr;  // [I]: results (the E-step still reads the old ones)
-    int* flags = nullptr;            // [NFLAGS]
-    volatile uint32_t* h_table = nullptr;  // pinned, [kRing][kTableWords]: seq, n_active, n_modes, pad, (mode, count)...
-    unsigned long long* h_stats = nullptr;  // pinned [4]
-    int* h_flags = nullptr;          // pinned [NFLAGS]
-    uint32_t seq_base = 0;           // rounds of earlier M-steps (the published sequence numbers go on)
+    double *d_F = nullptr, *d_A = nullptr;  // the handle's parameter arrays (borrowed, per M-step)
+    double *snap_F = nullptr, *snap_A = nullptr;  // [I]: the parameters the M-step started from
+    // pinned host memory the kernels write: the plans (number, active individuals, modes and
+    // counts, statistics), a finished individual's parameters
+    volatile uint32_t* h_table = nullptr;  // [kRing][kTableWords]
+    double *h_F = nullptr, *h_A = nullptr;  // [I]
+    unsigned long long stats_host[6] = {0, 0, 0, 0, 0, 0};  // of the last plan waited for
+    uint32_t seq_base = 0;           // plans of earlier M-steps (plans are numbered through the handle's life)
+    uint32_t mstep_no = 0;
   } dev;
 
   double dmax_finite = 0;         // largest finite distance of the loaded data
@@ -170,8 +173,10 @@ bool dbfgs_available(const FastState& fs);
 bool dbfgs_reserve(FastState& fs);
 void dbfgs_destroy(FastState& fs);
 // plan round 1 from the current parameters; nothing waits
-bool dbfgs_begin(FastState& fs, hipStream_t st, const double* d_indF, const double* d_alpha,
-                 bool F_fixed, bool alpha_fixed);
+// (d_indF / d_alpha: a finished individual's new parameters are written there, and to pinned
+// host memory)
+bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, bool F_fixed,
+                 bool alpha_fixed);
 // the values of round `round` into the machines, round + 1 planned; nothing waits
 // (n_in = the active individuals of that round, as dbfgs_wait_plan reported them)
 bool dbfgs_advance(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_in);
@@ -183,9 +188,9 @@ bool dbfgs_wait_plan(FastState& fs, hipStream_t st, uint32_t round, uint32_t* n_
 // launch the planned round
 bool dbfgs_launch_round(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_active,
                         const std::vector<FastState::ModeRange>& ranges, bool emit_estep);
-// results into d_indF / d_alpha, stats + flags to their pinned mirrors (valid after a sync);
-// rounds_used = the last round planned (the sequence numbers of the next M-step go on from there)
-bool dbfgs_end(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, uint32_t rounds_used);
+// after the empty plan of round last_round has arrived: fs.dev.h_F / h_A hold every individual's
+// parameters, fs.dev.stats_host the statistics (the next M-step's plans are numbered on from here)
+void dbfgs_end(FastState& fs, uint32_t last_round);
 bool fast_lkl_launch_planned(FastState& fs, hipStream_t st, const void* d_groups_by_ind,
                              const std::vector<FastState::ModeRange>& ranges, uint32_t n_active,
                              const uint32_t* d_worklists, const uint32_t* d_all, double* part,

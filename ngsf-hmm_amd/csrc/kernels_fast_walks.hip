@@ -397,11 +397,12 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
 __global__ void __launch_bounds__(256)
 k_fast_shard_combine(const GroupDesc* __restrict__ groups, uint32_t n_groups,
                      const double* __restrict__ recv, uint32_t world, uint64_t n,
-                     double* __restrict__ lkl_out, int* __restrict__ flags) {
+                     double* __restrict__ lkl_out, int* __restrict__ flags,
+                     const uint32_t* __restrict__ worklist = nullptr) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t g = (uint32_t)(t / MAXP), p = (uint32_t)(t % MAXP);
   if (g >= n_groups) return;
-  const GroupDesc& G = groups[g];
+  const GroupDesc& G = worklist ? groups[worklist[g]] : groups[g];
   if (p >= G.np) return;
   const uint64_t idx = G.out_idx[p];
   Op m = op_load(recv + idx * 6);
@@ -415,7 +416,7 @@ k_fast_shard_combine(const GroupDesc* __restrict__ groups, uint32_t n_groups,
   const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
   const double l = base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
   lkl_out[idx] = l;
-  if (!(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
+  if (flags && !(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
 }
 
 // The first objective round of an M-step carries every individual's current parameters as its
@@ -424,10 +425,11 @@ k_fast_shard_combine(const GroupDesc* __restrict__ groups, uint32_t n_groups,
 __global__ void __launch_bounds__(256)
 k_fast_shard_edges_from_round(const GroupDesc* __restrict__ groups, uint32_t n_groups,
                               const double* __restrict__ recv, uint32_t world, uint32_t rank,
-                              uint64_t n, double* __restrict__ edges) {
+                              uint64_t n, double* __restrict__ edges,
+                              const uint32_t* __restrict__ worklist = nullptr) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
-  const GroupDesc& G = groups[g];
+  const GroupDesc& G = worklist ? groups[worklist[g]] : groups[g];
   const uint64_t idx = G.out_idx[0];
   const double f = G.F[0];
   double u0 = 1 - f, u1 = f;
@@ -626,17 +628,17 @@ static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg
     SiteShard& sh = fs.shard;
     if ((uint64_t)n_pts * 6 > sh.cap) return false;
     hipLaunchKernelGGL(k_fast_lkl_finish<true>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, part,
-                       fs.base_c, sh.send, d_flags);
+                       fs.base_c, sh.send, d_flags, d_all);
     if (hipGetLastError() != hipSuccess) return false;
     if (sh.allgather(sh.user, (uint64_t)n_pts * 6 * sizeof(double)) != 0) return false;
     ++sh.n_gathers;
     hipLaunchKernelGGL(k_fast_shard_combine, dim3(((unsigned)ng * MAXP + 255) / 256), dim3(256), 0, st, dg,
-                       ng, sh.recv, sh.world, (uint64_t)n_pts, d_lkl, d_flags);
+                       ng, sh.recv, sh.world, (uint64_t)n_pts, d_lkl, d_flags, d_all);
     sh.edges_from_round = false;
 #ifndef NGHMM_NO_EDGE_MERGE  // (A/B builds: the E-step with an all-gather of its own)
     if (emit_estep && !fs.sw.no_fuse) {  // every individual is in the batch: the E-step's edges too
       hipLaunchKernelGGL(k_fast_shard_edges_from_round, dim3((ng + 255) / 256), dim3(256), 0, st, dg, ng,
-                         sh.recv, sh.world, sh.rank, (uint64_t)n_pts, sh.edges);
+                         sh.recv, sh.world, sh.rank, (uint64_t)n_pts, sh.edges, d_all);
       sh.edges_from_round = true;
     }
 #endif
@@ -659,9 +661,10 @@ bool fast_lkl_launch_planned(FastState& fs, hipStream_t st, const void* d_groups
                              const std::vector<FastState::ModeRange>& ranges, uint32_t n_active,
                              const uint32_t* d_worklists, const uint32_t* d_all, double* part,
                              double* d_lkl, bool emit_estep) {
-  if (fs.shard.world > 1) return false;  // (site shards keep the host-planned rounds)
+  // (a site shard exchanges the points' operators at their fixed positions, individual * 5 +
+  // slot: every rank plans the same groups, but lists them in an order of its own)
   return lkl_launch_groups(fs, st, reinterpret_cast<const GroupDesc*>(d_groups_by_ind), ranges,
-                           n_active, n_active * (uint32_t)MAXP, part, d_lkl, nullptr, emit_estep,
+                           n_active, (uint32_t)fs.I * (uint32_t)MAXP, part, d_lkl, nullptr, emit_estep,
                            d_worklists, fs.I, d_all);
 }
 

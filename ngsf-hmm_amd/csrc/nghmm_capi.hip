@@ -370,7 +370,8 @@ int bg_begin(nghmm_t* h) {
 }
 
 // start / stop the timer of one piece (nothing waits)
-int bg_open(nghmm_t* h, int slot) {
+int bg_open(nghmm_t* h, int slot, hipStream_t st) {
+  if (!st) st = h->stream;
   if (h->bg_used == h->bg_spans.size()) {
     nghmm_handle::BgSpan sp;
     const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
@@ -379,12 +380,12 @@ int bg_open(nghmm_t* h, int slot) {
     h->bg_spans.push_back(sp);
   }
   h->bg_spans[h->bg_used].slot = slot;
-  HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev0, h->stream));
+  HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev0, st));
   return NGHMM_OK;
 }
 
-int bg_close(nghmm_t* h) {
-  HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev1, h->stream));
+int bg_close(nghmm_t* h, hipStream_t st) {
+  HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev1, st ? st : h->stream));
   ++h->bg_used;
   return NGHMM_OK;
 }
@@ -564,7 +565,7 @@ int nghmm_destroy(nghmm_t* h) {
     h->parent->n_replicas.fetch_sub(1);
   }
   fast_destroy(h->fast);
-  for (hipEvent_t e : {h->aux_ev0, h->aux_ev1, h->aux_go})
+  for (hipEvent_t e : {h->aux_ev0, h->aux_ev1, h->aux_go, h->aux_done})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->aux_piece_ev)
     if (e) (void)hipEventDestroy(e);
@@ -783,6 +784,10 @@ struct MstepRun {
   bool estep_pending = false;
   bool bg_active = false;
   bool bg_begun = false;        // the iteration's timing spans and background flags are set up
+  // where the background work goes: the handle's stream (between the rounds), or -- rounds
+  // planned on the device -- a second stream, NEXT TO the rounds and their planning kernels
+  hipStream_t bg_stream = nullptr;
+  const double *estep_F = nullptr, *estep_A = nullptr;  // the parameters the E-step reads
   bool tile_major = false;      // est_maf reads the tile-major posteriors in place
   uint32_t bg_parts = 0, bg_next = 0;  // est_maf parts queued / already on the stream
   // host-side wall time of the phases (switch `timing`)
@@ -829,11 +834,12 @@ struct MstepRun {
     if (!have_walk && (r = ensure_emissions(h))) return r;
     if (!bg_begun && (r = bg_begin(h))) return r;
     bg_begun = true;
-    if ((r = bg_open(h, SLOT_FORWARD))) return r;
-    if (!fast_estep(h->fast, h->stream, h->d_indF, h->d_alpha, h->d_ind_lkl, h->d_flags_bg,
-                    have_walk))
+    hipStream_t bs = bg_stream ? bg_stream : h->stream;
+    if ((r = bg_open(h, SLOT_FORWARD, bs))) return r;
+    if (!fast_estep(h->fast, bs, estep_F ? estep_F : h->d_indF, estep_A ? estep_A : h->d_alpha,
+                    h->d_ind_lkl, h->d_flags_bg, have_walk))
       return NGHMM_ERR_HIP;
-    if ((r = bg_close(h))) return r;
+    if ((r = bg_close(h, bs))) return r;
     h->ms[SLOT_BACKWARD] = 0;
     h->launches[SLOT_BACKWARD] = 0;
     h->marg_valid = false;
@@ -855,13 +861,14 @@ struct MstepRun {
     if (bg_next >= bg_parts) return NGHMM_OK;
     const uint32_t part = bg_next++;
     int q;
-    if ((q = bg_open(h, SLOT_ESTMAF))) return q;
+    hipStream_t bs = bg_stream ? bg_stream : h->stream;
+    if ((q = bg_open(h, SLOT_ESTMAF, bs))) return q;
     if (!tile_major && (q = ensure_marg(h))) return q;
-    if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast),
+    if (!fast_estmaf(h->fast, bs, fast_gl_lin(h->fast),
                      tile_major ? h->fast.post : h->d_marg, h->S, h->I, h->I, h->d_freq,
                      tile_major, part, bg_parts))
       return NGHMM_ERR_HIP;
-    return bg_close(h);
+    return bg_close(h, bs);
   }
 
   int first_or_plain_round() {
@@ -966,7 +973,7 @@ struct MstepRun {
   // a word of pinned memory the planning kernel's last workgroup writes -- and launches them.
   // No copy, no event wait, no host arithmetic between two rounds.
   bool wants_device() const {
-    return h->mode == NGHMM_MODE_FAST && !before_round && !h->chain && h->g_n <= 1 &&
+    return h->mode == NGHMM_MODE_FAST && !before_round && h->g_n <= 1 &&
            !h->fast.sw.no_dev_bfgs && dbfgs_available(h->fast);
   }
 
@@ -979,6 +986,26 @@ struct MstepRun {
     }
     if ((rc = bg_begin(h))) return rc;  // timing spans of the rounds; flags of the background work
     bg_begun = true;
+    // The E-step's backward sweep and est_maf need round 1's walk and nothing else of the
+    // M-step: they go onto a second stream and run NEXT TO the later rounds, so that the chip
+    // has work while a planning kernel (one wave per individual) and its plan's way to the host
+    // would leave it idle.  The E-step reads the parameters the M-step started from (a copy the
+    // planning kernel of round 1 makes: finished individuals' new ones go into d_indF / d_alpha
+    // while the sweep may still be running).
+    const bool overlap = wants_background() && fast_estmaf_in_place(fs, h->I) && !fs.sw.no_bg_stream;
+    struct AuxDrain {  // nothing may be left running on the second stream when this returns
+      hipStream_t s = nullptr;
+      ~AuxDrain() { if (s) (void)hipStreamSynchronize(s); }
+    } drain;
+    if (overlap) {
+      if (!h->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+      if (!h->aux_go) HIP_TRY(hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
+      if (!h->aux_done) HIP_TRY(hipEventCreateWithFlags(&h->aux_done, hipEventDisableTiming));
+      if (!h->d_flags_bg && (rc = dev_alloc(&h->d_flags_bg, (size_t)NFLAGS))) return rc;
+      bg_stream = drain.s = h->aux_stream;
+      estep_F = fs.dev.snap_F;
+      estep_A = fs.dev.snap_A;
+    }
     h->ms[SLOT_BFGS] = 0;
     h->launches[SLOT_BFGS] = 0;
     estep_pending = fuse_estep;
@@ -1020,6 +1047,7 @@ struct MstepRun {
         return NGHMM_ERR_HIP;
       }
       if ((rc = bg_close(h))) return rc;
+      if (overlap && round == 1) HIP_TRY(hipEventRecord(h->aux_go, h->stream));  // the walk is there
       if ((rc = bg_open(h, SLOT_BFGS))) return rc;
       if (!dbfgs_advance(fs, h->stream, round, n_active)) {
         set_error("k_bfgs_advance failed to launch: %s", hipGetErrorString(hipGetLastError()));
@@ -1029,9 +1057,17 @@ struct MstepRun {
       // behind the round and its planning kernel: the E-step's backward sweep (round 1), est_maf
       // in parts (rounds 2, 3, ...) -- the GPU works on them while the plan travels to the host
       if (estep_pending) {
-        if ((rc = wants_background() ? start_background(emit) : estep_then_hook(emit))) return rc;
+        if (overlap) {  // the whole E-step + frequency step, next to everything that follows here
+          HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
+          if ((rc = start_background(emit))) return rc;
+          bg_parts = 1;
+          if ((rc = push_background_piece())) return rc;
+          HIP_TRY(hipEventRecord(h->aux_done, h->aux_stream));
+        } else if ((rc = wants_background() ? start_background(emit) : estep_then_hook(emit))) {
+          return rc;
+        }
         estep_pending = false;
-      } else if (bg_active) {
+      } else if (bg_active && !overlap) {
         if ((rc = push_background_piece())) return rc;
       }
       ++round;
@@ -1041,17 +1077,19 @@ struct MstepRun {
       std::fprintf(stderr, "[nghmm timing] mstep (device-planned): %.3f ms for %u rounds\n", t_lkl, round - 1);
     if (estep_pending && (rc = estep_then_hook(false))) return rc;
     if (bg_active) {  // what is left of the background work, then the frequency table
+      if (overlap) HIP_TRY(hipStreamWaitEvent(h->stream, h->aux_done, 0));
+      bg_stream = nullptr;
       while (bg_next < bg_parts)
         if ((rc = push_background_piece())) return rc;
       if ((rc = bg_open(h, SLOT_EMISSION))) return rc;
       if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
       if ((rc = bg_close(h))) return rc;
     }
-    if (!dbfgs_end(fs, h->stream, h->d_indF, h->d_alpha, round)) return NGHMM_ERR_HIP;
-    HIP_TRY(hipMemcpyAsync(h->h_indF.data(), h->d_indF, h->I * sizeof(double), hipMemcpyDeviceToHost,
-                           h->stream));
-    HIP_TRY(hipMemcpyAsync(h->h_alpha.data(), h->d_alpha, h->I * sizeof(double), hipMemcpyDeviceToHost,
-                           h->stream));
+    // (the plan that came out empty was published by the last kernel that touched the machines:
+    // every individual's parameters are in pinned memory, and on the device)
+    dbfgs_end(fs, round);
+    std::memcpy(h->h_indF.data(), fs.dev.h_F, h->I * sizeof(double));
+    std::memcpy(h->h_alpha.data(), fs.dev.h_A, h->I * sizeof(double));
     if (bg_active && ind_lkl)
       HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
                              h->stream));
@@ -1060,16 +1098,17 @@ struct MstepRun {
     h->launches[SLOT_LKL] = round - 1;
     if (rc) return rc;
     if (bg_active && freq_done) *freq_done = true;
-    if (fs.dev.h_flags[FLAG_INVALID_LKL]) {
+    const unsigned long long* sv = fs.dev.stats_host;
+    if (sv[5]) {
       set_error("invalid Lkl found!");
       return NGHMM_ERR_INVALID_LKL;
     }
-    h->lkl_redone += fs.dev.h_stats[4];
+    h->lkl_redone += sv[4];
     if (stats) {
-      stats->points = fs.dev.h_stats[0];
-      stats->ref_forward_calls = fs.dev.h_stats[1];
-      stats->ind_rounds = fs.dev.h_stats[2];
-      stats->rounds = (uint32_t)fs.dev.h_stats[3];
+      stats->points = sv[0];
+      stats->ref_forward_calls = sv[1];
+      stats->ind_rounds = sv[2];
+      stats->rounds = (uint32_t)sv[3];
     }
     return NGHMM_OK;
   }
