@@ -281,6 +281,11 @@ class Ctx:
     """What every part of a run needs: arguments, modules, this process's place in the job."""
 
 
+class ShardSetupRefused(RuntimeError):
+    """build_run: the ranks have agreed (one all-reduce) that at least one of them could not set
+    up its shard of a layout; nobody has entered the load's collectives."""
+
+
 def shard_shapes(ctx, shard):
     """What this rank's handle holds under `shard` ("sites" | "individuals" | None = one GPU):
     the slice of the ONE data set IndexedSim(I_tot, S_job) describes.  The N-rank job processes
@@ -347,7 +352,7 @@ def build_run(ctx, shard, agree=None):
             em.close()
         del gl, sim, pos
         torch.cuda.empty_cache()
-        raise RuntimeError(err or "another rank could not set up its shard")
+        raise ShardSetupRefused(err or "another rank could not set up its shard")
     if ctx.call_geno:   # a block of sites at a time, called and packed on the way in
         em.load_chunks_device(pos, sim.chunks(sh["ind_range"], sh["site_range"], chunk_sites=50_000),
                               space=0, call_geno=True)
@@ -1052,15 +1057,27 @@ def alt_sharding(ctx, steps, warmup, main_check):
     # every rank says whether the rank-local part of the set-up worked BEFORE any of them enters
     # the collectives of the load: a layout that does not fit this job (a size that does not
     # divide, memory) costs the line this object, not the run
+    agreed = []
+
     def agree(err):
+        agreed.append(True)
         return allreduce(ctx, [1.0 if err else 0.0], "max")[0] == 0.0
     run = None
     try:
         run = build_run(ctx, "individuals", agree)
         reset_params(run["em"])
-    except (ValueError, RuntimeError) as e:
-        if isinstance(e, ValueError):   # refused before any allocation, on every rank alike
-            agree(str(e))
+    except ShardSetupRefused as e:      # the ranks agreed that one of them could not set up
+        out["skipped"] = f"{type(e).__name__}: {e}"
+        return out
+    except ValueError as e:
+        if agreed:
+            # PAST the agreement point (the load, which contains collectives for individual
+            # shards): the other ranks are inside those collectives, an all-reduce from here
+            # would pair up with the wrong call.  Fatal for the job: main() tells the others.
+            raise
+        # refused before any allocation (shard_shapes: a size that does not divide), on every
+        # rank alike: each of them makes the agreement's all-reduce here instead
+        agree(str(e))
         out["skipped"] = f"{type(e).__name__}: {e}"
         return out
     em = run["em"]

@@ -64,6 +64,7 @@ struct nghmm_handle {
   hipEvent_t aux_piece_ev[kAuxPieces] = {};
   hipEvent_t aux_estep_ev[3] = {};             // ... the E-step next to the first rounds: its timing
   double* d_aux_params = nullptr;              // ... and its own copies of indF / alpha [2][I]
+  hipEvent_t param_snapshot_ev = nullptr;      // (borrowed) those copies are made: an M-step's new parameters wait for it
   bool blocking_sync = false;
   bool loaded = false;
   bool warmed = false;   // nghmm_emission has set up what the first EM iteration needs

@@ -65,7 +65,7 @@ struct DevPtrs {
   uint32_t* counts;
   const double* lkl;
   double *d_F, *d_A;              // the handle's parameters: a finished individual's go there ...
-  double *h_F, *h_A;              // ... and to their pinned host mirror
+  double *h_F, *h_A;              // ... and, when the M-step ends, all of them to their pinned host mirror
   double *snap_F, *snap_A;        // the parameters the M-step started from (the E-step's, which runs next to it)
   uint32_t* h_table;
   uint32_t I;
@@ -178,7 +178,6 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
 
   PHASE(0)  // problem + work arrays in LDS
   bool keep = false;        // the solver's arrays go back to memory
-  bool wrote_host = false;  // a finished individual's parameters went to pinned host memory
   if (lane == 0) {
     if constexpr (FIRST) {
       bfgs_problem_begin(p, D.d_F[i], D.d_A[i], F_fixed != 0, alpha_fixed != 0);
@@ -211,10 +210,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       } else if (bad) {
         p.acc_invalid = 1;  // EM.cpp:400-410: "invalid Lkl found!"
         p.active = 0;
-        wrote_host = true;
         D.prob[i] = p;
-        D.h_F[i] = p.x[0];
-        D.h_A[i] = p.x[1];
       } else {
         DevSolver s;
         if (started) s = D.solver[i];
@@ -237,11 +233,8 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
           D.solver[i] = s;
           keep = true;
         } else {
-          wrote_host = true;
           D.d_F[i] = p.x[0];
           D.d_A[i] = p.x[1];
-          D.h_F[i] = p.x[0];
-          D.h_A[i] = p.x[1];
         }
         D.prob[i] = p;
         PHASE(2)  // plan, descriptor, worklists, state out
@@ -262,13 +255,15 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
   // The last workgroup publishes plan P_out to the host: the modes present and their counts
   // (all lanes read the counters, a ballot compacts them) -- and, when the plan is empty, i.e.
   // the M-step is over, the accounting summed over the individuals.
-  if (__shfl((int)wrote_host, 0)) __threadfence_system();
-  else __threadfence();
+  __threadfence();
   __shared__ int is_last;
   if (lane == 0) is_last = atomicAdd(&cnt_out[kCntTicket], 1u) == gridDim.x - 1;
   __syncthreads();
   if (is_last) {
     __threadfence();
+    // all lanes read the counters and compact the modes present into LDS; ONE lane then writes
+    // the whole entry to host memory and, behind a system-scope fence, the plan's number
+    __shared__ uint32_t pub_mode[kModeSlots], pub_count[kModeSlots];
     uint32_t* t = D.h_table + (P_out % DevBfgs::kRing) * DevBfgs::kTableWords;
     const uint32_t n_all = __hip_atomic_load(&cnt_out[kCntAll], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t n_modes = 0;
@@ -280,15 +275,17 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       const uint64_t have = __ballot(c != 0);
       if (c != 0) {
         const uint32_t k = n_modes + (uint32_t)__popcll(have & ((1ull << lane) - 1));
-        t[4 + 2 * k] = slot_mode(sl);
-        t[5 + 2 * k] = c;
+        pub_mode[k] = slot_mode(sl);
+        pub_count[k] = c;
       }
       n_modes += (uint32_t)__popcll(have);
     }
-    if (n_all == 0) {  // the M-step's accounting
-      unsigned long long pts = 0, calls = 0, indr = 0, redone = 0, invalid = 0;
-      uint32_t rmax = 0;
+    unsigned long long pts = 0, calls = 0, indr = 0, redone = 0, invalid = 0;
+    uint32_t rmax = 0;
+    if (n_all == 0) {  // the M-step is over: every individual's parameters to the host, the accounting
       for (uint32_t k = lane; k < D.I; k += 64) {
+        D.h_F[k] = D.d_F[k];
+        D.h_A[k] = D.d_A[k];
         const BfgsProblem& q = D.prob[k];
         pts += q.acc_points;
         calls += q.acc_ref_calls;
@@ -306,22 +303,25 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
         const uint32_t o = __shfl_down(rmax, off);
         rmax = o > rmax ? o : rmax;
       }
-      if (lane == 0) {
-        const unsigned long long v[6] = {pts, calls, indr, rmax, redone, invalid};
-        for (int k = 0; k < 6; ++k) {
-          t[kTblStats + 2 * k] = (uint32_t)v[k];
-          t[kTblStats + 2 * k + 1] = (uint32_t)(v[k] >> 32);
-        }
-      }
     }
+    __threadfence_system();  // (the parameters above: every lane's own stores, before the barrier)
+    __syncthreads();
     if (lane == 0) {
+      t[3] = P_out;  // (the entry's second stamp: the host checks both)
+      for (uint32_t k = 0; k < n_modes; ++k) {
+        t[4 + 2 * k] = pub_mode[k];
+        t[5 + 2 * k] = pub_count[k];
+      }
+      const unsigned long long v[6] = {pts, calls, indr, rmax, redone, invalid};
+      for (int k = 0; k < 6; ++k) {
+        t[kTblStats + 2 * k] = (uint32_t)v[k];
+        t[kTblStats + 2 * k + 1] = (uint32_t)(v[k] >> 32);
+      }
       t[1] = n_all;
       t[2] = n_modes;
-      t[3] = round;
+      __threadfence_system();
+      __hip_atomic_store(&t[0], P_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
-    __syncthreads();
-    if (lane == 0) __hip_atomic_store(&t[0], P_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   PHASE(4)  // fence, ticket, publication
 }
@@ -410,6 +410,12 @@ bool dbfgs_reserve(FastState& fs) {
     return false;
   }
   std::memset(t, 0, DevBfgs::kRing * DevBfgs::kTableWords * sizeof(uint32_t));
+  // (hipMemset of device memory need not have finished when it returns, and the handle's stream
+  // does not wait for the null stream)
+  if (hipDeviceSynchronize() != hipSuccess) {
+    dbfgs_destroy(fs);
+    return false;
+  }
   d.seq_base = 0;
   d.mstep_no = 0;
   d.cap_I = I;
@@ -468,6 +474,7 @@ bool dbfgs_wait_plan(FastState& fs, hipStream_t st, uint32_t round, uint32_t* n_
       (void)hipGetLastError();
     }
   }
+  if (t[3] != P) return false;  // (one lane writes the entry, its number last: both stamps agree)
   *n_active = t[1];
   const uint32_t nm = t[2];
   ranges->clear();

@@ -1016,7 +1016,7 @@ struct MstepRun {
       return NGHMM_ERR_HIP;
     }
     if ((rc = bg_close(h))) return rc;
-    uint32_t round = 1, n_active = 0;
+    uint32_t round = 1, n_active = 0, prev_active = (uint32_t)h->I;
     std::vector<FastState::ModeRange> ranges;
     const bool yield = h->blocking_sync;
     for (;;) {
@@ -1026,6 +1026,13 @@ struct MstepRun {
         return NGHMM_ERR_HIP;
       }
       if (n_active == 0) break;
+      // (what a plan can be: round 1 has everybody, later rounds never more than the one before)
+      if ((round == 1 && n_active != h->I) || n_active > prev_active) {
+        set_error("the device-side M-step planned %u individuals for round %u after %u", n_active,
+                  round, prev_active);
+        return NGHMM_ERR_HIP;
+      }
+      prev_active = n_active;
       if (fs.sw.debug_modes) {
         std::fprintf(stderr, "[nghmm modes] round %u, %u active:", round, n_active);
         for (const auto& r : ranges)
@@ -1160,6 +1167,9 @@ struct MstepRun {
       if ((rc = bg_close(h))) return rc;
     }
     batch.result(h->h_indF.data(), h->h_alpha.data());
+    // (exact mode's overlapped E-step reads copies of the OLD parameters that its own stream
+    // makes: the new ones must not land before those copies are done)
+    if (h->param_snapshot_ev) HIP_TRY(hipStreamWaitEvent(h->stream, h->param_snapshot_ev, 0));
     HIP_TRY(hipMemcpyAsync(h->d_indF, h->h_indF.data(), h->I * sizeof(double), hipMemcpyHostToDevice,
                            h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_alpha, h->h_alpha.data(), h->I * sizeof(double),
@@ -1518,6 +1528,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
       HIP_TRY(hipMemcpyAsync(aF, h->d_indF, h->I * sizeof(double), hipMemcpyDeviceToDevice, as));
       HIP_TRY(hipMemcpyAsync(aA, h->d_alpha, h->I * sizeof(double), hipMemcpyDeviceToDevice, as));
       HIP_TRY(hipEventRecord(h->aux_estep_ev[0], as));
+      h->param_snapshot_ev = h->aux_estep_ev[0];
       (h->fast.sw.exact_serial ? launch_forward_exact : launch_forward_exact_pc)(
           as, h->d_eprob, h->d_pos, h->S, h->I, (uint32_t)h->I, nullptr, aF, aA, h->d_ind_lkl, h->d_fw,
           h->d_flags_bg);
@@ -1552,6 +1563,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     };
     rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, false, nullptr, nullptr, nullptr, false,
                          nullptr, before_round);
+    h->param_snapshot_ev = nullptr;
     while (rc == NGHMM_OK && next < n_pieces) rc = push(0);  // the rest, on the whole chip
     HIP_TRY(hipEventRecord(h->aux_ev1, h->aux_stream));
     HIP_TRY(hipEventSynchronize(h->aux_ev1));  // also when the M-step failed

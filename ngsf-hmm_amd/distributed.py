@@ -141,14 +141,19 @@ class FailureBeacon:
         sys.stderr.flush()
         os._exit(5)
 
-    def signal(self, message):
-        """This rank has failed: tell the others (idempotent)."""
+    def signal(self, message, linger=True):
+        """This rank has failed: tell the others (idempotent).  linger: stay alive for two
+        polling intervals afterwards -- the c10d store lives in rank 0's process, and a rank 0
+        that wrote the key and exited at once would take the key with it before anybody read it."""
         if not self._signalled:
             self._signalled = True
             try:
                 self.store.set(self.KEY, f"{self.rank}: {message}")
             except Exception:       # noqa: BLE001 - the store is gone: the job is ending anyway
-                pass
+                return
+            if linger:
+                import time
+                time.sleep(2 * self.poll_s)
 
     def _watch(self):
         while not self._stop.wait(self.poll_s):
@@ -156,7 +161,16 @@ class FailureBeacon:
                 if not self.store.check([self.KEY]):
                     continue
                 msg = self.store.get(self.KEY).decode(errors="replace")
-            except Exception:       # noqa: BLE001 - store closed (process group destroyed)
+            except Exception as e:  # noqa: BLE001
+                # The store no longer answers.  After close() that is the job ending in good
+                # order (process group destroyed).  Before it, the process that hosts the store
+                # -- rank 0 -- has died: under a launcher without an agent that kills the
+                # survivors (mpirun, srun) they would sit in their next collective until its
+                # timeout, so this too is a peer's failure.
+                if self._signalled or self._stop.is_set():
+                    return
+                self.on_peer_failure(f"0 (or the store's host): the job's store is lost "
+                                     f"({type(e).__name__}: {e})")
                 return
             if self._signalled or self._stop.is_set():
                 return              # (our own failure: the main thread is raising it)

@@ -19,6 +19,7 @@ import collections
 import csv
 import json
 import re
+import os
 import sys
 
 FAMILIES = {
@@ -99,9 +100,14 @@ def main():
         fam["lkl_batch"]["objective_rounds_in_pass"] = rounds
         fam["lkl_batch"]["hbm_bytes_per_round"] = fam["lkl_batch"]["hbm_bytes_in_pass"] / rounds
     res["families"] = fam
+    # which build these counters belong to (bench.py drops them for any other: profiles/build_id.py)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from build_id import build_id
+    res["build_id"] = build_id()
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, d in res.items():
-        print(k, {kk: (f"{vv:.4g}" if isinstance(vv, float) else vv) for kk, vv in d.items()})
+        if isinstance(d, dict):
+            print(k, {kk: (f"{vv:.4g}" if isinstance(vv, float) else vv) for kk, vv in d.items()})
 
 
 if __name__ == "__main__":

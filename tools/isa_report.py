@@ -6,7 +6,8 @@
           ngsf-hmm_amd/csrc/kernels_fast_$f.hip -o /tmp/kf_$f.s
   done
   cat /tmp/kf_walks.s /tmp/kf_estep.s /tmp/kf_estmaf.s > /tmp/kf.s
-  python tools/isa_report.py /tmp/kf.s > profiles/r04_isa_summary.txt
+  python tools/isa_report.py /tmp/kf.s > profiles/r05_isa_summary.txt
+  (tools/isa_summary.sh does all of it)
 
 For each kernel: registers / scratch / occupancy as the assembler reports them, and every
 basic block of >= 60 instructions with its opcode histogram (the loop bodies)."""
@@ -30,6 +31,10 @@ KERNELS = {
 
 
 def main():
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    from build_id import build_id
+    print("# build_id:", build_id(), "(profiles/build_id.py: the sources this assembly was made from)")
     lines = open(sys.argv[1]).read().split("\n")
     for title, sym in KERNELS.items():
         start = [i for i, l in enumerate(lines) if l.startswith(sym)][0]
