@@ -71,26 +71,28 @@ FP64_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 256 CUs x 4 SIMDs
                                         # VALU) instruction of a 64-wide wave takes 4 cycles;
                                         # x 64 lanes x 2 flop = the 78.6 TFLOP/s FP64 vector peak
 
-# The kernels of one fast-mode EM iteration, what bounds each and their
-# instruction counts per site from the device assembly (profiles/r04_isa_summary.txt, made by
-# tools/isa_report.py from `hipcc -S` of this build): loop body of 8 sites / 8.
+# The kernels of one fast-mode EM iteration and what bounds each.  Their
+# instruction counts per site come from the device assembly of THIS build: profiles/rNN_isa_summary.txt
+# (tools/isa_summary.sh: `hipcc -S` + tools/isa_report.py), parsed by isa_counts() below and used
+# only when the file carries the build id of the sources this run loads (profiles/build_id.py).
 KERNELS = {
     "lkl_later_rounds": dict(
-        bound="fp64_valu", fp64_per_site=698 / 8.0, valu_per_site=722 / 8.0,
+        bound="fp64_valu", isa="later objective rounds",
         kernel="k_fast_lkl_fd<2,2,true,false,SRC_PLAIN,2>",
         note="objective rounds 2.. of the L-BFGS-B M-step: 5 probe points share one pass over "
              "the 8 B emission ratio of every still-active individual; 87 FP64 instructions per "
              "site, 104 VGPRs, 4 waves per SIMD; the chip runs it at ~1.7 GHz (power limit), "
              "where this rate is ~85 % of what a register-resident FP64 stream sustains"),
     "lkl_first_round": dict(
-        bound="fp64_valu", fp64_per_site=855 / 8.0, valu_per_site=1021 / 8.0,
+        bound="fp64_valu", isa="fresh forward walk",
         kernel="k_fast_lkl_fd<2,2,true,true,SRC_FRESH,2>",
         note="round 1 = E-step's forward walk = emission refresh: reads the 16 B relative "
              "likelihoods, writes the 8 B emission ratio and 4 B of checkpoints; VALU-issue "
              "bound (128 VALU per site: the 5-point walk, the emissions, their ratio, the "
              "decode of the 16 B cells), 163 VGPRs, 3 waves per SIMD"),
     "est_maf": dict(
-        bound="fp64_valu", kernel="k_fast_estmaf<16,64,true> + _interp + _resume",
+        bound="fp64_valu", isa="est_maf: k_fast_estmaf<16, 64, true>",
+        kernel="k_fast_estmaf<16,64,true> + _interp + _resume",
         note="the reference's ~100 passes per site: 3 evaluated over all individuals, 12 "
              "Chebyshev nodes of a checked interpolant, the rest on the interpolant; 256 VGPRs, "
              "2 waves per SIMD, SQ_ACTIVE_INST_VALU 0.44 per wave"),
@@ -102,16 +104,59 @@ KERNELS = {
 }
 
 
-def estmaf_instr_per_site(i_tot):
-    """VALU / FP64 wave-instructions est_maf issues per site (profiles/r04_isa_summary.txt:
-    set-up block 283 / 150 for 16 individuals per lane, an exact pass 375 / 295 in three blocks,
-    a node evaluation 165 / 160; 3 exact passes and 12 nodes per site), scaled to the
-    individuals per lane of the cohort."""
+def this_build_id():
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from build_id import build_id
+    return build_id()
+
+
+def isa_counts():
+    """(counts, source, reason): per kernel of KERNELS the (instructions, VALU, FP64) of every basic
+    block of >= 100 instructions, in file order, from the latest profiles/rNN_isa_summary.txt --
+    or (None, file, why) when there is none for THIS build."""
+    import re
+    path = _latest_profile("isa_summary.txt")
+    if not path:
+        return None, None, "no profiles/rNN_isa_summary.txt"
+    text = open(os.path.join(ROOT, path)).read().split("\n")
+    m = re.match(r"# build_id: (\w+)", text[0]) if text else None
+    if not m:
+        return None, path, f"{path} carries no build id (made before round 5)"
+    if m.group(1) != this_build_id():
+        return None, path, (f"{path} is of build {m.group(1)}, the sources here are {this_build_id()}: "
+                            "re-run tools/isa_summary.sh")
+    out, cur = {}, None
+    for line in text:
+        if line.startswith("== "):
+            cur = next((k for k, v in KERNELS.items() if v.get("isa") and line[3:].startswith(v["isa"])), None)
+            if cur:
+                out[cur] = []
+        b = re.match(r"\s+block \S+: (\d+) instructions = (\d+) VALU \((\d+) FP64\)", line)
+        if b and cur and int(b.group(1)) >= 100:
+            out[cur].append(tuple(int(x) for x in b.groups()))
+    return out, path, None
+
+
+def walk_instr_per_site(blocks):
+    """lkl kernels: the loop body (the largest block) covers 8 sites."""
+    n, valu, fp64 = max(blocks)
+    return valu / 8.0, fp64 / 8.0
+
+
+def estmaf_instr_per_site(i_tot, blocks):
+    """VALU / FP64 wave-instructions est_maf issues per site from its five big blocks in file
+    order -- set-up of the per-individual constants (16 individuals per lane), an exact pass in
+    three blocks (sums, reduction, recursion), a node evaluation --: 3 exact passes and 12 nodes
+    per site, the per-individual parts scaled to the individuals per lane of the cohort.  None if
+    the assembly no longer has that shape."""
+    if len(blocks) != 5:
+        return None
+    (_, s_v, s_f), (_, p_v, p_f), (_, r_v, r_f), (_, c_v, c_f), (_, n_v, n_f) = blocks
     ni = min(16, -(-i_tot // 64))
     waves = max(1, -(-i_tot // 1024))
     sc = ni / 16.0
-    valu = waves * (283 * sc + 3 * (185 * sc + 104 + 86) + 12 * (165 * sc))
-    fp64 = waves * (150 * sc + 3 * (166 * sc + 51 + 78) + 12 * (160 * sc))
+    valu = waves * (s_v * sc + 3 * (p_v * sc + r_v + c_v) + 12 * (n_v * sc))
+    fp64 = waves * (s_f * sc + 3 * (p_f * sc + r_f + c_f) + 12 * (n_f * sc))
     return valu, fp64
 
 
@@ -126,10 +171,17 @@ PMC_SUMMARY = _latest_profile("pmc_summary.json")
 
 
 def pmc_summary():
-    """The committed rocprofv3 --pmc passes of the default workload (profiles/collect.sh ->
-    profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 correction), or
-    None.  Collected in one session with the round's profiles/rNN_bench_*.json."""
-    return json.load(open(os.path.join(ROOT, PMC_SUMMARY))) if PMC_SUMMARY else None
+    """(summary, reason): the committed rocprofv3 --pmc passes of the default workload
+    (profiles/collect.sh -> profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB units,
+    gfx950 correction) -- if they are of THIS build (profiles/build_id.py), else (None, why)."""
+    if not PMC_SUMMARY:
+        return None, "no profiles/rNN_pmc_summary.json"
+    summ = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
+    have = summ.get("build_id")
+    if have != this_build_id():
+        return None, (f"{PMC_SUMMARY} is of build {have}, the sources here are {this_build_id()}: counters "
+                      "of another build are not quoted (profiles/collect.sh)")
+    return summ, None
 
 
 def pmc_traffic(summ, I, C):
@@ -168,21 +220,39 @@ def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
     """The oracle (libm build = the reference's arithmetic; its L-BFGS-B core is pinned
     bit for bit to the reference object) timed on this box's host cores on a bounded
     sample of the same workload: per-individual phases threaded like the reference's
-    pool, the frequency loop serial as in the reference (EM.cpp:224).  `improved_cpu`:
-    the same sample with the frequency loop threaded over sites too (BASELINE.md section 4:
-    what a maintainer could get from the CPU without changing the arithmetic).
+    pool, the frequency loop serial as in the reference (EM.cpp:224).  The sample is a
+    slice of the benchmark's own data set (100 individuals x its first 4000 sites), and
+    the timed iterations start from the state after 5 GPU-computed EM iterations -- the
+    optimizer's 4-round steady state, which the GPU's timed iterations are in (`cold_start`:
+    the same from --freq 0.1 --indF 0.1,0.2, whose first iterations take 18, 11, 6 rounds).
+    `improved_cpu`: the frequency loop threaded over sites too (what a
+    maintainer could get from the CPU without changing the arithmetic).
     full_c2: additionally one EM iteration of BASELINE.json configs[1] (100 x 100k) in
     full, about a minute on a 256-thread host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
+    import torch
     cores = os.cpu_count() or 1
     orc = orclib.Oracle("libm")
+    dev = torch.device("cuda", 0)
 
-    def timed(n_ind, n_sites, max_iters, budget, thread_freq):
-        d = pkg.simulate.simulate(n_ind, n_sites, seed=777)
-        gl = pkg.simulate.normalise_log_gl(d.gl)
-        em = orclib.OracleEM(orc, gl, d.pos_dist_mb)
-        em.set_params(0.1, 0.2, 0.1)
+    def sample(n_ind, n_sites, s_tot):
+        sim = pkg.simulate.IndexedSim(n_ind, s_tot, dev, seed=12345)
+        gl_d, pos_d = sim.gl((0, n_ind), (0, n_sites)), sim.pos_dist(0, n_sites)
+        torch.cuda.synchronize()
+        with pkg.NgsFHMM(n_ind, n_sites, mode=pkg.MODE_FAST) as h:
+            h.load_device(gl_d.data_ptr(), pos_d.data_ptr())
+            h.set_params(0.1, 0.2, 0.1)
+            h.init_emission()
+            for _ in range(5):
+                h.iter_EM()
+            warm = (h.indF.copy(), h.alpha.copy(), h.freq.copy())
+        return gl_d.cpu().numpy(), pos_d.cpu().numpy(), warm
+
+    def timed(gl, pos, start, max_iters, budget, thread_freq):
+        n_sites, n_ind = gl.shape[0], gl.shape[1]
+        em = orclib.OracleEM(orc, gl, pos)
+        em.set_params(*start)
         em.init_emission()
         thr = min(cores, n_sites if thread_freq else n_ind)
         t0 = time.time()
@@ -198,38 +268,47 @@ def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
         return res
 
     n_ind, n_sites = 100, 4000
-    v, iters, dt, thr, fw, mp = timed(n_ind, n_sites, 3, seconds_budget, False)
+    gl, pos, warm = sample(n_ind, n_sites, 100_000)
+    cold = (0.1, 0.2, 0.1)
+    v, iters, dt, thr, fw, mp = timed(gl, pos, warm, 3, seconds_budget, False)
     out = {
         "value": v,
         "unit": "site-ind updates/s",
         "cores": thr,
         "kind": "port",
-        "sample": f"{n_ind} ind x {n_sites} sites, {iters} EM iterations in {dt:.1f} s, oracle libm "
-                  f"build, per-individual phases on {thr} threads, allele-frequency "
-                  f"loop serial as in the reference (EM.cpp:224)",
+        "sample": f"{n_ind} ind x the first {n_sites} sites of the 100 x 100k data set, {iters} EM iterations in "
+                  f"{dt:.1f} s from the state after 5 GPU-computed iterations (the steady state the GPU "
+                  f"is timed in), oracle libm build, per-individual phases on {thr} threads, "
+                  f"allele-frequency loop serial as in the reference (EM.cpp:224)",
         "forward_passes_per_ind_iter": fw,
         "est_maf_passes_per_site": mp,
     }
-    v2, it2, dt2, thr2, _, _ = timed(n_ind, n_sites, 3, seconds_budget / 2, True)
+    vc, itc, dtc, _, fwc, _ = timed(gl, pos, cold, 3, seconds_budget / 2, False)
+    out["cold_start"] = {"value": vc, "unit": "site-ind updates/s", "cores": thr,
+                         "forward_passes_per_ind_iter": fwc,
+                         "sample": f"the same sample from --freq 0.1 --indF 0.1,0.2, {itc} iterations in {dtc:.1f} s"}
+    v2, it2, dt2, thr2, _, _ = timed(gl, pos, warm, 3, seconds_budget / 2, True)
     out["improved_cpu"] = {
         "value": v2, "unit": "site-ind updates/s", "cores": thr2,
-        "sample": f"same {n_ind} x {n_sites} sample, {it2} iterations in {dt2:.1f} s, allele-frequency "
+        "sample": f"same sample and start, {it2} iterations in {dt2:.1f} s, allele-frequency "
                   f"loop threaded over sites as well ({thr2} threads): not the reference's "
                   f"behaviour (its loop is serial, EM.cpp:224), same arithmetic"}
     # BASELINE.md section 4's full-size CPU numbers (configs[1] in full, a 1000 x 10k slice of
-    # configs[2], one thread, the "improved CPU") take minutes: measured once per round on the
-    # GPU box's host with tools/cpu_baseline.py and committed; this run's sample above is the
-    # live cross-check of the same code on this host
+    # configs[2], one thread, the "improved CPU"; median of 3 runs of 3 iterations, warm and
+    # cold) take many minutes: measured once per round on the GPU box's host with
+    # tools/cpu_baseline.py and committed; this run's sample above is the live cross-check of
+    # the same code on this host
     committed = _latest_profile("cpu_baseline.json")
     if committed:
         out["baseline_md_section4"] = dict(json.load(open(os.path.join(ROOT, committed))),
                                            source=f"{committed} (tools/cpu_baseline.py)")
     if full_c2:
-        v3, it3, dt3, thr3, _, _ = timed(100, 100_000, 1, 1e9, False)
+        gl2, pos2, warm2 = sample(100, 100_000, 100_000)
+        v3, it3, dt3, thr3, _, _ = timed(gl2, pos2, warm2, 1, 1e9, False)
         out["configs1_full"] = {
             "value": v3, "unit": "site-ind updates/s", "cores": thr3,
             "sample": f"BASELINE configs[1] in full: 100 ind x 100k sites, {it3} EM iteration in "
-                      f"{dt3:.1f} s, frequency loop serial as in the reference"}
+                      f"{dt3:.1f} s from the warm state, frequency loop serial as in the reference"}
     return out
 
 
@@ -268,6 +347,16 @@ PARITY = {
                   "output files)",
     "per_call": "1e-9 (tested): fast mode vs the oracle per call and teacher-forced per iteration: "
                 "log-likelihoods 1e-12, posteriors / frequencies 1e-9 relative; Viterbi paths identical",
+    "baseline_sizes_vs_oracle": "tests/test_gpu_baseline_oracle.py (-m gpu): configs[1] in full (100 x 100k "
+                                "of this data set) and a 1000 x 10k slice of configs[2] -- exact mode "
+                                "BITWISE against the oracle over a whole EM iteration + Viterbi; fast mode per "
+                                "call: log-likelihoods 1e-12, posteriors within the ORACLE's own distance "
+                                "from binary128 (measured there), frequencies 1e-12 when the oracle's est_maf "
+                                "is fed the GPU's posteriors",
+    "device_optimizer": "tests/test_gpu_devbfgs.py: the L-BFGS-B machines advanced on the device "
+                        "(kernels_bfgs.hip) against the same machines on the host -- every array and the "
+                        "optimizer's accounting bit for bit; on the CPU the device's solver type against "
+                        "class Lbfgsb, which is pinned to the reference's object code",
     "end_to_end_indF": "3.5e-5 max (median 3.5e-7) vs exact mode after 25 iterations at 200 x 50k; the "
                        "reference differs from itself by 1e-5 under another compiler flag (SURVEY "
                        "finding 4): the finite-difference L-BFGS-B amplifies last-bit differences, so "
@@ -275,6 +364,30 @@ PARITY = {
 }
 
 CHECK_REF = os.path.join(ROOT, "profiles", "check_n1.json")
+
+
+def parity_object():
+    """PARITY + the measured pairs of tests/test_gpu_baseline_oracle.py's 10^6-site test (committed
+    as profiles/rNN_parity_1M.json by the round's collection): fast mode and the oracle (the
+    reference's log-space doubles) both against the binary128 anchor at the benchmarked chain length."""
+    out = dict(PARITY)
+    path = _latest_profile("parity_1M.json")
+    if path:
+        m = json.load(open(os.path.join(ROOT, path)))
+        c = m["chains"]
+        out["one_million_sites_vs_binary128"] = {
+            "source": path + " (tests/test_gpu_baseline_oracle.py::test_one_million_site_chains_against_binary128)",
+            "log_likelihood_rel": {"fast": max(v["lkl_fast"] for v in c.values()),
+                                   "oracle": max(v["lkl_oracle"] for v in c.values())},
+            "posteriors_abs": {"fast": max(v["post_fast"] for v in c.values()),
+                               "oracle": max(v["post_oracle"] for v in c.values())},
+            "est_maf_1000_individuals_rel": {"fast": m["est_maf_1000_individuals"]["freq_fast"],
+                                             "oracle": m["est_maf_1000_individuals"]["freq_oracle"]},
+            "reading": "fast mode's distance from exact mode at 1000 x 1M (posteriors 2e-5, frequencies 1e-5: "
+                       "tests/test_gpu_fullsize.py) is the REFERENCE formulation's own rounding at 10^6 "
+                       "sites, not fast mode's; est_maf is the one routine where the oracle is the more "
+                       "accurate side (interpolated passes, checked to 1e-13)"}
+    return out
 
 
 class Ctx:
@@ -455,6 +568,45 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
                 ref_calls=ref_calls, each_ms=each_ms, each_rounds=each_rounds, steps=steps, warmup=warmup)
 
 
+def handles_of(em):
+    hm = getattr(em, "hmm", em)
+    return list(getattr(hm, "handles", [hm]))
+
+
+def serial_kernel_loop(ctx, run, n, replicas=()):
+    """n more iterations (continuing the timed loop's run, i.e. its steady state) with the
+    library's switch `no_bg_stream`: the E-step's sweep and est_maf between the objective rounds
+    on the ONE stream instead of next to them on a second.  In the timed loop kernels of the two
+    streams share the chip, and a kernel's event span then holds its neighbours' work too; here
+    they run one after the other, so a span is that kernel's own duration -- what a roofline
+    fraction needs, and what rocprofv3 --kernel-trace of `bench.py --serial_kernels` shows.
+    Not part of `value`."""
+    em = run["em"]
+    hs = handles_of(em) + list(replicas)
+    for h in hs:
+        h.set_switch("no_bg_stream", 1)
+    try:
+        fam = {k: 0.0 for k in FAMILIES}
+        launches = dict.fromkeys(fam, 0)
+        rounds = ind_rounds = 0
+        barrier(ctx)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            st = em.iter_EM()
+            rounds += st.rounds
+            ind_rounds += st.ind_rounds
+            for k in fam:
+                ms, c = em.hmm.kernel_ms(k)
+                fam[k] += ms
+                launches[k] += c
+        barrier(ctx)
+        dt = time.perf_counter() - t0
+    finally:
+        for h in hs:
+            h.set_switch("no_bg_stream", 0)
+    return dict(fam=fam, launches=launches, rounds=rounds, ind_rounds=ind_rounds, steps=n, dt=dt)
+
+
 def result_check(ctx, run, iterations=2):
     """Two EM iterations from the starting values, reduced to numbers that do not depend on how
     the job is sharded: the N-rank line's `check` must equal the one-GPU line's (log-likelihood
@@ -617,6 +769,11 @@ def main():
     ap.add_argument("--no_exact_line", action="store_true",
                     help="N = 1: skip the bit-exact mode's bounded run (`exact_mode` in the line)")
     ap.add_argument("--no_check", action="store_true", help="skip the cross-N result check")
+    ap.add_argument("--serial_kernels", action="store_true",
+                    help="fast mode: the whole run with the background work (backward sweep, est_maf) "
+                         "between the objective rounds on one stream, not next to them on a second "
+                         "(what profiles/collect.sh traces: every kernel's span is then its own; "
+                         "`value` is lower than the default run's)")
     ap.add_argument("--write_check", action="store_true",
                     help="N = 1: store this line's `check` in profiles/check_n1.json, which N > 1 "
                          "lines compare themselves with (`vs_n1`)")
@@ -766,9 +923,17 @@ def run_rank(args):
             h.init_emission()
             replicas.append(h)
 
+    if args.serial_kernels:
+        for h in handles_of(em) + replicas:
+            h.set_switch("no_bg_stream", 1)
     tl = timed_loop(ctx, run, args.steps, args.warmup, replicas)
     dt, fam, launches = tl["dt"], tl["fam"], tl["launches"]
     rounds, points, ind_rounds, ref_calls = tl["rounds"], tl["points"], tl["ind_rounds"], tl["ref_calls"]
+    # per-kernel durations for the roofline: from iterations whose kernels run one after the
+    # other (fast mode overlaps them on two streams in the timed loop)
+    kt = None
+    if args.mode == "fast" and not args.serial_kernels and args.replicas == 1:
+        kt = serial_kernel_loop(ctx, run, max(1, min(5, args.steps)))
 
     per_rank = None
     if world > 1:
@@ -803,6 +968,11 @@ def run_rank(args):
 
     if rank == 0:
         K = max(args.steps, 1)
+        fam_timed = dict(fam)
+        if kt is not None:      # the roofline's kernel times: the sequential loop's
+            fam, launches, ind_rounds_k, K_k = kt["fam"], kt["launches"], kt["ind_rounds"], kt["steps"]
+        else:
+            ind_rounds_k, K_k = ind_rounds, K
         # site shards: all individuals x the job's sites (an emulated rank: x its own range)
         units = float(I_tot) * (S_job if by_sites and V == 1 else S) * K * args.replicas
         if not by_sites and V > 1:
@@ -820,13 +990,15 @@ def run_rank(args):
         glq = 0.25 if call_geno else 16.0     # ... in the interleaved copy the forward walk reads
         # ---- every kernel of the iteration against BOTH roofs; `bound` names its limiter ----
         # times: HIP events on the library's stream around each kernel family (nghmm_kernel_ms)
-        pmc = pmc_traffic(pmc_summary() if (args.workload == "c3" and fast and world == 1 and V == 1 and
-                                            not args.n_ind and not args.n_sites) else None,
-                          I, C_waves)
+        pmc_summ, pmc_why = (pmc_summary() if (args.workload == "c3" and fast and world == 1 and V == 1 and
+                                               not args.n_ind and not args.n_sites)
+                             else (None, "PMC passes exist for the default workload on one GPU only"))
+        pmc = pmc_traffic(pmc_summ, I, C_waves)
+        isa, isa_path, isa_why = isa_counts()
         rows = {}
         n_first = launches["lkl_first"]
         later_ms = fam["lkl_batch"] - fam["lkl_first"]
-        later_ind = max(ind_rounds - I * n_first, 0)
+        later_ind = max(ind_rounds_k - I * n_first, 0)
         later_launches = max(launches["lkl_batch"] - n_first, 0)
         if fast:
             if n_first and fam["lkl_first"] > 0:
@@ -853,27 +1025,31 @@ def run_rank(args):
             secs = r["ms"] * 1e-3
             gbs = r["bytes"] / secs / 1e9
             e = {"bound": meta["bound"], "kernel": meta["kernel"],
-                 "ms_per_em_iteration": r["ms"] / K, "launches": r["launches"],
+                 "ms_per_em_iteration": r["ms"] / K_k, "launches": r["launches"],
                  "avg_launch_ms": r["ms"] / r["launches"],
                  "hbm": {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                          "traffic_bytes_per_launch": r["traffic"]},
                  "note": meta["note"]}
-            if name == "est_maf":
-                valu, fp64 = estmaf_instr_per_site(est_inds)
-                w_valu, w_fp64, per = valu * r["sites"], fp64 * r["sites"], {"valu": valu, "fp64": fp64}
-            elif "valu_per_site" in meta:
-                w_valu = meta["valu_per_site"] * r["sites_ind"] / 64.0
-                w_fp64 = meta["fp64_per_site"] * r["sites_ind"] / 64.0
-                per = {"valu": meta["valu_per_site"], "fp64": meta["fp64_per_site"]}
-            else:
-                w_valu = w_fp64 = None
+            w_valu = w_fp64 = None
+            blocks = (isa or {}).get(name)
+            if name == "est_maf" and blocks:
+                vf = estmaf_instr_per_site(est_inds, blocks)
+                if vf:
+                    w_valu, w_fp64, per = vf[0] * r["sites"], vf[1] * r["sites"], {"valu": vf[0], "fp64": vf[1]}
+            elif meta.get("isa") and blocks:
+                v, f = walk_instr_per_site(blocks)
+                w_valu, w_fp64, per = v * r["sites_ind"] / 64.0, f * r["sites_ind"] / 64.0, {"valu": v, "fp64": f}
             if w_valu:
                 e["fp64_valu"] = {"achieved_wave_instr_per_s": w_fp64 / secs, "peak": FP64_ISSUE_PEAK,
                                   "frac": w_fp64 / secs / FP64_ISSUE_PEAK,
                                   "valu_issue_frac": w_valu / secs / FP64_ISSUE_PEAK,
                                   "instr_per_site": per,
-                                  "source": "profiles/r04_isa_summary.txt (device assembly of this build)"}
+                                  "source": f"{isa_path} (device assembly of this build, id {this_build_id()})"}
+            elif meta["bound"] == "fp64_valu":
+                e["fp64_valu"] = {"achieved_wave_instr_per_s": None, "peak": FP64_ISSUE_PEAK, "frac": None,
+                                  "instr_per_site": None,
+                                  "reason": isa_why or f"{isa_path}: no blocks for this kernel"}
             roof_all[name] = e
         if not fast:   # exact mode: latency-bound chains, not a roofline candidate
             for k in ("forward", "backward", "lkl_batch", "est_maf"):
@@ -882,7 +1058,18 @@ def run_rank(args):
                                    "launches": launches[k]}
         # the contract's object: the kernel that takes the most time, against ITS roof
         dom = max(roof_all, key=lambda k: roof_all[k]["ms_per_em_iteration"]) if roof_all else None
-        if dom and roof_all[dom]["bound"] == "fp64_valu":
+        if dom and roof_all[dom]["bound"] == "fp64_valu" and roof_all[dom]["fp64_valu"]["frac"] is None:
+            # no instruction counts for this build: the dominant kernel against the HBM roof only
+            d = roof_all[dom]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["hbm"]["achieved_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["hbm"]["frac"],
+                        "traffic": d["hbm"]["traffic_bytes_per_launch"],
+                        "algorithmic_bytes_per_launch": d["hbm"]["algorithmic_bytes_per_launch"],
+                        "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                        "device_kernel": d["kernel"],
+                        "note": "this kernel is FP64-issue bound (DESIGN.md section 4), but "
+                                + d["fp64_valu"]["reason"] + ": only its HBM fraction can be stated"}
+        elif dom and roof_all[dom]["bound"] == "fp64_valu":
             d = roof_all[dom]
             roofline = {"bound": "fp64_valu", "kernel": dom, "achieved": d["fp64_valu"]["achieved_wave_instr_per_s"],
                         "peak": FP64_ISSUE_PEAK, "unit": "FP64 wave-instructions/s",
@@ -907,8 +1094,15 @@ def run_rank(args):
                         "note": "exact mode: sequential log-space chains (DESIGN.md section 4)"}
         if roofline.get("traffic") is not None:
             roofline["traffic_source"] = (f"{PMC_SUMMARY}: rocprofv3 --pmc FETCH_SIZE / "
-                                          "WRITE_SIZE passes of this workload and build "
-                                          "(profiles/collect.sh), not measured in this run")
+                                          f"WRITE_SIZE passes of this workload and THIS build (id "
+                                          f"{this_build_id()}, profiles/collect.sh), not measured in this run")
+        else:
+            roofline["traffic_source"] = pmc_why
+        roofline["kernel_times"] = (
+            f"HIP events over {K_k} iterations that follow the timed loop with the library's switch "
+            "no_bg_stream (every kernel alone on the chip; in the timed loop the backward sweep and "
+            "est_maf run on a second stream next to the objective rounds and the spans overlap)"
+            if kt is not None else "HIP events over the timed loop")
         each = tl["each_ms"]
         n_run = min(20, len(each))
         vs_n1 = None
@@ -916,8 +1110,12 @@ def run_rank(args):
             key = check_key(ctx, run)
             ref = json.load(open(CHECK_REF)) if os.path.exists(CHECK_REF) else {}
             if world == 1 and args.write_check and args.replicas == 1:
-                ref[key] = check
+                ref[key] = dict(check, build_id=this_build_id())
                 json.dump(ref, open(CHECK_REF, "w"), indent=1, sort_keys=True)
+            elif world > 1 and key in ref and ref[key].get("build_id") != this_build_id():
+                vs_n1 = {"ok": None, "note": f"profiles/check_n1.json holds the one-GPU `check` of build "
+                                             f"{ref[key].get('build_id')}, the sources here are "
+                                             f"{this_build_id()}: not compared (bench.py --write_check on one GPU)"}
             elif world > 1 and key in ref:
                 vs_n1 = dict(compare_checks(check, ref[key]),
                              source="profiles/check_n1.json: the `check` of a one-GPU run of this "
@@ -964,7 +1162,8 @@ def run_rank(args):
                                     f"GPU (all-to-all of posteriors, all-gather of frequencies)")},
             "roofline": roofline,
             "roofline_all_kernels": roof_all,
-            "per_step_kernel_ms": {k: fam[k] / K for k in fam if k != "lkl_first"},
+            "per_step_kernel_ms": {k: fam[k] / K_k for k in fam if k != "lkl_first"},
+            "per_step_kernel_ms_timed_loop": {k: fam_timed[k] / K for k in fam_timed if k != "lkl_first"},
             # the metric is EM iterations/s and a run is >= 10 iterations from the starting values
             # (parse_args.cpp:5-34 min_iters 10): `ms_per_step` is the steady state after the
             # warm-up iterations, these are the run's first iterations themselves
@@ -978,7 +1177,7 @@ def run_rank(args):
             "vs_n1": vs_n1,
             "alt_sharding": alt,
             "exact_mode": exact_line,
-            "parity": PARITY,
+            "parity": parity_object(),
             "predicted": (None if V == 1 else {
                 "emulated_rank_of": V,
                 "shard": "sites" if by_sites else "individuals",

@@ -272,10 +272,30 @@ def test_cli_packed_default_equals_no_pack(pkg, data):
                                   "--min_iters", 2, "--max_iters", 3, "--mode", mode, "--verbose", 0,
                                   *extra])
                 outs.append(out)
+            if mode == "fast":
+                # the packed handle on the GENERAL est_maf kernels (switch estmaf_no_called): then
+                # packed and unpacked differ in nothing but where a cell's likelihoods come from
+                # (2-bit code + class table, or three doubles), and every file must be the
+                # unpacked run's byte for byte -- this pins the packed emission / est_maf reads
+                out = os.path.join(tmp, f"pk_{name}_{mode}_nc")
+                cli_util.run_cli(["--geno", paths[key], *flags, "--pos", paths["pos_gz"], "--n_ind", I,
+                                  "--n_sites", S, "--freq", 0.1, "--indF", "0.1,0.2", "--out", out,
+                                  "--min_iters", 2, "--max_iters", 3, "--mode", mode, "--verbose", 0],
+                                 env=dict(os.environ, NGHMM_ESTMAF_NO_CALLED="1"))
+                for ext in (".indF", ".ibd", ".geno"):
+                    assert open(out + ext, "rb").read() == open(outs[1] + ext, "rb").read(), (name, ext)
             for ext in (".indF", ".ibd", ".geno"):
                 a, b = open(outs[0] + ext, "rb").read(), open(outs[1] + ext, "rb").read()
                 if mode == "exact":
                     assert a == b, (name, mode, ext)
+                    continue
+                if ext == ".indF":      # lkl, (indF, alpha) per individual, a frequency per site
+                    ta, tb = a.decode().split(), b.decode().split()
+                    assert len(ta) == len(tb)
+                    assert [x == "NA" for x in ta] == [x == "NA" for x in tb]
+                    va = np.array([float(x) for x in ta if x != "NA"])
+                    vb = np.array([float(x) for x in tb if x != "NA"])
+                    assert np.all(np.abs(va - vb) <= 2e-6 + 1e-6 * np.abs(vb)), np.abs(va - vb).max()
                     continue
                 # fast mode: a packed handle's est_maf is the called genotypes' closed form
                 # (k_fast_estmaf_called_sums), an unpacked one's the general kernel's interpolated

@@ -132,6 +132,10 @@ def test_bench_multi_rank_path_on_one_gpu(pkg):
     assert odd["value"] > 0 and "do not divide" in odd["alt_sharding"]["skipped"]
     sw = run("--gpus", "2", "--scaling", "weak")
     assert sw["config"]["n_sites"] == 2 * one["config"]["n_sites"] and sw["config"]["n_ind_total"] == 64
+    # ... and weak scaling in the other layout: every rank its own 64 individuals
+    swi = run("--gpus", "2", "--scaling", "weak", "--shard", "individuals")
+    assert swi["config"]["n_ind_total"] == 128 and swi["config"]["n_ind_per_gpu"] == 64 and swi["value"] > 0
+    assert swi["scaling"] == "weak" and swi["check"]["rounds"][0] >= 2
     # BASELINE configs[4]'s path at smoke size: --call_geno, 2-bit packed handles, the site
     # shards built from exchanged genotype codes
     cg = run("--gpus", "2", workload="tinycg")           # site shards, and individual shards as `alt_sharding`
