@@ -535,6 +535,10 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
         st = iterate_all()
         each_ms.append((time.perf_counter() - t) * 1e3)
         each_rounds.append(int(st.rounds))
+        if os.environ.get("NGHMM_DEBUG_CHECK"):
+            import numpy as np
+            lk = np.asarray(em.ind_lkl if getattr(em, "ind_lkl", None) is not None else em.hmm.ind_lkl)
+            sys.stderr.write(f"[loop r{ctx.rank}] rounds {st.rounds} lkl sum {lk.sum()!r}\n")
         return st
 
     for _ in range(warmup):
@@ -616,11 +620,17 @@ def result_check(ctx, run, iterations=2):
     em, hmm = run["em"], run["em"].hmm
     I_tot, S_job = run["I_tot"], run["S_job"]
     reset_params(em)
+    dbg = os.environ.get("NGHMM_DEBUG_CHECK")
+    if dbg:
+        sys.stderr.write(f"[check r{ctx.rank}] start indF {hmm.indF[:3]} alpha {hmm.alpha[:3]} freq {hmm.freq[:3]}\n")
     out = {"iterations": iterations, "tot_lkl": [], "rounds": [], "ind_rounds": [], "points": []}
     rounds_agree = True
     for _ in range(iterations):
         st = em.iter_EM()
         lkl = np.asarray(em.ind_lkl if em.ind_lkl is not None else hmm.ind_lkl, dtype=np.float64)
+        if dbg:
+            sys.stderr.write(f"[check r{ctx.rank}] iter: rounds {st.rounds} points {st.points} lkl sum {lkl.sum()!r} "
+                             f"lkl {lkl[:3]} indF {hmm.indF[:3]} alpha {hmm.alpha[:3]} freq {hmm.freq[:3]}\n")
         if run["by_sites"]:            # the chain's values, the same on every rank
             tot = float(lkl.sum())
             r = allreduce(ctx, [st.rounds, -float(st.rounds)], "max")
@@ -635,6 +645,16 @@ def result_check(ctx, run, iterations=2):
             out["ind_rounds"].append(int(c[0]))
             out["points"].append(int(c[1]))
         out["tot_lkl"].append(tot)
+    if dbg and out["rounds"][0] <= 3:
+        for sw in (1, 0, 1):
+            for h in handles_of(em):
+                h.set_switch("no_dev_bfgs", sw)
+            reset_params(em)
+            st = em.iter_EM()
+            lkl = np.asarray(em.ind_lkl if em.ind_lkl is not None else hmm.ind_lkl, dtype=np.float64)
+            sys.stderr.write(f"[check r{ctx.rank}] AGAIN no_dev_bfgs={sw}: rounds {st.rounds} lkl sum {lkl.sum()!r} indF {hmm.indF[:3]}\n")
+        for h in handles_of(em):
+            h.set_switch("no_dev_bfgs", 0)
     indF, alpha = hmm.indF, hmm.alpha
     if run["by_sites"]:
         out["indF_sum"], out["alpha_sum"] = float(indF.sum()), float(alpha.sum())
@@ -929,11 +949,6 @@ def run_rank(args):
     tl = timed_loop(ctx, run, args.steps, args.warmup, replicas)
     dt, fam, launches = tl["dt"], tl["fam"], tl["launches"]
     rounds, points, ind_rounds, ref_calls = tl["rounds"], tl["points"], tl["ind_rounds"], tl["ref_calls"]
-    # per-kernel durations for the roofline: from iterations whose kernels run one after the
-    # other (fast mode overlaps them on two streams in the timed loop)
-    kt = None
-    if args.mode == "fast" and not args.serial_kernels and args.replicas == 1:
-        kt = serial_kernel_loop(ctx, run, max(1, min(5, args.steps)))
 
     per_rank = None
     if world > 1:
@@ -946,6 +961,12 @@ def run_rank(args):
     # (the accounting of the timed loop, before the check's iterations add to it)
     collective_bytes = None if world == 1 else em.collective_bytes_per_iter()
     exch_calls = (em.exchange.calls, em.exchange.bytes, em.exchange.host_ms) if by_sites and em.exchange else None
+    # per-kernel durations for the roofline: from iterations whose kernels run one after the
+    # other (fast mode overlaps them on two streams in the timed loop); after the timed loop's
+    # accounting has been taken, before the check resets the parameters
+    kt = None
+    if args.mode == "fast" and not args.serial_kernels and args.replicas == 1:
+        kt = serial_kernel_loop(ctx, run, max(1, min(5, args.steps)))
     check = None
     if not args.no_check and V == 1:
         check = result_check(ctx, run)

@@ -143,7 +143,10 @@ int nghmm_load_gl_device(nghmm_t* h, const double* d_gl_site_major, const double
  *   nghmm_load_geno_sites        called genotypes [n_sites][I] as the reader sees them, -1
  *                                (missing), 0, 1, 2 (shared/read_data.cpp:88-98); a value > 2 is
  *                                NGHMM_ERR_ARG ("Genotypes must be coded as {-1,0,1,2} !")
- * The whole-matrix loaders above are these three calls in a row. */
+ * The whole-matrix loaders above are these three calls in a row.
+ * Device buffers (the _dev / _device loaders): the library runs on a stream of its own that
+ * waits for no other, so these calls wait for the WHOLE device (hipDeviceSynchronize) before
+ * they read the caller's buffer -- whatever stream wrote it, it is complete. */
 int nghmm_load_begin(nghmm_t* h, const double* pos_dist_mb);
 int nghmm_load_begin_dev(nghmm_t* h, const double* d_pos_dist_mb);
 int nghmm_load_gl_raw_sites(nghmm_t* h, uint64_t site_begin, uint64_t n_sites,

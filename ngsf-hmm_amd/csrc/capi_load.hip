@@ -139,6 +139,11 @@ static int load_begin_dev(nghmm_t* h, const double* d_pos) {
     set_error("a replica shares its parent's data: load into the parent, before creating replicas");
     return NGHMM_ERR_ARG;
   }
+  // The caller's device buffers were written on streams this library knows nothing of (torch's,
+  // say), and the handle's own stream is a non-blocking one that waits for none of them: a load
+  // waits for the whole device before it reads them.  (Round 5: a distance table still being
+  // computed on torch's stream was copied too early -- an intermittent, silent wrong data set.)
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyAsync(h->d_pos, d_pos, h->S * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (h->packed) {
     HIP_TRY(hipMemsetAsync(h->d_codes, 0, ((size_t)h->I * h->S / 16 + 2) * sizeof(uint32_t), h->stream));
@@ -220,9 +225,11 @@ static int load_sites_impl(nghmm_t* h, uint64_t site_begin, uint64_t n_sites, co
   if ((rc = use_device(h))) return rc;
   if ((rc = claim_sites(h, site_begin, n_sites))) return rc;
   const uint64_t n_cells = n_sites * h->I;
-  if (src_on_device)
+  if (src_on_device) {
+    if (hipDeviceSynchronize() != hipSuccess) return fail_load(h, NGHMM_ERR_HIP);  // (as load_begin_dev)
     return fail_load(h, ingest_chunk(h, site_begin, n_sites, src, false, prepare, space,
                                      call_geno, check_nan));
+  }
   double* dst = h->packed ? nullptr : h->d_gl + site_begin * h->I * 3;
   if (h->packed) {
     if ((rc = ensure_stage(h, n_cells * 3))) return fail_load(h, rc);

@@ -165,6 +165,7 @@ int nghmm_load_geno_site_shard_dev(nghmm_t* h, const uint8_t* d_codes_bytes) {
   if (h->d_codes_shard) (void)hipFree(h->d_codes_shard);
   h->d_codes_shard = nullptr;
   if ((rc = dev_alloc(&h->d_codes_shard, n / 16 + 2))) return rc;
+  HIP_TRY(hipDeviceSynchronize());  // the caller's buffer: written on a stream of its own (capi_load.hip)
   launch_bytes_to_codes(h->stream, d_codes_bytes, n, h->d_codes_shard);
   HIP_TRY(hipGetLastError());
   HIP_TRY(sync_stream(h));
@@ -184,6 +185,7 @@ int nghmm_load_gl_site_shard_dev(nghmm_t* h, const double* d_gl_site_shard) {
   if (h->d_gl_shard) (void)hipFree(h->d_gl_shard);
   h->d_gl_shard = nullptr;
   if ((rc = dev_alloc(&h->d_gl_shard, n))) return rc;
+  HIP_TRY(hipDeviceSynchronize());  // the caller's buffer: written on a stream of its own (capi_load.hip)
   HIP_TRY(hipMemcpyAsync(h->d_gl_shard, d_gl_site_shard, n * sizeof(double),
                          hipMemcpyDeviceToDevice, h->stream));
   if (h->mode == NGHMM_MODE_FAST) fast_exp(h->stream, h->d_gl_shard, h->d_gl_shard, n);

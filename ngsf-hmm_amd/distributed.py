@@ -253,6 +253,9 @@ class GpuBackend:
             for s0, c in chunks:
                 self.sync()                 # the library reads on its own stream
                 yield s0, c.shape[0], c.data_ptr()
+        # (`pos` too is a tensor torch may still be computing on ITS stream: the library copies it
+        # on its own, non-blocking one as soon as the load begins -- before the first chunk's sync)
+        self.sync()
         self.hmm.load_chunks_device(pos.data_ptr(), feed(), space=space, call_geno=call_geno)
 
     @property
@@ -686,6 +689,8 @@ class SiteShardedEM:
             for lo, c in chunks:          # one chunk alive at a time
                 torch.cuda.synchronize(self.device)   # the library reads on its own stream
                 yield lo, c.shape[0], c.data_ptr()
+        import torch
+        torch.cuda.synchronize(self.device)   # `pos`: copied as the load begins, before the first chunk
         self.hmm.load_chunks_device(pos.data_ptr(), feed(), space=space, call_geno=call_geno)
 
     def set_params(self, indF, alpha, freq):
