@@ -645,16 +645,6 @@ def result_check(ctx, run, iterations=2):
             out["ind_rounds"].append(int(c[0]))
             out["points"].append(int(c[1]))
         out["tot_lkl"].append(tot)
-    if dbg and out["rounds"][0] <= 3:
-        for sw in (1, 0, 1):
-            for h in handles_of(em):
-                h.set_switch("no_dev_bfgs", sw)
-            reset_params(em)
-            st = em.iter_EM()
-            lkl = np.asarray(em.ind_lkl if em.ind_lkl is not None else hmm.ind_lkl, dtype=np.float64)
-            sys.stderr.write(f"[check r{ctx.rank}] AGAIN no_dev_bfgs={sw}: rounds {st.rounds} lkl sum {lkl.sum()!r} indF {hmm.indF[:3]}\n")
-        for h in handles_of(em):
-            h.set_switch("no_dev_bfgs", 0)
     indF, alpha = hmm.indF, hmm.alpha
     if run["by_sites"]:
         out["indF_sum"], out["alpha_sum"] = float(indF.sum()), float(alpha.sum())
