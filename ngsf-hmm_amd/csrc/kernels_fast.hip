@@ -262,7 +262,7 @@ const SwitchName kSwitches[] = {
     {"exact_bg_depth", &Switches::exact_bg_depth}, {"estmaf_exact_sel", &Switches::estmaf_exact_sel},
     {"exact_estep_overlap", &Switches::exact_estep_overlap},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
-    {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs},
+    {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs}, {"estmaf_w2", &Switches::estmaf_w2},
     {"no_bg_stream", &Switches::no_bg_stream}};
 
 }  // namespace

@@ -35,6 +35,7 @@ struct Switches {
   int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
   int timing = 0;             // host-side phase times of every M-step on stderr
   int debug_modes = 0;        // kernel versions of every objective round on stderr
+  int estmaf_w2 = 0;          // est_maf of 513..1024 individuals on two waves of 8 per lane (measured: see DESIGN.md)
   int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
   int no_bg_stream = 0;       // device-planned rounds: backward sweep and est_maf between the rounds on the one stream, not next to them on a second
   static Switches from_env();

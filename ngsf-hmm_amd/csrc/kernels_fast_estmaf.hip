@@ -1387,6 +1387,9 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       else if (I_tot <= 256) LAUNCH_TILE(4, 64);
       else if (I_tot <= 512) LAUNCH_TILE(8, 64);
       else if (I_tot <= 768) LAUNCH_TILE(12, 64);
+      // (experiment, switch estmaf_w2: a site of 513 .. 1024 individuals on TWO waves of 8
+      // individuals per lane -- half the per-individual constants per wave, more waves per SIMD)
+      else if (I_tot <= 1024 && fs.sw.estmaf_w2) LAUNCH_TILE(8, 128);
       else if (I_tot <= 1024) LAUNCH_TILE(16, 64);
       // several waves per site: a lane's slot k holds individual thread + BLOCK k, so a cohort
       // in the lower half of a size class leaves the upper slots of EVERY lane empty -- 12
