@@ -549,6 +549,10 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
         with em.beacon.guard():
             raise ctx.pkg.NgsFHMMError(-3, "invalid MAF! (injected by NGHMM_BENCH_FAIL_RANK)")
     em.reset_timing()
+    ex = getattr(em, "exchange", None)
+    if ex is not None and hasattr(ex, "take_log"):
+        ctx.torch.cuda.synchronize()
+        ex.take_log()
     fam = {k: 0.0 for k in FAMILIES}
     launches = dict.fromkeys(fam, 0)
     rounds = points = ind_rounds = ref_calls = 0
@@ -568,8 +572,10 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
     dt = time.perf_counter() - t0
     if ctx.world > 1:
         dt = float(allreduce(ctx, [dt], "max")[0])
+    exchange_log = ex.take_log() if ex is not None and hasattr(ex, "take_log") else None
     return dict(dt=dt, fam=fam, launches=launches, rounds=rounds, points=points, ind_rounds=ind_rounds,
-                ref_calls=ref_calls, each_ms=each_ms, each_rounds=each_rounds, steps=steps, warmup=warmup)
+                ref_calls=ref_calls, each_ms=each_ms, each_rounds=each_rounds, steps=steps, warmup=warmup,
+                exchange_log=exchange_log)
 
 
 def handles_of(em):
@@ -1223,6 +1229,7 @@ def run_rank(args):
                 k: max(r["exchange_ms_per_iter"][k] for r in per_rank)
                 for k in per_rank[0]["exchange_ms_per_iter"]}),
             "per_rank": per_rank,
+            "all_gather_rounds": all_gather_rounds(per_rank) if (per_rank and by_sites) else None,
             "bfgs": {"rounds_per_iter": rounds / K, "points_per_iter": points / K,
                      "ind_rounds_per_iter": ind_rounds / K,
                      "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},
@@ -1233,6 +1240,26 @@ def run_rank(args):
         sys.stdout.flush()
     if world > 1 or args.emulate_rccl:
         dist.destroy_process_group()
+
+
+def all_gather_rounds(per_rank):
+    """The all-gathers of the last timed iteration side by side over the ranks: per call (round)
+    the slowest and the fastest rank's duration on the stream.  A collective ends for everybody
+    when the last part has arrived, so a rank that reaches it early measures the others' lag as
+    its own duration: max - min over the ranks is the skew between them at that round, min the
+    wire time.  What a first multi-GPU run needs to explain its own efficiency."""
+    calls = [p.get("all_gather_ms_calls_last_iter") or [] for p in per_rank]
+    n = min((len(c) for c in calls), default=0)
+    if not n:
+        return None
+    rows = [{"call": k, "min_ms": min(c[k] for c in calls), "max_ms": max(c[k] for c in calls)} for k in range(n)]
+    for r in rows:
+        r["skew_ms"] = r["max_ms"] - r["min_ms"]
+    return {"calls_per_iteration": n, "per_call": rows,
+            "sum_min_ms": sum(r["min_ms"] for r in rows), "sum_max_ms": sum(r["max_ms"] for r in rows),
+            "sum_skew_ms": sum(r["skew_ms"] for r in rows),
+            "note": "one all-gather per objective round (+ the E-step's when it is not merged): duration on the "
+                    "handle's stream by HIP events under nccl, the host's clock under gloo"}
 
 
 def rank_clocks(ctx, run, tl):
@@ -1246,6 +1273,12 @@ def rank_clocks(ctx, run, tl):
         mine["exchange_ms_per_iter"] = {"all_gather_host_calls": ex.host_ms / K_}
         mine["all_gathers_per_iter"] = ex.calls / K_
         mine["all_gather_bytes_per_iter"] = ex.bytes / K_
+        # every all-gather of the timed loop's LAST iteration (one per objective round: the calls
+        # are the same on every rank, so rank 0 can set them side by side), and all of them summed
+        log = tl.get("exchange_log") or []
+        per_iter = int(round(ex.calls / K_)) if K_ else 0
+        mine["all_gather_ms_calls_last_iter"] = log[-per_iter:] if per_iter and len(log) >= per_iter else log
+        mine["exchange_ms_per_iter"]["all_gather_on_stream"] = sum(log) / K_ if log else None
     else:
         mine["exchange_ms_per_iter"] = {
             "all_to_all": em.timing["a2a_ms"] / K_,

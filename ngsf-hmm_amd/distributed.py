@@ -599,6 +599,11 @@ class SiteExchange:
         self.calls = 0
         self.bytes = 0
         self.host_ms = 0.0
+        # every call's duration, for the line a multi-GPU run prints about itself: under nccl a
+        # pair of events on the handle's stream around the collective (it starts when this
+        # rank's part is ready and ends when the slowest rank's has arrived: duration = wire time
+        # + waiting for the others), otherwise the host's clock; `take_log()` reads and clears
+        self._log = []
         self._stream = None
         if send.is_cuda and stream_ptr is not None:
             import torch
@@ -629,12 +634,33 @@ class SiteExchange:
                 torch.cuda.synchronize(part.device)
             elif part.is_cuda:
                 with torch.cuda.stream(self._stream):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     dist.all_gather_into_tensor(whole, part)
+                    e1.record()
+                if len(self._log) < 65536:
+                    self._log.append((e0, e1))
+                self.calls += 1
+                self.bytes += n_bytes
+                self.host_ms += (time.perf_counter() - t0) * 1e3
+                return
             else:
                 dist.all_gather_into_tensor(whole, part)
         self.calls += 1
         self.bytes += n_bytes
-        self.host_ms += (time.perf_counter() - t0) * 1e3
+        dt = (time.perf_counter() - t0) * 1e3
+        self.host_ms += dt
+        if len(self._log) < 65536:
+            self._log.append(dt)
+
+    def take_log(self):
+        """Milliseconds of every call since the last take_log() (call after the stream has
+        drained: event pairs are read here)."""
+        out = []
+        for x in self._log:
+            out.append(x if isinstance(x, float) else float(x[0].elapsed_time(x[1])))
+        self._log = []
+        return out
 
 
 class SiteShardedEM:

@@ -325,28 +325,34 @@ def test_bench_four_ranks_on_the_full_workload_reproduce_the_one_gpu_job(pkg):
           json.dumps({k: alt[k] for k in ("value", "ms_per_step", "exchange_ms")}))
 
 
-def test_bench_config5_shape_two_ranks_reproduce_the_one_gpu_job(pkg):
+@pytest.mark.parametrize("ranks,n_sites", [(2, 200_000), (5, 100_000)])
+def test_bench_config5_shape_ranks_reproduce_the_one_gpu_job(pkg, ranks, n_sites):
     """BASELINE configs[4]'s shape through bench.py -- 5000 individuals, 25 chromosomes, --call_geno
     (2-bit packed handles, the called genotypes' closed-form frequency step over all 5000) -- at
-    200 000 sites: two ranks (gloo on one GPU) as site shards and, embedded, as individual shards
-    (genotype codes exchanged once, posteriors every iteration) give the one-GPU line's `check`."""
+    200 000 sites on two ranks and at 100 000 on five (gloo on one GPU; a box admits six
+    processes on its card): as site shards and, embedded, as individual shards (genotype codes
+    exchanged once, posteriors every iteration) the ranks give the one-GPU line's `check` --
+    launcher, IndexedSim slicing over the 25 chromosomes (ragged site ranges: 25 chromosomes do
+    not split evenly over five ranks' ranges) and the cross-N comparison for the packed layout."""
     sys.path.insert(0, ROOT)
     import bench
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGHMM_BENCH_BACKEND")}
 
     def run(*extra):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--n_sites", "200000",
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--n_sites", str(n_sites),
                "--steps", "2", "--warmup", "1", "--no_cpu_baseline", *extra]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
-    one, two = run(), run("--gpus", "2")
+    one, two = run(), run("--gpus", str(ranks))
     assert "packed" in one["config"]["workload"] and one["config"]["n_ind_total"] == 5000
-    assert two["config"]["n_sites_per_gpu"] == 100_000 and two["config"]["sharding"].startswith("sites:")
+    assert two["config"]["n_sites_per_gpu"] == n_sites // ranks and two["config"]["sharding"].startswith("sites:")
+    assert two["all_gather_rounds"]["calls_per_iteration"] >= 2          # every round's all-gather, side by side
+    assert len(two["per_rank"]) == ranks
     alt = two["alt_sharding"]
-    assert alt["sharding"] == "individuals" and alt["n_ind_per_gpu"] == 2500 and "skipped" not in alt
+    assert alt["sharding"] == "individuals" and alt["n_ind_per_gpu"] == 5000 // ranks and "skipped" not in alt
     for name, chk in (("site shards", two["check"]), ("individual shards", alt["check"])):
         d = bench.compare_checks(chk, one["check"])
         print(name, "vs N=1:", json.dumps(d))
