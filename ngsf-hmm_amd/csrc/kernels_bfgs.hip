@@ -105,25 +105,19 @@ __device__ inline void build_group(const BfgsProblem& p, uint32_t i, const DevPt
   G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.allow_xdeg2 != 0);
 }
 
-// individual i into plan P
-__device__ inline void enlist(const DevPtrs& D, uint32_t P, uint32_t i, uint32_t mode) {
-  uint32_t* cnt = D.counts + (P % DevBfgs::kRing) * kCntStride;
-  const uint32_t par = P & 1u, slot = mode_slot(mode);
-  const uint32_t pos = atomicAdd(&cnt[slot], 1u);
-  D.worklists[((uint64_t)par * kModeSlots + slot) * D.I + pos] = i;
-  const uint32_t pa = atomicAdd(&cnt[kCntAll], 1u);
-  D.all[(uint64_t)par * D.I + pa] = i;
-}
-
-// One individual per workgroup (= one wave): the machines of different individuals are at
-// different places of the algorithm, lanes of one wave would take their branches one after the
-// other.  Lane 0 walks; all 64 lanes move the individual's work arrays between memory and LDS.
+// One individual per WAVE, kWg waves (individuals) per workgroup: the machines of different
+// individuals are at different places of the algorithm -- lanes of one wave would take their
+// branches one after the other -- so lane 0 of a wave walks its individual's machine while all 64
+// lanes move that individual's work arrays between memory and the wave's part of LDS.  What the
+// workgroup's individuals add to the plan goes through ONE atomic per counter and workgroup (a
+// thousand waves adding one by one to the same three words would wait for each other longer than
+// a machine's step takes).
 //
-// FIRST: plan P_out from the current parameters of individual blockIdx.x (no values yet).
-// Else: the values of plan P_out - 1 into the machine of the blockIdx.x-th individual of that
-// plan, P_out planned.  Plans are numbered through the handle's life (slot = P mod kRing,
-// worklists by parity), so every kernel finds its counters zeroed by the one two before it.
-#ifdef NGHMM_BFGS_TIMING   // phase times of the slowest workgroup (tools/bfgs_phase_timing.py)
+// FIRST: plan P_out from the current parameters (no values yet).  Else: the values of plan
+// P_out - 1 into the machines of that plan's individuals, P_out planned.  Plans are numbered
+// through the handle's life (slot = P mod kRing, worklists by parity), so every kernel finds its
+// counters zeroed by the one two before it.
+#ifdef NGHMM_BFGS_TIMING   // phase times of the slowest wave (tools/bfgs_phase_timing.py)
 __device__ unsigned long long g_bfgs_phase[8];
 #define PHASE(k)                                                                      \
   if (lane == 0) {                                                                    \
@@ -135,29 +129,41 @@ __device__ unsigned long long g_bfgs_phase[8];
 #define PHASE(k)
 #endif
 
+constexpr int kWg = 4;  // 4 x 10 KB of LDS: three workgroups per CU
+struct WaveLds {
+  double arr[kArr];
+  BfgsProblem p;
+  GroupDesc g;
+};
+static_assert(kWg * sizeof(WaveLds) <= 65536, "one workgroup's LDS");
+
 template <bool FIRST>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kWg)
 k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_fixed, int alpha_fixed) {
 #ifdef NGHMM_BFGS_TIMING
   unsigned long long t_phase = wall_clock64();
 #endif
-  __shared__ double lds[kArr];
-  __shared__ BfgsProblem p_lds;
-  __shared__ GroupDesc g_lds;
-  const int lane = threadIdx.x;
+  __shared__ WaveLds wl[kWg];
+  __shared__ uint32_t wg_slot[kWg];   // mode slot + 1 of the wave's individual in the next plan, 0: none
+  __shared__ uint32_t wg_pos[kWg], wg_all;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t* cnt_out = D.counts + (P_out % DevBfgs::kRing) * kCntStride;
   if (blockIdx.x == 0) {  // the slot after next is nobody's at the moment
-    for (uint32_t k = lane; k < kCntStride; k += 64)
+    for (uint32_t k = threadIdx.x; k < kCntStride; k += 64 * kWg)
       D.counts[((P_out + 1) % DevBfgs::kRing) * kCntStride + k] = 0;
   }
-  const uint32_t i = FIRST ? blockIdx.x : D.all[(uint64_t)((P_out - 1) & 1u) * D.I + blockIdx.x];
-  BfgsProblem& p = p_lds;
-  GroupDesc& G = g_lds;
+  const uint32_t w_idx = blockIdx.x * kWg + wv;
+  const bool have = w_idx < n_in;  // (wave-uniform)
+  const uint32_t i = !have ? 0u : FIRST ? w_idx : D.all[(uint64_t)((P_out - 1) & 1u) * D.I + w_idx];
+  double* lds = wl[wv].arr;
+  BfgsProblem& p = wl[wv].p;
+  GroupDesc& G = wl[wv].g;
   bool started = false;
+  if (lane == 0) wg_slot[wv] = 0;
   if constexpr (!FIRST) {
-    if (lane == 0) p = D.prob[i];
+    if (have && lane == 0) p = D.prob[i];
     __syncthreads();
-    started = p.started != 0;
+    started = have && p.started != 0;
     if (started) {  // (else start_bound zeroes the block)
       // (every load of the block in flight at once: 20 per lane)
       const double* src = D.arrays + (uint64_t)i * kArr;
@@ -178,7 +184,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
 
   PHASE(0)  // problem + work arrays in LDS
   bool keep = false;        // the solver's arrays go back to memory
-  if (lane == 0) {
+  if (have && lane == 0) {
     if constexpr (FIRST) {
       bfgs_problem_begin(p, D.d_F[i], D.d_A[i], F_fixed != 0, alpha_fixed != 0);
       D.snap_F[i] = p.x[0];
@@ -190,7 +196,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       D.last_mode[i] = G.mode;
       p.acc_points = G.np;
       D.prob[i] = p;
-      enlist(D, P_out, i, G.mode);
+      wg_slot[wv] = mode_slot(G.mode) + 1;
     } else {
       double lklv[5] = {0, 0, 0, 0, 0};
       bool bad = false;
@@ -204,7 +210,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
         // a probe left the pattern kernel's shared scale: the same points by the general kernel
         D.groups[i].mode = 0;
         D.last_mode[i] = 0;
-        enlist(D, P_out, i, 0);
+        wg_slot[wv] = mode_slot(0) + 1;
         ++p.acc_redone;  // (not a round of the optimizer's: n_rounds counts evaluations it asked for)
         D.prob[i] = p;
       } else if (bad) {
@@ -229,7 +235,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
           D.groups[i] = G;
           D.last_mode[i] = G.mode;
           p.acc_points += G.np;
-          enlist(D, P_out, i, G.mode);
+          wg_slot[wv] = mode_slot(G.mode) + 1;
           D.solver[i] = s;
           keep = true;
         } else {
@@ -237,7 +243,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
           D.d_A[i] = p.x[1];
         }
         D.prob[i] = p;
-        PHASE(2)  // plan, descriptor, worklists, state out
+        PHASE(2)  // plan, descriptor, state out
       }
     }
   }
@@ -250,19 +256,49 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       for (int j = lane; j < kArr; j += 64) dst[j] = lds[j];
     }
   }
-
   PHASE(3)  // work arrays back
-  // The last workgroup publishes plan P_out to the host: the modes present and their counts
-  // (all lanes read the counters, a ballot compacts them) -- and, when the plan is empty, i.e.
-  // the M-step is over, the accounting summed over the individuals.
-  __threadfence();
-  __shared__ int is_last;
-  if (lane == 0) is_last = atomicAdd(&cnt_out[kCntTicket], 1u) == gridDim.x - 1;
+
+  // the workgroup's individuals into plan P_out: one atomic per mode present among them (its
+  // worklist), one for the list of everybody, one ticket
   __syncthreads();
-  if (is_last) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    uint32_t n_new = 0;
+    for (int a = 0; a < kWg; ++a) {
+      const uint32_t sl = wg_slot[a];
+      if (sl == 0) continue;
+      ++n_new;
+      bool first = true;   // first wave of the workgroup with this mode: it reserves for all of them
+      for (int b2 = 0; b2 < a; ++b2) first = first && wg_slot[b2] != sl;
+      if (!first) continue;
+      uint32_t n_same = 0;
+      for (int b2 = a; b2 < kWg; ++b2) n_same += wg_slot[b2] == sl ? 1u : 0u;
+      uint32_t pos = atomicAdd(&cnt_out[sl - 1], n_same);
+      for (int b2 = a; b2 < kWg; ++b2)
+        if (wg_slot[b2] == sl) wg_pos[b2] = pos++;
+    }
+    wg_all = n_new ? atomicAdd(&cnt_out[kCntAll], n_new) : 0u;
+  }
+  __syncthreads();
+  if (lane == 0 && wg_slot[wv] != 0) {
+    const uint32_t par = P_out & 1u, sl = wg_slot[wv] - 1;
+    D.worklists[((uint64_t)par * kModeSlots + sl) * D.I + wg_pos[wv]] = i;
+    uint32_t before = 0;
+    for (int a = 0; a < wv; ++a) before += wg_slot[a] != 0 ? 1u : 0u;
+    D.all[(uint64_t)par * D.I + wg_all + before] = i;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&cnt_out[kCntTicket], 1u) == gridDim.x - 1;
+  __syncthreads();
+
+  // The last workgroup publishes plan P_out to the host: the modes present and their counts
+  // (wave 0 reads the counters, a ballot compacts them) -- and, when the plan is empty, i.e.
+  // the M-step is over, every individual's parameters and the accounting summed over them.
+  if (is_last && wv == 0) {
     __threadfence();
-    // all lanes read the counters and compact the modes present into LDS; ONE lane then writes
-    // the whole entry to host memory and, behind a system-scope fence, the plan's number
+    // ONE lane then writes the whole entry to host memory and, behind a system-scope fence, the
+    // plan's number
     __shared__ uint32_t pub_mode[kModeSlots], pub_count[kModeSlots];
     uint32_t* t = D.h_table + (P_out % DevBfgs::kRing) * DevBfgs::kTableWords;
     const uint32_t n_all = __hip_atomic_load(&cnt_out[kCntAll], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -272,13 +308,13 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       const uint32_t c = sl < kModeSlots
                              ? __hip_atomic_load(&cnt_out[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                              : 0u;
-      const uint64_t have = __ballot(c != 0);
+      const uint64_t have_m = __ballot(c != 0);
       if (c != 0) {
-        const uint32_t k = n_modes + (uint32_t)__popcll(have & ((1ull << lane) - 1));
+        const uint32_t k = n_modes + (uint32_t)__popcll(have_m & ((1ull << lane) - 1));
         pub_mode[k] = slot_mode(sl);
         pub_count[k] = c;
       }
-      n_modes += (uint32_t)__popcll(have);
+      n_modes += (uint32_t)__popcll(have_m);
     }
     unsigned long long pts = 0, calls = 0, indr = 0, redone = 0, invalid = 0;
     uint32_t rmax = 0;
@@ -304,8 +340,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
         rmax = o > rmax ? o : rmax;
       }
     }
-    __threadfence_system();  // (the parameters above: every lane's own stores, before the barrier)
-    __syncthreads();
+    __threadfence_system();  // (the parameters above: a wave's stores, complete before its lane 0 goes on)
     if (lane == 0) {
       t[3] = P_out;  // (the entry's second stamp: the host checks both)
       for (uint32_t k = 0; k < n_modes; ++k) {
@@ -323,7 +358,7 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       __hip_atomic_store(&t[0], P_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  PHASE(4)  // fence, ticket, publication
+  PHASE(4)  // plan entries, ticket, publication
 }
 
 DevPtrs dev_ptrs(const FastState& fs, double* d_F, double* d_A) {
@@ -441,7 +476,8 @@ bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha,
   const uint32_t n = (uint32_t)fs.I;
   d.d_F = d_indF;
   d.d_A = d_alpha;
-  hipLaunchKernelGGL(k_bfgs_advance<true>, dim3(n), dim3(64), 0, st, dev_ptrs(fs, d_indF, d_alpha),
+  hipLaunchKernelGGL(k_bfgs_advance<true>, dim3((n + kWg - 1) / kWg), dim3(64 * kWg), 0, st,
+                     dev_ptrs(fs, d_indF, d_alpha),
                      d.seq_base + 1, n, 1u, F_fixed ? 1 : 0, alpha_fixed ? 1 : 0);
   return hipGetLastError() == hipSuccess;
 }
@@ -449,7 +485,8 @@ bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha,
 bool dbfgs_advance(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_in) {
   DevBfgs& d = fs.dev;
   if (n_in == 0) return false;
-  hipLaunchKernelGGL(k_bfgs_advance<false>, dim3(n_in), dim3(64), 0, st, dev_ptrs(fs, d.d_F, d.d_A),
+  hipLaunchKernelGGL(k_bfgs_advance<false>, dim3((n_in + kWg - 1) / kWg), dim3(64 * kWg), 0, st,
+                     dev_ptrs(fs, d.d_F, d.d_A),
                      d.seq_base + round + 1, n_in, round + 1, 0, 0);
   return hipGetLastError() == hipSuccess;
 }
