@@ -1,6 +1,6 @@
 #!/bin/bash
 # One session on the GPU box = every number of the round from the same build:
-#   bash profiles/collect_all.sh r04
+#   bash profiles/collect_all.sh r05
 # kernel trace + PMC passes of the default workload (profiles/collect.sh), then the bench lines:
 # default (1000 x 1M), one rank's compute of the 2 / 4 / 8-GPU strong-scaling points (both shardings),
 # configs[1] (100 x 100k) alone and with replicas, config 5's per-GPU share.
@@ -8,7 +8,7 @@
 # lines, `collect_all.sh r04 2` = the other workloads; the committed profiles/<tag>_pmc_summary.json of
 # part 1 must be in place for part 2's lines to carry `traffic`)
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -44,10 +44,10 @@ python3 bench.py --workload c5 --emulate_ranks 8 --no_cpu_baseline > $OUT/${TAG}
 # the called genotypes' est_maf (k_fast_estmaf_called_sums: one sweep over codes and posteriors) on
 # config 5's rank: kernel trace + FETCH_SIZE / WRITE_SIZE passes of a two-iteration run
 C5="bench.py --workload c5 --emulate_ranks 8 --steps 2 --warmup 1 --no_cpu_baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5trace -o trace -- python3 $C5 > /dev/null 2> $OUT/c5trace.err
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5trace -o trace -- python3 $C5 > /dev/null 2> $OUT/c5trace.err
 cp "$(find $OUT/c5trace -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_c5_rank_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c5fetch -o fetch -- python3 $C5 > /dev/null 2> $OUT/c5fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c5write -o write -- python3 $C5 > /dev/null 2> $OUT/c5write.err
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c5fetch -o fetch -- python3 $C5 > /dev/null 2> $OUT/c5fetch.err
+timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c5write -o write -- python3 $C5 > /dev/null 2> $OUT/c5write.err
 python3 profiles/summarize_called.py $OUT/${TAG}_c5_rank_kernel_stats.csv \
   "$(find $OUT/c5fetch -name '*counter_collection.csv' | head -1)" \
   "$(find $OUT/c5write -name '*counter_collection.csv' | head -1)" 5000 625000 > $OUT/${TAG}_c5_estmaf_called.json

@@ -24,6 +24,7 @@ FAMILIES = {
     "est_maf": ("k_fast_estmaf", "k_fast_estmaf_resume", "k_fast_estmaf_rows",
                 "k_fast_estmaf_rows_resume", "k_fast_estmaf_interp", "k_fast_estmaf_stream",
                 "k_fast_post_to_site_major"),
+    "bfgs": ("k_bfgs_advance",),
 }
 
 

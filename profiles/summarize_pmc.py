@@ -30,6 +30,7 @@ FAMILIES = {
                 "k_fast_estmaf_rows_resume", "k_fast_estmaf_interp", "k_fast_estmaf_stream",
                 "k_fast_estmaf_called_sums", "k_fast_estmaf_called_passes"),
     "emission": ("k_fast_emission", "k_fast_freq_interleave"),
+    "bfgs": ("k_bfgs_advance",),
 }
 
 
