@@ -404,6 +404,14 @@ void nghmm_free_host(void* p);
  *                     rounds instead of next to the first of them (default 1)
  *   timing            1: host-side phase times of every M-step on stderr
  *   debug_modes       1: kernel versions of every objective round on stderr
+ *   no_dev_bfgs       1: fast mode's L-BFGS-B machines on the host, every round a round trip
+ *                     (rounds 1-4; default 0: on the device, kernels_bfgs.hip -- same results)
+ *   no_bg_stream      1: with the machines on the device, backward sweep and est_maf between the
+ *                     objective rounds on the handle's one stream instead of next to them on a
+ *                     second (what bench.py --serial_kernels and profiles/collect.sh run: every
+ *                     kernel's span is then its own)
+ *   estmaf_w2         1: est_maf of 513 .. 1024 individuals on two waves of 8 per lane (measured
+ *                     slower: 10.1 vs 8.5 ms at 1000 x 1M)
  * Fixed at creation (environment only): fast_c (waves per individual), spin_sync (replicas
  * wait spinning).  Unknown names return NGHMM_ERR_ARG.  Outside the handle: NGHMM_HOST_THREADS
  * (host threads of the L-BFGS-B state machines, read once per process). */
