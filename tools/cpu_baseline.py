@@ -59,13 +59,16 @@ def timed(name, gl, pos, start, threads, thread_freq, runs, iters, start_name):
     orc = orclib.Oracle("libm")
     S, I = gl.shape[0], gl.shape[1]
     secs, passes = [], None
-    for _ in range(runs):
+    for r in range(runs):
         em = orclib.OracleEM(orc, gl, pos)
         em.set_params(*start)
         assert em.init_emission() == 0
         t0 = time.time()
-        for _ in range(iters):
+        for k in range(iters):
             assert em.iterate(1, False, False, threads, thread_freq) == 0
+            # (a line per iteration: the GPU box ends a command that stays silent for 7 minutes)
+            sys.stderr.write(f"  {name}: run {r + 1}/{runs}, iteration {k + 1}/{iters} at {time.time() - t0:.1f} s\n")
+            sys.stderr.flush()
         secs.append(time.time() - t0)
         passes = em.lkl_calls / (I * iters)
         em.close()
