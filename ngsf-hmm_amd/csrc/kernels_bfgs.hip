@@ -474,6 +474,15 @@ bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha,
   DevBfgs& d = fs.dev;
   if (d.cap_I != fs.I || fs.I == 0) return false;
   const uint32_t n = (uint32_t)fs.I;
+  if (!d.clean) {
+    // the M-step before this one did not reach its end (an error on its way): plans of it may
+    // have been published and counters left behind.  Clear the counters (on the stream: the
+    // kernel below comes after) and number on from well past anything that can be in the table.
+    if (hipMemsetAsync(d.counts, 0, (size_t)DevBfgs::kRing * kCntStride * sizeof(uint32_t), st) != hipSuccess)
+      return false;
+    d.seq_base += 4096;
+  }
+  d.clean = false;
   d.d_F = d_indF;
   d.d_A = d_alpha;
   hipLaunchKernelGGL(k_bfgs_advance<true>, dim3((n + kWg - 1) / kWg), dim3(64 * kWg), 0, st,
@@ -540,6 +549,7 @@ void dbfgs_end(FastState& fs, uint32_t last_round) {
   DevBfgs& d = fs.dev;
   d.seq_base += last_round;
   ++d.mstep_no;
+  d.clean = true;
 }
 
 }  // namespace nghmm

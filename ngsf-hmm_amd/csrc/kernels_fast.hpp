@@ -136,6 +136,7 @@ struct FastState {
     unsigned long long stats_host[6] = {0, 0, 0, 0, 0, 0};  // of the last plan waited for
     uint32_t seq_base = 0;           // plans of earlier M-steps (plans are numbered through the handle's life)
     uint32_t mstep_no = 0;
+    bool clean = true;               // the last M-step reached its end (else: dbfgs_begin starts over)
   } dev;
 
   double dmax_finite = 0;         // largest finite distance of the loaded data
