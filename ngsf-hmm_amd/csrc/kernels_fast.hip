@@ -263,6 +263,7 @@ const SwitchName kSwitches[] = {
     {"exact_estep_overlap", &Switches::exact_estep_overlap},
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs}, {"estmaf_w2", &Switches::estmaf_w2},
+    {"dbg_abort_round", &Switches::dbg_abort_round},
     {"no_bg_stream", &Switches::no_bg_stream}};
 
 }  // namespace

@@ -36,6 +36,7 @@ struct Switches {
   int timing = 0;             // host-side phase times of every M-step on stderr
   int debug_modes = 0;        // kernel versions of every objective round on stderr
   int estmaf_w2 = 0;          // est_maf of 513..1024 individuals on two waves of 8 per lane (measured: see DESIGN.md)
+  int dbg_abort_round = 0;    // test hook: a device-planned M-step returns an error after this round
   int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
   int no_bg_stream = 0;       // device-planned rounds: backward sweep and est_maf between the rounds on the one stream, not next to them on a second
   static Switches from_env();

@@ -1061,6 +1061,11 @@ struct MstepRun {
         return NGHMM_ERR_HIP;
       }
       if ((rc = bg_close(h))) return rc;
+      if (fs.sw.dbg_abort_round > 0 && round == (uint32_t)fs.sw.dbg_abort_round) {
+        // (test hook: an M-step that ends early, with plans published and counters left behind)
+        set_error("M-step ended after round %u by the switch dbg_abort_round", round);
+        return NGHMM_ERR_HIP;
+      }
       // behind the round and its planning kernel: the E-step's backward sweep (round 1), est_maf
       // in parts (rounds 2, 3, ...) -- the GPU works on them while the plan travels to the host
       if (estep_pending) {

@@ -110,28 +110,30 @@ def test_device_mstep_of_a_replica_and_stats_of_the_reference(pkg):
 
 
 def test_an_mstep_that_ends_early_leaves_the_handle_usable(pkg):
-    """An M-step that fails on its way (here: `invalid MAF!` from the emission refresh a stand-alone
-    M-step starts with, after round 1 has been planned on the device) leaves plans published and
-    counters behind; the next M-step starts over (dbfgs_begin) and gives what a fresh handle gives."""
+    """An M-step that returns on its way (a launch failure, say; here the test switch
+    dbg_abort_round after round 2) has plans published in pinned memory and counters left behind;
+    the next M-step starts over (dbfgs_begin: counters cleared, plan numbers far ahead) and gives
+    what a fresh handle gives, bit for bit."""
     I, S = 40, 3000
     d = pkg.simulate.simulate(I, S, seed=21, n_chrom=2, indF="r", freq=0.25, alpha=0.2)
     gl = pkg.simulate.normalise_log_gl(d.gl)
-    bad = np.full(S, 0.2)
-    bad[17] = 1.5                                   # HMM.cpp:145-146: maf outside [0, 1]
     with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as h, pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as fresh:
         for x in (h, fresh):
             x.load(gl, d.pos_dist_mb)
         h.set_params(0.1, 0.2, 0.2)
         h.init_emission()
         h.iter_EM()                                 # (a clean M-step first)
+        h.set_switch("dbg_abort_round", 2)
         with pytest.raises(pkg.NgsFHMMError) as ei:
-            h.set_params(0.1, 0.2, bad)
-            h.mstep_indf()
-        assert "invalid MAF" in str(ei.value)
+            h.iter_EM()
+        assert "dbg_abort_round" in str(ei.value)
+        h.set_switch("dbg_abort_round", 0)
+        h.synchronize()
         for x in (h, fresh):
             x.set_params(0.1, 0.2, 0.2)
             x.init_emission()
-        sa, sb = h.iter_EM(), fresh.iter_EM()
-        assert _stats(sa) == _stats(sb)
-        assert np.array_equal(h.indF, fresh.indF) and np.array_equal(h.alpha, fresh.alpha)
-        assert np.array_equal(h.ind_lkl, fresh.ind_lkl) and np.array_equal(h.freq, fresh.freq)
+        for _ in range(3):
+            sa, sb = h.iter_EM(), fresh.iter_EM()
+            assert _stats(sa) == _stats(sb)
+            assert np.array_equal(h.indF, fresh.indF) and np.array_equal(h.alpha, fresh.alpha)
+            assert np.array_equal(h.ind_lkl, fresh.ind_lkl) and np.array_equal(h.freq, fresh.freq)
