@@ -43,6 +43,7 @@ struct BfgsProblem {
   uint8_t slot_used[5];
   uint8_t slot_nonfinite[5];
   uint8_t have_eval, started, active;
+  uint8_t big_valid;  // device: the machine's matrices (ws .. wa) have been written to memory (else: zeros)
 };
 
 NGHMM_HD inline bool bfgs_nonfinite(double v) { return !(v - v == 0.0); }  // NaN or +-inf
@@ -72,6 +73,7 @@ NGHMM_HD inline void bfgs_problem_begin(BfgsProblem& p, double F, double alpha, 
   p.have_eval = 0;
   p.started = 0;
   p.active = 1;
+  p.big_valid = 0;
 }
 
 struct LibmPow {
@@ -127,15 +129,10 @@ NGHMM_HD inline void bfgs_plan(BfgsProblem& p) {
         p.slot_used[k] && (bfgs_nonfinite(p.pt[k][0]) || bfgs_nonfinite(p.pt[k][1]));
 }
 
-// The round's values into the machine: objective and finite-difference gradient
-// (bfgs.cpp:22-65), then setulb_ calls until it wants another evaluation or ends
-// (bfgs.cpp:108-133).  lklv[k] = forward log-likelihood of slot k (read where the slot is used
-// and finite).  `start(p)` begins the solver at p.x with p's bounds (nbd 2,2; FACTR, PGTOL:
-// bfgs.h:24-25).  ref_calls += the objective calls the reference would have made.
-// Returns true when the problem wants another round, false when it has finished (p.active = 0).
-template <class Solver, class Start>
-NGHMM_HD inline bool bfgs_consume(BfgsProblem& p, Solver& solver, const double lklv[5],
-                                  uint64_t& ref_calls, Start start) {
+// The round's values as objective and finite-difference gradient (bfgs.cpp:22-65) at p.x.
+// lklv[k] = forward log-likelihood of slot k (read where the slot is used and finite).  Returns
+// the objective calls the reference spends on one such evaluation.
+NGHMM_HD inline uint64_t bfgs_gradient(BfgsProblem& p, const double lklv[5]) {
   // objective = -forward log-likelihood; non-finite parameters give -INF... i.e.
   // lkl = INF and the function returns -lkl (EM.cpp:454-463)
   double fv[5] = {0, 0, 0, 0, 0};
@@ -171,31 +168,49 @@ NGHMM_HD inline bool bfgs_consume(BfgsProblem& p, Solver& solver, const double l
     if (p.x[i] >= p.ub[i] && g < 0.0) g = 0.0;
     p.grad[i] = g;
   }
-  ref_calls += calls;
   p.eval_x[0] = p.x[0];
   p.eval_x[1] = p.x[1];
   p.have_eval = 1;
+  return calls;
+}
 
+// One setulb_ call (bfgs.cpp:108-133) and what findmax_bfgs does with its answer:
+// 0 = call again (NEW_X, or the START call asking for f and g at the point just evaluated:
+// same x, same values, bfgs.cpp:901,114-121), 1 = wants another round, 2 = finished
+// (p.active = 0).  `calls`: what bfgs_gradient returned for the evaluation in hand.
+template <class Solver>
+NGHMM_HD inline int bfgs_step(BfgsProblem& p, Solver& solver, uint64_t calls, uint64_t& ref_calls) {
+  const LbfgsbTask task = solver.advance(&p.like, p.grad);
+  p.x[0] = solver.x()[0];
+  p.x[1] = solver.x()[1];
+  if (task == LbfgsbTask::EvalFG) {
+    if (p.have_eval && bfgs_same_bits(p.x, p.eval_x)) {
+      ref_calls += calls;
+      return 0;
+    }
+    return 1;
+  }
+  if (task == LbfgsbTask::NewX) return 0;
+  p.active = 0;
+  return 2;
+}
+
+// The round's values into the machine: gradient, then setulb_ calls until it wants another
+// evaluation or ends.  `start(p)` begins the solver at p.x with p's bounds (nbd 2,2; FACTR,
+// PGTOL: bfgs.h:24-25).  ref_calls += the objective calls the reference would have made.
+// Returns true when the problem wants another round, false when it has finished (p.active = 0).
+template <class Solver, class Start>
+NGHMM_HD inline bool bfgs_consume(BfgsProblem& p, Solver& solver, const double lklv[5],
+                                  uint64_t& ref_calls, Start start) {
+  const uint64_t calls = bfgs_gradient(p, lklv);
+  ref_calls += calls;
   if (!p.started) {
     start(p);
     p.started = 1;
   }
   for (;;) {
-    const LbfgsbTask task = solver.advance(&p.like, p.grad);
-    p.x[0] = solver.x()[0];
-    p.x[1] = solver.x()[1];
-    if (task == LbfgsbTask::EvalFG) {
-      if (p.have_eval && bfgs_same_bits(p.x, p.eval_x)) {
-        // the START call asks for f and g at the point just evaluated
-        // (bfgs.cpp:901,114-121): same x, same values.
-        ref_calls += calls;
-        continue;
-      }
-      return true;  // wants a new round
-    }
-    if (task == LbfgsbTask::NewX) continue;
-    p.active = 0;
-    return false;
+    const int r = bfgs_step(p, solver, calls, ref_calls);
+    if (r) return r == 1;
   }
 }
 

@@ -44,7 +44,10 @@ namespace {
 
 constexpr int kN = 2, kM = 10;                                   // MVAL, shared/bfgs.h:23
 constexpr int kArr = (int)LbfgsbPtrs::doubles(kN, kM);           // 1238 doubles per individual
-constexpr int kStage = (kArr + 63) / 64;                         // ... = 20 per lane
+constexpr int kVec = 7 * kN;                                     // x l u z r d t: the doubles [0, 14)
+constexpr int kMat = (int)LbfgsbPtrs::matrices(kN, kM);          // ws .. wa: the doubles [14, 1234)
+constexpr int kStage = (kMat + 63) / 64;                         // ... = 20 per lane
+static_assert(kVec + kMat + (4 * kN + 1) / 2 == kArr, "vectors | matrices | index arrays");
 using DevSolver = LbfgsbT<PtrStore>;
 using DevBfgs = FastState::DevBfgs;
 constexpr uint32_t kCntAll = kModeSlots, kCntTicket = kModeSlots + 1, kCntStride = kModeSlots + 3;
@@ -164,26 +167,19 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
     if (have && lane == 0) p = D.prob[i];
     __syncthreads();
     started = have && p.started != 0;
-    if (started) {  // (else start_bound zeroes the block)
-      // (every load of the block in flight at once: 20 per lane)
+    if (started) {  // (else start_bound zeroes them)
+      // the machine's vectors and index arrays: 18 doubles.  Its matrices (ws .. wa, 1220
+      // doubles) only when a step needs them -- below
       const double* src = D.arrays + (uint64_t)i * kArr;
-      double v[kStage];
-#pragma unroll
-      for (int t = 0; t < kStage; ++t) {
-        const int j = lane + 64 * t;
-        v[t] = j < kArr ? src[j] : 0.0;
-      }
-#pragma unroll
-      for (int t = 0; t < kStage; ++t) {
-        const int j = lane + 64 * t;
-        if (j < kArr) lds[j] = v[t];
-      }
+      if (lane < kVec) lds[lane] = src[lane];
+      else if (lane < kVec + kArr - kVec - kMat) lds[kMat + lane] = src[kMat + lane];
     }
     __syncthreads();
   }
 
   PHASE(0)  // problem + work arrays in LDS
   bool keep = false;        // the solver's arrays go back to memory
+  bool walk = false;        // (lane 0) the round's values are good: the machine takes its step
   if (have && lane == 0) {
     if constexpr (FIRST) {
       bfgs_problem_begin(p, D.d_F[i], D.d_A[i], F_fixed != 0, alpha_fixed != 0);
@@ -218,14 +214,69 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
         p.active = 0;
         D.prob[i] = p;
       } else {
-        DevSolver s;
+        // (the walk itself is further down: every lane of the wave takes part in its staging)
+        walk = true;
+      }
+    }
+  }
+
+  // ---- the machine's walk (bfgs_consume, bfgs_problem.hpp, with the matrices staged lazily) ----
+  // A step that continues a line search, or the first step of a machine, touches the vectors
+  // only; the matrices are needed once an L-BFGS-B iteration has ended (NEW_X: update, Cholesky
+  // factors, Cauchy point, subspace step).  So the wave brings them in -- from memory, or as the
+  // zeros a new machine starts from -- when lane 0's solver is about to take such a step, and
+  // writes them back only if it did.
+  bool mats_here = false;
+  if constexpr (!FIRST) {
+    DevSolver s;
+    uint64_t calls = 0, rc = 0;
+    int state = 2;  // 0: call setulb again, 1: wants another round, 2: finished / nothing to walk
+    walk = __shfl((int)walk, 0) != 0;
+    if (walk) {
+      if (lane == 0) {
+        double lklv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          lklv[k] = (p.slot_used[k] && !p.slot_nonfinite[k]) ? D.lkl[(uint64_t)i * 5 + k] : 0.0;
         if (started) s = D.solver[i];
         s.st_.bind(lds, kN, kM);
-        uint64_t rc = 0;
-        const bool again = bfgs_consume(p, s, lklv, rc, [&](BfgsProblem& q) {
+        calls = bfgs_gradient(p, lklv);
+        rc = calls;
+        if (!p.started) {
           const int nbd[2] = {2, 2};
-          s.start_bound(kN, kM, q.x, q.lb, q.ub, nbd, 1.0e6, 1.0e-3);  // FACTR, PGTOL: bfgs.h:24-25
-        });
+          s.start_bound(kN, kM, p.x, p.lb, p.ub, nbd, 1.0e6, 1.0e-3, false);  // FACTR, PGTOL: bfgs.h:24-25
+          p.started = 1;
+          p.big_valid = 0;
+        }
+      }
+      state = 0;
+      while (state == 0) {
+        int need = 0;  // 1: load the matrices, 2: they are zeros
+        if (lane == 0 && !mats_here && s.phase_ == LbfgsbPhase::NewX) need = p.big_valid ? 1 : 2;
+        need = __shfl(need, 0);
+        if (need) {
+          const double* src = D.arrays + (uint64_t)i * kArr + kVec;
+          double v[kStage];
+#pragma unroll
+          for (int t = 0; t < kStage; ++t) {
+            const int j = lane + 64 * t;
+            v[t] = (need == 1 && j < kMat) ? src[j] : 0.0;
+          }
+#pragma unroll
+          for (int t = 0; t < kStage; ++t) {
+            const int j = lane + 64 * t;
+            if (j < kMat) lds[kVec + j] = v[t];
+          }
+          mats_here = true;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) state = bfgs_step(p, s, calls, rc);
+        state = __shfl(state, 0);
+      }
+    }
+    if (walk && lane == 0) {
+      {
+        const bool again = state == 1;
         p.acc_ref_calls += (uint32_t)rc;
         PHASE(1)  // solver scalars in, gradient, setulb calls
         if (again) {
@@ -242,18 +293,21 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
           D.d_F[i] = p.x[0];
           D.d_A[i] = p.x[1];
         }
+        if (keep && mats_here) p.big_valid = 1;
         D.prob[i] = p;
         PHASE(2)  // plan, descriptor, state out
       }
     }
-  }
-
-  if constexpr (!FIRST) {
-    __syncthreads();
+    // vectors and index arrays back if the machine goes on; the matrices if this step wrote them
+    __builtin_amdgcn_wave_barrier();
     if (__shfl((int)keep, 0)) {
       double* dst = D.arrays + (uint64_t)i * kArr;
+      if (lane < kVec) dst[lane] = lds[lane];
+      else if (lane < kVec + kArr - kVec - kMat) dst[kMat + lane] = lds[kMat + lane];
+      if (mats_here) {
 #pragma unroll 4
-      for (int j = lane; j < kArr; j += 64) dst[j] = lds[j];
+        for (int j = lane; j < kMat; j += 64) dst[kVec + j] = lds[kVec + j];
+      }
     }
   }
   PHASE(3)  // work arrays back

@@ -59,6 +59,10 @@ struct LbfgsbPtrs {
   int *nbd = nullptr, *index = nullptr, *iwhere = nullptr, *indx2 = nullptr;
   // doubles one problem of size (n, m) needs behind those pointers (the four int arrays
   // packed two to a double at the end)
+  // ... of which the matrices ws .. wa, behind the 7n doubles of the vectors
+  NGHMM_HD static constexpr size_t matrices(int n, int m) {
+    return (size_t)2 * n * m + (size_t)3 * m * m + (size_t)8 * m * m + (size_t)8 * m;
+  }
   NGHMM_HD static constexpr size_t doubles(int n, int m) {
     return (size_t)7 * n + (size_t)2 * n * m + (size_t)3 * m * m + (size_t)8 * m * m +
            (size_t)8 * m + (size_t)(4 * n + 1) / 2;
@@ -271,13 +275,21 @@ struct LbfgsbT {
   // Begin a minimisation of size (n, m) on a store whose pointers are bound: the work arrays
   // zeroed as the reference calloc()s them per findmax_bfgs call (bfgs.cpp:103-105), x0 and
   // the bounds copied in (nbd[i] = 0 none, 1 lower, 2 both, 3 upper: bfgs.h:27-33).
+  // zero_matrices = false: only the vectors and index arrays are zeroed here -- the caller zeroes
+  // ws .. wa (the doubles [7n, 7n + matrices(n, m)) of the block) before the solver first touches
+  // them, which is not before its first iteration has ended (kernels_bfgs.hip stages them lazily)
   NGHMM_HD void start_bound(int n, int m, const double* x0, const double* l, const double* u,
-                            const int* nbd, double factr, double pgtol) {
+                            const int* nbd, double factr, double pgtol, bool zero_matrices = true) {
     clear_scalars();
     n_ = n;
     m_ = m;
-    const size_t nd = LbfgsbPtrs::doubles(n, m);
-    for (size_t k = 0; k < nd; ++k) st_.x[k] = 0.0;  // one block from x on (LbfgsbPtrs::bind)
+    if (zero_matrices) {
+      const size_t nd = LbfgsbPtrs::doubles(n, m);
+      for (size_t k = 0; k < nd; ++k) st_.x[k] = 0.0;  // one block from x on (LbfgsbPtrs::bind)
+    } else {
+      for (int k = 0; k < 7 * n; ++k) st_.x[k] = 0.0;
+      for (int k = 0; k < 4 * n; ++k) st_.nbd[k] = 0;    // nbd, index, iwhere, indx2: one run of ints
+    }
     for (int i = 0; i < n; ++i) {
       st_.x[i] = x0[i];
       st_.l[i] = l[i];
