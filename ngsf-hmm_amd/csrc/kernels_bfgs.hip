@@ -9,10 +9,12 @@
 // live in device memory and one small kernel per round (k_bfgs_advance) does everything the host
 // did between two rounds:
 //
-//   * one LANE per individual, six individuals per workgroup: the solver's work arrays (1238
+//   * one WAVE per individual, four per workgroup, lane 0 walking: the solver's work arrays (1238
 //     doubles for n = 2, m = 10: ws, wy, sy, ss, wt, wn, snd, wa, ...) are staged in LDS --
 //     the routines are chains of dependent little loops over them, and LDS latency is a sixth of
-//     L2's -- by all 64 lanes of the workgroup, walked by the individual's lane, and written back;
+//     L2's -- by all 64 lanes of the wave, walked by lane 0, and written back; the matrices
+//     (1220 of the doubles) only when a step ends an L-BFGS-B iteration: a line-search step
+//     touches 18 doubles;
 //   * the round's values (d_lkl[individual * 5 + slot], left there by k_fast_lkl_finish) become
 //     objective + finite-difference gradient (bfgs.cpp:22-65), the solver (lbfgsb_core.hpp, the
 //     same LbfgsbT<> the host runs) advances until it wants another evaluation or ends
