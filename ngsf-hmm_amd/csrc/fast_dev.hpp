@@ -139,6 +139,43 @@ __device__ __forceinline__ void op_step(Op& m, double ce0, double ce1, double g0
   m.a11 = fma(g1, s1, ce1 * m.a11);
 }
 
+// The same site with the operator kept as M / c ("kappa form", the objective kernels' SMALL
+// versions): M_s / c_s = (I + kappa_s 1 q^T) diag(1, rho_s) with kappa = (1 - c) / c = expm1(alpha d),
+//   row' = (row_0 + g0 (row.1),  rho row_1 + g1 (row.1)),   g0 = kappa q0,  g1 = kappa q1 rho
+// -- four instructions per row instead of five, every term non-negative as before (no
+// cancellation), and the factor left out is known in closed form: prod_s c_s = exp(-alpha sum_s d_s)
+// over the lane-chunk (chunk_scale, formed at load), put back once at the end of the walk.  At a
+// chromosome start (c = 0) kappa is KAPPA_START = 2^200: the row's own part is then below the
+// last bit of the other by a factor 2^-200 / q >= 2^-150, i.e. the rank-one operator 1 q^T diag(e)
+// bit for bit, times a power of two that the end of the walk takes out of the exponent.
+constexpr int KAPPA_START_EXP = 200;
+__device__ __forceinline__ void op_step_k(Op& m, double rho, double g0, double g1) {
+  const double s0 = m.a00 + m.a01;
+  const double s1 = m.a10 + m.a11;
+  m.a00 = fma(g0, s0, m.a00);
+  m.a01 = fma(g1, s0, rho * m.a01);
+  m.a10 = fma(g0, s1, m.a10);
+  m.a11 = fma(g1, s1, rho * m.a11);
+}
+
+// expm1(x) / x for 0 <= x <= 2^-6 (the first dropped term x^7/8! < 6e-18): the caller multiplies
+__device__ __forceinline__ double expm1_over_x_tiny(double x) {
+  double p = 1.0 / 5040.0;
+  p = fma(p, x, 1.0 / 720.0);
+  p = fma(p, x, 1.0 / 120.0);
+  p = fma(p, x, 1.0 / 24.0);
+  p = fma(p, x, 1.0 / 6.0);
+  p = fma(p, x, 0.5);
+  return fma(p, x, 1.0);
+}
+
+// expm1(x) of the alpha probes' x = (alpha_probe - alpha_0) d, to the degree exp_small<DEG> has
+template <int DEG>
+__device__ __forceinline__ double expm1_small(double x) {
+  if constexpr (DEG == 2) return fma(0.5 * x, x, x);
+  else return fma(fma(x, fma(x, 1.0 / 24, 1.0 / 6), 0.5) * x, x, x);
+}
+
 // sum over the wave in a fixed (butterfly) order: the same bits in every lane and every run
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -292,6 +329,8 @@ struct LklArrays {
   double u_lin;                         // packed handle: linear likelihood of a uniform cell
   double* __restrict__ base_c;          // [I][C]: sum of log e0 over the wave's sites (see top)
   const double* __restrict__ gl_scale_c; // [I][C]: sum of the cells' largest log likelihoods, or null
+  const double2* __restrict__ chunk_scale; // [C][64]: (sum of the finite distances, number of
+                                           // chromosome starts) of a lane-chunk (op_step_k)
 };
 
 // The interleaved copy of the likelihoods holds each cell RELATIVE TO ITS LARGEST value: a
@@ -461,7 +500,8 @@ bool dalloc(T** p, size_t n) {
 
 inline LklArrays lkl_arrays(const FastState& fs) {
   return LklArrays{fs.e_il, fs.pos_il, reinterpret_cast<const double2*>(fs.glq_il), fs.freq_il,
-                   fs.e_il,  fs.geno_il, fs.u_lin, fs.base_c, fs.gl_scale_c};
+                   fs.e_il,  fs.geno_il, fs.u_lin, fs.base_c, fs.gl_scale_c,
+                   reinterpret_cast<const double2*>(fs.chunk_scale)};
 }
 
 }  // namespace

@@ -117,6 +117,20 @@ k_fast_pos_interleave(const double* __restrict__ pos, uint64_t S, uint64_t T, ui
   }
 }
 
+// What the kappa-form walks (fast_dev.hpp: op_step_k) leave out of a lane-chunk's operator: the
+// sum of its finite distances, in site order, and the number of its chromosome starts.
+__global__ void __launch_bounds__(64)
+k_fast_chunk_scale(const double* __restrict__ pos_il, uint64_t T, double2* __restrict__ chunk_scale) {
+  const double* dp = pos_il + (uint64_t)blockIdx.x * T * 64 + threadIdx.x;
+  double sum = 0.0, starts = 0.0;
+  for (uint64_t t = 0; t < T; ++t) {
+    const double d = dp[t * 64];
+    if (d < 1e30) sum += d;
+    else starts += 1.0;
+  }
+  chunk_scale[(uint64_t)blockIdx.x * 64 + threadIdx.x] = double2{sum, starts};
+}
+
 // freq[S] -> interleaved [C][T][64] for the fresh forward walk (padding: 0, which makes both
 // the dense padding likelihoods (1, 1, 1) and the packed padding code 0 the identity emission
 // (1, 1) exactly); flags an
@@ -355,6 +369,7 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   const size_t slack = 8 * 64;  // the pipelines read one group past the last lane-chunk
   if (!dalloc(&fs.pos_il, (size_t)fs.Spad + slack)) return false;
   if (hipMemset(fs.pos_il + fs.Spad, 0, slack * sizeof(double)) != hipSuccess) return false;
+  if (!dalloc(&fs.chunk_scale, (size_t)2 * fs.J)) return false;
   if (!dalloc(&fs.gl_scale_c, (size_t)I * C)) return false;
   if (packed) {
     const size_t words = cells / 16 + slack;
@@ -388,6 +403,7 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
   fs.called_table = parent.called_table;
   fs.gl_lin = parent.gl_lin;
   fs.pos_il = parent.pos_il;
+  fs.chunk_scale = parent.chunk_scale;
   fs.glq_il = parent.glq_il;
   fs.gl_scale_c = parent.gl_scale_c;
   fs.dmax_finite = parent.dmax_finite;
@@ -402,7 +418,7 @@ void fast_destroy(FastState& fs) {
   for (void* p : run)
     if (p) (void)hipFree(p);
   if (fs.owns_data) {
-    void* data[] = {fs.pos_il, fs.glq_il, fs.gl_scale_c, fs.gl_lin, fs.geno_il, fs.cls_lin};
+    void* data[] = {fs.pos_il, fs.chunk_scale, fs.glq_il, fs.gl_scale_c, fs.gl_lin, fs.geno_il, fs.cls_lin};
     for (void* p : data)
       if (p) (void)hipFree(p);
   }
@@ -447,6 +463,8 @@ bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double
                      0, st, gl_log, fs.I, fs.S, fs.T, fs.C, fs.gl_scale_c);
   hipLaunchKernelGGL(k_fast_pos_interleave, dim3(1024), dim3(256), 0, st, d_pos, fs.S, fs.T, fs.C,
                      fs.pos_il);
+  hipLaunchKernelGGL(k_fast_chunk_scale, dim3(fs.C), dim3(64), 0, st, fs.pos_il, fs.T,
+                     reinterpret_cast<double2*>(fs.chunk_scale));
   // the largest finite distance decides when the objective kernel may use its
   // small-argument exp for the alpha +- eh probes
   unsigned long long* d_m = reinterpret_cast<unsigned long long*>(fs.bound);

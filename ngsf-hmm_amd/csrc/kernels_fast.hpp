@@ -82,6 +82,8 @@ struct FastState {
   double* e_il = nullptr;         // emission ratios e1/e0, interleaved [I][C][T][64]
   double* base_c = nullptr;       // [I][C]: sum of log e0 over the wave's sites
   double* pos_il = nullptr;       // distances, interleaved [C][T][64]
+  double* chunk_scale = nullptr;  // [C][64] x (sum of the finite distances, number of chromosome
+                                  // starts) over a lane-chunk's T sites (fast_dev.hpp: op_step_k)
   double* glq_il = nullptr;       // linear GL relative to the cell's largest, interleaved like
                                   // e_il, 16 B per cell (kernels_fast.hip: glq_encode)
   double* gl_scale_c = nullptr;   // [I][C]: sum of the cells' largest log GL over the wave's sites

@@ -9,16 +9,27 @@ namespace nghmm {
 
 namespace {
 
-// The main loop of one wave for the finite-difference pattern.  Per site and lane:
-// one exp (a degree-7 polynomial when alpha * d_max <= 2^-6: SMALL), the products shared
-// by all points, 12 instructions per F-probe and 20 per alpha-probe; one exponent (point
-// 0's) rescales all points, which are perturbations of each other.
+// The main loop of one wave for the finite-difference pattern.  Per site and lane: one
+// exp(-alpha d) (SMALL, alpha * d_max <= 2^-6: a polynomial), the products shared by all points,
+// and per point the two rows' update; one exponent (point 0's) rescales all points, which are
+// perturbations of each other.
+//
+// SMALL versions run in the kappa form (fast_dev.hpp: op_step_k; NGHMM_KFORM=0 builds the earlier
+// form for A/B): the operators are kept divided by c_s = exp(-alpha d_s), whose product over the
+// lane-chunk the end of the walk puts back -- 10 instructions for point 0 (the two rows 8), 10 per
+// F probe, 15 per alpha probe (kappa_probe = kappa m + (m - 1), m = exp((alpha_probe - alpha_0) d)
+// tiny-argument), 10 shared: 75 per site for the five points where the c form spends 87.
+#ifndef NGHMM_KFORM
+#define NGHMM_KFORM 1
+#endif
 template <int NF, int NA, bool SMALL, bool EMIT, int XDEG, bool OWNEX, typename Src>
 __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc& G,
                                            Op (&R)[MAXP], EmitPtrs emit, uint64_t wave,
-                                           int lane) {
+                                           int lane, const double2* __restrict__ chunk_scale,
+                                           uint32_t chunk) {
   static_assert(NB * UG == CK && RENORM == CK, "checkpoints are stored right after a rescale");
   constexpr int NPT = 1 + NF + NA;
+  constexpr bool KF = SMALL && NGHMM_KFORM != 0;
   const uint64_t nblk = T / CK;
   const double al0 = G.A[0];
   const double q1 = G.F[0], q0 = 1 - q1;
@@ -29,7 +40,7 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
     rho1[f] = G.F[1 + f] / q1;
   }
 #pragma unroll
-  for (int a = 0; a < NA; ++a) dal[a] = al0 - G.A[1 + NF + a];
+  for (int a = 0; a < NA; ++a) dal[a] = KF ? G.A[1 + NF + a] - al0 : al0 - G.A[1 + NF + a];
   int exc = 0;
   // Software pipeline: NB buffers of UG sites.  A buffer is refilled right after it
   // has been consumed, i.e. (NB-1) groups = 6 sites before it is needed again, which
@@ -50,29 +61,52 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
       for (int u = 0; u < UG; ++u) {
         double rho, d;
         src.get(buf[b][u], t0 + (uint64_t)b * UG + u, rho, d);
-        double c0;
-        if constexpr (SMALL) {
-          // chromosome starts are stored as d = 1e30: c = 0 there (the polynomial of the
-          // huge argument is finite; masking its bits keeps the loop body branch-free)
-          const uint64_t keep = (d < 1e30) ? ~0ull : 0ull;
-          c0 = ngh_from_bits(ngh_bits(exp_tiny7(-al0 * d)) & keep);
+        if constexpr (KF) {
+          // chromosome starts are stored as d = 1e30: kappa = 2^200 there (selects keep the loop
+          // body branch-free; the polynomial of the huge argument is finite and dropped), and
+          // the alpha probes see d = 0, i.e. the same kappa
+          const bool start = !(d < 1e30);
+          const double dc = (NA > 0 && start) ? 0.0 : d;
+          const double x = al0 * dc;
+          const double kp = expm1_over_x_tiny(x) * x;
+          const double kap = start ? __builtin_ldexp(1.0, KAPPA_START_EXP) : kp;
+          const double eq1 = q1 * rho;
+          const double g0 = kap * q0, g1 = kap * eq1;
+          op_step_k(R[0], rho, g0, g1);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) op_step_k(R[1 + f], rho, g0 * rho0[f], g1 * rho1[f]);
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            // |x| <= 1e-3 on every finite distance (checked by the host)
+            const double mm1 = expm1_small<XDEG>(dal[a] * dc);
+            const double ka = fma(kap, 1.0 + mm1, mm1);
+            op_step_k(R[1 + NF + a], rho, ka * q0, ka * eq1);
+          }
         } else {
-          c0 = coanc(al0, d);
-        }
-        const double a0 = 1 - c0;
-        const double ce0 = c0, ce1 = c0 * rho;  // emissions (1, rho)
-        const double eq0 = q0, eq1 = rho * q1;
-        const double g0 = a0 * eq0, g1 = a0 * eq1;
-        op_step(R[0], ce0, ce1, g0, g1);
+          double c0;
+          if constexpr (SMALL) {
+            // chromosome starts are stored as d = 1e30: c = 0 there (the polynomial of the
+            // huge argument is finite; masking its bits keeps the loop body branch-free)
+            const uint64_t keep = (d < 1e30) ? ~0ull : 0ull;
+            c0 = ngh_from_bits(ngh_bits(exp_tiny7(-al0 * d)) & keep);
+          } else {
+            c0 = coanc(al0, d);
+          }
+          const double a0 = 1 - c0;
+          const double ce0 = c0, ce1 = c0 * rho;  // emissions (1, rho)
+          const double eq0 = q0, eq1 = rho * q1;
+          const double g0 = a0 * eq0, g1 = a0 * eq1;
+          op_step(R[0], ce0, ce1, g0, g1);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) op_step(R[1 + f], ce0, ce1, g0 * rho0[f], g1 * rho1[f]);
+          for (int f = 0; f < NF; ++f) op_step(R[1 + f], ce0, ce1, g0 * rho0[f], g1 * rho1[f]);
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-          // |x| <= 1e-3 on every finite distance (checked by the host); at d = 1e30 the
-          // polynomial is huge but finite and multiplies c0 = 0
-          const double m = exp_small<XDEG>(dal[a] * d);
-          const double am = fma(-c0, m, 1.0);
-          op_step(R[1 + NF + a], ce0 * m, ce1 * m, am * eq0, am * eq1);
+          for (int a = 0; a < NA; ++a) {
+            // |x| <= 1e-3 on every finite distance (checked by the host); at d = 1e30 the
+            // polynomial is huge but finite and multiplies c0 = 0
+            const double m = exp_small<XDEG>(dal[a] * d);
+            const double am = fma(-c0, m, 1.0);
+            op_step(R[1 + NF + a], ce0 * m, ce1 * m, am * eq0, am * eq1);
+          }
         }
       }
 #pragma unroll
@@ -108,12 +142,30 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
     if constexpr (EMIT) {  // first round of an M-step: point 0 is the E-step's forward walk
       // (no bound check, to keep the loop one basic block: the store after the last block
       // lands in the unused slot 0 of the next wave, or in the array's slack)
+      // (kappa form: a checkpoint is the prefix operator times a positive factor, and the
+      // backward sweep normalises every site's posterior by its own sum)
       emit_checkpoint(emit.ckpt, wave, nblk, t0 / CK + 1, lane, R[0]);
     }
   }
   if constexpr (!OWNEX) {
 #pragma unroll
     for (int p = 0; p < NPT; ++p) R[p].ex = exc;
+  }
+  if constexpr (KF) {
+    // back to the operators themselves: prod_s c_s = exp(-alpha sum_s d_s) over the lane-chunk's
+    // finite distances, and 2^-200 per chromosome start
+    const double2 cs = chunk_scale[(uint64_t)chunk * 64 + lane];
+    const int e_starts = -KAPPA_START_EXP * (int)cs.y;
+    const double s0 = exp_nonpos(-al0 * cs.x);
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      const double sp = p < 1 + NF ? s0 : exp_nonpos(-G.A[p] * cs.x);
+      R[p].a00 *= sp;
+      R[p].a01 *= sp;
+      R[p].a10 *= sp;
+      R[p].a11 *= sp;
+      R[p].ex += e_starts;
+    }
   }
 }
 
@@ -233,7 +285,7 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
   using Src = SrcOf<SRC>;
   Src src(arr, wave_base, pos_base);
   static_assert(!(OWNEX && EMIT), "an emitting round's checkpoints assume point 0's scale");
-  lkl_run_fd<NF, NA, SMALL, EMIT, XDEG, OWNEX>(src, T, G, R, emit, i * C + c, lane);
+  lkl_run_fd<NF, NA, SMALL, EMIT, XDEG, OWNEX>(src, T, G, R, emit, i * C + c, lane, arr.chunk_scale, c);
   if constexpr (SRC != SRC_PLAIN) {  // fresh walk: the wave's part of sum log e0
     const double bl = wave_sum(src.base.log_value());
     if (lane == 0) arr.base_c[i * C + c] = bl + (arr.gl_scale_c ? arr.gl_scale_c[i * C + c] : 0.0);

@@ -255,6 +255,68 @@ def test_one_million_site_chains_against_binary128(pkg, orc_libm):
     assert e_f <= 1e-12 and e_o <= 1e-12
 
 
+def test_objective_probe_points_at_one_million_sites_against_binary128(pkg, orc_libm):
+    """The M-step's objective kernels at the benchmarked chain length: the five points of a
+    finite-difference gradient (shared/bfgs.cpp:22-43: x, F +- eh, alpha +- eh) for individuals
+    0-1 of bench.py's data set over all 10^6 sites, through nghmm_lkl_batch, against the binary128
+    anchor and beside the oracle.  At the simulation's true parameters (alpha d_max < 2^-6) that is
+    the kappa-form kernel (fast_dev.hpp: op_step_k -- operators kept divided by exp(-alpha d), the
+    product put back per lane-chunk), at the starting values the general-exp version.  Asserted:
+    every point within 1e-14 relative of the anchor and no further from it than the oracle; the
+    DIFFERENCES the optimizer's gradient is made of (f(x + eh) - f(x - eh), values ~1e-2 ... 1e1
+    between numbers ~1e6) no further from the anchor's than the oracle's are."""
+    import torch
+    dev = torch.device("cuda", 0)
+    I, S = 2, 1_000_000
+    sim = pkg.simulate.IndexedSim(1000, S, dev, seed=12345)
+    gl_d, pos_d = sim.gl((0, I), (0, S)), sim.pos_dist(0, S)
+    torch.cuda.synchronize()
+    gl, pos = gl_d.cpu().numpy(), pos_d.cpu().numpy()
+    hp = orclib.HpAnchor()
+    out = {}
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as fa:
+        fa.load_device(gl_d.data_ptr(), pos_d.data_ptr())
+        for name, (F0, A0, f0) in {"true_values_kappa_form": (0.5, 0.01, 0.2),
+                                   "start_values_general_exp": (0.1, 0.2, 0.1)}.items():
+            em = orclib.OracleEM(orc_libm, gl, pos)
+            em.set_params(F0, A0, f0)
+            assert em.init_emission() == 0
+            fa.set_params(F0, A0, f0)
+            fa.init_emission()
+            ehF, ehA = (1e-8 * (F0 + 1)) ** 0.67, (1e-8 * (A0 + 1)) ** 0.67
+            pts = [(F0, A0), (F0 + ehF, A0), (F0 - ehF, A0), (F0, A0 + ehA), (F0, A0 - ehA)]
+            ind = np.repeat(np.arange(I), 5)
+            F = np.tile([q[0] for q in pts], I)
+            A = np.tile([q[1] for q in pts], I)
+            got = fa.lkl(ind, F, A)
+            fr = np.full(S, f0)
+            with ThreadPoolExecutor(min(10, _threads())) as pool:
+                anchor = np.array(list(pool.map(
+                    lambda k: hp.forward_backward(gl[:, ind[k]], fr, pos, F[k], A[k], want_post=False)[0],
+                    range(len(ind)))))
+                oracle = np.array(list(pool.map(
+                    lambda k: -orc_libm.lkl([F[k], A[k]], em.e_prob[ind[k]], pos), range(len(ind)))))
+            rel_f = float(np.max(np.abs(got - anchor) / np.abs(anchor)))
+            rel_o = float(np.max(np.abs(oracle - anchor) / np.abs(anchor)))
+            # the gradient's differences: F (points 1, 2) and alpha (points 3, 4), per individual
+            dif = lambda v: np.concatenate([v[1::5] - v[2::5], v[3::5] - v[4::5]])
+            d_a, d_f, d_o = dif(anchor), dif(got), dif(oracle)
+            err_f, err_o = float(np.max(np.abs(d_f - d_a))), float(np.max(np.abs(d_o - d_a)))
+            out[name] = {"lkl_rel_fast": rel_f, "lkl_rel_oracle": rel_o, "difference_abs_err_fast": err_f,
+                         "difference_abs_err_oracle": err_o, "differences": d_a.tolist()}
+            print(f"1M sites, {name}: five points vs binary128 -- lkl rel fast {rel_f:.1e} oracle {rel_o:.1e}; "
+                  f"gradient differences abs err fast {err_f:.1e} oracle {err_o:.1e} (of {np.abs(d_a).min():.1e} "
+                  f"... {np.abs(d_a).max():.1e})")
+            assert rel_f <= 1e-14 and rel_f <= max(rel_o, 4e-16)
+            # (the anchor's values are binary128 results rounded to double: their differences carry
+            # 2 ulp of 1e6 = 2.4e-10 themselves)
+            assert err_f <= max(err_o, 1e-9)
+            em.close()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_1M_probes.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 @pytest.mark.parametrize("I,S,seed", [(2, 4000, 1003), (2, 3777, 1017), (3, 4096, 1021), (5, 2500, 1033)])
 def test_est_maf_difference_is_the_oracles_posterior_rounding(pkg, orc_libm, I, S, seed):
     """tools/fuzz_shapes.py found frequencies 5e-9 ... 7e-9 relative off the oracle at I = 2,
