@@ -144,11 +144,28 @@ __device__ __forceinline__ void op_step(Op& m, double ce0, double ce1, double g0
 //   row' = (row_0 + g0 (row.1),  rho row_1 + g1 (row.1)),   g0 = kappa q0,  g1 = kappa q1 rho
 // -- four instructions per row instead of five, every term non-negative as before (no
 // cancellation), and the factor left out is known in closed form: prod_s c_s = exp(-alpha sum_s d_s)
-// over the lane-chunk (chunk_scale, formed at load), put back once at the end of the walk.  At a
-// chromosome start (c = 0) kappa is KAPPA_START = 2^200: the row's own part is then below the
-// last bit of the other by a factor 2^-200 / q >= 2^-150, i.e. the rank-one operator 1 q^T diag(e)
-// bit for bit, times a power of two that the end of the walk takes out of the exponent.
-constexpr int KAPPA_START_EXP = 200;
+// over the lane-chunk (chunk_scale, formed at load), put back once at the end of the walk.
+// Chromosome starts (c = 0; stored as d = kDStart) need no select: the argument alpha d is
+// clamped to KAPPA_XMAX = 2^16, where the polynomial gives K ~ 2^99.7 for every alpha >= 1e-15 -- the
+// row's own part is then 1 / (K q) of the other, at most 1e-15 (q >= 1e-15, EM.cpp:425; 1e-24 at
+// q = 1e-6): the rank-one operator 1 q^T diag(e) to rounding, times a constant that the end of
+// the walk divides out again per start.  Eight starts in a row between two rescales are 2^798:
+// 2^225 of the double range are left for that block's emission ratios (the c form had 2^1023).
+// The alpha probes' small exponential sees the distance clamped to KAPPA_DCLAMP (above every
+// finite distance these kernels are given: |alpha_0 - alpha_probe| d_max <= 1e-3 with probes >= 4e-6
+// apart), so their constant is that of point 0 within a few per cent and the points' common
+// exponent holds however many starts a lane-chunk has.
+constexpr double kDStart = 1e22;           // a chromosome start in pos_il (exp(-alpha d) = 0, alpha >= 1e-15)
+constexpr double KAPPA_XMAX = 65536.0;     // 2^16 <= 1e-15 * kDStart
+constexpr double KAPPA_DCLAMP = 1000.0;
+// min of two numbers that are not NaN: the one instruction (fmin() canonicalises a loaded operand
+// first, a v_max_f64 x, x per site)
+__device__ __forceinline__ double min_num(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void op_step_k(Op& m, double rho, double g0, double g1) {
   const double s0 = m.a00 + m.a01;
   const double s1 = m.a10 + m.a11;
@@ -265,8 +282,17 @@ __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small, bool 
 // Recognise the finite-difference pattern of one objective + gradient evaluation
 // (bfgs_batch.cpp plan(): x, then the F probes, then the alpha probes) with alpha probes
 // close enough for exp_small<4> (or <2>) on every finite distance of this data set.
+//
+// alpha_small_min: the small-alpha versions run in the kappa form (op_step_k), which forms
+// kappa = expm1(alpha d) to full precision, where the reference's 1 - exp(-alpha d) (HMM.cpp:130-139)
+// carries the rounding of exp(-alpha d) to the 2^-53 grid below 1 -- a RELATIVE error 1e-16 / (alpha d)
+// of the switching probability, which a tract boundary that the data force into a stretch of n
+// sites turns into ~1e-16 / (sqrt(n) alpha d) of log-likelihood: nothing at alpha d ~ 1e-3, visible
+// at alpha d < ~1e-8, 0.1 at alpha's lower bound 1e-15 (measured).  Individuals whose alpha is
+// that small (alpha * mean finite distance < 1e-6) take the general-exp version, whose c = exp(-alpha
+// d), 1 - c round as the reference's do.
 __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits,
-                           bool allow_xdeg2) {
+                           bool allow_xdeg2, double alpha_small_min) {
   if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
   int nf = 0, na = 0;
   bool ownex = false;
@@ -301,7 +327,8 @@ __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, 
   const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
                   (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
   if (!ok) return 0;
-  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625, allow_xdeg2 && na > 0 && xmax <= 1e-5) |
+  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625 && G.A[0] >= alpha_small_min,
+                 allow_xdeg2 && na > 0 && xmax <= 1e-5) |
          (ownex ? FD_OWNEX : 0u);
 }
 

@@ -75,7 +75,7 @@ struct DevPtrs {
   uint32_t* h_table;
   uint32_t I;
   // fd_pattern's view of the data
-  double dmax;
+  double dmax, alpha_small_min;
   uint64_t T;
   int packed, allow_xdeg2;
 };
@@ -107,7 +107,7 @@ __device__ inline void build_group(const BfgsProblem& p, uint32_t i, const DevPt
     ++np;
   }
   G.np = np;
-  G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.allow_xdeg2 != 0);
+  G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.allow_xdeg2 != 0, D.alpha_small_min);
 }
 
 // One individual per WAVE, kWg waves (individuals) per workgroup: the machines of different
@@ -438,6 +438,7 @@ DevPtrs dev_ptrs(const FastState& fs, double* d_F, double* d_A) {
   D.h_table = const_cast<uint32_t*>(d.h_table);
   D.I = (uint32_t)fs.I;
   D.dmax = fs.dmax_finite;
+  D.alpha_small_min = fs.alpha_small_min;
   D.T = fs.T;
   D.packed = fs.packed ? 1 : 0;
   D.allow_xdeg2 = fs.sw.no_xdeg2 ? 0 : 1;

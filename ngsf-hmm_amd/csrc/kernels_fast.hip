@@ -93,7 +93,7 @@ k_fast_max_finite(const double* __restrict__ pos, uint64_t S, unsigned long long
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < S;
        k += (uint64_t)gridDim.x * blockDim.x) {
     const double d = pos[k];
-    if (d >= 0 && d < 1e30) {
+    if (d >= 0 && d < kDStart) {
       const unsigned long long b = ngh_bits(d);
       m = b > m ? b : m;
     }
@@ -111,9 +111,9 @@ k_fast_pos_interleave(const double* __restrict__ pos, uint64_t S, uint64_t T, ui
     const uint64_t c = ct / T, t = ct % T;
     const uint64_t s = (c * 64 + lane) * T + t;
     // padding: d = 0 -> c = 1 -> identity transition; chromosome starts: +inf is stored
-    // as 1e30 (exp(-alpha 1e30) = 0 for every alpha >= 1e-15, and no inf*0 can arise)
+    // as kDStart = 1e22 (exp(-alpha 1e22) = 0 for every alpha >= 1e-15, and no inf*0 can arise)
     const double d = (s < S) ? pos[s] : 0.0;
-    pos_il[k] = (d < 1e30) ? d : 1e30;
+    pos_il[k] = (d < kDStart) ? d : kDStart;
   }
 }
 
@@ -125,7 +125,7 @@ k_fast_chunk_scale(const double* __restrict__ pos_il, uint64_t T, double2* __res
   double sum = 0.0, starts = 0.0;
   for (uint64_t t = 0; t < T; ++t) {
     const double d = dp[t * 64];
-    if (d < 1e30) sum += d;
+    if (d < kDStart) sum += d;
     else starts += 1.0;
   }
   chunk_scale[(uint64_t)blockIdx.x * 64 + threadIdx.x] = double2{sum, starts};
@@ -407,6 +407,7 @@ bool fast_create_replica(FastState& fs, const FastState& parent) {
   fs.glq_il = parent.glq_il;
   fs.gl_scale_c = parent.gl_scale_c;
   fs.dmax_finite = parent.dmax_finite;
+  fs.alpha_small_min = parent.alpha_small_min;
   return fast_alloc_run_state(fs);
 }
 
@@ -474,6 +475,18 @@ bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double
   if (hipMemcpyAsync(&bits, d_m, sizeof bits, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
   if (hipStreamSynchronize(st) != hipSuccess) return false;
   std::memcpy(&fs.dmax_finite, &bits, sizeof bits);
+  {  // mean finite distance, from the lane-chunks' sums (padding sites are d = 0 and no sites)
+    std::vector<double> cs((size_t)2 * fs.J);
+    if (hipMemcpy(cs.data(), fs.chunk_scale, cs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      return false;
+    double sum = 0, starts = 0;
+    for (size_t k = 0; k < fs.J; ++k) {
+      sum += cs[2 * k];
+      starts += cs[2 * k + 1];
+    }
+    const double n_finite = (double)fs.S - starts;
+    fs.alpha_small_min = (n_finite > 0 && sum > 0) ? 1e-6 / (sum / n_finite) : HUGE_VAL;
+  }
   return hipGetLastError() == hipSuccess;
 }
 

@@ -143,6 +143,8 @@ struct FastState {
   } dev;
 
   double dmax_finite = 0;         // largest finite distance of the loaded data
+  double alpha_small_min = 0;     // 1e-6 / mean finite distance: below it no small-alpha (kappa
+                                  // form) objective kernel (fast_dev.hpp: fd_pattern)
   uint8_t* redo = nullptr;        // per-site "needs the careful est_maf route" flags
   size_t redo_cap = 0;
   uint8_t* est_status = nullptr;  // est_maf per-site state machine (see k_fast_estmaf):

@@ -18,7 +18,7 @@ namespace {
 // form for A/B): the operators are kept divided by c_s = exp(-alpha d_s), whose product over the
 // lane-chunk the end of the walk puts back -- 10 instructions for point 0 (the two rows 8), 10 per
 // F probe, 15 per alpha probe (kappa_probe = kappa m + (m - 1), m = exp((alpha_probe - alpha_0) d)
-// tiny-argument), 10 shared: 75 per site for the five points where the c form spends 87.
+// tiny-argument), 11 shared: 71 per site for the five points where the c form spends 87 (+ 3).
 #ifndef NGHMM_KFORM
 #define NGHMM_KFORM 1
 #endif
@@ -62,32 +62,29 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
         double rho, d;
         src.get(buf[b][u], t0 + (uint64_t)b * UG + u, rho, d);
         if constexpr (KF) {
-          // chromosome starts are stored as d = 1e30: kappa = 2^200 there (selects keep the loop
-          // body branch-free; the polynomial of the huge argument is finite and dropped), and
-          // the alpha probes see d = 0, i.e. the same kappa
-          const bool start = !(d < 1e30);
-          const double dc = (NA > 0 && start) ? 0.0 : d;
-          const double x = al0 * dc;
-          const double kp = expm1_over_x_tiny(x) * x;
-          const double kap = start ? __builtin_ldexp(1.0, KAPPA_START_EXP) : kp;
+          // (chromosome starts, d = kDStart: the clamps give every point its constant kappa,
+          // fast_dev.hpp; the loop body stays branch- and select-free)
+          const double x = min_num(al0 * d, KAPPA_XMAX);
+          const double kap = expm1_over_x_tiny(x) * x;
           const double eq1 = q1 * rho;
           const double g0 = kap * q0, g1 = kap * eq1;
           op_step_k(R[0], rho, g0, g1);
 #pragma unroll
           for (int f = 0; f < NF; ++f) op_step_k(R[1 + f], rho, g0 * rho0[f], g1 * rho1[f]);
+          const double dcl = min_num(d, KAPPA_DCLAMP);
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
             // |x| <= 1e-3 on every finite distance (checked by the host)
-            const double mm1 = expm1_small<XDEG>(dal[a] * dc);
+            const double mm1 = expm1_small<XDEG>(dal[a] * dcl);
             const double ka = fma(kap, 1.0 + mm1, mm1);
             op_step_k(R[1 + NF + a], rho, ka * q0, ka * eq1);
           }
         } else {
           double c0;
           if constexpr (SMALL) {
-            // chromosome starts are stored as d = 1e30: c = 0 there (the polynomial of the
+            // chromosome starts are stored as d = kDStart: c = 0 there (the polynomial of the
             // huge argument is finite; masking its bits keeps the loop body branch-free)
-            const uint64_t keep = (d < 1e30) ? ~0ull : 0ull;
+            const uint64_t keep = (d < kDStart) ? ~0ull : 0ull;
             c0 = ngh_from_bits(ngh_bits(exp_tiny7(-al0 * d)) & keep);
           } else {
             c0 = coanc(al0, d);
@@ -101,7 +98,7 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
           for (int f = 0; f < NF; ++f) op_step(R[1 + f], ce0, ce1, g0 * rho0[f], g1 * rho1[f]);
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
-            // |x| <= 1e-3 on every finite distance (checked by the host); at d = 1e30 the
+            // |x| <= 1e-3 on every finite distance (checked by the host); at d = kDStart the
             // polynomial is huge but finite and multiplies c0 = 0
             const double m = exp_small<XDEG>(dal[a] * d);
             const double am = fma(-c0, m, 1.0);
@@ -153,9 +150,8 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
   }
   if constexpr (KF) {
     // back to the operators themselves: prod_s c_s = exp(-alpha sum_s d_s) over the lane-chunk's
-    // finite distances, and 2^-200 per chromosome start
+    // finite distances, and per chromosome start the constant kappa the point had there
     const double2 cs = chunk_scale[(uint64_t)chunk * 64 + lane];
-    const int e_starts = -KAPPA_START_EXP * (int)cs.y;
     const double s0 = exp_nonpos(-al0 * cs.x);
 #pragma unroll
     for (int p = 0; p < NPT; ++p) {
@@ -164,7 +160,25 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
       R[p].a01 *= sp;
       R[p].a10 *= sp;
       R[p].a11 *= sp;
-      R[p].ex += e_starts;
+    }
+    if (cs.y > 0.0) {  // (a few lane-chunks of a data set)
+      const double k0 = expm1_over_x_tiny(KAPPA_XMAX) * KAPPA_XMAX;
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        double kp = k0;
+        if (p >= 1 + NF) {
+          const double mm1 = expm1_small<XDEG>(dal[p - 1 - NF < NA ? p - 1 - NF : 0] * KAPPA_DCLAMP);
+          kp = fma(k0, 1.0 + mm1, mm1);
+        }
+        const double inv = 1.0 / kp;
+        for (int n = (int)cs.y; n > 0; --n) {
+          R[p].a00 *= inv;
+          R[p].a01 *= inv;
+          R[p].a10 *= inv;
+          R[p].a11 *= inv;
+          renorm(R[p]);
+        }
+      }
     }
   }
 }
@@ -550,7 +564,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed, !fs.sw.no_xdeg2);
+    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed, !fs.sw.no_xdeg2, fs.alpha_small_min);
     groups.push_back(G);
   }
   // one kernel per loop-body version: sort the groups by mode (stable, so still in

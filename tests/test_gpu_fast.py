@@ -315,6 +315,50 @@ def test_fast_objective_kernel_variants(pkg, orc_libm, mid_sim, pattern, alpha0)
     hmm.close()
 
 
+@pytest.mark.parametrize("alpha0", [1e-15, 1e-6, 2e-5, 0.01, 0.04])
+def test_fast_kappa_form_at_chromosome_starts(pkg, orc_libm, mid_sim, alpha0):
+    """The small-alpha objective kernels keep their operators divided by exp(-alpha d) (kappa
+    form, fast_dev.hpp: op_step_k) and meet c = 0 at chromosome starts through two clamps instead
+    of a select.  A data set full of starts -- every seventh site over a stretch, eight in a row
+    (a whole block between two rescales), pairs, the very last site, next to the three the
+    simulation has -- at alpha from its lower bound (EM.cpp:427) up to the small-argument limit.
+    Below alpha * mean distance = 1e-6 (here alpha < ~1e-5) the general-exp kernel takes the points:
+    there the reference's 1 - exp(-alpha d) is mostly the rounding of exp(-alpha d), which the kappa
+    form's exact expm1 does not reproduce (0.015 of log-likelihood at alpha = 1e-15, measured;
+    fast_dev.hpp: fd_pattern).  Every point against the oracle at 1e-12, the probes'
+    differences against the oracle's, the fused round's E-step log-likelihood (its lane
+    operators come out of the same walk) and posteriors too."""
+    d, gl = mid_sim
+    pos = d.pos_dist_mb.copy()
+    starts = list(range(1000, 1500, 7)) + list(range(2000, 2008)) + [3000, 3001, 3500, 3502, d.n_sites - 1]
+    pos[starts] = np.inf
+    F0 = 0.3
+    hmm, em = _pair(pkg, orc_libm, gl, pos, indF=F0, alpha=alpha0)
+    em.init_emission(); hmm.init_emission()
+    ehF = (1e-8 * (abs(F0) + 1)) ** 0.67
+    ehA = (1e-8 * (abs(alpha0) + 1)) ** 0.67
+    pts = [(F0, alpha0), (F0 + ehF, alpha0), (F0 - ehF, alpha0)]
+    pts += [(F0, alpha0 + ehA), (F0, alpha0 - ehA)] if alpha0 - ehA > 1e-15 else [(F0, alpha0 + 2 * ehA)]
+    npt = len(pts)
+    ind = np.repeat(np.arange(d.n_ind), npt)
+    F = np.tile([p[0] for p in pts], d.n_ind)
+    A = np.tile([p[1] for p in pts], d.n_ind)
+    got = hmm.lkl(ind, F, A)
+    e = em.e_prob
+    want = np.array([-orc_libm.lkl([F[p], A[p]], e[ind[p]], pos) for p in range(len(ind))])
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    for k in range(1, npt):
+        np.testing.assert_allclose(got[k::npt] - got[0::npt], want[k::npt] - want[0::npt],
+                                   rtol=1e-4, atol=2e-8)
+    assert em.estep() == 0
+    hmm.estep_mstep(True, True)          # the emitting walk alone: nothing to optimise
+    np.testing.assert_allclose(hmm.ind_lkl, em.ind_lkl, rtol=1e-12)
+    np.testing.assert_allclose(hmm.marg_prob, em.marg, rtol=RTOL, atol=1e-12)
+    st = hmm.estep_mstep()               # and with the rounds behind it
+    assert st.rounds >= 1 and np.all(np.isfinite(hmm.indF)) and np.all(np.isfinite(hmm.alpha))
+    hmm.close()
+
+
 def test_fast_fused_walk_through_the_general_kernel(pkg, orc_libm):
     """A data set with one very long finite distance (2000 Mb): the alpha probes' exp(-+ eh d)
     shortcut does not hold there (|eh d| > 1e-3), so every group takes the general objective
