@@ -171,6 +171,15 @@ constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back
 #if NGHMM_EST_EN == 8
 __constant__ double kChebC[EN] = {0.9807852804032304, 0.8314696123025452, 0.5555702330196023, 0.19509032201612833, -0.1950903220161282, -0.555570233019602, -0.8314696123025453, -0.9807852804032304};
 __constant__ double kChebW[EN] = {0.19509032201612825, -0.5555702330196022, 0.8314696123025452, -0.9807852804032304, 0.9807852804032304, -0.8314696123025455, 0.5555702330196022, -0.1950903220161286};
+#elif NGHMM_EST_EN == 9
+__constant__ double kChebC[EN] = {0.984807753012208, 0.8660254037844387, 0.6427876096865394, 0.3420201433256688, 6.123233995736766e-17, -0.3420201433256685, -0.6427876096865394, -0.8660254037844385, -0.984807753012208};
+__constant__ double kChebW[EN] = {0.17364817766693033, -0.49999999999999994, 0.766044443118978, -0.9396926207859083, 1.0, -0.9396926207859084, 0.766044443118978, -0.5000000000000003, 0.17364817766693028};
+#elif NGHMM_EST_EN == 10
+__constant__ double kChebC[EN] = {0.9876883405951378, 0.8910065241883679, 0.7071067811865476, 0.4539904997395468, 0.15643446504023092, -0.1564344650402306, -0.4539904997395467, -0.7071067811865475, -0.8910065241883678, -0.9876883405951377};
+__constant__ double kChebW[EN] = {0.15643446504023087, -0.45399049973954675, 0.7071067811865475, -0.8910065241883678, 0.9876883405951378, -0.9876883405951378, 0.8910065241883679, -0.7071067811865476, 0.45399049973954686, -0.15643446504023098};
+#elif NGHMM_EST_EN == 11
+__constant__ double kChebC[EN] = {0.9898214418809327, 0.9096319953545184, 0.7557495743542583, 0.5406408174555977, 0.2817325568414298, 2.83276944882399e-16, -0.28173255684142967, -0.5406408174555972, -0.7557495743542582, -0.9096319953545182, -0.9898214418809327};
+__constant__ double kChebW[EN] = {0.14231483827328514, -0.4154150130018864, 0.6548607339452851, -0.8412535328311811, 0.9594929736144974, -1.0, 0.9594929736144974, -0.8412535328311814, 0.6548607339452852, -0.4154150130018867, 0.14231483827328517};
 #elif NGHMM_EST_EN == 12
 __constant__ double kChebC[EN] = {0.9914448613738104, 0.9238795325112867, 0.7933533402912352, 0.6087614290087207, 0.38268343236508984, 0.1305261922200517, -0.1305261922200516, -0.3826834323650895, -0.6087614290087207, -0.793353340291235, -0.9238795325112867, -0.9914448613738104};
 __constant__ double kChebW[EN] = {0.13052619222005157, -0.3826834323650898, 0.6087614290087207, -0.7933533402912352, 0.9238795325112867, -0.9914448613738104, 0.9914448613738104, -0.9238795325112868, 0.7933533402912352, -0.6087614290087209, 0.3826834323650899, -0.130526192220052};
@@ -181,7 +190,7 @@ __constant__ double kChebW[EN] = {0.11196447610330786, -0.3302790619551671, 0.53
 __constant__ double kChebC[EN] = {0.9951847266721969, 0.9569403357322088, 0.881921264348355, 0.773010453362737, 0.6343932841636455, 0.4713967368259978, 0.29028467725446233, 0.09801714032956077, -0.09801714032956065, -0.29028467725446216, -0.4713967368259977, -0.6343932841636454, -0.773010453362737, -0.8819212643483549, -0.9569403357322088, -0.9951847266721968};
 __constant__ double kChebW[EN] = {0.0980171403295606, -0.29028467725446233, 0.47139673682599764, -0.6343932841636455, 0.773010453362737, -0.8819212643483549, 0.9569403357322089, -0.9951847266721968, 0.9951847266721969, -0.9569403357322089, 0.881921264348355, -0.7730104533627371, 0.6343932841636455, -0.47139673682599786, 0.2902846772544624, -0.09801714032956083};
 #else
-#error "NGHMM_EST_EN must be 8, 12, 14 or 16"
+#error "NGHMM_EST_EN must be 8 ... 12, 14 or 16"
 #endif
 
 // W = BLOCK/64 waves per site, NI individuals per lane held in registers.  With
