@@ -325,11 +325,11 @@ def test_bench_four_ranks_on_the_full_workload_reproduce_the_one_gpu_job(pkg):
           json.dumps({k: alt[k] for k in ("value", "ms_per_step", "exchange_ms")}))
 
 
-@pytest.mark.parametrize("ranks,n_sites", [(2, 200_000), (4, 100_000)])
+@pytest.mark.parametrize("ranks,n_sites", [(2, 200_000), (4, 102_400)])
 def test_bench_config5_shape_ranks_reproduce_the_one_gpu_job(pkg, ranks, n_sites):
     """BASELINE configs[4]'s shape through bench.py -- 5000 individuals, 25 chromosomes, --call_geno
     (2-bit packed handles, the called genotypes' closed-form frequency step over all 5000) -- at
-    200 000 sites on two ranks and at 100 000 on four (gloo on one GPU; a box admits six
+    200 000 sites on two ranks and at 102 400 on four (whole 16-site code words per rank; gloo on one GPU; a box admits six
     processes on its card and this test process is one of them, so four ranks leave a margin): as
     site shards and, embedded, as individual shards (genotype codes
     exchanged once, posteriors every iteration) the ranks give the one-GPU line's `check` --
