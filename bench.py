@@ -80,22 +80,23 @@ KERNELS = {
         bound="fp64_valu", isa="later objective rounds",
         kernel="k_fast_lkl_fd<2,2,true,false,SRC_PLAIN,2>",
         note="objective rounds 2.. of the L-BFGS-B M-step: 5 probe points share one pass over "
-             "the 8 B emission ratio of every still-active individual; 87 FP64 instructions per "
-             "site, 104 VGPRs, 4 waves per SIMD; the chip runs it at ~1.7 GHz (power limit), "
-             "where this rate is ~85 % of what a register-resident FP64 stream sustains"),
+             "the 8 B emission ratio of every still-active individual; kappa form (operators kept "
+             "divided by exp(-alpha d): 4 instructions per row instead of 5), 74 FP64 instructions "
+             "per site (c form: 87), 4 waves per SIMD; the chip runs it at ~1.7 GHz (power limit)"),
     "lkl_first_round": dict(
-        bound="fp64_valu", isa="fresh forward walk",
+        bound="hbm", isa="fresh forward walk",
         kernel="k_fast_lkl_fd<2,2,true,true,SRC_FRESH,2>",
         note="round 1 = E-step's forward walk = emission refresh: reads the 16 B relative "
-             "likelihoods, writes the 8 B emission ratio and 4 B of checkpoints; VALU-issue "
-             "bound (128 VALU per site: the 5-point walk, the emissions, their ratio, the "
-             "decode of the 16 B cells), 163 VGPRs, 3 waves per SIMD"),
+             "likelihoods, writes the 8 B emission ratio and 4 B of checkpoints; with the walk in "
+             "the kappa form (113 VALU per site, 128 in the c form) the kernel sits on its memory "
+             "side: 0.68 of the HBM roof = 87 % of the 6.29 TB/s a copy reaches; 3 waves per SIMD"),
     "est_maf": dict(
         bound="fp64_valu", isa="est_maf: k_fast_estmaf<16, 64, true>",
         kernel="k_fast_estmaf<16,64,true> + _interp + _resume",
         note="the reference's ~100 passes per site: 3 evaluated over all individuals, 12 "
              "Chebyshev nodes of a checked interpolant, the rest on the interpolant; 256 VGPRs, "
-             "2 waves per SIMD, SQ_ACTIVE_INST_VALU 0.44 per wave"),
+             "2 waves per SIMD, SQ_ACTIVE_INST_VALU 0.43 per wave; neither roof is reached: a site's "
+             "load phase and its serial passes are only partly under the other wave's arithmetic"),
     "backward_sweep": dict(
         bound="hbm", kernel="k_fast_bounds + k_fast_bwd_recompute8",
         note="boundary vectors + backward sweep with block-wise forward recomputation: 8 B "
@@ -134,6 +135,8 @@ def isa_counts():
         b = re.match(r"\s+block \S+: (\d+) instructions = (\d+) VALU \((\d+) FP64\)", line)
         if b and cur and int(b.group(1)) >= 100:
             out[cur].append(tuple(int(x) for x in b.groups()))
+        if cur and "est_maf model (" in line:
+            out[cur + ":model"] = {n: (int(v), int(f)) for n, v, f in re.findall(r"(\w+) (\d+)/(\d+)", line)}
     return out, path, None
 
 
@@ -143,21 +146,25 @@ def walk_instr_per_site(blocks):
     return valu / 8.0, fp64 / 8.0
 
 
-def estmaf_instr_per_site(i_tot, blocks):
-    """VALU / FP64 wave-instructions est_maf issues per site from its five big blocks in file
-    order -- set-up of the per-individual constants (16 individuals per lane), an exact pass in
-    three blocks (sums, reduction, recursion), a node evaluation --: 3 exact passes and 12 nodes
-    per site, the per-individual parts scaled to the individuals per lane of the cohort.  None if
-    the assembly no longer has that shape."""
-    if len(blocks) != 5:
+def estmaf_instr_per_site(i_tot, model):
+    """VALU / FP64 wave-instructions est_maf issues per site, from the parts tools/isa_report.py
+    recognises in its assembly (`est_maf model`: set-up of the per-individual constants for 16
+    individuals per lane; an exact pass = sums + reduction + recursion; a node evaluation; the
+    addition of the parked node sums): 3 exact passes and 12 nodes per site, the per-individual
+    parts scaled to the individuals per lane of the cohort.  None without the model line.
+    (Until round 5 the node loop was counted with the code it falls through to, 208 instructions
+    for 139: 3 388 VALU per site where SQ_INSTS_VALU counts 2 830.)"""
+    if not model:
         return None
-    (_, s_v, s_f), (_, p_v, p_f), (_, r_v, r_f), (_, c_v, c_f), (_, n_v, n_f) = blocks
     ni = min(16, -(-i_tot // 64))
     waves = max(1, -(-i_tot // 1024))
     sc = ni / 16.0
-    valu = waves * (s_v * sc + 3 * (p_v * sc + r_v + c_v) + 12 * (n_v * sc))
-    fp64 = waves * (s_f * sc + 3 * (p_f * sc + r_f + c_f) + 12 * (n_f * sc))
-    return valu, fp64
+    out = []
+    for k in (0, 1):
+        g = lambda name: model[name][k]
+        out.append(waves * (g("setup") * sc + 3 * (g("pass") * sc + g("reduction") + g("recursion"))
+                            + 12 * g("node") * sc + g("node_tail")))
+    return tuple(out)
 
 
 def _latest_profile(suffix):
@@ -1051,9 +1058,20 @@ def run_rank(args):
             w_valu = w_fp64 = None
             blocks = (isa or {}).get(name)
             if name == "est_maf" and blocks:
-                vf = estmaf_instr_per_site(est_inds, blocks)
+                vf = estmaf_instr_per_site(est_inds, (isa or {}).get("est_maf:model"))
                 if vf:
-                    w_valu, w_fp64, per = vf[0] * r["sites"], vf[1] * r["sites"], {"valu": vf[0], "fp64": vf[1]}
+                    per = {"valu": vf[0], "fp64": vf[1],
+                           "what": "from the assembly's parts: an upper bound (the build decision's "
+                                   "block is counted with every exact pass)"}
+                    # the counted instructions of this build's PMC pass, when there is one: the
+                    # assembly model then only supplies the FP64 share
+                    k = (pmc_summ or {}).get("k_fast_estmaf<16, 64, true>")
+                    if k and k.get("insts_valu_per_launch") and k.get("avg_grid_threads") and est_inds == 1000:
+                        v_pmc = k["insts_valu_per_launch"] / (k["avg_grid_threads"] / 64.0)
+                        per = {"valu": v_pmc, "fp64": vf[1] * v_pmc / vf[0], "assembly_model_valu": vf[0],
+                               "what": f"VALU: SQ_INSTS_VALU per site of this build's PMC pass ({PMC_SUMMARY}); "
+                                       "FP64: that count times the FP64 share of the assembly's parts"}
+                    w_valu, w_fp64 = per["valu"] * r["sites"], per["fp64"] * r["sites"]
             elif meta.get("isa") and blocks:
                 v, f = walk_instr_per_site(blocks)
                 w_valu, w_fp64, per = v * r["sites_ind"] / 64.0, f * r["sites_ind"] / 64.0, {"valu": v, "fp64": f}

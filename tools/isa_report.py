@@ -10,7 +10,10 @@
   (tools/isa_summary.sh does all of it)
 
 For each kernel: registers / scratch / occupancy as the assembler reports them, and every
-basic block of >= 60 instructions with its opcode histogram (the loop bodies)."""
+basic block of >= 60 instructions with its opcode histogram (the loop bodies).  A block ends at a
+label OR behind a branch: the code a loop falls through to when it ends carries no label of its
+own (until round 5 it was counted into the loop body above it -- est_maf's node loop read 208
+instructions for its 139)."""
 import re
 import sys
 from collections import Counter
@@ -46,7 +49,11 @@ def main():
                 cur = [m.group(1), []]
                 blocks.append(cur)
             elif cur is not None and l.startswith("\t") and not l.strip().startswith((".", ";")):
-                cur[1].append(l.strip().split(";")[0].strip())
+                ins = l.strip().split(";")[0].strip()
+                cur[1].append(ins)
+                if ins.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
+                    cur = [cur[0] + "+", []]      # the fall-through part: a block of its own
+                    blocks.append(cur)
         print("==", title)
         for l in lines[end:end + 60]:
             if any(t in l for t in ("NumVgprs:", "ScratchSize:", "Occupancy:", "NumSgprs:")):
@@ -64,7 +71,37 @@ def main():
             print(f"   block {name}: {len(ins)} instructions = {valu} VALU ({f64} FP64) + {vmem} VMEM + "
                   f"{lds} LDS + {salu} scalar")
             print("      ", ", ".join(f"{k} {v}" for k, v in c.most_common(12)))
+        if "k_fast_estmaf<16" in title:
+            estmaf_model(blocks)
         print()
+
+
+def estmaf_model(blocks):
+    """est_maf's parts by what only they contain (the blocks' order and sizes move with the
+    compiler): set-up of the per-individual constants (the input selects), an exact pass = the
+    lanes' sums (the packed pair reduction starts there: v_permlane32_swap) + the reduction (the
+    readlanes) + the serial recursion and the build decision (every FP64 block from there to the
+    node loop: an upper bound, the decision runs once or twice per site), a node evaluation (the
+    loop that parks its sums in LDS), the addition of the parked sums behind it."""
+    def vf(ins):
+        c = Counter(x.split()[0] for x in ins)
+        return (sum(v for k, v in c.items() if k.startswith("v_")), sum(v for k, v in c.items() if "f64" in k))
+    def find(pred):
+        return next((i for i, (_, ins) in enumerate(blocks) if pred(Counter(x.split()[0] for x in ins))), None)
+    i_set = find(lambda c: c["v_cndmask_b32_e64"] + c["v_cndmask_b32_e32"] >= 30)
+    i_pass = find(lambda c: c["v_permlane32_swap_b32_e32"] >= 2 and c["v_rcp_f64_e32"] >= 4)
+    i_red = find(lambda c: c["v_readlane_b32"] >= 20)
+    i_node = find(lambda c: c["ds_write_b128"] >= 1 and c["v_rcp_f64_e32"] == 4 and c["v_readlane_b32"] == 2)
+    if None in (i_set, i_pass, i_red, i_node) or not (i_pass < i_red < i_node):
+        print("   est_maf model: not recognised")
+        return
+    rec = [vf(ins) for _, ins in blocks[i_red + 1:i_node]]
+    rec = (sum(v for v, _ in rec), sum(f for _, f in rec))
+    tail = next((vf(ins) for _, ins in blocks[i_node + 1:i_node + 6]
+                 if sum(1 for x in ins if x.startswith("ds_read_b128")) >= 8), (0, 0))
+    parts = [("setup", vf(blocks[i_set][1])), ("pass", vf(blocks[i_pass][1])), ("reduction", vf(blocks[i_red][1])),
+             ("recursion", rec), ("node", vf(blocks[i_node][1])), ("node_tail", tail)]
+    print("   est_maf model (VALU/FP64 wave-instructions): " + ", ".join(f"{n} {v}/{f}" for n, (v, f) in parts))
 
 
 if __name__ == "__main__":
