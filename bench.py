@@ -149,9 +149,10 @@ def walk_instr_per_site(blocks):
 def estmaf_instr_per_site(i_tot, model):
     """VALU / FP64 wave-instructions est_maf issues per site, from the parts tools/isa_report.py
     recognises in its assembly (`est_maf model`: set-up of the per-individual constants for 16
-    individuals per lane; an exact pass = sums + reduction + recursion; a node evaluation; the
-    addition of the parked node sums): 3 exact passes and 12 nodes per site, the per-individual
-    parts scaled to the individuals per lane of the cohort.  None without the model line.
+    individuals per lane; an exact pass = sums with their reduction + recursion; the interpolant's
+    check, once; a node evaluation; the addition of the parked node sums): 3 exact passes and 12
+    nodes per site, the per-individual parts scaled to the individuals per lane of the cohort.
+    None without the model line.
     (Until round 5 the node loop was counted with the code it falls through to, 208 instructions
     for 139: 3 388 VALU per site where SQ_INSTS_VALU counts 2 830.)"""
     if not model:
@@ -162,7 +163,7 @@ def estmaf_instr_per_site(i_tot, model):
     out = []
     for k in (0, 1):
         g = lambda name: model[name][k]
-        out.append(waves * (g("setup") * sc + 3 * (g("pass") * sc + g("reduction") + g("recursion"))
+        out.append(waves * (g("setup") * sc + 3 * (g("pass") * sc + g("recursion")) + g("check")
                             + 12 * g("node") * sc + g("node_tail")))
     return tuple(out)
 

@@ -79,10 +79,11 @@ def main():
 def estmaf_model(blocks):
     """est_maf's parts by what only they contain (the blocks' order and sizes move with the
     compiler): set-up of the per-individual constants (the input selects), an exact pass = the
-    lanes' sums (the packed pair reduction starts there: v_permlane32_swap) + the reduction (the
-    readlanes) + the serial recursion and the build decision (every FP64 block from there to the
-    node loop: an upper bound, the decision runs once or twice per site), a node evaluation (the
-    loop that parks its sums in LDS), the addition of the parked sums behind it."""
+    lanes' sums with their packed pair reduction (v_permlane32_swap) + the serial recursion and the
+    build decision (every block from the check to the node loop: an upper bound, the decision runs
+    once or twice per site), the interpolant's check against an exact pass (three wave sums: the
+    readlanes; once per site), a node evaluation (the loop that parks its sums in LDS), the
+    addition of the parked sums behind it."""
     def vf(ins):
         c = Counter(x.split()[0] for x in ins)
         return (sum(v for k, v in c.items() if k.startswith("v_")), sum(v for k, v in c.items() if "f64" in k))
@@ -99,7 +100,7 @@ def estmaf_model(blocks):
     rec = (sum(v for v, _ in rec), sum(f for _, f in rec))
     tail = next((vf(ins) for _, ins in blocks[i_node + 1:i_node + 6]
                  if sum(1 for x in ins if x.startswith("ds_read_b128")) >= 8), (0, 0))
-    parts = [("setup", vf(blocks[i_set][1])), ("pass", vf(blocks[i_pass][1])), ("reduction", vf(blocks[i_red][1])),
+    parts = [("setup", vf(blocks[i_set][1])), ("pass", vf(blocks[i_pass][1])), ("check", vf(blocks[i_red][1])),
              ("recursion", rec), ("node", vf(blocks[i_node][1])), ("node_tail", tail)]
     print("   est_maf model (VALU/FP64 wave-instructions): " + ", ".join(f"{n} {v}/{f}" for n, (v, f) in parts))
 

@@ -1,0 +1,9 @@
+for c in 40 45 49 53 57 64; do
+  NGHMM_FAST_C=$c python bench.py --steps 10 --warmup 6 --no_cpu_baseline --no_exact_line --no_check > gpurun_out/sweepc_$c.json 2>/dev/null
+  python - $c <<'PY'
+import json,sys
+c=sys.argv[1]
+d=json.loads(open(f"gpurun_out/sweepc_{c}.json").read().strip().splitlines()[-1])
+print(c, round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['per_step_kernel_ms'].items()}, flush=True)
+PY
+done
