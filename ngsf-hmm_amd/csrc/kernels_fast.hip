@@ -348,6 +348,14 @@ bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed) {
   // -- the 64-lane operator tree of every point -- is that of about a dozen sites
   while (C > 1 && (S + 64 * C - 1) / (64 * C) < (C > 64 ? 32u : 16u)) --C;
   if (C < 1) C = 1;
+  // ... and 64 sites per lane where the cohort still fills the chip one and a half times over at
+  // that (>= 24576 waves): the site shard of an eight-GPU run, 1000 x 125 000 -- 3.76 ms per
+  // iteration at 49 waves per individual (40 sites per lane), 3.63 at 25 (80): with the kappa
+  // form a walk ends in three exponentials per lane on top of the operator trees
+  if (fs.sw.fast_c < 1) {
+    const uint64_t c64 = S / (64 * 64);
+    if (c64 >= 1 && c64 < C && I * c64 >= 24576) C = c64;
+  }
   if (fs.sw.fast_c < 1) {
     // sites per lane are rounded up to whole groups of 8 (16: packed), which at a few dozen
     // sites per lane pads a lot (100 x 100k: 24.4 -> 32 sites per lane, 31 %): take the count
