@@ -564,6 +564,14 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
     fam = {k: 0.0 for k in FAMILIES}
     launches = dict.fromkeys(fam, 0)
     rounds = points = ind_rounds = ref_calls = 0
+    # Kernel-family times (HIP events around the families, nghmm_kernel_ms): exact mode always
+    # records them; fast mode only with the switch `spans` -- the events are packets the queue
+    # works through between two kernels, 0.05 ms per iteration (8 % of configs[1]'s) -- so the
+    # timed iterations run without them and a few more iterations of the same steady state
+    # behind the timed region collect them (scaled to K iterations; not part of `value`).
+    # (--serial_kernels, what profiles/collect.sh traces: events in the timed iterations themselves,
+    # so that the trace and the line speak of the same iterations)
+    in_loop = ctx.args.mode != "fast" or ctx.args.serial_kernels
     barrier(ctx)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -572,15 +580,42 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
         points += st.points
         ind_rounds += st.ind_rounds
         ref_calls += st.ref_forward_calls
-        for k in fam:
-            ms, n = em.hmm.kernel_ms(k)
-            fam[k] += ms
-            launches[k] += n
+        if in_loop:
+            for k in fam:
+                ms, n = em.hmm.kernel_ms(k)
+                fam[k] += ms
+                launches[k] += n
     barrier(ctx)
     dt = time.perf_counter() - t0
     if ctx.world > 1:
         dt = float(allreduce(ctx, [dt], "max")[0])
     exchange_log = ex.take_log() if ex is not None and hasattr(ex, "take_log") else None
+    if not in_loop:
+        hs = handles_of(em) + list(replicas)
+        n_sp = max(1, min(5, steps))
+        saved_timing = dict(em.timing) if isinstance(getattr(em, "timing", None), dict) else None
+        saved_ex = (ex.calls, ex.bytes, ex.host_ms) if ex is not None and hasattr(ex, "calls") else None
+        for h in hs:
+            h.set_switch("spans", 1)
+        try:
+            for _ in range(n_sp):
+                iterate_all()
+                for k in fam:
+                    ms, n = em.hmm.kernel_ms(k)
+                    fam[k] += ms * steps / n_sp
+                    launches[k] += n * steps / n_sp
+        finally:
+            for h in hs:
+                h.set_switch("spans", 0)
+        # (the accounting of the timed region is what the line reports)
+        if saved_timing is not None:
+            em.timing.clear()
+            em.timing.update(saved_timing)
+        if saved_ex is not None:
+            ex.calls, ex.bytes, ex.host_ms = saved_ex
+            if hasattr(ex, "take_log"):
+                ctx.torch.cuda.synchronize()
+                ex.take_log()
     return dict(dt=dt, fam=fam, launches=launches, rounds=rounds, points=points, ind_rounds=ind_rounds,
                 ref_calls=ref_calls, each_ms=each_ms, each_rounds=each_rounds, steps=steps, warmup=warmup,
                 exchange_log=exchange_log)
@@ -603,6 +638,7 @@ def serial_kernel_loop(ctx, run, n, replicas=()):
     hs = handles_of(em) + list(replicas)
     for h in hs:
         h.set_switch("no_bg_stream", 1)
+        h.set_switch("spans", 1)
     try:
         fam = {k: 0.0 for k in FAMILIES}
         launches = dict.fromkeys(fam, 0)
@@ -622,6 +658,7 @@ def serial_kernel_loop(ctx, run, n, replicas=()):
     finally:
         for h in hs:
             h.set_switch("no_bg_stream", 0)
+            h.set_switch("spans", 0)
     return dict(fam=fam, launches=launches, rounds=rounds, ind_rounds=ind_rounds, steps=n, dt=dt)
 
 
@@ -950,6 +987,7 @@ def run_rank(args):
     if args.serial_kernels:
         for h in handles_of(em) + replicas:
             h.set_switch("no_bg_stream", 1)
+            h.set_switch("spans", 1)
     tl = timed_loop(ctx, run, args.steps, args.warmup, replicas)
     dt, fam, launches = tl["dt"], tl["fam"], tl["launches"]
     rounds, points, ind_rounds, ref_calls = tl["rounds"], tl["points"], tl["ind_rounds"], tl["ref_calls"]
@@ -1138,7 +1176,14 @@ def run_rank(args):
             f"HIP events over {K_k} iterations that follow the timed loop with the library's switch "
             "no_bg_stream (every kernel alone on the chip; in the timed loop the backward sweep and "
             "est_maf run on a second stream next to the objective rounds and the spans overlap)"
-            if kt is not None else "HIP events over the timed loop")
+            if kt is not None else
+            ("HIP events over the timed loop" if (args.mode != "fast" or args.serial_kernels) else
+             f"HIP events over {max(1, min(5, args.steps))} iterations that follow the timed loop (fast mode "
+             "records them on request only, switch `spans`: the timed iterations carry none)"))
+        roofline["timed_loop"] = ("no timing events inside the timed iterations (fast mode; switch `spans` off): "
+                                  "`per_step_kernel_ms_timed_loop` comes from iterations behind them, two streams "
+                                  "as in the timed loop" if (args.mode == "fast" and not args.serial_kernels) else
+                                  "timing events inside the timed iterations")
         each = tl["each_ms"]
         n_run = min(20, len(each))
         vs_n1 = None

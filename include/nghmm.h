@@ -412,6 +412,11 @@ void nghmm_free_host(void* p);
  *                     kernel's span is then its own)
  *   estmaf_w2         1: est_maf of 513 .. 1024 individuals on two waves of 8 per lane (measured
  *                     slower: 10.1 vs 8.5 ms at 1000 x 1M)
+ *   spans             1: fast mode records the timing events behind nghmm_kernel_ms around the
+ *                     kernel families of nghmm_mstep_indf / nghmm_estep_mstep / nghmm_iter_em
+ *                     (default 0: the events are packets the queue works through between two
+ *                     kernels, 0.05 ms per EM iteration -- 8 % of an iteration of 100 x 100 000;
+ *                     nghmm_kernel_ms then reads 0 for those calls); exact mode always records
  * Fixed at creation (environment only): fast_c (waves per individual), spin_sync (replicas
  * wait spinning).  Unknown names return NGHMM_ERR_ARG.  Outside the handle: NGHMM_HOST_THREADS
  * (host threads of the L-BFGS-B state machines, read once per process). */
@@ -430,7 +435,8 @@ int nghmm_synchronize(nghmm_t* h);
  * part of slot 3 spent in the round that doubled as the E-step's forward walk
  * (nghmm_estep_mstep), 7 the kernels that advance the L-BFGS-B machines on the device between
  * two rounds (fast mode; 0 where the host advances them).  Also the launch count behind each
- * slot. */
+ * slot.  Fast mode's M-step and fused iteration time their kernels only with the switch
+ * `spans` (nghmm_set_switch; NGHMM_SPANS=1) and report 0 without it. */
 int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches);
 
 #ifdef __cplusplus

@@ -278,7 +278,7 @@ const SwitchName kSwitches[] = {
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs}, {"estmaf_w2", &Switches::estmaf_w2},
     {"dbg_abort_round", &Switches::dbg_abort_round},
-    {"no_bg_stream", &Switches::no_bg_stream}};
+    {"no_bg_stream", &Switches::no_bg_stream}, {"spans", &Switches::spans}};
 
 }  // namespace
 

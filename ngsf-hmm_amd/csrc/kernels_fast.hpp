@@ -39,6 +39,7 @@ struct Switches {
   int dbg_abort_round = 0;    // test hook: a device-planned M-step returns an error after this round
   int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
   int no_bg_stream = 0;       // device-planned rounds: backward sweep and est_maf between the rounds on the one stream, not next to them on a second
+  int spans = 0;              // fast mode: timing events around the kernel families of a fused iteration, for nghmm_kernel_ms (0.05 ms per iteration: 8 % of configs[1]'s)
   static Switches from_env();
   // false: no switch of that name
   bool set(const char* name, long value);

@@ -361,17 +361,30 @@ int emission_impl(nghmm_t* h) {
 }
 
 // ---- background pieces of a fused iteration (see nghmm_handle::BgSpan) ----
+// The pieces' timers are events on the stream, and an event is a packet the queue has to work
+// through between two kernels: 20 of them per iteration are 0.05 ms -- 8 % of an iteration of
+// 100 x 100 000, 2 % of a rank of eight's, nothing at 1000 x 1 M.  Fast mode records them only
+// with the switch `spans` (nghmm_kernel_ms of a fused iteration needs it); exact mode, whose
+// iterations take seconds, always.
+static bool spans_on(const nghmm_t* h) { return h->mode != NGHMM_MODE_FAST || h->fast.sw.spans != 0; }
+
 int bg_begin(nghmm_t* h) {
   int rc;
   if (!h->d_flags_bg && (rc = dev_alloc(&h->d_flags_bg, (size_t)NFLAGS))) return rc;
   HIP_TRY(hipMemsetAsync(h->d_flags_bg, 0, NFLAGS * sizeof(int), h->stream));
   h->bg_used = 0;
+  if (!spans_on(h))  // (no piece of this iteration is timed: nghmm_kernel_ms reads 0, not an earlier call's time)
+    for (int slot : {SLOT_EMISSION, SLOT_FORWARD, SLOT_BACKWARD, SLOT_LKL, SLOT_ESTMAF, SLOT_LKL_FIRST, SLOT_BFGS}) {
+      h->ms[slot] = 0;
+      h->launches[slot] = 0;
+    }
   return NGHMM_OK;
 }
 
 // start / stop the timer of one piece (nothing waits)
 int bg_open(nghmm_t* h, int slot, hipStream_t st) {
   if (!st) st = h->stream;
+  if (!spans_on(h)) return NGHMM_OK;
   if (h->bg_used == h->bg_spans.size()) {
     nghmm_handle::BgSpan sp;
     const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
@@ -385,6 +398,7 @@ int bg_open(nghmm_t* h, int slot, hipStream_t st) {
 }
 
 int bg_close(nghmm_t* h, hipStream_t st) {
+  if (!spans_on(h)) return NGHMM_OK;
   HIP_TRY(hipEventRecord(h->bg_spans[h->bg_used].ev1, st ? st : h->stream));
   ++h->bg_used;
   return NGHMM_OK;

@@ -564,6 +564,9 @@ class NgsFHMM:
 
     # -- measurement -------------------------------------------------------
     def kernel_ms(self, name):
+        """(milliseconds, launches) of a kernel family in the last call that ran it.  Fast mode's
+        M-step and fused iteration time their kernels only after ``set_switch("spans", 1)`` (the
+        events cost 0.05 ms per iteration) and report 0 without it; include/nghmm.h."""
         ms = C.c_double(0)
         n = C.c_uint32(0)
         self._check(self.lib.nghmm_kernel_ms(self._h, KERNEL_SLOTS[name], C.byref(ms), C.byref(n)))

@@ -87,8 +87,18 @@ def test_whole_iterations_on_the_device_equal_the_host_machines(pkg, I, S, nchr,
             assert a[4] == b[4], (it, a[4], b[4])
         assert np.array_equal(host[-1], dev[-1])
         assert dev[0][4][0] > dev[-2][4][0]        # the first iteration needs more rounds than the sixth
+        # the kernels of a fused iteration are timed on request only (switch `spans`: its events
+        # are packets between the kernels): nothing by default, the same bits with it
+        assert h.kernel_ms("bfgs")[0] == 0 and h.kernel_ms("est_maf")[0] == 0
+        h.set_switch("spans", 1)
+        timed = run(h)
+        h.set_switch("spans", 0)
+        for a, b in zip(dev[:-1], timed[:-1]):
+            for x, y in zip(a[:4], b[:4]):
+                assert np.array_equal(x, y)
         bf, n = h.kernel_ms("bfgs")
-        assert bf > 0                              # the device's planning kernels ran (slot 7)
+        assert bf > 0 and n >= 1                   # the device's planning kernels ran (slot 7)
+        assert h.kernel_ms("est_maf")[0] > 0 and h.kernel_ms("lkl_batch")[0] > 0
 
 
 def test_device_mstep_of_a_replica_and_stats_of_the_reference(pkg):

@@ -342,6 +342,7 @@ def test_config5_shape_at_one_gpu_share(pkg):
     assert (lk0[:3] < keep[0] + keep[7]).all() and (keep[0] < 0).all()
     st = h.iter_EM()
     lk1 = h.ind_lkl.copy()
+    h.set_switch("spans", 1)                                         # (kernel times below)
     h.iter_EM()
     lk2 = h.ind_lkl.copy()
     assert np.isfinite(lk2).all() and lk2.sum() > lk1.sum()          # EM ascends

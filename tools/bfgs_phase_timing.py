@@ -22,6 +22,7 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * 8)()
 names = ["stage in", "consume (solver)", "plan + out", "arrays back", "fence + publish"]
 with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as h:
+    h.set_switch("spans", 1)    # kernel times of the fused iterations (off by default)
     h.load_device(gl.data_ptr(), pos.data_ptr())
     h.set_params(0.1, 0.2, 0.1)
     h.init_emission()

@@ -16,6 +16,7 @@ dev = torch.device("cuda", 0)
 mode = pkg.MODE_FAST | (pkg.GENO_PACKED if wl.get("call_geno") else 0)
 sim = pkg.simulate.IndexedSim(I, S, dev, seed=12345, n_chrom=wl.get("n_chrom", 1))
 with pkg.NgsFHMM(I, S, mode=mode) as h:
+    h.set_switch("spans", 1)    # kernel times of the fused iterations (off by default)
     pos = sim.pos_dist(0, S)
     if wl.get("call_geno"):
         def feed():

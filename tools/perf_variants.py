@@ -43,6 +43,7 @@ def main():
                 pos[k * (S // n_chrom)] = float("inf")
         torch.cuda.synchronize()
         hmm = pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST)
+        hmm.set_switch("spans", 1)    # kernel times of the fused iterations (off by default)
         hmm.load_device(gl.data_ptr(), pos.data_ptr())
         del gl, pos
         hmm.set_params(opt.get("indF0", 0.1), opt.get("alpha0", 0.2), 0.1)
