@@ -57,6 +57,10 @@ struct nghmm_handle {
   int device = 0, mode = NGHMM_MODE_EXACT;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
+  // pinned landing places of what every call reads back -- the error flags, and a fused iteration's
+  // log-likelihoods: a copy to pageable memory is staged and waited for by the runtime, one each
+  int* h_flags_pin = nullptr;      // [NFLAGS]
+  double* h_lkl_pin = nullptr;     // [I]
   // exact mode, fused iteration: est_maf on a second stream underneath the objective rounds
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev0 = nullptr, aux_ev1 = nullptr, aux_go = nullptr, aux_done = nullptr;

@@ -65,8 +65,10 @@ int clear_flags(nghmm_t* h) {
 
 // Reads the kernel error flags and maps them to the reference's fatal errors.
 int check_flags(nghmm_t* h, const int* d_flags) {
-  int f[NFLAGS];
-  HIP_TRY(hipMemcpyAsync(f, d_flags ? d_flags : h->d_flags, sizeof f, hipMemcpyDeviceToHost,
+  if (!h->h_flags_pin)
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_flags_pin), NFLAGS * sizeof(int), hipHostMallocDefault));
+  int* f = h->h_flags_pin;
+  HIP_TRY(hipMemcpyAsync(f, d_flags ? d_flags : h->d_flags, NFLAGS * sizeof(int), hipMemcpyDeviceToHost,
                          h->stream));
   HIP_TRY(sync_stream(h));
   if (f[FLAG_INVALID_LKL]) {
@@ -586,6 +588,8 @@ int nghmm_destroy(nghmm_t* h) {
   for (hipEvent_t e : h->aux_estep_ev)
     if (e) (void)hipEventDestroy(e);
   if (h->d_aux_params) (void)hipFree(h->d_aux_params);
+  if (h->h_flags_pin) (void)hipHostFree(h->h_flags_pin);
+  if (h->h_lkl_pin) (void)hipHostFree(h->h_lkl_pin);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1116,10 +1120,15 @@ struct MstepRun {
     dbfgs_end(fs, round);
     std::memcpy(h->h_indF.data(), fs.dev.h_F, h->I * sizeof(double));
     std::memcpy(h->h_alpha.data(), fs.dev.h_A, h->I * sizeof(double));
-    if (bg_active && ind_lkl)
-      HIP_TRY(hipMemcpyAsync(ind_lkl, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+    const bool lkl_out = bg_active && ind_lkl;
+    if (lkl_out) {  // (through pinned memory: the copy waits for nothing, bg_finish waits once for everything)
+      if (!h->h_lkl_pin)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_lkl_pin), h->I * sizeof(double), hipHostMallocDefault));
+      HIP_TRY(hipMemcpyAsync(h->h_lkl_pin, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
                              h->stream));
+    }
     rc = bg_finish(h);  // waits for the stream; the spans' times; the background work's flags
+    if (lkl_out) std::memcpy(ind_lkl, h->h_lkl_pin, h->I * sizeof(double));
     h->ms[SLOT_LKL] += h->ms[SLOT_LKL_FIRST];
     h->launches[SLOT_LKL] = round - 1;
     if (rc) return rc;
