@@ -9,10 +9,10 @@ line() {  # ms_per_step of a bench run
 C="--no_cpu_baseline --no_exact_line --no_check"
 for rep in 1 2 3; do
   for p in 0 1; do
-    export NGHMM_SPANS=$p
+    export NGHMM_NO_BG_STREAM=$p
     a=$(python3 bench.py --workload c2 --steps 200 --warmup 20 $C | line)
     b=$(python3 bench.py --emulate_ranks 8 --steps 20 --warmup 6 $C | line)
     c=$(python3 bench.py --steps 10 --warmup 6 $C | line)
-    echo "rep $rep spans $p: c2 $a  rank-of-8 $b  n1 $c"
+    echo "rep $rep no_bg_stream $p: c2 $a  rank-of-8 $b  n1 $c"
   done
 done
