@@ -574,7 +574,14 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
     in_loop = ctx.args.mode != "fast" or ctx.args.serial_kernels
     barrier(ctx)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    # (site shards under nccl: a pair of events around every all-gather -- the LAST timed
+    # iteration's calls are set side by side over the ranks, the others carry none)
+    ex_timed = ex is not None and hasattr(ex, "timed")
+    if ex_timed:
+        ex.timed = False
+    for i_step in range(steps):
+        if ex_timed and i_step == steps - 1:
+            ex.timed = True
         st = one()
         rounds += st.rounds
         points += st.points
@@ -590,6 +597,8 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
     if ctx.world > 1:
         dt = float(allreduce(ctx, [dt], "max")[0])
     exchange_log = ex.take_log() if ex is not None and hasattr(ex, "take_log") else None
+    if ex_timed:
+        ex.timed = False
     if not in_loop:
         hs = handles_of(em) + list(replicas)
         n_sp = max(1, min(5, steps))
@@ -1342,7 +1351,9 @@ def rank_clocks(ctx, run, tl):
         log = tl.get("exchange_log") or []
         per_iter = int(round(ex.calls / K_)) if K_ else 0
         mine["all_gather_ms_calls_last_iter"] = log[-per_iter:] if per_iter and len(log) >= per_iter else log
-        mine["exchange_ms_per_iter"]["all_gather_on_stream"] = sum(log) / K_ if log else None
+        # (events only in the last timed iteration under nccl; every call under gloo / emulation)
+        n_logged = len(log) / per_iter if per_iter else 0
+        mine["exchange_ms_per_iter"]["all_gather_on_stream"] = sum(log) / n_logged if n_logged else None
     else:
         mine["exchange_ms_per_iter"] = {
             "all_to_all": em.timing["a2a_ms"] / K_,

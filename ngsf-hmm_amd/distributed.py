@@ -604,6 +604,9 @@ class SiteExchange:
         # rank's part is ready and ends when the slowest rank's has arrived: duration = wire time
         # + waiting for the others), otherwise the host's clock; `take_log()` reads and clears
         self._log = []
+        # (the pair of events is two more packets on the stream per call: a caller that times a loop
+        # clears `timed` and sets it for the iterations it wants to see)
+        self.timed = True
         self._stream = None
         if send.is_cuda and stream_ptr is not None:
             import torch
@@ -634,12 +637,15 @@ class SiteExchange:
                 torch.cuda.synchronize(part.device)
             elif part.is_cuda:
                 with torch.cuda.stream(self._stream):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    dist.all_gather_into_tensor(whole, part)
-                    e1.record()
-                if len(self._log) < 65536:
-                    self._log.append((e0, e1))
+                    if self.timed:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        dist.all_gather_into_tensor(whole, part)
+                        e1.record()
+                        if len(self._log) < 65536:
+                            self._log.append((e0, e1))
+                    else:
+                        dist.all_gather_into_tensor(whole, part)
                 self.calls += 1
                 self.bytes += n_bytes
                 self.host_ms += (time.perf_counter() - t0) * 1e3
