@@ -1134,6 +1134,34 @@ def run_rank(args):
                                   "instr_per_site": None,
                                   "reason": isa_why or f"{isa_path}: no blocks for this kernel"}
             roof_all[name] = e
+        # the iteration as a whole (north_star: "as fraction of HBM roofline"): algorithmic bytes and
+        # FP64 wave-instructions of its four kernels per EM iteration against the TIMED loop's
+        # iteration (wall clock, everything in it), next to the kernels' own sum
+        roof_iter = None
+        if fast and roof_all:
+            it_bytes = sum(r["bytes"] for r in rows.values()) / K_k
+            it_traffic = [roof_all[n]["hbm"]["traffic_bytes_per_launch"] for n in rows]
+            it_traffic = (sum(t * rows[n]["launches"] for t, n in zip(it_traffic, rows)) / K_k
+                          if all(t is not None for t in it_traffic) else None)
+            it_fp64 = [roof_all[n].get("fp64_valu", {}).get("achieved_wave_instr_per_s") for n in rows
+                       if roof_all[n]["bound"] == "fp64_valu" or "fp64_valu" in roof_all[n]]
+            it_fp64 = (sum(roof_all[n]["fp64_valu"]["achieved_wave_instr_per_s"] * rows[n]["ms"] * 1e-3
+                           for n in rows if roof_all[n].get("fp64_valu", {}).get("achieved_wave_instr_per_s")) / K_k
+                       if it_fp64 and all(v is not None for v in it_fp64) else None)
+            wall_s = dt / K
+            roof_iter = {"ms_per_em_iteration": wall_s * 1e3,
+                         "kernels_ms_per_em_iteration": sum(r["ms"] for r in rows.values()) / K_k,
+                         "algorithmic_bytes_per_em_iteration": it_bytes,
+                         "traffic_bytes_per_em_iteration": it_traffic,
+                         "hbm": {"achieved_GBps": it_bytes / wall_s / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                 "frac": it_bytes / wall_s / 1e9 / HBM_PEAK_GBS},
+                         "fp64_valu": ({"achieved_wave_instr_per_s": it_fp64 / wall_s, "peak": FP64_ISSUE_PEAK,
+                                        "frac": it_fp64 / wall_s / FP64_ISSUE_PEAK,
+                                        "wave_instr_per_em_iteration": it_fp64}
+                                       if it_fp64 else None),
+                         "note": "the four kernels of roofline_all_kernels (objective rounds first / later, est_maf, "
+                                 "backward sweep) per EM iteration of THIS line's timed loop; the backward sweep's "
+                                 "instructions are not counted (HBM-bound: no assembly block model for it)"}
         if not fast:   # exact mode: latency-bound chains, not a roofline candidate
             for k in ("forward", "backward", "lkl_batch", "est_maf"):
                 if launches[k] and fam[k] > 0:
@@ -1252,6 +1280,7 @@ def run_rank(args):
                                     f"GPU (all-to-all of posteriors, all-gather of frequencies)")},
             "roofline": roofline,
             "roofline_all_kernels": roof_all,
+            "roofline_iteration": roof_iter,
             "per_step_kernel_ms": {k: fam[k] / K_k for k in fam if k != "lkl_first"},
             "per_step_kernel_ms_timed_loop": {k: fam_timed[k] / K for k in fam_timed if k != "lkl_first"},
             # the metric is EM iterations/s and a run is >= 10 iterations from the starting values
