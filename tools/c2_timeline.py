@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """One steady-state EM iteration out of a rocprofv3 kernel trace: every dispatch with its queue,
 its start relative to the iteration's first kernel, its duration and the gap to the previous
-dispatch's end on the same queue.  An iteration starts at a fresh walk (the emitting k_fast_lkl_fd); the one printed is the last but two of the trace."""
+dispatch's end on the same queue.  An iteration starts at a fresh walk (the emitting k_fast_lkl_fd); the one printed is the 13th of the
+trace -- inside the timed loop of `bench.py --steps 10 --warmup 6` (tools/c2_timeline.sh); the last ten of
+that run are bench.py's own measuring loops (events on, then one stream), where kernels run one after the other.
+  python tools/c2_timeline.py kernel_trace.csv [iteration]"""
 import csv
 import re
 import sys
@@ -20,7 +23,7 @@ if len(starts) < 4:
     # fall back: the kernel name of the first walk is whatever starts most iterations
     print("no fresh-walk kernels found; kernel names:", sorted({short(r["Kernel_Name"]) for r in rows}))
     sys.exit(0)
-which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 a, b = starts[which], starts[which + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 last_end = {}
