@@ -52,6 +52,32 @@ WORKLOADS = {
                name="100 ind x 100k sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
                     "--freq 0.1 --indF 0.1,0.2"),
     "tiny": dict(n_ind=64, n_sites=20_000, name="64 ind x 20k sites (smoke)"),
+    # ---- the same sizes off examples/test.sh's operating point (F 0.5, alpha 0.01, freq 0.2, depth 2):
+    # the simulator's `r` options (scripts/ngsF-HMMsim.R:108-110,127-129,146-148: indF, alpha ~ U(0,1)
+    # per individual, freq ~ U(0,1) per site), its default depth 5 (:77) or test.sh's 2, 2 % of the
+    # cells without a read; a transition rate far above the small-alpha kernels' range
+    "c3r": dict(n_ind=1000, n_sites=1_000_000,
+                sim=dict(indF="r", alpha="r", freq="r", depth=5.0, missing_rate=0.02),
+                name="1000 ind x 1M sites, --indF r --alpha r --freq r (U(0,1) each), depth 5, 2 % missing "
+                     "cells, --freq_est 1, --freq 0.1 --indF 0.1,0.2"),
+    "c3r2": dict(n_ind=1000, n_sites=1_000_000,
+                 sim=dict(indF="r", alpha="r", freq="r", depth=2.0, missing_rate=0.02),
+                 name="1000 ind x 1M sites, --indF r --alpha r --freq r (U(0,1) each), depth 2, 2 % missing "
+                      "cells, --freq_est 1, --freq 0.1 --indF 0.1,0.2"),
+    "c2r": dict(n_ind=100, n_sites=100_000,
+                sim=dict(indF="r", alpha="r", freq="r", depth=5.0, missing_rate=0.02),
+                name="100 ind x 100k sites, --indF r --alpha r --freq r (U(0,1) each), depth 5, 2 % missing "
+                     "cells, --freq_est 1, --freq 0.1 --indF 0.1,0.2"),
+    "c3hi": dict(n_ind=1000, n_sites=1_000_000, sim=dict(alpha=2.0),
+                 name="1000 ind x 1M sites, true alpha 2 (alpha d_max > 2^-6: general-exp objective kernels in "
+                      "the steady state), F 0.5, freq 0.2, depth 2, --freq_est 1, --freq 0.1 --indF 0.1,0.2"),
+    # likelihood cohorts above 1024 individuals: est_maf on several waves per site
+    "c2k": dict(n_ind=2000, n_sites=200_000,
+                name="2000 ind x 200k sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
+                     "--freq 0.1 --indF 0.1,0.2"),
+    "c5k": dict(n_ind=5000, n_sites=100_000,
+                name="5000 ind x 100k sites, synthetic log-GL (ngsF-HMMsim model), --freq_est 1, "
+                     "--freq 0.1 --indF 0.1,0.2"),
     # BASELINE.json configs[4]: needs 8 GPUs (625 individuals x 5M sites each, 21 B per cell
     # packed); c5share is exactly one GPU's share of it, without the exchange
     "c5": dict(n_ind=5000, n_sites=5_000_000, n_chrom=25, call_geno=True,
@@ -224,7 +250,15 @@ def pmc_traffic(summ, I, C):
     return out
 
 
-def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
+def make_sim(pkg, wl, n_ind, n_sites, device):
+    """The workload's data set (simulate.IndexedSim, seed 12345): any slice of it is bit for bit the
+    slice of the whole, so every part of a run -- the ranks of a job, the CPU sample, the exact
+    mode's slice -- sees the same cells."""
+    return pkg.simulate.IndexedSim(n_ind, n_sites, device, seed=12345, n_chrom=wl.get("n_chrom", 1),
+                                   **wl.get("sim", {}))
+
+
+def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False, wl=None):
     """The oracle (libm build = the reference's arithmetic; its L-BFGS-B core is pinned
     bit for bit to the reference object) timed on this box's host cores on a bounded
     sample of the same workload: per-individual phases threaded like the reference's
@@ -245,7 +279,7 @@ def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
     dev = torch.device("cuda", 0)
 
     def sample(n_ind, n_sites, s_tot):
-        sim = pkg.simulate.IndexedSim(n_ind, s_tot, dev, seed=12345)
+        sim = make_sim(pkg, {"sim": (wl or {}).get("sim", {})}, n_ind, s_tot, dev)
         gl_d, pos_d = sim.gl((0, n_ind), (0, n_sites)), sim.pos_dist(0, n_sites)
         torch.cuda.synchronize()
         with pkg.NgsFHMM(n_ind, n_sites, mode=pkg.MODE_FAST) as h:
@@ -284,7 +318,9 @@ def cpu_baseline(pkg, seconds_budget=20.0, full_c2=False):
         "unit": "site-ind updates/s",
         "cores": thr,
         "kind": "port",
-        "sample": f"{n_ind} ind x the first {n_sites} sites of the 100 x 100k data set, {iters} EM iterations in "
+        "sample": f"{n_ind} ind x the first {n_sites} sites of the 100 x 100k data set"
+                  + (f" of this workload's regime ({(wl or {}).get('sim')})" if (wl or {}).get("sim") else "")
+                  + f", {iters} EM iterations in "
                   f"{dt:.1f} s from the state after 5 GPU-computed iterations (the steady state the GPU "
                   f"is timed in), oracle libm build, per-individual phases on {thr} threads, "
                   f"allele-frequency loop serial as in the reference (EM.cpp:224)",
@@ -458,8 +494,7 @@ def build_run(ctx, shard, agree=None):
         else:
             em = dd.ShardedEM(pkg, sh["I"], sh["S"], device_index=ctx.local_rank, mode=ctx.mode,
                               rank=ctx.rank, world=ctx.world, emulate_ranks=V)
-        sim = pkg.simulate.IndexedSim(sh["I_tot"], sh["S_job"], ctx.device, seed=12345,
-                                      n_chrom=ctx.wl.get("n_chrom", 1))
+        sim = make_sim(pkg, ctx.wl, sh["I_tot"], sh["S_job"], ctx.device)
         pos = sim.pos_dist(*sh["site_range"])
         if not ctx.call_geno:
             gl = sim.gl(sh["ind_range"], sh["site_range"])
@@ -557,6 +592,12 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
         with em.beacon.guard():
             raise ctx.pkg.NgsFHMMError(-3, "invalid MAF! (injected by NGHMM_BENCH_FAIL_RANK)")
     em.reset_timing()
+    # which kernel versions the objective rounds take and how many sites of the frequency step leave
+    # its common route (include/nghmm_debug.h): counted over the timed iterations only
+    fast_handles = handles_of(em) if ctx.args.mode == "fast" else []
+    for h in fast_handles:
+        h.mode_counts(reset=True)
+        h.estmaf_counts(reset=True)
     ex = getattr(em, "exchange", None)
     if ex is not None and hasattr(ex, "take_log"):
         ctx.torch.cuda.synchronize()
@@ -599,6 +640,12 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
     exchange_log = ex.take_log() if ex is not None and hasattr(ex, "take_log") else None
     if ex_timed:
         ex.timed = False
+    mode_counts, estmaf_counts = {}, {}
+    for h in fast_handles:
+        for k, v in h.mode_counts().items():
+            mode_counts[k] = mode_counts.get(k, 0) + v
+        for k, v in h.estmaf_counts().items():
+            estmaf_counts[k] = estmaf_counts.get(k, 0) + v
     if not in_loop:
         hs = handles_of(em) + list(replicas)
         n_sp = max(1, min(5, steps))
@@ -627,7 +674,7 @@ def timed_loop(ctx, run, steps, warmup, replicas=()):
                 ex.take_log()
     return dict(dt=dt, fam=fam, launches=launches, rounds=rounds, points=points, ind_rounds=ind_rounds,
                 ref_calls=ref_calls, each_ms=each_ms, each_rounds=each_rounds, steps=steps, warmup=warmup,
-                exchange_log=exchange_log)
+                exchange_log=exchange_log, mode_counts=mode_counts, estmaf_counts=estmaf_counts)
 
 
 def handles_of(em):
@@ -761,8 +808,7 @@ def exact_mode_line(ctx, budget_s=5.0):
     import numpy as np
     torch, pkg = ctx.torch, ctx.pkg
     I, S = ctx.wl["n_ind"], min(100_000, ctx.wl["n_sites"])
-    sim = pkg.simulate.IndexedSim(I, ctx.wl["n_sites"], ctx.device, seed=12345,
-                                  n_chrom=ctx.wl.get("n_chrom", 1))
+    sim = make_sim(pkg, ctx.wl, I, ctx.wl["n_sites"], ctx.device)
     gl, pos = sim.gl((0, I), (0, S)), sim.pos_dist(0, S)
     torch.cuda.synchronize()
     res = {}
@@ -1332,16 +1378,36 @@ def run_rank(args):
                 for k in per_rank[0]["exchange_ms_per_iter"]}),
             "per_rank": per_rank,
             "all_gather_rounds": all_gather_rounds(per_rank) if (per_rank and by_sites) else None,
+            "regime": regime_object(tl, K, I, S_job if by_sites else S, world * V if by_sites else 1),
             "bfgs": {"rounds_per_iter": rounds / K, "points_per_iter": points / K,
                      "ind_rounds_per_iter": ind_rounds / K,
                      "reference_forward_passes_per_ind_iter": ref_calls / (K * I)},
         }
         if not args.no_cpu_baseline and world == 1:   # on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(pkg, full_c2=args.cpu_full_c2)
+            out["cpu_baseline"] = cpu_baseline(pkg, full_c2=args.cpu_full_c2, wl=wl)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1 or args.emulate_rccl:
         dist.destroy_process_group()
+
+
+def regime_object(tl, K, n_ind, n_sites, site_shards):
+    """Where the timed iterations spent their individual-rounds and sites: the share of every
+    loop-body version of the objective kernels (fd_pattern: `s` = small-alpha kappa form, a polynomial
+    per site instead of an exponential; `general` = an exponential per point and site) and the share
+    of the frequency step's sites that left its common route (exact passes, one checked
+    interpolant, the rest on it).  This rank's handle(s)."""
+    mc, ec = tl.get("mode_counts") or {}, tl.get("estmaf_counts") or {}
+    if not mc and not ec:
+        return None
+    tot = float(sum(mc.values())) or 1.0
+    sites = float(n_sites) / site_shards * K
+    return {"objective_kernel_versions": {k: {"ind_rounds_per_iter": v / K, "share": v / tot}
+                                          for k, v in sorted(mc.items(), key=lambda kv: -kv[1])},
+            "small_alpha_share": sum(v for k, v in mc.items() if k != "general" and "s" in k) / tot,
+            "general_kernel_share": mc.get("general", 0) / tot,
+            "est_maf_sites_off_the_common_route": {k: {"sites_per_iter": v / K, "share": v / sites}
+                                                   for k, v in ec.items()}}
 
 
 def all_gather_rounds(per_rank):

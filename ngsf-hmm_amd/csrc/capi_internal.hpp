@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/nghmm.h"
+#include "../../include/nghmm_debug.h"
 #include "bfgs_batch.hpp"
 #include "kernels.hpp"
 #include "kernels_fast.hpp"

@@ -423,7 +423,7 @@ void fast_destroy(FastState& fs) {
   dbfgs_destroy(fs);
   void* run[] = {fs.e_il, fs.base_c, fs.freq_il, fs.post, fs.ckpt, fs.lane_ops, fs.bound, fs.lanes[0].part,
                  fs.lanes[0].grp_dev, fs.lanes[1].part, fs.lanes[1].grp_dev, fs.redo, fs.est_status,
-                 fs.est_state, fs.shard.edges};
+                 fs.est_state, fs.est_counts, fs.shard.edges};
   for (void* p : run)
     if (p) (void)hipFree(p);
   if (fs.owns_data) {

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <vector>
 
 #include "glview.hpp"
@@ -150,6 +151,20 @@ struct FastState {
   size_t redo_cap = 0;
   uint8_t* est_status = nullptr;  // est_maf per-site state machine (see k_fast_estmaf):
   double* est_state = nullptr;    // [EST_FIELDS][redo_cap] loop state + interval node values
+  // diagnostics (include/nghmm_debug.h): individual-rounds by loop-body version of the objective
+  // kernels since the last reset; est_maf's rare routes, counted on the device by the sites that
+  // take them (EstCount below)
+  std::map<uint32_t, uint64_t> mode_ind_rounds;
+  uint32_t* est_counts = nullptr;  // [EST_COUNTS]
+};
+
+// est_maf's routes off the common one (exact passes, one checked interpolant, the rest on it)
+enum EstCount {
+  EST_CNT_CHECK_FAILED = 0,  // the interpolant missed the next exact pass by > 1e-11: exact passes to the end
+  EST_CNT_RESUMED = 1,       // left its interval or a stopping decision too close to call: a second interval
+  EST_CNT_RESUMED_AGAIN = 2, // ... and once more: exact passes to the end
+  EST_CNT_LOGSPACE = 3,      // a cell whose linear weights all vanish: the reference-order log-space route
+  EST_COUNTS = 4
 };
 
 bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed = false);

@@ -251,7 +251,7 @@ __device__ __forceinline__ void estmaf_site(
     uint64_t I_blk, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
     uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride, int fresh,
     int n_exact, int allow_build, uint64_t site, const double* __restrict__ tile_col,
-    double (&xch)[2][ESTMAF_MAXW][2],
+    uint32_t* __restrict__ cnt, double (&xch)[2][ESTMAF_MAXW][2],
     double2 (&nodebuf)[(BLOCK == 64 && NI >= 8) ? EN : 1][(BLOCK == 64 && NI >= 8) ? 65 : 1],
     double2 (&xnode)[(BLOCK == 64 && NI >= 8) ? 1 : EN][(BLOCK == 64 && NI >= 8) ? 1 : BLOCK / 64]) {
   constexpr int W = BLOCK / 64;
@@ -424,6 +424,7 @@ __device__ __forceinline__ void estmaf_site(
       const double bn = wave_sum_uniform(q * my_gn) / Sq, bd = wave_sum_uniform(q * my_gd) / Sq;
       interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);
       check = false;
+      if (!interp_ok && tix == 0) atomicAdd(cnt + EST_CNT_CHECK_FAILED, 1u);  // (rare)
     }
     num = fma(r, sn, num);
     den = fma(r, sd, den + tF_sum);
@@ -589,7 +590,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
               uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
               double* __restrict__ freq_out, uint8_t* __restrict__ redo,
               uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride,
-              int n_exact, int allow_build, uint64_t blk0) {
+              int n_exact, int allow_build, uint64_t blk0, uint32_t* __restrict__ cnt) {
   // W == 1: per-lane partial sums of the interval's nodes (see the build); the pad makes lane
   // j's reads of row j conflict-free (few individuals per lane, NI < 8: the 16 KB would cap
   // the waves per CU for nothing -- those kernels reduce every node in registers like the
@@ -610,7 +611,7 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
     site = blockIdx.x;
   }
   estmaf_site<NI, BLOCK, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status, state,
-                               state_stride, 1, n_exact, allow_build, site, tile_col, xch, nodebuf,
+                               state_stride, 1, n_exact, allow_build, site, tile_col, cnt, xch, nodebuf,
                                xnode);
 }
 
@@ -624,7 +625,7 @@ k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
                      double* __restrict__ freq_out, uint8_t* __restrict__ redo,
                      uint8_t* __restrict__ status, double* __restrict__ state,
                      uint64_t state_stride, int n_exact, int allow_build, uint64_t row0,
-                     uint64_t row1) {
+                     uint64_t row1, uint32_t* __restrict__ cnt) {
   ESTMAF_SHARED(NI, BLOCK);
   const int lane = threadIdx.x & 63;
   for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
@@ -632,14 +633,16 @@ k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
     const bool need = s < S_own && in_tile_rows(s, TILE ? tile_T : 0, row0, row1) &&
                       status[s] == EST_EXACT;
     uint64_t mask = __ballot(need);  // the same in every wave of the workgroup
+    if (mask && threadIdx.x == 0)
+      atomicAdd(cnt + (allow_build ? EST_CNT_RESUMED : EST_CNT_RESUMED_AGAIN), (uint32_t)__popcll(mask));
     if constexpr (BLOCK > 64) __syncthreads();  // ... all have read before anyone writes a status
     while (mask) {
       const uint64_t site = base + (uint64_t)__builtin_ctzll(mask);
       mask &= mask - 1;
       const double* tile_col = TILE ? estmaf_tile_col(marg_blocks, site, tile_T, I_tot) : nullptr;
       estmaf_site<NI, BLOCK, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status,
-                                   state, state_stride, 0, n_exact, allow_build, site, tile_col, xch,
-                                   nodebuf, xnode);
+                                   state, state_stride, 0, n_exact, allow_build, site, tile_col, cnt,
+                                   xch, nodebuf, xnode);
       if constexpr (BLOCK > 64) __syncthreads();  // the shared buffers serve the next site
     }
   }
@@ -674,7 +677,8 @@ __device__ __forceinline__ void estmaf_rows_sites(
     const GlView& gl, const double* __restrict__ marg_blocks, uint64_t S_own, uint64_t I_tot,
     uint64_t I_blk, double* __restrict__ freq_out, uint8_t* __restrict__ redo,
     uint8_t* __restrict__ status, double* __restrict__ state, uint64_t state_stride, int fresh,
-    int n_exact, int allow_build, uint64_t site, const double* __restrict__ tile_col, bool done) {
+    int n_exact, int allow_build, uint64_t site, const double* __restrict__ tile_col, bool done,
+    uint32_t* __restrict__ cnt) {
   static_assert(EN <= 16, "a row's lanes hold the interval's node sums");
   // Control flow is kept WAVE-UNIFORM: the rows of a wave are at different points of their
   // recursions (one hands its site over while another still needs exact passes), but every
@@ -786,8 +790,10 @@ __device__ __forceinline__ void estmaf_rows_sites(
       const double q = (j < EN) ? kChebW[nj] / t : 0.0;
       const double Sq = row_sum(q);
       const double bn = row_sum(q * my_gn) / Sq, bd = row_sum(q * my_gd) / Sq;
-      if (check && !done)
+      if (check && !done) {
         interp_ok = fabs(bn - sn) <= EST_TOL * fabs(sn) && fabs(bd - sd) <= EST_TOL * fabs(sd);
+        if (!interp_ok && j == 0) atomicAdd(cnt + EST_CNT_CHECK_FAILED, 1u);  // (rare)
+      }
       check = false;
     }
     // ---- the recursion and the row's decisions ----
@@ -881,7 +887,7 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
                    uint64_t I_tot, uint64_t I_blk, uint64_t tile_T, double* __restrict__ freq_out,
                    uint8_t* __restrict__ redo, uint8_t* __restrict__ status,
                    double* __restrict__ state, uint64_t state_stride, int n_exact,
-                   int allow_build) {
+                   int allow_build, uint32_t* __restrict__ cnt) {
   const int lane = threadIdx.x, row = lane >> 4;
   uint64_t site;
   const double* tile_col = nullptr;
@@ -904,7 +910,7 @@ k_fast_estmaf_rows(const GlView gl, const double* __restrict__ marg_blocks, uint
   }
   if (__builtin_amdgcn_ballot_w64(!done) == 0) return;  // nothing to do in this wave
   estmaf_rows_sites<NI, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status, state,
-                              state_stride, 1, n_exact, allow_build, site, tile_col, done);
+                              state_stride, 1, n_exact, allow_build, site, tile_col, done, cnt);
 }
 
 // resuming sites (see k_fast_estmaf_resume): the wave reads 64 statuses at a time and gives the
@@ -915,11 +921,14 @@ k_fast_estmaf_rows_resume(const GlView gl, const double* __restrict__ marg_block
                           uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
                           double* __restrict__ freq_out, uint8_t* __restrict__ redo,
                           uint8_t* __restrict__ status, double* __restrict__ state,
-                          uint64_t state_stride, int n_exact, int allow_build) {
+                          uint64_t state_stride, int n_exact, int allow_build,
+                          uint32_t* __restrict__ cnt) {
   const int lane = threadIdx.x, row = lane >> 4;
   for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
     const uint64_t s = base + lane;
     uint64_t mask = __ballot(s < S_own && status[s] == EST_EXACT);
+    if (mask && lane == 0)
+      atomicAdd(cnt + (allow_build ? EST_CNT_RESUMED : EST_CNT_RESUMED_AGAIN), (uint32_t)__popcll(mask));
     while (mask) {
       uint64_t site = 0;
       bool done = true;
@@ -937,7 +946,8 @@ k_fast_estmaf_rows_resume(const GlView gl, const double* __restrict__ marg_block
       const double* tile_col =
           TILE ? (done ? marg_blocks : estmaf_tile_col(marg_blocks, site, tile_T, I_tot)) : nullptr;
       estmaf_rows_sites<NI, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status,
-                                  state, state_stride, 0, n_exact, allow_build, site, tile_col, done);
+                                  state, state_stride, 0, n_exact, allow_build, site, tile_col, done,
+                                  cnt);
     }
   }
 }
@@ -1219,7 +1229,7 @@ __global__ void __launch_bounds__(256)
 k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
                      uint64_t S_own, uint64_t I_tot, uint64_t I_blk, uint64_t tile_T,
                      double* __restrict__ freq_out, const uint8_t* __restrict__ redo,
-                     uint64_t row0, uint64_t row1) {
+                     uint64_t row0, uint64_t row1, uint32_t* __restrict__ cnt) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -1233,6 +1243,7 @@ k_fast_estmaf_stream(const GlView gl, const double* __restrict__ marg_blocks,
     const uint64_t s = base + lane;
     const bool need = s < S_own && in_tile_rows(s, tile_T, row0, row1) && redo[s];
     uint64_t mask = __ballot(need);
+    if (mask && lane == 0) atomicAdd(cnt + EST_CNT_LOGSPACE, (uint32_t)__popcll(mask));
     while (mask) {
       const int b = __builtin_ctzll(mask);
       mask &= mask - 1;
@@ -1268,6 +1279,11 @@ bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major
 
 // per-site state of the frequency step (flags, status, the interpolant's node values)
 bool fast_estmaf_reserve(FastState& fs, uint64_t S_own) {
+  if (!fs.est_counts) {
+    if (hipMalloc((void**)&fs.est_counts, EST_COUNTS * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMemset(fs.est_counts, 0, EST_COUNTS * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipDeviceSynchronize() != hipSuccess) return false;  // (the handle's stream waits for no other)
+  }
   if (S_own <= fs.redo_cap) return true;
   if (fs.redo) (void)hipFree(fs.redo);
   if (fs.est_status) (void)hipFree(fs.est_status);
@@ -1321,7 +1337,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                        row0, row1);
     // a called heterozygote at posterior IBD = 1 (the reference keeps a finite -1e15 there)
     hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
-                       I_tot, I_blk, tile_T, d_freq_out, fs.redo, row0, row1);
+                       I_tot, I_blk, tile_T, d_freq_out, fs.redo, row0, row1, fs.est_counts);
     return hipGetLastError() == hipSuccess;
   }
   // Interpolated passes (see k_fast_estmaf) unless NGHMM_ESTMAF_INTERP=0, which runs
@@ -1339,12 +1355,12 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B), 0, st,    \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
                          d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
-                         n_exact, allow_build, (uint64_t)0);                                    \
+                         n_exact, allow_build, (uint64_t)0, fs.est_counts);                     \
     else                                                                                        \
       hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, false>), dim3(scan_wgs), dim3(B), 0, st,   \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
                          d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
-                         n_exact, allow_build, row0, row1);                                     \
+                         n_exact, allow_build, row0, row1, fs.est_counts);                      \
   } while (0)
 #define LAUNCH_TILE(N, B)                                                                       \
   do {                                                                                          \
@@ -1352,12 +1368,12 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)nblk), dim3(B), 0, st,     \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
-                         allow_build, blk0);                                                    \
+                         allow_build, blk0, fs.est_counts);                                     \
     else                                                                                        \
       hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, true>), dim3(scan_wgs), dim3(B), 0, st,    \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
-                         allow_build, row0, row1);                                              \
+                         allow_build, row0, row1, fs.est_counts);                               \
   } while (0)
 #define LAUNCH_ROWS(N, TL)                                                                      \
   do {                                                                                          \
@@ -1366,12 +1382,12 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                          dim3((unsigned)((TL) ? fs.Spad / 4 : (S_own + 3) / 4)), dim3(64), 0,   \
                          st, d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out, \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
-                         allow_build);                                                          \
+                         allow_build, fs.est_counts);                                           \
     else                                                                                        \
       hipLaunchKernelGGL((k_fast_estmaf_rows_resume<N, TL>), dim3(scan_wgs), dim3(64), 0, st,    \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
-                         allow_build);                                                          \
+                         allow_build, fs.est_counts);                                           \
   } while (0)
   // up to 128 individuals: four sites per wave (k_fast_estmaf_rows)
   const bool rows = I_tot <= 128 && !fs.sw.estmaf_no_rows;
@@ -1439,7 +1455,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     if (!launch(0, 0, 0)) return false;  // whatever is left finishes on exact passes
   }
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
-                     I_tot, I_blk, tile_T, d_freq_out, redo, row0, row1);
+                     I_tot, I_blk, tile_T, d_freq_out, redo, row0, row1, fs.est_counts);
 #undef LAUNCH_NI
 #undef LAUNCH_TILE
 #undef LAUNCH_ROWS

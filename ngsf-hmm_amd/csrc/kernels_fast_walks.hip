@@ -578,6 +578,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     L.mode_ranges.push_back({groups[k].mode, k, e - k});
     k = e;
   }
+  for (const auto& r : L.mode_ranges) fs.mode_ind_rounds[r.mode] += r.count;
   if (fs.sw.debug_modes) {  // which loop-body versions this round uses
     std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
     for (const auto& r : L.mode_ranges) {

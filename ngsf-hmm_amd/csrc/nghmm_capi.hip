@@ -1051,6 +1051,7 @@ struct MstepRun {
         return NGHMM_ERR_HIP;
       }
       prev_active = n_active;
+      for (const auto& r : ranges) fs.mode_ind_rounds[r.mode] += r.count;
       if (fs.sw.debug_modes) {
         std::fprintf(stderr, "[nghmm modes] round %u, %u active:", round, n_active);
         for (const auto& r : ranges)
@@ -1702,6 +1703,37 @@ int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches) {
   if (!h || slot < 0 || slot >= NSLOTS) return NGHMM_ERR_ARG;
   if (ms) *ms = h->ms[slot];
   if (launches) *launches = h->launches[slot];
+  return NGHMM_OK;
+}
+
+int nghmm_debug_mode_counts(nghmm_t* h, nghmm_mode_count* out, uint32_t cap, uint32_t* n, int reset) {
+  g_last_error.clear();
+  if (!h || (!out && cap)) return NGHMM_ERR_ARG;
+  uint32_t k = 0;
+  for (const auto& kv : h->fast.mode_ind_rounds) {
+    if (k < cap) out[k] = nghmm_mode_count{kv.first, kv.second};
+    ++k;
+  }
+  if (n) *n = k;
+  if (reset) h->fast.mode_ind_rounds.clear();
+  return NGHMM_OK;
+}
+
+int nghmm_debug_estmaf_counts(nghmm_t* h, uint64_t out[4], int reset) {
+  g_last_error.clear();
+  if (!h || !out) return NGHMM_ERR_ARG;
+  for (int k = 0; k < 4; ++k) out[k] = 0;
+  if (!h->fast.est_counts) return NGHMM_OK;  // no frequency step yet (or exact mode)
+  int rc;
+  if ((rc = use_device(h))) return rc;
+  uint32_t v[EST_COUNTS];
+  HIP_TRY(sync_stream(h));
+  HIP_TRY(hipMemcpy(v, h->fast.est_counts, sizeof v, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; ++k) out[k] = v[k];
+  if (reset) {
+    HIP_TRY(hipMemset(h->fast.est_counts, 0, sizeof v));
+    HIP_TRY(hipDeviceSynchronize());
+  }
   return NGHMM_OK;
 }
 

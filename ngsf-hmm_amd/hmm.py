@@ -44,6 +44,10 @@ class NgsFHMMError(RuntimeError):
         self.message = message
 
 
+class ModeCount(C.Structure):        # nghmm_mode_count (include/nghmm_debug.h)
+    _fields_ = [("mode", C.c_uint32), ("ind_rounds", C.c_uint64)]
+
+
 class MstepStats(C.Structure):
     _fields_ = [("rounds", C.c_uint32), ("points", C.c_uint64),
                 ("ref_forward_calls", C.c_uint64), ("ind_rounds", C.c_uint64)]
@@ -124,6 +128,8 @@ def load_library():
         "nghmm_synchronize": (i32, [vp]),
         "nghmm_kernel_ms": (i32, [vp, i32, dp, C.POINTER(u32)]),
         "nghmm_set_switch": (i32, [vp, C.c_char_p, C.c_long]),
+        "nghmm_debug_mode_counts": (i32, [vp, C.POINTER(ModeCount), u32, C.POINTER(u32), i32]),
+        "nghmm_debug_estmaf_counts": (i32, [vp, C.POINTER(u64), i32]),
         "nghmm_alloc_host": (vp, [u64]),
         "nghmm_free_host": (None, [vp]),
         "nghmm_site_shard_bytes": (u64, [vp]),
@@ -166,7 +172,7 @@ EXPORTED_SYMBOLS = [
     "nghmm_group_mstep_freq",
     "nghmm_fast_layout", "nghmm_stream",
     "nghmm_synchronize",
-    "nghmm_kernel_ms", "nghmm_set_switch",
+    "nghmm_kernel_ms", "nghmm_set_switch", "nghmm_debug_mode_counts", "nghmm_debug_estmaf_counts",
     "nghmm_site_shard_bytes", "nghmm_site_shard_setup", "nghmm_viterbi_shard_forward",
     "nghmm_viterbi_shard_back", "nghmm_chain_setup", "nghmm_chain_iter_em", "nghmm_chain_mstep_freq",
     "nghmm_chain_viterbi", "nghmm_alloc_host", "nghmm_free_host",
@@ -260,7 +266,7 @@ class NgsFHMM:
         return not self._h
 
     def set_switch(self, name, value):
-        """A measurement / debugging switch of this handle (nghmm_set_switch, include/nghmm.h)."""
+        """A measurement / debugging switch of this handle (nghmm_set_switch, include/nghmm_debug.h)."""
         self._check(self.lib.nghmm_set_switch(self._h, name.encode(), int(value)))
 
     def __del__(self):
@@ -574,6 +580,30 @@ class NgsFHMM:
 
     def synchronize(self):
         self._check(self.lib.nghmm_synchronize(self._h))
+
+    @staticmethod
+    def mode_name(mode):
+        """A loop-body version of the objective kernels as debug_modes prints it: 2F2As2 = two F
+        probes, two alpha probes, small-alpha (kappa) form, degree-2 alpha probes."""
+        if mode == 0:
+            return "general"
+        return (f"{(mode >> 2) & 3}F{mode & 3}A" + ("s" if mode & 0x200 else "") +
+                ("2" if mode & 0x400 else "") + ("e" if mode & 0x800 else ""))
+
+    def mode_counts(self, reset=False):
+        """{kernel version: individual-rounds it evaluated} of the objective rounds so far
+        (nghmm_debug_mode_counts)."""
+        buf = (ModeCount * 160)()
+        n = C.c_uint32(0)
+        self._check(self.lib.nghmm_debug_mode_counts(self._h, buf, 160, C.byref(n), int(reset)))
+        return {self.mode_name(buf[k].mode): int(buf[k].ind_rounds) for k in range(min(n.value, 160))}
+
+    def estmaf_counts(self, reset=False):
+        """Sites of the allele-frequency step that left its common route (nghmm_debug_estmaf_counts)."""
+        v = (C.c_uint64 * 4)()
+        self._check(self.lib.nghmm_debug_estmaf_counts(self._h, v, int(reset)))
+        return {"check_failed": int(v[0]), "resumed": int(v[1]), "resumed_again": int(v[2]),
+                "log_space": int(v[3])}
 
 
 class Group:

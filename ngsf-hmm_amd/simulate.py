@@ -284,18 +284,22 @@ class IndexedSim:
 
     ``IndexedSim(I_tot, S_tot, device, ...)`` describes the whole data set; ``pos_dist(s0, s1)``
     and ``chunks(ind_range, site_range)`` produce any slice of it.  float parameters or "r"
-    (uniform per individual / per site, ngsF-HMMsim.R:108-148)."""
+    (uniform per individual / per site, ngsF-HMMsim.R:108-148).  ``true_params(ind_range)`` gives
+    the (indF, alpha) the paths were drawn with."""
 
     LOOKBACK = 16384
 
     def __init__(self, n_ind, n_sites, device, *, freq=0.2, indF=0.5, alpha=0.01, depth=2.0,
-                 error=0.01, seed=12345, n_chrom=1):
+                 error=0.01, seed=12345, n_chrom=1, missing_rate=0.0):
         import torch
         self.torch = torch
         self.I, self.S = int(n_ind), int(n_sites)
         self.device = device
         self.seed = int(seed)
         self.depth, self.error = float(depth), float(error)
+        # cells without a read whatever the depth (a stream of its own: the other fields of the
+        # data set do not depend on the rate)
+        self.missing_rate = float(missing_rate)
         self.per_chr = -(-self.S // max(1, int(n_chrom)))
         self.n_chrom = int(n_chrom)
         self._freq, self._indF, self._alpha = freq, indF, alpha
@@ -390,6 +394,11 @@ class IndexedSim:
             st = torch.where(last >= 0, st, self._state_before(i_idx, F, A, lo))
         return st
 
+    def true_params(self, ind_range=None):
+        i0, i1 = ind_range if ind_range is not None else (0, self.I)
+        i_idx = self.torch.arange(i0, i1, device=self.device, dtype=self.torch.int64)[:, None]
+        return (self._per_ind(self._indF, 20, i_idx)[:, 0], self._per_ind(self._alpha, 21, i_idx)[:, 0])
+
     # -- slices -------------------------------------------------------------------------------
     def chunks(self, ind_range=None, site_range=None, chunk_sites=20000):
         """Generator of (site_begin - s0, gl [n][I_loc][3]) over the slice: normalised
@@ -414,6 +423,8 @@ class IndexedSim:
             geno = h1 + h2                                                   # [I][n]
             dep = torch.searchsorted(self.pois_cdf, self._u(14, i_idx, s), right=True)
             dep.clamp_(max=self.kmax)
+            if self.missing_rate > 0:
+                dep[self._u(16, i_idx, s) < self.missing_rate] = 0
             u = self._u(15, i_idx, s)
             base = (dep * 3 + geno) * self.kmax
             nA = torch.zeros_like(dep)

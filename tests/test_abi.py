@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "nghmm.h")).read()
+    # the drop-in boundary and the measurement / debugging entry points next to it
+    text = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("nghmm.h", "nghmm_debug.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = set(re.findall(r"\b(nghmm_[a-z_0-9]+)\s*\(", text))
     return sorted(names)

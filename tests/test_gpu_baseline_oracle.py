@@ -56,36 +56,58 @@ def _far_from_threshold(p, margin):
     return (np.abs(p - EPS) > margin) & (np.abs(p - (1 - EPS)) > margin)
 
 
+# the simulator's `r` options (scripts/ngsF-HMMsim.R:108-110,127-129,146-148: indF, alpha ~ U(0,1) per
+# individual, freq ~ U(0,1) per site), its default depth 5 (:77), 2 % of the cells without a read
+# -- bench.py's workloads c3r / c2r -- and a transition rate far above the small-alpha kernels'
+# range (c3hi)
+REGIME_R = dict(indF="r", alpha="r", freq="r", depth=5.0, missing_rate=0.02)
+REGIME_HI = dict(alpha=2.0)
 CASES = {
-    # name: (I_tot, S_tot of the data set, individuals, site range)
-    "config2_100x100k_in_full": (100, 100_000, (0, 100), (0, 100_000)),
-    "config3_slice_1000x10k": (1000, 1_000_000, (0, 1000), (0, 10_000)),
+    # name: (I_tot, S_tot of the data set, individuals, site range, the data set's regime, start)
+    # start "test.sh": --freq 0.1 --indF 0.1,0.2 (examples/test.sh); "true": the parameters the
+    # data were simulated with (clamped as parse_args.cpp:239-242,270-271 clamps initial values) --
+    # per-individual indF / alpha, per-site frequencies: the state an EM run of that data set is in
+    "config2_100x100k_in_full": (100, 100_000, (0, 100), (0, 100_000), {}, "test.sh"),
+    "config3_slice_1000x10k": (1000, 1_000_000, (0, 1000), (0, 10_000), {}, "test.sh"),
+    "c2r_100x100k_in_full_true_values": (100, 100_000, (0, 100), (0, 100_000), REGIME_R, "true"),
+    "c3r_slice_1000x10k_true_values": (1000, 1_000_000, (0, 1000), (0, 10_000), REGIME_R, "true"),
+    "c3r_slice_1000x10k_start_values": (1000, 1_000_000, (0, 1000), (0, 10_000), REGIME_R, "test.sh"),
+    "c3hi_slice_1000x10k_true_values": (1000, 1_000_000, (0, 1000), (0, 10_000), REGIME_HI, "true"),
+    "c3hi_100x100k_true_values": (100, 100_000, (0, 100), (0, 100_000), REGIME_HI, "true"),
 }
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_baseline_size_against_the_oracle(pkg, orc_det, orc_libm, case):
     import torch
-    I_tot, S_tot, (i0, i1), (s0, s1) = CASES[case]
+    I_tot, S_tot, (i0, i1), (s0, s1), regime, start = CASES[case]
     I, S = i1 - i0, s1 - s0
     nt = _threads()
     dev = torch.device("cuda", 0)
-    sim = pkg.simulate.IndexedSim(I_tot, S_tot, dev, seed=12345)      # bench.py's data set
+    sim = pkg.simulate.IndexedSim(I_tot, S_tot, dev, seed=12345, **regime)      # bench.py's data set
     gl_d, pos_d = sim.gl((i0, i1), (s0, s1)), sim.pos_dist(s0, s1)
     torch.cuda.synchronize()
     gl, pos = gl_d.cpu().numpy(), pos_d.cpu().numpy()
+    if start == "true":
+        tF, tA = sim.true_params((i0, i1))
+        F0 = np.clip(tF.cpu().numpy(), 1e-6, 1 - 1e-6)
+        A0 = np.clip(tA.cpu().numpy(), 1e-6, 1 - 1e-6) if isinstance(regime.get("alpha"), str) \
+            else tA.cpu().numpy()
+        f0 = np.clip(sim.site_freq(s0, s1).cpu().numpy(), 1e-3, 1 - 1e-3)
+    else:
+        F0, A0, f0 = np.full(I, 0.1), np.full(I, 0.2), np.full(S, 0.1)
     t_or = time.time()
 
     # ---- exact mode == oracle (det), bit for bit: one whole iter_EM, then Viterbi -------------
     em = orclib.OracleEM(orc_det, gl, pos)
-    em.set_params(0.1, 0.2, 0.1)
+    em.set_params(F0, A0, f0)
     assert em.init_emission() == 0
     assert em.iterate(1, False, False, nt, True) == 0      # (est_maf's sites are independent:
     t_or = time.time() - t_or                               # threading them changes no bit)
     t_ex = time.time()
     with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT) as ex:
         ex.load_device(gl_d.data_ptr(), pos_d.data_ptr())
-        ex.set_params(0.1, 0.2, 0.1)
+        ex.set_params(F0, A0, f0)
         ex.init_emission()
         st = ex.iter_EM()
         assert np.array_equal(ex.ind_lkl, em.ind_lkl), "ind_lkl differs from the oracle"
@@ -101,12 +123,12 @@ def test_baseline_size_against_the_oracle(pkg, orc_det, orc_libm, case):
 
     # ---- fast mode against the oracle (libm: the reference's arithmetic), per call -----------
     em = orclib.OracleEM(orc_libm, gl, pos)
-    em.set_params(0.1, 0.2, 0.1)
+    em.set_params(F0, A0, f0)
     assert em.init_emission() == 0 and em.estep(nt) == 0
     hp = orclib.HpAnchor()
     with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as fa:
         fa.load_device(gl_d.data_ptr(), pos_d.data_ptr())
-        fa.set_params(0.1, 0.2, 0.1)
+        fa.set_params(F0, A0, f0)
         fa.init_emission()
         lk = fa.estep().copy()
         np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-12)
@@ -118,9 +140,8 @@ def test_baseline_size_against_the_oracle(pkg, orc_det, orc_libm, case):
         # binary128 anchor -- fast mode must sit within 1e-11 of it, and the fast-oracle
         # difference must be no larger than the ORACLE's distance from the anchor.
         sample = sorted(set([0, I // 3, I - 1]))
-        freq0 = np.full(S, 0.1)
         with ThreadPoolExecutor(len(sample)) as pool:
-            anchors = list(pool.map(lambda i: hp.forward_backward(gl[:, i], freq0, pos, 0.1, 0.2), sample))
+            anchors = list(pool.map(lambda i: hp.forward_backward(gl[:, i], f0, pos, F0[i], A0[i]), sample))
         e_fast = e_orc = d_fo = 0.0
         for i, (t_lk, t_post) in zip(sample, anchors):
             ok = _far_from_threshold(t_post, 2e-6)
