@@ -134,6 +134,7 @@ struct nghmm_handle {
     int slot = 0;
   };
   int* d_flags_bg = nullptr;
+  bool flags_bg_clear = false;   // the last iteration's epilogue kernel left d_flags_bg zeroed
   std::vector<BgSpan> bg_spans;
   size_t bg_used = 0;
   // replicas (nghmm_create_replica): share the parent's data arrays (d_gl / d_codes /

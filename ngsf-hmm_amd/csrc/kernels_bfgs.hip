@@ -417,6 +417,21 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
   PHASE(4)  // plan entries, ticket, publication
 }
 
+// the end of a fused iteration (FastState::DevBfgs::h_epi): see dbfgs_epilogue
+__global__ void __launch_bounds__(256)
+k_iter_epilogue(int* __restrict__ d_flags, uint32_t n_flags, const double* __restrict__ d_lkl, uint32_t I,
+                double* __restrict__ h_lkl, uint32_t* __restrict__ h_epi, uint32_t seq) {
+  if (d_lkl)
+    for (uint32_t k = threadIdx.x; k < I; k += blockDim.x) h_lkl[k] = d_lkl[k];
+  if (threadIdx.x < n_flags) {
+    h_epi[threadIdx.x] = (uint32_t)d_flags[threadIdx.x];
+    d_flags[threadIdx.x] = 0;  // the next iteration's background work starts from clear flags
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&h_epi[kEpiFlags], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 DevPtrs dev_ptrs(const FastState& fs, double* d_F, double* d_A) {
   const DevBfgs& d = fs.dev;
   DevPtrs D;
@@ -487,14 +502,20 @@ bool dbfgs_reserve(FastState& fs) {
   d.prob = prob;
   d.solver = solver;
   d.groups = groups;
-  void *t = nullptr, *hf = nullptr, *ha = nullptr;
+  void *t = nullptr, *hf = nullptr, *ha = nullptr, *el = nullptr, *ep = nullptr;
   const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
   ok = ok && hipHostMalloc(&t, DevBfgs::kRing * DevBfgs::kTableWords * sizeof(uint32_t), flags) == hipSuccess &&
        hipHostMalloc(&hf, I * sizeof(double), flags) == hipSuccess &&
-       hipHostMalloc(&ha, I * sizeof(double), flags) == hipSuccess;
+       hipHostMalloc(&ha, I * sizeof(double), flags) == hipSuccess &&
+       hipHostMalloc(&el, I * sizeof(double), flags) == hipSuccess &&
+       hipHostMalloc(&ep, (kEpiFlags + 1) * sizeof(uint32_t), flags) == hipSuccess;
   d.h_table = static_cast<volatile uint32_t*>(t);
   d.h_F = static_cast<double*>(hf);
   d.h_A = static_cast<double*>(ha);
+  d.h_epi_lkl = static_cast<double*>(el);
+  d.h_epi = static_cast<volatile uint32_t*>(ep);
+  if (ep) std::memset(ep, 0, (kEpiFlags + 1) * sizeof(uint32_t));
+  d.epi_seq = 0;
   ok = ok && hipMemset(d.counts, 0, (size_t)DevBfgs::kRing * kCntStride * sizeof(uint32_t)) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
@@ -523,7 +544,48 @@ void dbfgs_destroy(FastState& fs) {
   if (d.h_table) (void)hipHostFree(const_cast<uint32_t*>(d.h_table));
   if (d.h_F) (void)hipHostFree(d.h_F);
   if (d.h_A) (void)hipHostFree(d.h_A);
+  if (d.h_epi_lkl) (void)hipHostFree(d.h_epi_lkl);
+  if (d.h_epi) (void)hipHostFree(const_cast<uint32_t*>(d.h_epi));
   d = DevBfgs();
+}
+
+void dbfgs_invalidate(FastState& fs) {
+  DevBfgs& d = fs.dev;
+  if (!d.preplanned) return;
+  // a plan has been published and its counters are set: the next dbfgs_begin starts over as after
+  // an M-step that did not reach its end
+  d.preplanned = false;
+  d.clean = false;
+}
+
+bool dbfgs_epilogue(FastState& fs, hipStream_t st, int* d_flags, uint32_t n_flags, const double* d_lkl) {
+  DevBfgs& d = fs.dev;
+  if (!d.h_epi || n_flags > kEpiFlags) return false;
+  ++d.epi_seq;
+  if (d.epi_seq == 0) ++d.epi_seq;
+  hipLaunchKernelGGL(k_iter_epilogue, dim3(1), dim3(256), 0, st, d_flags, n_flags, d_lkl, (uint32_t)fs.I,
+                     d.h_epi_lkl, const_cast<uint32_t*>(d.h_epi), d.epi_seq);
+  return hipGetLastError() == hipSuccess;
+}
+
+bool dbfgs_wait_epilogue(FastState& fs, hipStream_t st, int* flags_out, uint32_t n_flags, bool yield) {
+  DevBfgs& d = fs.dev;
+  const volatile uint32_t* w = d.h_epi + kEpiFlags;
+  uint32_t spins = 0;
+  bool drained = false;
+  for (;;) {
+    if (__atomic_load_n(const_cast<const uint32_t*>(w), __ATOMIC_ACQUIRE) == d.epi_seq) break;
+    if (yield && (spins & 0x3fu) == 0x3fu) std::this_thread::yield();
+    if ((++spins & 0x3fffu) == 0) {
+      if (drained) return false;
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) drained = true;
+      else if (q != hipErrorNotReady) return false;
+      (void)hipGetLastError();
+    }
+  }
+  for (uint32_t k = 0; k < n_flags; ++k) flags_out[k] = (int)d.h_epi[k];
+  return true;
 }
 
 bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, bool F_fixed,
@@ -531,6 +593,15 @@ bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha,
   DevBfgs& d = fs.dev;
   if (d.cap_I != fs.I || fs.I == 0) return false;
   const uint32_t n = (uint32_t)fs.I;
+  if (d.preplanned) {
+    // round 1 of this M-step was planned when the last one ended, from the parameters the handle
+    // still holds: its plan is in the table (or on its way)
+    if (d.pre_F_fixed == F_fixed && d.pre_alpha_fixed == alpha_fixed && d.d_F == d_indF && d.d_A == d_alpha) {
+      d.preplanned = false;
+      return true;
+    }
+    dbfgs_invalidate(fs);
+  }
   if (!d.clean) {
     // the M-step before this one did not reach its end (an error on its way): plans of it may
     // have been published and counters left behind.  Clear the counters (on the stream: the
@@ -607,6 +678,17 @@ void dbfgs_end(FastState& fs, uint32_t last_round) {
   d.seq_base += last_round;
   ++d.mstep_no;
   d.clean = true;
+}
+
+// the next M-step's round 1 planned now (see FastState::DevBfgs::preplanned); nothing waits
+bool dbfgs_preplan(FastState& fs, hipStream_t st, bool F_fixed, bool alpha_fixed) {
+  DevBfgs& d = fs.dev;
+  if (!d.clean || d.preplanned) return false;
+  if (!dbfgs_begin(fs, st, d.d_F, d.d_A, F_fixed, alpha_fixed)) return false;
+  d.preplanned = true;
+  d.pre_F_fixed = F_fixed;
+  d.pre_alpha_fixed = alpha_fixed;
+  return true;
 }
 
 }  // namespace nghmm

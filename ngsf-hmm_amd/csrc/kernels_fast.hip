@@ -278,7 +278,8 @@ const SwitchName kSwitches[] = {
     {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
     {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs}, {"estmaf_w2", &Switches::estmaf_w2},
     {"dbg_abort_round", &Switches::dbg_abort_round},
-    {"no_bg_stream", &Switches::no_bg_stream}, {"spans", &Switches::spans}};
+    {"no_bg_stream", &Switches::no_bg_stream}, {"spans", &Switches::spans},
+    {"no_epilogue", &Switches::no_epilogue}, {"no_preplan", &Switches::no_preplan}};
 
 }  // namespace
 
@@ -443,6 +444,7 @@ GlView fast_gl_lin(const FastState& fs) {
 }
 
 bool fast_load(FastState& fs, hipStream_t st, const GlView& gl_log, const double* d_pos) {
+  dbfgs_invalidate(fs);  // (a plan made in advance looked at the old data's distances)
   fs.gl_log = gl_log;
   fs.d_pos = d_pos;
   fs.e_stale = true;

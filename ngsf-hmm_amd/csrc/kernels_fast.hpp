@@ -40,6 +40,8 @@ struct Switches {
   int dbg_abort_round = 0;    // test hook: a device-planned M-step returns an error after this round
   int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
   int no_bg_stream = 0;       // device-planned rounds: backward sweep and est_maf between the rounds on the one stream, not next to them on a second
+  int no_epilogue = 0;        // device-planned iteration: its end by copies and a stream synchronisation instead of the epilogue kernel's pinned word
+  int no_preplan = 0;         // ... and the next M-step's first round planned when it starts, not when this one ends
   int spans = 0;              // fast mode: timing events around the kernel families of a fused iteration, for nghmm_kernel_ms (0.05 ms per iteration: 8 % of configs[1]'s)
   static Switches from_env();
   // false: no switch of that name
@@ -142,6 +144,18 @@ struct FastState {
     uint32_t seq_base = 0;           // plans of earlier M-steps (plans are numbered through the handle's life)
     uint32_t mstep_no = 0;
     bool clean = true;               // the last M-step reached its end (else: dbfgs_begin starts over)
+    // The NEXT M-step's first plan, made when this one ended (the handle's parameters are final
+    // then, and nothing else enters it): its planning kernel and the plan's way to the host are
+    // off the next iteration's critical path.  Void as soon as anything writes the parameters or
+    // reloads the data (dbfgs_invalidate).
+    bool preplanned = false;
+    bool pre_F_fixed = false, pre_alpha_fixed = false;
+    // End of a fused iteration without a copy or an event: a one-workgroup kernel behind the last
+    // piece of work writes the error flags and the log-likelihoods to pinned memory and, behind a
+    // system-scope fence, a sequence number the host polls (dbfgs_epilogue / dbfgs_wait_epilogue).
+    double* h_epi_lkl = nullptr;     // [I] pinned
+    volatile uint32_t* h_epi = nullptr;  // [kEpiFlags] flags, then the sequence word
+    uint32_t epi_seq = 0;
   } dev;
 
   double dmax_finite = 0;         // largest finite distance of the loaded data
@@ -195,6 +209,14 @@ bool fast_lkl_covers_everyone(const FastState& fs);
 bool dbfgs_available(const FastState& fs);
 bool dbfgs_reserve(FastState& fs);
 void dbfgs_destroy(FastState& fs);
+// the parameters (or the data) are about to change under a plan made in advance: drop it
+void dbfgs_invalidate(FastState& fs);
+// iteration's end: flags [n_flags ints, device; zeroed again for the next iteration] and
+// log-likelihoods [I, device; may be null] to pinned memory, then the sequence word; nothing waits
+constexpr uint32_t kEpiFlags = 8;
+bool dbfgs_epilogue(FastState& fs, hipStream_t st, int* d_flags, uint32_t n_flags, const double* d_lkl);
+// wait (polling) for that word; flags_out [n_flags]; false: the stream ran dry without it
+bool dbfgs_wait_epilogue(FastState& fs, hipStream_t st, int* flags_out, uint32_t n_flags, bool yield);
 // plan round 1 from the current parameters; nothing waits
 // (d_indF / d_alpha: a finished individual's new parameters are written there, and to pinned
 // host memory)
@@ -214,6 +236,7 @@ bool dbfgs_launch_round(FastState& fs, hipStream_t st, uint32_t round, uint32_t 
 // after the empty plan of round last_round has arrived: fs.dev.h_F / h_A hold every individual's
 // parameters, fs.dev.stats_host the statistics (the next M-step's plans are numbered on from here)
 void dbfgs_end(FastState& fs, uint32_t last_round);
+bool dbfgs_preplan(FastState& fs, hipStream_t st, bool F_fixed, bool alpha_fixed);
 bool fast_lkl_launch_planned(FastState& fs, hipStream_t st, const void* d_groups_by_ind,
                              const std::vector<FastState::ModeRange>& ranges, uint32_t n_active,
                              const uint32_t* d_worklists, const uint32_t* d_all, double* part,

@@ -63,6 +63,9 @@ int clear_flags(nghmm_t* h) {
   return NGHMM_OK;
 }
 
+// the kernels' error flags as the reference's fatal errors
+static int map_flags(const int* f);
+
 // Reads the kernel error flags and maps them to the reference's fatal errors.
 int check_flags(nghmm_t* h, const int* d_flags) {
   if (!h->h_flags_pin)
@@ -71,6 +74,10 @@ int check_flags(nghmm_t* h, const int* d_flags) {
   HIP_TRY(hipMemcpyAsync(f, d_flags ? d_flags : h->d_flags, NFLAGS * sizeof(int), hipMemcpyDeviceToHost,
                          h->stream));
   HIP_TRY(sync_stream(h));
+  return map_flags(f);
+}
+
+static int map_flags(const int* f) {
   if (f[FLAG_INVALID_LKL]) {
     set_error("invalid Lkl found!");
     return NGHMM_ERR_INVALID_LKL;
@@ -373,7 +380,9 @@ static bool spans_on(const nghmm_t* h) { return h->mode != NGHMM_MODE_FAST || h-
 int bg_begin(nghmm_t* h) {
   int rc;
   if (!h->d_flags_bg && (rc = dev_alloc(&h->d_flags_bg, (size_t)NFLAGS))) return rc;
-  HIP_TRY(hipMemsetAsync(h->d_flags_bg, 0, NFLAGS * sizeof(int), h->stream));
+  // (the last iteration's epilogue kernel has read the flags and cleared them again: no packet)
+  if (!h->flags_bg_clear) HIP_TRY(hipMemsetAsync(h->d_flags_bg, 0, NFLAGS * sizeof(int), h->stream));
+  h->flags_bg_clear = false;
   h->bg_used = 0;
   if (!spans_on(h))  // (no piece of this iteration is timed: nghmm_kernel_ms reads 0, not an earlier call's time)
     for (int slot : {SLOT_EMISSION, SLOT_FORWARD, SLOT_BACKWARD, SLOT_LKL, SLOT_ESTMAF, SLOT_LKL_FIRST, SLOT_BFGS}) {
@@ -672,6 +681,7 @@ int nghmm_set_params(nghmm_t* h, const double* indF, const double* alpha, const 
   if (!h) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
+  if (indF || alpha) dbfgs_invalidate(h->fast);
   if (indF) {
     std::memcpy(h->h_indF.data(), indF, h->I * sizeof(double));
     HIP_TRY(hipMemcpyAsync(h->d_indF, indF, h->I * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1122,14 +1132,35 @@ struct MstepRun {
     std::memcpy(h->h_indF.data(), fs.dev.h_F, h->I * sizeof(double));
     std::memcpy(h->h_alpha.data(), fs.dev.h_A, h->I * sizeof(double));
     const bool lkl_out = bg_active && ind_lkl;
-    if (lkl_out) {  // (through pinned memory: the copy waits for nothing, bg_finish waits once for everything)
-      if (!h->h_lkl_pin)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_lkl_pin), h->I * sizeof(double), hipHostMallocDefault));
-      HIP_TRY(hipMemcpyAsync(h->h_lkl_pin, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
-                             h->stream));
+    if (!spans_on(h) && fs.dev.h_epi && !fs.sw.no_epilogue) {
+      // The iteration's end without a copy, an event or a stream synchronisation: a one-workgroup
+      // kernel behind everything writes the background work's flags and the log-likelihoods to
+      // pinned memory and a word the host polls -- and BEHIND it goes the next M-step's first
+      // planning kernel (dbfgs_preplan: the parameters are final), whose 20-30 us and whose plan's
+      // way to the host then cost the next iteration nothing.
+      if (!dbfgs_epilogue(fs, h->stream, h->d_flags_bg, (uint32_t)NFLAGS, lkl_out ? h->d_ind_lkl : nullptr)) {
+        set_error("the iteration's epilogue kernel failed to launch: %s", hipGetErrorString(hipGetLastError()));
+        return NGHMM_ERR_HIP;
+      }
+      h->flags_bg_clear = true;
+      if (!fs.sw.no_preplan) (void)dbfgs_preplan(fs, h->stream, indF_fixed != 0, alpha_fixed != 0);
+      int f[NFLAGS];
+      if (!dbfgs_wait_epilogue(fs, h->stream, f, (uint32_t)NFLAGS, yield)) {
+        set_error("the iteration's epilogue kernel did not report: %s", hipGetErrorString(hipGetLastError()));
+        return NGHMM_ERR_HIP;
+      }
+      if (lkl_out) std::memcpy(ind_lkl, fs.dev.h_epi_lkl, h->I * sizeof(double));
+      rc = map_flags(f);
+    } else {
+      if (lkl_out) {  // (through pinned memory: the copy waits for nothing, bg_finish waits once for everything)
+        if (!h->h_lkl_pin)
+          HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_lkl_pin), h->I * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(h->h_lkl_pin, h->d_ind_lkl, h->I * sizeof(double), hipMemcpyDeviceToHost,
+                               h->stream));
+      }
+      rc = bg_finish(h);  // waits for the stream; the spans' times; the background work's flags
+      if (lkl_out) std::memcpy(ind_lkl, h->h_lkl_pin, h->I * sizeof(double));
     }
-    rc = bg_finish(h);  // waits for the stream; the spans' times; the background work's flags
-    if (lkl_out) std::memcpy(ind_lkl, h->h_lkl_pin, h->I * sizeof(double));
     h->ms[SLOT_LKL] += h->ms[SLOT_LKL_FIRST];
     h->launches[SLOT_LKL] = round - 1;
     if (rc) return rc;
@@ -1163,6 +1194,7 @@ struct MstepRun {
       return fuse_estep ? estep_then_hook(false) : NGHMM_OK;
 
     if (wants_device()) return run_device(stats, freq_done);
+    dbfgs_invalidate(h->fast);  // (this M-step writes the parameters a plan made in advance started from)
 
     auto t0 = clock::now();
     // (fast mode: getgradient's step by detmath on host and device alike, bfgs_problem.hpp)
