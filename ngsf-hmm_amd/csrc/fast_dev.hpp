@@ -519,6 +519,35 @@ __device__ __forceinline__ double base_sum(const double* __restrict__ base_c, ui
   return wave_sum(acc);
 }
 
+// ---- the end of an objective round: lkl = log( q . prod_c R_c . 1 ) ----
+// The ordered product of one point's C chunk operators (part_g: the group's [C][MAXP][5]) by a
+// wave: lane l multiplies the operators of chunks l*K .. l*K + K - 1 (K = ceil(C / 64): one chunk
+// per lane up to 64 chunks), an ordered shuffle tree the lanes'; lane 0 holds the result.
+// Shared by k_fast_lkl_finish and the planning kernel (kernels_bfgs.hip), which finishes its own
+// individual's points: the same operations in the same order, the same bits.
+__device__ __forceinline__ Op lkl_point_product(const double* __restrict__ part_g, uint32_t C, uint32_t p,
+                                                int lane) {
+  const uint32_t K = (C + 63) / 64;
+  Op m{1.0, 0.0, 0.0, 1.0, 0};
+  if ((uint32_t)lane * K < C) m = op_load(part_g + (((uint64_t)(uint32_t)lane * K) * MAXP + p) * 5);
+  for (uint32_t u = 1; u < K; ++u) {
+    const uint32_t k = (uint32_t)lane * K + u;
+    if (k < C) m = op_mul(m, op_load(part_g + ((uint64_t)k * MAXP + p) * 5));
+  }
+  for (int off = 1; off < 64; off <<= 1) {
+    const Op o = op_shfl_down(m, off);
+    if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
+  }
+  return m;
+}
+
+// base = the sum of log e0 over the individual's sites (the same for every point)
+__device__ __forceinline__ double lkl_point_value(const Op& m, double F, double base) {
+  const double q0 = 1 - F, q1 = F;
+  const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
+  return base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
+}
+
 template <typename T>
 bool dalloc(T** p, size_t n) {
   if (n == 0) n = 1;

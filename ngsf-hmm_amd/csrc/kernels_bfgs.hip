@@ -68,7 +68,14 @@ struct DevPtrs {
   uint32_t* worklists;
   uint32_t* all;
   uint32_t* counts;
-  const double* lkl;
+  double* lkl;
+  // the round's partial operators [I][C][MAXP][5] and sums of log e0 [I][C]: a handle that holds
+  // whole chains finishes its individuals' points here (fast_dev.hpp: lkl_point_product); a site
+  // shard's values come combined over the ranks (finish == 0)
+  const double* part;
+  const double* base_c;
+  uint32_t C;
+  int finish;
   double *d_F, *d_A;              // the handle's parameters: a finished individual's go there ...
   double *h_F, *h_A;              // ... and, when the M-step ends, all of them to their pinned host mirror
   double *snap_F, *snap_A;        // the parameters the M-step started from (the E-step's, which runs next to it)
@@ -179,6 +186,21 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
     __syncthreads();
   }
 
+  if constexpr (!FIRST) {
+    // the round's values of this individual, from the partial operators its objective waves left:
+    // what k_fast_lkl_finish does with a workgroup per individual (the same operations in the same
+    // order) -- the whole wave takes part, lane 0 keeps the values
+    if (have && D.finish) {
+      const GroupDesc& Gd = D.groups[i];
+      const uint32_t np = Gd.np;
+      const double base = base_sum(D.base_c + (uint64_t)i * D.C, D.C, lane);
+      const double* part_g = D.part + (uint64_t)i * D.C * MAXP * 5;
+      for (uint32_t q = 0; q < np && q < (uint32_t)MAXP; ++q) {
+        const Op m = lkl_point_product(part_g, D.C, q, lane);
+        if (lane == 0) D.lkl[Gd.out_idx[q]] = lkl_point_value(m, Gd.F[q], base);
+      }
+    }
+  }
   PHASE(0)  // problem + work arrays in LDS
   bool keep = false;        // the solver's arrays go back to memory
   bool walk = false;        // (lane 0) the round's values are good: the machine takes its step
@@ -444,12 +466,16 @@ DevPtrs dev_ptrs(const FastState& fs, double* d_F, double* d_A) {
   D.all = d.all;
   D.counts = d.counts;
   D.lkl = d.lkl;
+  D.part = d.part;
+  D.base_c = fs.base_c;
+  D.C = fs.C;
+  D.finish = fs.shard.world <= 1 ? 1 : 0;
   D.d_F = d_F;
   D.d_A = d_A;
   D.h_F = d.h_F;
   D.h_A = d.h_A;
-  D.snap_F = d.snap_F;
-  D.snap_A = d.snap_A;
+  D.snap_F = d.snap_F + (uint64_t)d.snap_set * fs.I;
+  D.snap_A = d.snap_A + (uint64_t)d.snap_set * fs.I;
   D.h_table = const_cast<uint32_t*>(d.h_table);
   D.I = (uint32_t)fs.I;
   D.dmax = fs.dmax_finite;
@@ -497,8 +523,8 @@ bool dbfgs_reserve(FastState& fs) {
             dmalloc(&groups, I) && dmalloc(&d.last_mode, I) &&
             dmalloc(&d.worklists, (size_t)2 * kModeSlots * I) && dmalloc(&d.all, 2 * I) &&
             dmalloc(&d.counts, (size_t)DevBfgs::kRing * kCntStride) &&
-            dmalloc(&d.lkl, 5 * I) && dmalloc(&d.part, I * fs.C * MAXP * 5) && dmalloc(&d.snap_F, I) &&
-            dmalloc(&d.snap_A, I);
+            dmalloc(&d.lkl, 5 * I) && dmalloc(&d.part, I * fs.C * MAXP * 5) && dmalloc(&d.snap_F, 2 * I) &&
+            dmalloc(&d.snap_A, 2 * I);
   d.prob = prob;
   d.solver = solver;
   d.groups = groups;
@@ -613,11 +639,15 @@ bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha,
   d.clean = false;
   d.d_F = d_indF;
   d.d_A = d_alpha;
+  d.snap_set ^= 1u;
   hipLaunchKernelGGL(k_bfgs_advance<true>, dim3((n + kWg - 1) / kWg), dim3(64 * kWg), 0, st,
                      dev_ptrs(fs, d_indF, d_alpha),
                      d.seq_base + 1, n, 1u, F_fixed ? 1 : 0, alpha_fixed ? 1 : 0);
   return hipGetLastError() == hipSuccess;
 }
+
+const double* dbfgs_start_F(const FastState& fs) { return fs.dev.snap_F + (uint64_t)fs.dev.snap_set * fs.I; }
+const double* dbfgs_start_A(const FastState& fs) { return fs.dev.snap_A + (uint64_t)fs.dev.snap_set * fs.I; }
 
 bool dbfgs_advance(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_in) {
   DevBfgs& d = fs.dev;

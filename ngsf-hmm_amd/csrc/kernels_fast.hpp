@@ -135,7 +135,11 @@ struct FastState {
     double* lkl = nullptr;           // [5 I]
     double* part = nullptr;          // [I][C][MAXP][5]
     double *d_F = nullptr, *d_A = nullptr;  // the handle's parameter arrays (borrowed, per M-step)
-    double *snap_F = nullptr, *snap_A = nullptr;  // [I]: the parameters the M-step started from
+    // [2][I]: the parameters the M-step started from, which the E-step next to it reads -- two
+    // sets, by M-step parity: the NEXT M-step's first plan is made (and its set written) while
+    // this one's backward sweep may still be reading (dbfgs_preplan)
+    double *snap_F = nullptr, *snap_A = nullptr;
+    uint32_t snap_set = 0;           // the set of the M-step that dbfgs_begin started last
     // pinned host memory the kernels write: the plans (number, active individuals, modes and
     // counts, statistics), a finished individual's parameters
     volatile uint32_t* h_table = nullptr;  // [kRing][kTableWords]
@@ -222,6 +226,9 @@ bool dbfgs_wait_epilogue(FastState& fs, hipStream_t st, int* flags_out, uint32_t
 // host memory)
 bool dbfgs_begin(FastState& fs, hipStream_t st, double* d_indF, double* d_alpha, bool F_fixed,
                  bool alpha_fixed);
+// the parameters that M-step started from (device, [I] each)
+const double* dbfgs_start_F(const FastState& fs);
+const double* dbfgs_start_A(const FastState& fs);
 // the values of round `round` into the machines, round + 1 planned; nothing waits
 // (n_in = the active individuals of that round, as dbfgs_wait_plan reported them)
 bool dbfgs_advance(FastState& fs, hipStream_t st, uint32_t round, uint32_t n_in);

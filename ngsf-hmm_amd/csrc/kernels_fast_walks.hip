@@ -414,37 +414,23 @@ k_fast_lkl_finish(const GroupDesc* __restrict__ groups, uint32_t n_groups, uint3
   if (p >= G.np) return;
   // sum of log e0 over the individual's sites: the same for every point
   const double base = base_sum(base_c + (uint64_t)G.ind * C, C, lane);
-  {
-    const uint32_t K = (C + 63) / 64;
-    Op m{1.0, 0.0, 0.0, 1.0, 0};
-    if ((uint32_t)lane * K < C) m = op_load(part + (((uint64_t)g * C + (uint32_t)lane * K) * MAXP + p) * 5);
-    for (uint32_t u = 1; u < K; ++u) {
-      const uint32_t k = (uint32_t)lane * K + u;
-      if (k < C) m = op_mul(m, op_load(part + (((uint64_t)g * C + k) * MAXP + p) * 5));
-    }
-    for (int off = 1; off < 64; off <<= 1) {
-      const Op o = op_shfl_down(m, off);
-      if ((lane & (2 * off - 1)) == 0) m = op_mul(m, o);
-    }
-    if (lane == 0) {
-      if constexpr (SHARD) {
-        double* o = lkl_out + (uint64_t)G.out_idx[p] * 6;
-        o[0] = m.a00;
-        o[1] = m.a01;
-        o[2] = m.a10;
-        o[3] = m.a11;
-        o[4] = (double)m.ex;
-        o[5] = base;
-      } else {
-        const double q0 = 1 - G.F[p], q1 = G.F[p];
-        const double v0 = fma(q0, m.a00, q1 * m.a10), v1 = fma(q0, m.a01, q1 * m.a11);
-        const double l = base + (log(v0 + v1) + (double)m.ex * 0.6931471805599453094);
-        lkl_out[G.out_idx[p]] = l;
-        // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
-        // in linear space; the host re-evaluates such points with the general kernel
-        // (device-planned rounds pass no flags: k_bfgs_advance looks at the values itself)
-        if (flags && !(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
-      }
+  const Op m = lkl_point_product(part + (uint64_t)g * C * MAXP * 5, C, p, lane);
+  if (lane == 0) {
+    if constexpr (SHARD) {
+      double* o = lkl_out + (uint64_t)G.out_idx[p] * 6;
+      o[0] = m.a00;
+      o[1] = m.a01;
+      o[2] = m.a10;
+      o[3] = m.a11;
+      o[4] = (double)m.ex;
+      o[5] = base;
+    } else {
+      const double l = lkl_point_value(m, G.F[p], base);
+      lkl_out[G.out_idx[p]] = l;
+      // NaN or +-inf: overflow of a probe against point 0's scale, or no probability mass left
+      // in linear space; the host re-evaluates such points with the general kernel
+      // (device-planned rounds pass no flags: k_bfgs_advance looks at the values itself)
+      if (flags && !(fabs(l) < __builtin_huge_val())) flags[FLAG_INVALID_LKL] = 1;
     }
   }
 }
@@ -628,7 +614,8 @@ static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg
                               const std::vector<FastState::ModeRange>& mode_ranges, uint32_t ng,
                               uint32_t n_pts, double* part, double* d_lkl, int* d_flags,
                               bool emit_estep, const uint32_t* d_worklists = nullptr,
-                              uint64_t wl_stride = 0, const uint32_t* d_all = nullptr) {
+                              uint64_t wl_stride = 0, const uint32_t* d_all = nullptr,
+                              bool finish_elsewhere = false) {
   if (ng == 0) return true;
   const LklArrays arr = lkl_arrays(fs);
   // first round of an M-step inside nghmm_estep_mstep: point 0 of every individual is the
@@ -711,8 +698,11 @@ static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg
 #endif
     return hipGetLastError() == hipSuccess;
   }
-  hipLaunchKernelGGL(k_fast_lkl_finish<false>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, part,
-                     fs.base_c, d_lkl, d_flags, d_all);
+  // (device-planned rounds: the planning kernel behind the round finishes its own individual's
+  // points -- one launch and one kernel boundary fewer per round)
+  if (!finish_elsewhere)
+    hipLaunchKernelGGL(k_fast_lkl_finish<false>, dim3(ng), dim3(64 * MAXP), 0, st, dg, ng, fs.C, part,
+                       fs.base_c, d_lkl, d_flags, d_all);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -732,7 +722,7 @@ bool fast_lkl_launch_planned(FastState& fs, hipStream_t st, const void* d_groups
   // slot: every rank plans the same groups, but lists them in an order of its own)
   return lkl_launch_groups(fs, st, reinterpret_cast<const GroupDesc*>(d_groups_by_ind), ranges,
                            n_active, (uint32_t)fs.I * (uint32_t)MAXP, part, d_lkl, nullptr, emit_estep,
-                           d_worklists, fs.I, d_all);
+                           d_worklists, fs.I, d_all, /*finish_elsewhere=*/fs.shard.world <= 1);
 }
 
 bool fast_lkl_covers_everyone(const FastState& fs) {

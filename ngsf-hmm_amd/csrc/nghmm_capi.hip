@@ -1031,8 +1031,6 @@ struct MstepRun {
       if (!h->aux_done) HIP_TRY(hipEventCreateWithFlags(&h->aux_done, hipEventDisableTiming));
       if (!h->d_flags_bg && (rc = dev_alloc(&h->d_flags_bg, (size_t)NFLAGS))) return rc;
       bg_stream = drain.s = h->aux_stream;
-      estep_F = fs.dev.snap_F;
-      estep_A = fs.dev.snap_A;
     }
     h->ms[SLOT_BFGS] = 0;
     h->launches[SLOT_BFGS] = 0;
@@ -1044,9 +1042,44 @@ struct MstepRun {
       return NGHMM_ERR_HIP;
     }
     if ((rc = bg_close(h))) return rc;
+    if (overlap) {  // (the set this M-step's first planning kernel wrote -- maybe when the last M-step ended)
+      estep_F = dbfgs_start_F(fs);
+      estep_A = dbfgs_start_A(fs);
+    }
     uint32_t round = 1, n_active = 0, prev_active = (uint32_t)h->I;
     std::vector<FastState::ModeRange> ranges;
     const bool yield = h->blocking_sync;
+    // the iteration ends by a word in pinned memory (dbfgs_epilogue) unless its kernels are timed
+    const bool zero_copy = !spans_on(h) && fs.dev.h_epi && !fs.sw.no_epilogue;
+    // ... written by the SECOND stream behind est_maf and the frequency table, which nothing on the
+    // handle's stream reads before the next iteration's walk: the M-step's end waits for nothing
+    const bool aux_epilogue = zero_copy && fuse_freq && ind_lkl != nullptr;
+    bool aux_tail_queued = true;   // (overlap) est_maf .. epilogue are on the second stream, behind the sweep
+    struct StaleGuard {            // ... whose emission ratios are stale once this M-step is over, however it ends
+      FastState& fs;
+      bool on = false;
+      ~StaleGuard() { if (on) fs.e_stale = true; }
+    } stale_when_over{h->fast};
+    auto queue_aux_tail = [&]() -> int {
+      int q;
+      if ((q = push_background_piece())) return q;
+      if (aux_epilogue) {
+        if (!fast_refresh_freq_table(h->fast, h->aux_stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
+        // (the emission ratios the remaining rounds read are those of the OLD frequencies, as the
+        // reference's M-step reads the old e_prob (EM.cpp:198-201 before :252-257): stale only once
+        // this M-step is over)
+        h->fast.e_stale = false;
+        stale_when_over.on = true;
+        if (!dbfgs_epilogue(fs, h->aux_stream, h->d_flags_bg, (uint32_t)NFLAGS, h->d_ind_lkl)) {
+          set_error("the iteration's epilogue kernel failed to launch: %s", hipGetErrorString(hipGetLastError()));
+          return NGHMM_ERR_HIP;
+        }
+      } else {
+        HIP_TRY(hipEventRecord(h->aux_done, h->aux_stream));
+      }
+      aux_tail_queued = true;
+      return NGHMM_OK;
+    };
     for (;;) {
       if (!dbfgs_wait_plan(fs, h->stream, round, &n_active, &ranges, yield)) {
         set_error("the device-side M-step did not publish round %u: %s", round,
@@ -1099,15 +1132,19 @@ struct MstepRun {
       // in parts (rounds 2, 3, ...) -- the GPU works on them while the plan travels to the host
       if (estep_pending) {
         if (overlap) {  // the whole E-step + frequency step, next to everything that follows here
+          // (the sweep now; est_maf's launches -- six of them, 20-40 us of this thread -- once
+          // round 2 is on its way: round 1's planning kernel is shorter than that, and its plan
+          // would wait for the host)
           HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
           if ((rc = start_background(emit))) return rc;
           bg_parts = 1;
-          if ((rc = push_background_piece())) return rc;
-          HIP_TRY(hipEventRecord(h->aux_done, h->aux_stream));
+          aux_tail_queued = false;
         } else if ((rc = wants_background() ? start_background(emit) : estep_then_hook(emit))) {
           return rc;
         }
         estep_pending = false;
+      } else if (overlap && bg_active && !aux_tail_queued) {
+        if ((rc = queue_aux_tail())) return rc;
       } else if (bg_active && !overlap) {
         if ((rc = push_background_piece())) return rc;
       }
@@ -1117,7 +1154,8 @@ struct MstepRun {
     if (fs.sw.timing)
       std::fprintf(stderr, "[nghmm timing] mstep (device-planned): %.3f ms for %u rounds\n", t_lkl, round - 1);
     if (estep_pending && (rc = estep_then_hook(false))) return rc;
-    if (bg_active) {  // what is left of the background work, then the frequency table
+    if (bg_active && overlap && !aux_tail_queued && (rc = queue_aux_tail())) return rc;  // (an M-step of one round)
+    if (bg_active && !(overlap && aux_epilogue)) {  // what is left of the background work, then the frequency table
       if (overlap) HIP_TRY(hipStreamWaitEvent(h->stream, h->aux_done, 0));
       bg_stream = nullptr;
       while (bg_next < bg_parts)
@@ -1126,26 +1164,29 @@ struct MstepRun {
       if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags_bg)) return NGHMM_ERR_HIP;
       if ((rc = bg_close(h))) return rc;
     }
+    bg_stream = nullptr;
     // (the plan that came out empty was published by the last kernel that touched the machines:
     // every individual's parameters are in pinned memory, and on the device)
     dbfgs_end(fs, round);
     std::memcpy(h->h_indF.data(), fs.dev.h_F, h->I * sizeof(double));
     std::memcpy(h->h_alpha.data(), fs.dev.h_A, h->I * sizeof(double));
     const bool lkl_out = bg_active && ind_lkl;
-    if (!spans_on(h) && fs.dev.h_epi && !fs.sw.no_epilogue) {
+    if (zero_copy) {
       // The iteration's end without a copy, an event or a stream synchronisation: a one-workgroup
-      // kernel behind everything writes the background work's flags and the log-likelihoods to
-      // pinned memory and a word the host polls -- and BEHIND it goes the next M-step's first
-      // planning kernel (dbfgs_preplan: the parameters are final), whose 20-30 us and whose plan's
-      // way to the host then cost the next iteration nothing.
-      if (!dbfgs_epilogue(fs, h->stream, h->d_flags_bg, (uint32_t)NFLAGS, lkl_out ? h->d_ind_lkl : nullptr)) {
+      // kernel behind the background work (on ITS stream when it has one: flags and log-likelihoods
+      // are its products) writes them to pinned memory and a word the host polls.  The next
+      // M-step's first planning kernel goes onto the handle's stream at once (dbfgs_preplan: the
+      // parameters are final): its 20-30 us and its plan's way to the host then cost the next
+      // iteration nothing.
+      if (!(overlap && aux_epilogue) &&
+          !dbfgs_epilogue(fs, h->stream, h->d_flags_bg, (uint32_t)NFLAGS, lkl_out ? h->d_ind_lkl : nullptr)) {
         set_error("the iteration's epilogue kernel failed to launch: %s", hipGetErrorString(hipGetLastError()));
         return NGHMM_ERR_HIP;
       }
       h->flags_bg_clear = true;
       if (!fs.sw.no_preplan) (void)dbfgs_preplan(fs, h->stream, indF_fixed != 0, alpha_fixed != 0);
       int f[NFLAGS];
-      if (!dbfgs_wait_epilogue(fs, h->stream, f, (uint32_t)NFLAGS, yield)) {
+      if (!dbfgs_wait_epilogue(fs, overlap && aux_epilogue ? h->aux_stream : h->stream, f, (uint32_t)NFLAGS, yield)) {
         set_error("the iteration's epilogue kernel did not report: %s", hipGetErrorString(hipGetLastError()));
         return NGHMM_ERR_HIP;
       }
