@@ -332,6 +332,34 @@ __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, 
          (ownex ? FD_OWNEX : 0u);
 }
 
+// Every recognised pattern runs on the kernel of the FULL one -- two F probes, two alpha probes:
+// a probe the optimizer did not ask for (a parameter on a bound: a one-sided difference,
+// shared/bfgs.cpp:36-41; a fixed parameter) is filled with a copy of point 0, in the positions
+// the kernel expects (0: x, 1-2: F probes, 3-4: alpha probes).  The points of a group do not enter
+// each other's arithmetic (one exponent, point 0's, rescales all of them), so the real points'
+// values are the same bits as in a kernel of their own pattern; a copy takes point 0's operations
+// (F ratios 1, alpha difference 0) and writes point 0's value to point 0's place.  One kernel per
+// (small-alpha, degree, exponent) instead of one per pattern as well: a round of individuals at
+// different bounds is one launch, not up to six (and the library a fifth of the objective code).
+__host__ __device__ inline void fd_pad(GroupDesc& G) {
+  if (!(G.mode & FD_FLAG)) return;
+  const uint32_t nf = (G.mode >> 2) & 3u, na = G.mode & 3u;
+  if (nf == 2 && na == 2) return;
+  GroupDesc P = G;
+  for (uint32_t k = 0; k < 2; ++k) {
+    const uint32_t sf = k < nf ? 1 + k : 0, sa = k < na ? 1 + nf + k : 0;
+    P.F[1 + k] = G.F[sf];
+    P.A[1 + k] = G.A[sf];
+    P.out_idx[1 + k] = G.out_idx[sf];
+    P.F[3 + k] = G.F[sa];
+    P.A[3 + k] = G.A[sa];
+    P.out_idx[3 + k] = G.out_idx[sa];
+  }
+  P.np = 5;
+  P.mode = (G.mode & ~0xfu) | (2u << 2) | 2u;
+  G = P;
+}
+
 // compact index of a mode (0 = general): the device-planned rounds keep one worklist per mode
 constexpr uint32_t kModeSlots = 1 + 8 * 16;
 __host__ __device__ constexpr uint32_t mode_slot(uint32_t mode) {

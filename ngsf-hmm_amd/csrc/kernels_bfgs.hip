@@ -117,6 +117,14 @@ __device__ inline void build_group(const BfgsProblem& p, uint32_t i, const DevPt
   G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.allow_xdeg2 != 0, D.alpha_small_min);
 }
 
+// (the number of points the optimizer asked for: G.np before fd_pad fills the pattern up)
+__device__ inline uint32_t build_group_padded(const BfgsProblem& p, uint32_t i, const DevPtrs& D, GroupDesc& G) {
+  build_group(p, i, D, G);
+  const uint32_t asked = G.np;
+  fd_pad(G);
+  return asked;
+}
+
 // One individual per WAVE, kWg waves (individuals) per workgroup: the machines of different
 // individuals are at different places of the algorithm -- lanes of one wave would take their
 // branches one after the other -- so lane 0 of a wave walks its individual's machine while all 64
@@ -211,10 +219,9 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       D.snap_A[i] = p.x[1];
       bfgs_plan<DetPow>(p);
       p.n_rounds = 1;
-      build_group(p, i, D, G);
+      p.acc_points = build_group_padded(p, i, D, G);
       D.groups[i] = G;
       D.last_mode[i] = G.mode;
-      p.acc_points = G.np;
       D.prob[i] = p;
       wg_slot[wv] = mode_slot(G.mode) + 1;
     } else {
@@ -306,10 +313,9 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
         if (again) {
           bfgs_plan<DetPow>(p);
           ++p.n_rounds;
-          build_group(p, i, D, G);
+          p.acc_points += build_group_padded(p, i, D, G);
           D.groups[i] = G;
           D.last_mode[i] = G.mode;
-          p.acc_points += G.np;
           wg_slot[wv] = mode_slot(G.mode) + 1;
           D.solver[i] = s;
           keep = true;

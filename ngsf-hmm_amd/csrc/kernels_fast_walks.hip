@@ -551,6 +551,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     }
     G.np = np;
     G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed, !fs.sw.no_xdeg2, fs.alpha_small_min);
+    fd_pad(G);
     groups.push_back(G);
   }
   // one kernel per loop-body version: sort the groups by mode (stable, so still in
@@ -649,19 +650,11 @@ static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg
     hipLaunchKernelGGL((k_fast_lkl_fd<NF, NA, SM, false, SRC_PLAIN, XD, true>), grid, block, 0, st, arr, \
                        fs.T, fs.C, dg, r.begin, part, emit, wl);                \
     break;
-#define FD_CASE(NF, NA)       \
-  FD_CASE1(NF, NA, false, 4)  \
-  FD_CASE1(NF, NA, true, 4)   \
-  FD_CASE1(NF, NA, false, 2)  \
-  FD_CASE1(NF, NA, true, 2)
-      FD_CASE(2, 2)
-      FD_CASE(1, 2)
-      FD_CASE(2, 1)
-      FD_CASE(1, 1)
-      FD_CASE(0, 2)
-#undef FD_CASE
-      FD_CASE1(2, 0, false, 4)  // no alpha probe: nothing for the degree to choose
-      FD_CASE1(2, 0, true, 4)
+      // (every recognised pattern is padded to the full one: fast_dev.hpp, fd_pad)
+      FD_CASE1(2, 2, false, 4)
+      FD_CASE1(2, 2, true, 4)
+      FD_CASE1(2, 2, false, 2)
+      FD_CASE1(2, 2, true, 2)
 #undef FD_CASE1
 #undef FD_LAUNCH
       default:
