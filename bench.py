@@ -389,8 +389,14 @@ PARITY = {
               "written): restated, anchored by a binary128 model and path enumeration",
     "exact_mode": "bit-identical to the oracle's det build end to end (every array, Viterbi paths, "
                   "output files)",
-    "per_call": "1e-9 (tested): fast mode vs the oracle per call and teacher-forced per iteration: "
-                "log-likelihoods 1e-12, posteriors / frequencies 1e-9 relative; Viterbi paths identical",
+    "per_call": "fast mode vs the oracle per call and teacher-forced per iteration: log-likelihoods 1e-12 and "
+                "Viterbi paths identical at every size; frequencies 1e-9 relative when both sides are fed the same "
+                "posteriors; POSTERIORS within 1e-9 only on chains up to ~10^5 sites -- the oracle (the reference's "
+                "log-space doubles) itself drifts from a binary128 evaluation with the chain length, to 7.5e-6 at the "
+                "10^6 sites this line is timed on, where fast mode stays within 2e-14 of binary128 (`by_chain_length` "
+                "below: tests/test_gpu_baseline_oracle.py::test_fast_mode_against_binary128_by_chain_length).  At the "
+                "benchmarked size the timed mode does NOT match the reference's posteriors to 1e-9; exact mode "
+                "(bit-identical to the oracle, ~500 x slower) does",
     "baseline_sizes_vs_oracle": "tests/test_gpu_baseline_oracle.py (-m gpu): configs[1] in full (100 x 100k "
                                 "of this data set) and a 1000 x 10k slice of configs[2] -- exact mode "
                                 "BITWISE against the oracle over a whole EM iteration + Viterbi; fast mode per "
@@ -415,6 +421,17 @@ def parity_object():
     as profiles/rNN_parity_1M.json by the round's collection): fast mode and the oracle (the
     reference's log-space doubles) both against the binary128 anchor at the benchmarked chain length."""
     out = dict(PARITY)
+    path = _latest_profile("parity_by_length.json")
+    if path:
+        m = json.load(open(os.path.join(ROOT, path)))
+        out["by_chain_length"] = {
+            "source": path,
+            "posteriors_abs_vs_binary128": {S: {"fast": v["post_fast"], "oracle": v["post_oracle"],
+                                                "fast_vs_oracle": v["post_fast_vs_oracle"]}
+                                            for S, v in m["by_length"].items()},
+            "log_likelihood_rel_vs_binary128": {S: {"fast": v["lkl_fast"], "oracle": v["lkl_oracle"]}
+                                                for S, v in m["by_length"].items()},
+            "fast_vs_oracle_posteriors_within_1e-9_up_to_S": m.get("fast_vs_oracle_posteriors_within_1e-9_up_to_S")}
     path = _latest_profile("parity_1M.json")
     if path:
         m = json.load(open(os.path.join(ROOT, path)))

@@ -95,15 +95,15 @@ int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches);
  *
  * nghmm_debug_estmaf_counts: sites of the allele-frequency step (est_maf, gen_func.cpp:974-1009)
  * that left its common route -- out[0] the interpolant's check failed (the site ran every
- * remaining pass over all individuals), out[1] resumed on exact passes with a second interval,
- * out[2] resumed once more without one, out[3] redone in the reference's log-space order (a cell
- * whose linear weights all vanish). */
+ * remaining pass over all individuals), out[1] left its interval and got a second, out[2] a
+ * third, out[3] redone in the reference's log-space order (a cell whose linear weights all
+ * vanish), out[4] left its third interval too and finished on exact passes. */
 typedef struct {
   uint32_t mode;
   uint64_t ind_rounds;
 } nghmm_mode_count;
 int nghmm_debug_mode_counts(nghmm_t* h, nghmm_mode_count* out, uint32_t cap, uint32_t* n, int reset);
-int nghmm_debug_estmaf_counts(nghmm_t* h, uint64_t out[4], int reset);
+int nghmm_debug_estmaf_counts(nghmm_t* h, uint64_t out[5], int reset);
 
 #ifdef __cplusplus
 }

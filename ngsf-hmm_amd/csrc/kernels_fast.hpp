@@ -180,9 +180,10 @@ struct FastState {
 enum EstCount {
   EST_CNT_CHECK_FAILED = 0,  // the interpolant missed the next exact pass by > 1e-11: exact passes to the end
   EST_CNT_RESUMED = 1,       // left its interval or a stopping decision too close to call: a second interval
-  EST_CNT_RESUMED_AGAIN = 2, // ... and once more: exact passes to the end
+  EST_CNT_RESUMED_AGAIN = 2, // ... and once more: a third
   EST_CNT_LOGSPACE = 3,      // a cell whose linear weights all vanish: the reference-order log-space route
-  EST_COUNTS = 4
+  EST_CNT_EXACT_TAIL = 4,    // left its third interval as well: exact passes to the end
+  EST_COUNTS = 5
 };
 
 bool fast_create(FastState& fs, uint64_t I, uint64_t S, bool packed = false);

@@ -625,7 +625,7 @@ k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
                      double* __restrict__ freq_out, uint8_t* __restrict__ redo,
                      uint8_t* __restrict__ status, double* __restrict__ state,
                      uint64_t state_stride, int n_exact, int allow_build, uint64_t row0,
-                     uint64_t row1, uint32_t* __restrict__ cnt) {
+                     uint64_t row1, uint32_t* __restrict__ cnt, int cnt_slot) {
   ESTMAF_SHARED(NI, BLOCK);
   const int lane = threadIdx.x & 63;
   for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
@@ -633,8 +633,7 @@ k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
     const bool need = s < S_own && in_tile_rows(s, TILE ? tile_T : 0, row0, row1) &&
                       status[s] == EST_EXACT;
     uint64_t mask = __ballot(need);  // the same in every wave of the workgroup
-    if (mask && threadIdx.x == 0)
-      atomicAdd(cnt + (allow_build ? EST_CNT_RESUMED : EST_CNT_RESUMED_AGAIN), (uint32_t)__popcll(mask));
+    if (mask && threadIdx.x == 0) atomicAdd(cnt + cnt_slot, (uint32_t)__popcll(mask));
     if constexpr (BLOCK > 64) __syncthreads();  // ... all have read before anyone writes a status
     while (mask) {
       const uint64_t site = base + (uint64_t)__builtin_ctzll(mask);
@@ -922,13 +921,12 @@ k_fast_estmaf_rows_resume(const GlView gl, const double* __restrict__ marg_block
                           double* __restrict__ freq_out, uint8_t* __restrict__ redo,
                           uint8_t* __restrict__ status, double* __restrict__ state,
                           uint64_t state_stride, int n_exact, int allow_build,
-                          uint32_t* __restrict__ cnt) {
+                          uint32_t* __restrict__ cnt, int cnt_slot) {
   const int lane = threadIdx.x, row = lane >> 4;
   for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
     const uint64_t s = base + lane;
     uint64_t mask = __ballot(s < S_own && status[s] == EST_EXACT);
-    if (mask && lane == 0)
-      atomicAdd(cnt + (allow_build ? EST_CNT_RESUMED : EST_CNT_RESUMED_AGAIN), (uint32_t)__popcll(mask));
+    if (mask && lane == 0) atomicAdd(cnt + cnt_slot, (uint32_t)__popcll(mask));
     while (mask) {
       uint64_t site = 0;
       bool done = true;
@@ -1360,7 +1358,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, false>), dim3(scan_wgs), dim3(B), 0, st,   \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
                          d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
-                         n_exact, allow_build, row0, row1, fs.est_counts);                      \
+                         n_exact, allow_build, row0, row1, fs.est_counts, cnt_slot);            \
   } while (0)
 #define LAUNCH_TILE(N, B)                                                                       \
   do {                                                                                          \
@@ -1373,7 +1371,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, true>), dim3(scan_wgs), dim3(B), 0, st,    \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
-                         allow_build, row0, row1, fs.est_counts);                               \
+                         allow_build, row0, row1, fs.est_counts, cnt_slot);                     \
   } while (0)
 #define LAUNCH_ROWS(N, TL)                                                                      \
   do {                                                                                          \
@@ -1387,11 +1385,11 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       hipLaunchKernelGGL((k_fast_estmaf_rows_resume<N, TL>), dim3(scan_wgs), dim3(64), 0, st,    \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
-                         allow_build, fs.est_counts);                                           \
+                         allow_build, fs.est_counts, cnt_slot);                                 \
   } while (0)
   // up to 128 individuals: four sites per wave (k_fast_estmaf_rows)
   const bool rows = I_tot <= 128 && !fs.sw.estmaf_no_rows;
-  auto launch = [&](int fresh, int n_exact, int allow_build) -> bool {
+  auto launch = [&](int fresh, int n_exact, int allow_build, int cnt_slot = 0) -> bool {
     if (rows) {
       if (tile_major) {
         if (I_tot <= 16) LAUNCH_ROWS(1, true);
@@ -1449,10 +1447,14 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     if (!launch(1, EST_K0, 1)) return false;
     hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
                        fs.est_status, fs.est_state, fs.redo_cap, tile_T, row0, row1);
-    if (!launch(0, 1, 1)) return false;  // sites that left their interval: one more
-    hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
-                       fs.est_status, fs.est_state, fs.redo_cap, tile_T, row0, row1);
-    if (!launch(0, 0, 0)) return false;  // whatever is left finishes on exact passes
+    // sites that left their interval -- a frequency far from the 0.01 every site starts at: the
+    // odds then travel several times their value (gen_func.cpp:976) -- get a second and a third
+    for (int again = 0; again < 2; ++again) {
+      if (!launch(0, 1, 1, again ? EST_CNT_RESUMED_AGAIN : EST_CNT_RESUMED)) return false;
+      hipLaunchKernelGGL(k_fast_estmaf_interp, igrid, dim3(256), 0, st, S_own, d_freq_out, fs.redo,
+                         fs.est_status, fs.est_state, fs.redo_cap, tile_T, row0, row1);
+    }
+    if (!launch(0, 0, 0, EST_CNT_EXACT_TAIL)) return false;  // whatever is left finishes on exact passes
   }
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
                      I_tot, I_blk, tile_T, d_freq_out, redo, row0, row1, fs.est_counts);

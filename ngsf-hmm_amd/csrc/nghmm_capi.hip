@@ -1792,17 +1792,17 @@ int nghmm_debug_mode_counts(nghmm_t* h, nghmm_mode_count* out, uint32_t cap, uin
   return NGHMM_OK;
 }
 
-int nghmm_debug_estmaf_counts(nghmm_t* h, uint64_t out[4], int reset) {
+int nghmm_debug_estmaf_counts(nghmm_t* h, uint64_t out[5], int reset) {
   g_last_error.clear();
   if (!h || !out) return NGHMM_ERR_ARG;
-  for (int k = 0; k < 4; ++k) out[k] = 0;
+  for (int k = 0; k < 5; ++k) out[k] = 0;
   if (!h->fast.est_counts) return NGHMM_OK;  // no frequency step yet (or exact mode)
   int rc;
   if ((rc = use_device(h))) return rc;
   uint32_t v[EST_COUNTS];
   HIP_TRY(sync_stream(h));
   HIP_TRY(hipMemcpy(v, h->fast.est_counts, sizeof v, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 4; ++k) out[k] = v[k];
+  for (int k = 0; k < 5; ++k) out[k] = v[k];
   if (reset) {
     HIP_TRY(hipMemset(h->fast.est_counts, 0, sizeof v));
     HIP_TRY(hipDeviceSynchronize());

@@ -600,10 +600,10 @@ class NgsFHMM:
 
     def estmaf_counts(self, reset=False):
         """Sites of the allele-frequency step that left its common route (nghmm_debug_estmaf_counts)."""
-        v = (C.c_uint64 * 4)()
+        v = (C.c_uint64 * 5)()
         self._check(self.lib.nghmm_debug_estmaf_counts(self._h, v, int(reset)))
-        return {"check_failed": int(v[0]), "resumed": int(v[1]), "resumed_again": int(v[2]),
-                "log_space": int(v[3])}
+        return {"check_failed": int(v[0]), "second_interval": int(v[1]), "third_interval": int(v[2]),
+                "log_space": int(v[3]), "exact_tail": int(v[4])}
 
 
 class Group:
