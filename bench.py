@@ -391,9 +391,9 @@ PARITY = {
                   "output files)",
     "per_call": "fast mode vs the oracle per call and teacher-forced per iteration: log-likelihoods 1e-12 and "
                 "Viterbi paths identical at every size; frequencies 1e-9 relative when both sides are fed the same "
-                "posteriors; POSTERIORS within 1e-9 only on chains up to ~10^5 sites -- the oracle (the reference's "
-                "log-space doubles) itself drifts from a binary128 evaluation with the chain length, to 7.5e-6 at the "
-                "10^6 sites this line is timed on, where fast mode stays within 2e-14 of binary128 (`by_chain_length` "
+                "posteriors; POSTERIORS within 1e-9 only on chains up to ~10^4 sites (5.8e-10 there, 3.2e-8 at 10^5, "
+                "2.4e-7 at 3 x 10^5) -- the oracle (the reference's log-space doubles) itself drifts from a binary128 "
+                "evaluation with the chain length, to 7.5e-6 at the 10^6 sites this line is timed on, where fast mode stays within 2e-14 of binary128 (`by_chain_length` "
                 "below: tests/test_gpu_baseline_oracle.py::test_fast_mode_against_binary128_by_chain_length).  At the "
                 "benchmarked size the timed mode does NOT match the reference's posteriors to 1e-9; exact mode "
                 "(bit-identical to the oracle, ~500 x slower) does",
