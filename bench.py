@@ -366,10 +366,15 @@ def launch_ranks(args):
     n_dev = torch.cuda.device_count()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if n_dev < args.gpus and "NGHMM_BENCH_BACKEND" not in env:
+    if args.dry_launch:
+        # the launcher, the rendezvous, the collectives' preflight and every rank's shard arithmetic
+        # WITHOUT a GPU call: what an N-rank run does before it touches its card, rehearsed on the CPU
+        env["NGHMM_BENCH_BACKEND"] = "gloo"
+    elif n_dev < args.gpus and "NGHMM_BENCH_BACKEND" not in env:
         # fewer GPUs than ranks (a one-GPU box): functional run only -- every rank on cuda:0,
-        # collectives through gloo staged on the host; the line says so
-        if n_dev < 1 or args.gpus > 4:
+        # collectives through gloo staged on the host; the line says so.  At most six processes
+        # may share one card on the build's GPU boxes.
+        if n_dev < 1 or args.gpus > 6:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
         env["NGHMM_BENCH_BACKEND"] = "gloo"
         env["NGHMM_BENCH_ONE_GPU"] = "1"
@@ -735,6 +740,29 @@ def serial_kernel_loop(ctx, run, n, replicas=()):
     return dict(fam=fam, launches=launches, rounds=rounds, ind_rounds=ind_rounds, steps=n, dt=dt)
 
 
+def cold_run(ctx, run, iterations=20):
+    """The run a user gets: `iterations` EM iterations from the starting values of examples/test.sh
+    (--freq 0.1 --indF 0.1,0.2), timed as a whole between barriers (MAX over ranks) and one by one --
+    a run has at least min_iters = 10 iterations (parse_args.cpp:5-34, EM.cpp:56), and its first ones
+    take several times the objective rounds of the steady state `value` is measured in."""
+    em = run["em"]
+    reset_params(em)
+    each_ms, rounds, ind_rounds = [], [], 0
+    barrier(ctx)
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        t = time.perf_counter()
+        st = em.iter_EM()
+        each_ms.append((time.perf_counter() - t) * 1e3)
+        rounds.append(int(st.rounds))
+        ind_rounds += int(st.ind_rounds)
+    barrier(ctx)
+    dt = time.perf_counter() - t0
+    if ctx.world > 1:
+        dt = float(allreduce(ctx, [dt], "max")[0])
+    return dict(dt=dt, each_ms=each_ms, rounds=rounds, ind_rounds=ind_rounds, iterations=iterations)
+
+
 def result_check(ctx, run, iterations=2):
     """Two EM iterations from the starting values, reduced to numbers that do not depend on how
     the job is sharded: the N-rank line's `check` must equal the one-GPU line's (log-likelihood
@@ -902,6 +930,12 @@ def main():
     ap.add_argument("--no_exact_line", action="store_true",
                     help="N = 1: skip the bit-exact mode's bounded run (`exact_mode` in the line)")
     ap.add_argument("--no_check", action="store_true", help="skip the cross-N result check")
+    ap.add_argument("--dry_launch", action="store_true",
+                    help="N > 1: everything an N-rank run does BEFORE it touches a GPU -- the child launcher, the "
+                         "rendezvous, the known-answer preflight of the collectives (gloo, CPU tensors), every "
+                         "rank's shard of both layouts -- and nothing after: one JSON line, no measurement")
+    ap.add_argument("--no_cold", action="store_true",
+                    help="skip the 20 iterations from the starting values behind the timed loop (`value_cold20`)")
     ap.add_argument("--serial_kernels", action="store_true",
                     help="fast mode: the whole run with the background work (backward sweep, est_maf) "
                          "between the objective rounds on one stream, not next to them on a second "
@@ -985,6 +1019,8 @@ def run_rank(args):
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, "
                              f"--gpus says {args.gpus}")
+    if args.dry_launch:
+        return dry_launch(ctx, restore_stdout, backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ctx.local_rank = local_rank
@@ -1081,6 +1117,9 @@ def run_rank(args):
     kt = None
     if args.mode == "fast" and not args.serial_kernels and args.replicas == 1:
         kt = serial_kernel_loop(ctx, run, max(1, min(5, args.steps)))
+    cold = None
+    if args.mode == "fast" and args.replicas == 1 and V == 1 and not args.no_cold:
+        cold = cold_run(ctx, run)
     check = None
     if not args.no_check and V == 1:
         check = result_check(ctx, run)
@@ -1112,6 +1151,7 @@ def run_rank(args):
         units = float(I_tot) * (S_job if by_sites and V == 1 else S) * K * args.replicas
         if not by_sites and V > 1:
             units = float(I) * S * K
+        units_per_iter = units / K
         est_sites = S if by_sites else S / (world * V)       # what one rank's est_maf covers
         est_inds = I if by_sites else I_tot
         call_geno = ctx.call_geno
@@ -1352,6 +1392,10 @@ def run_rank(args):
             "first_iterations_ms": each[:args.warmup] if args.warmup else each[:min(3, len(each))],
             "first_iterations_rounds": tl["each_rounds"][:max(args.warmup, min(3, len(each)))],
             "run_of_20_ms_per_iter": (sum(each[:20]) / 20 if len(each) >= 20 else None),
+            # THE RUN A USER GETS next to the steady state: 20 iterations from --freq 0.1 --indF 0.1,0.2
+            # (a run is >= 10, parse_args.cpp:5-34), same units, same accounting of algorithmic bytes
+            "value_cold20": (None if cold is None else units_per_iter * cold["iterations"] / cold["dt"]),
+            "cold20": (None if cold is None else cold20_object(cold, units_per_iter, I, S, glq, glb, est_sites, est_inds)),
             "run_ms_per_iter": {"iterations": n_run, "value": sum(each[:n_run]) / max(n_run, 1),
                                 "note": "mean wall time of the run's first iterations, warm-up included "
                                         "(this rank's clock)"},
@@ -1406,6 +1450,57 @@ def run_rank(args):
         sys.stdout.flush()
     if world > 1 or args.emulate_rccl:
         dist.destroy_process_group()
+
+
+def cold20_object(cold, units_per_iter, I, S, glq, glb, est_sites, est_inds):
+    """`value_cold20`'s details: every iteration's wall time and objective rounds, and the run's
+    algorithmic HBM bytes by the same per-kernel model as roofline_iteration (this rank: a first round
+    over all individuals, 8 B per site of every later individual-round, backward sweep, est_maf)."""
+    n = cold["iterations"]
+    later = max(cold["ind_rounds"] - I * n, 0)
+    by = ((glq + 12.0) * S * I + 20.0 * S * I + (glb + 8.0) * est_sites * est_inds) * n + 8.0 * S * later
+    return {"iterations": n, "ms_per_iter": cold["dt"] / n * 1e3, "iterations_ms": cold["each_ms"],
+            "rounds": cold["rounds"], "ind_rounds_per_iter": cold["ind_rounds"] / n,
+            "site_ind_updates_per_s": units_per_iter * n / cold["dt"],
+            "algorithmic_bytes_per_iteration": by / n,
+            "hbm": {"achieved_GBps": by / cold["dt"] / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                    "frac": by / cold["dt"] / 1e9 / HBM_PEAK_GBS},
+            "start": "--freq 0.1 --indF 0.1,0.2 (examples/test.sh)"}
+
+
+def dry_launch(ctx, restore_stdout, backend):
+    """`--dry_launch`: the part of an N-rank run that comes before its first GPU call, on the CPU."""
+    args, dd, dist = ctx.args, ctx.dd, ctx.dist
+    if ctx.world < 2:
+        raise SystemExit("--dry_launch rehearses a multi-rank launch: --gpus N with N > 1")
+    preflight = dd.preflight(None)                  # CPU tensors through the group's collectives
+    restore_stdout()
+    ctx.wl = dict(WORKLOADS[args.workload])
+    ctx.call_geno = bool(ctx.wl.get("call_geno"))
+    mine = {"rank": ctx.rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}
+    for shard in ("sites", "individuals"):
+        try:
+            sh = shard_shapes(ctx, shard)
+            mine[shard] = {"n_ind": sh["I"], "n_sites": sh["S"], "ind_range": list(sh["ind_range"]),
+                           "site_range": list(sh["site_range"])}
+        except ValueError as e:
+            mine[shard] = {"refused": str(e)}
+    ranks = [None] * ctx.world
+    dist.all_gather_object(ranks, mine)
+    dist.barrier()
+    if ctx.rank == 0:
+        # the shards tile the job: every site (individual) belongs to exactly one rank
+        for shard, key, total in (("sites", "site_range", ctx.wl["n_sites"]), ("individuals", "ind_range", ctx.wl["n_ind"])):
+            got = [r[shard] for r in ranks if "refused" not in r[shard]]
+            if len(got) == ctx.world:
+                cuts = sorted(tuple(g[key]) for g in got)
+                assert cuts[0][0] == 0 and cuts[-1][1] == total and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])), cuts
+        print(json.dumps({"dry_launch": True, "n_gpus": ctx.world, "backend": backend, "workload": ctx.wl["name"],
+                          "preflight": preflight, "ranks": ranks,
+                          "note": "launcher, rendezvous, collectives and shard arithmetic of an N-rank run without a "
+                                  "GPU call: not a measurement"}))
+        sys.stdout.flush()
+    dist.destroy_process_group()
 
 
 def regime_object(tl, K, n_ind, n_sites, site_shards):

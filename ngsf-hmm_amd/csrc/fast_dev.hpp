@@ -297,6 +297,7 @@ __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, 
   int nf = 0, na = 0;
   bool ownex = false;
   double xmax = 0;  // largest |alpha_0 - alpha_probe| d over the data's finite distances
+  double damax = 0;  // largest |alpha_0 - alpha_probe|
   for (uint32_t p = 1; p < G.np; ++p) {
     if (G.A[p] == G.A[0] && G.F[p] > 0 && G.F[p] < 1) {
       if (na) return 0;  // F probes come first
@@ -320,6 +321,7 @@ __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, 
     } else if (G.F[p] == G.F[0] && fabs(G.A[p] - G.A[0]) * dmax <= 1e-3) {
       ++na;
       xmax = fmax(xmax, fabs(G.A[p] - G.A[0]) * dmax);
+      damax = fmax(damax, fabs(G.A[p] - G.A[0]));
     } else {
       return 0;
     }
@@ -327,7 +329,13 @@ __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, 
   const bool ok = (nf == 2 && na == 2) || (nf == 1 && na == 2) || (nf == 2 && na == 1) ||
                   (nf == 1 && na == 1) || (nf == 2 && na == 0) || (nf == 0 && na == 2);
   if (!ok) return 0;
-  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625 && G.A[0] >= alpha_small_min,
+  // The kappa form's alpha probes see the distance clamped to KAPPA_DCLAMP (op_step_k above): right
+  // only while every finite distance is below it, and their constant at a chromosome start stays
+  // near point 0's only while |alpha_0 - alpha_probe| KAPPA_DCLAMP is small.  The M-step's own
+  // probes (eh <= 2.3e-5 apart, distances <= 46 Mb: dbfgs_available) are far inside both; points a
+  // caller of nghmm_lkl_batch chooses need not be, and then take the general-exp version.
+  const bool kappa_ok = na == 0 || (dmax < KAPPA_DCLAMP && damax * KAPPA_DCLAMP <= 0.05);
+  return fd_mode(nf, na, G.A[0] * dmax <= 0.015625 && G.A[0] >= alpha_small_min && kappa_ok,
                  allow_xdeg2 && na > 0 && xmax <= 1e-5) |
          (ownex ? FD_OWNEX : 0u);
 }

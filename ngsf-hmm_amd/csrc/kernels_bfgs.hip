@@ -149,6 +149,7 @@ __device__ unsigned long long g_bfgs_phase[8];
 #define PHASE(k)
 #endif
 
+constexpr uint32_t kRedone = 0xffffffffu;  // last_mode: the round was a site shard's repeat by the general kernel
 constexpr int kWg = 4;  // 4 x 10 KB of LDS: three workgroups per CU
 struct WaveLds {
   double arr[kArr];
@@ -233,10 +234,17 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
           lklv[k] = D.lkl[(uint64_t)i * 5 + k];
           bad = bad || bfgs_nonfinite(lklv[k]);
         }
-      if (bad && D.last_mode[i] != 0) {
+      // A handle that holds whole chains repeats a pattern kernel's non-finite values with the
+      // general kernel, and takes the general kernel's for final.  Site shards: every rank sees the
+      // same (combined) values but chose its kernel by its OWN sites' distances (fd_pattern), so
+      // "was it a pattern kernel" differs between ranks, and ranks that disagree about a repeat
+      // disagree about the number of exchanges.  There the rule is the same for everybody: ONE
+      // repeat by the general kernel whatever ran before (kRedone marks it), then final.
+      const bool may_repeat = D.finish ? D.last_mode[i] != 0 : D.last_mode[i] != kRedone;
+      if (bad && may_repeat) {
         // a probe left the pattern kernel's shared scale: the same points by the general kernel
         D.groups[i].mode = 0;
-        D.last_mode[i] = 0;
+        D.last_mode[i] = D.finish ? 0u : kRedone;
         wg_slot[wv] = mode_slot(0) + 1;
         ++p.acc_redone;  // (not a round of the optimizer's: n_rounds counts evaluations it asked for)
         D.prob[i] = p;

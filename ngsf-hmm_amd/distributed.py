@@ -116,10 +116,20 @@ class FailureBeacon:
       stderr and ``os._exit(5)``, a fresh exit (never an exec) that ends the waiting rank with a
       non-zero code and the failing rank's message within ``poll_s``.
 
+    A store that no longer ANSWERS is a weaker sign than the key: the store lives in rank 0 (or
+    the launcher), and a rank 0 that has finished in good order takes it along while another rank
+    may still be writing its shard's outputs.  Its loss counts as a peer's failure only when it is
+    seen on ``LOST_POLLS`` consecutive looks (a transient socket error is not one) AND this rank is
+    inside a guarded block at each of them -- i.e. in an EM iteration, where a partner that is gone
+    means a collective that never completes.  Outside (post-processing, shutdown) the watcher just
+    stops.  Callers that go on working after their last iteration need nothing more; ``close()``
+    before that work also stops the polling.
+
     Documented behaviour, not a recovery protocol: after a peer's fatal the job is over, as it
     is in the reference (`error()` + `exit(-1)`, gen_func.cpp:12-18)."""
 
     KEY = "nghmm_failed_rank"
+    LOST_POLLS = 3
 
     def __init__(self, rank, poll_s=0.25, on_peer_failure=None, store=None):
         import threading
@@ -130,6 +140,7 @@ class FailureBeacon:
         base = store if store is not None else dist.distributed_c10d._get_default_store()
         self.store = dist.PrefixStore("nghmm_beacon", base)
         self._signalled = False
+        self._busy = 0              # guarded blocks this rank is inside (its EM iterations)
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._watch, name="nghmm-failure-beacon", daemon=True)
         self._thread.start()
@@ -156,19 +167,27 @@ class FailureBeacon:
                 time.sleep(2 * self.poll_s)
 
     def _watch(self):
+        lost = 0
         while not self._stop.wait(self.poll_s):
             try:
                 if not self.store.check([self.KEY]):
+                    lost = 0
                     continue
                 msg = self.store.get(self.KEY).decode(errors="replace")
             except Exception as e:  # noqa: BLE001
                 # The store no longer answers.  After close() that is the job ending in good
-                # order (process group destroyed).  Before it, the process that hosts the store
-                # -- rank 0 -- has died: under a launcher without an agent that kills the
-                # survivors (mpirun, srun) they would sit in their next collective until its
-                # timeout, so this too is a peer's failure.
+                # order (process group destroyed); outside an iteration it is rank 0 having
+                # finished before this rank -- nothing to act on.  INSIDE one, and repeatedly, the
+                # process that hosts the store has died: under a launcher without an agent that
+                # kills the survivors (mpirun, srun) they would sit in their next collective until
+                # its timeout, so this too is a peer's failure.
                 if self._signalled or self._stop.is_set():
                     return
+                if self._busy <= 0:
+                    return
+                lost += 1
+                if lost < self.LOST_POLLS:
+                    continue
                 self.on_peer_failure(f"0 (or the store's host): the job's store is lost "
                                      f"({type(e).__name__}: {e})")
                 return
@@ -186,9 +205,11 @@ class FailureBeacon:
 
         class _G:
             def __enter__(self):
+                beacon._busy += 1
                 return beacon
 
             def __exit__(self, et, ev, tb):
+                beacon._busy -= 1
                 if ev is not None and not isinstance(ev, (KeyboardInterrupt, GeneratorExit)):
                     beacon.signal(f"{type(ev).__name__}: {ev}")
                 return False

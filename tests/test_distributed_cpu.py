@@ -393,3 +393,71 @@ def test_a_failing_rank_ends_the_others_instead_of_hanging_them(tmp_path, failin
     assert (f"rank {failing}: NgsFHMMError" in outs[other] and "invalid MAF!" in outs[other]) or \
         "the job's store is lost" in outs[other], outs[other]
     assert "SURVIVOR_WAS_NOT_STOPPED" not in outs[other]
+
+
+CLEAN_EXIT_WORKER = r'''
+import importlib, os, sys, time
+import torch
+import torch.distributed as dist
+from datetime import timedelta
+sys.path.insert(0, ROOT)
+dd = importlib.import_module("ngsf-hmm_amd.distributed")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=300))
+beacon = dd.make_beacon(rank, world, poll_s=0.1)
+part = torch.full((8,), float(rank), dtype=torch.float64)
+whole = torch.empty(8 * world, dtype=torch.float64)
+for _ in range(3):                               # the job's iterations, guarded as ShardedEM guards them
+    with beacon.guard():
+        dist.all_gather_into_tensor(whole, part)
+if rank == 0:
+    # rank 0 (the store's host) has nothing left to do and leaves, without ceremony
+    print("RANK0_DONE", flush=True)
+    os._exit(0)
+# the other rank writes its shard's outputs for a while: the store is gone under its watcher
+time.sleep(1.5)
+print("RANK1_FINISHED_ITS_OUTPUTS", flush=True)
+beacon.close()
+os._exit(0)
+'''
+
+
+def test_a_rank_that_outlives_rank_zero_is_not_killed(tmp_path):
+    """The c10d store lives in rank 0.  When rank 0 ends in good order a rank that is still writing
+    its outputs finds the store gone: outside an EM iteration that is NOT a peer's failure (round-5
+    advisory: the watcher used to end such a rank with exit code 5 and truncated outputs)."""
+    world = 2
+    script = tmp_path / "clean_exit_worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\n" + CLEAN_EXIT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert procs[0].returncode == 0 and "RANK0_DONE" in outs[0], outs[0]
+    assert procs[1].returncode == 0 and "RANK1_FINISHED_ITS_OUTPUTS" in outs[1], outs[1]
+    assert "a peer failed" not in outs[1], outs[1]
+
+
+def test_bench_eight_rank_dry_launch():
+    """`bench.py --gpus 8 --dry_launch`: the child launcher, the rendezvous of eight ranks, the
+    known-answer preflight of the collectives and every rank's shard of the default workload in
+    both layouts -- what an 8-GPU run does before its first GPU call, on the CPU (the build's
+    one-GPU boxes admit at most six processes on a card, so the eight-rank launch itself is
+    rehearsed here).  The shards tile the 1000 x 1M job."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry_launch"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry_launch"] is True and line["n_gpus"] == 8 and line["preflight"]["world"] == 8
+    ranks = sorted(line["ranks"], key=lambda x: x["rank"])
+    assert [x["rank"] for x in ranks] == list(range(8))
+    assert ranks[0]["sites"]["site_range"][0] == 0 and ranks[-1]["sites"]["site_range"][1] == 1_000_000
+    assert all(a["sites"]["site_range"][1] == b["sites"]["site_range"][0] for a, b in zip(ranks, ranks[1:]))
+    assert [x["individuals"]["ind_range"] for x in ranks] == [[125 * k, 125 * (k + 1)] for k in range(8)]

@@ -622,3 +622,31 @@ def test_zero_linear_mass_is_where_the_two_modes_part(pkg, orc_det):
         others = np.delete(ind, bad_i)
         np.testing.assert_allclose(h.lkl(others, np.full(I - 1, 0.1), np.full(I - 1, 0.2)),
                                    want[others], rtol=1e-12)
+
+
+def test_fast_alpha_probes_on_data_with_a_distance_beyond_the_kappa_clamp(pkg, orc_libm, mid_sim):
+    """The small-alpha (kappa form) kernels give their alpha probes the distance clamped to 1000 Mb
+    (fast_dev.hpp: KAPPA_DCLAMP) -- right only while every finite distance is below that.  The
+    M-step's own probes never meet such data (dbfgs_available: distances <= 46 Mb), but a caller of
+    nghmm_lkl_batch chooses its points: (F, a), (F, a +- 5e-7) with a = 1e-5 on a data set with one
+    gap of 1500 Mb passes the pattern's |da| d_max <= 1e-3 and alpha d_max <= 2^-6.  fd_pattern
+    must then refuse the kappa form (round-5 advisory: it did not, and the probes' likelihoods were
+    silently those of a 1000 Mb gap): every point against the oracle at 1e-12, and the probes'
+    differences from f(x) against the oracle's."""
+    d, gl = mid_sim
+    pos = d.pos_dist_mb.copy()
+    pos[2500] = 1500.0
+    F0, a0, da = 0.3, 1e-5, 5e-7
+    hmm, em = _pair(pkg, orc_libm, gl, pos, indF=F0, alpha=a0)
+    em.init_emission(); hmm.init_emission()
+    pts = [(F0, a0), (F0, a0 + da), (F0, a0 - da)]
+    ind = np.repeat(np.arange(d.n_ind), 3)
+    F = np.tile([p[0] for p in pts], d.n_ind)
+    A = np.tile([p[1] for p in pts], d.n_ind)
+    got = hmm.lkl(ind, F, A)
+    e = em.e_prob
+    want = np.array([-orc_libm.lkl([F[p], A[p]], e[ind[p]], pos) for p in range(len(ind))])
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    for k in (1, 2):
+        np.testing.assert_allclose(got[k::3] - got[0::3], want[k::3] - want[0::3], rtol=1e-4, atol=2e-8)
+    hmm.close()
