@@ -16,52 +16,34 @@ extern "C" {
 #endif
 
 /* Measurement and debugging switches of a handle.  None changes a result beyond rounding (the
- * kernels, their order on the stream or what is printed; DESIGN.md section 7 says what each is
- * for).  A handle reads them from the environment ONCE, in nghmm_create -- NGHMM_<NAME> with
- * the name in capitals; a variable that is set without a number counts as 1 -- and a replica
- * inherits its parent's; later only this call changes them:
- *   pipeline          two-lane objective rounds: -1 by cohort size (default), 0 off, 1 on
- *   no_bg             1: backward sweep and est_maf after the objective rounds, not behind them
- *   bg_parts          est_maf goes behind the rounds in this many parts (default 2)
- *   no_fuse           1: E-step and M-step each make a forward walk of their own
- *   eager_emission    1: stored emissions refreshed right after every frequency update
- *   estmaf_interp     0: every est_maf pass evaluated over all individuals (default 1)
- *   estmaf_sitemajor  1: est_maf on a site-major copy of the posteriors
- *   estmaf_no_rows    1: small cohorts take a wave per site instead of four sites per wave
+ * kernels, or their order on the streams).  A handle reads them from the environment ONCE, in
+ * nghmm_create -- NGHMM_<NAME> with the name in capitals; a variable that is set without a number
+ * counts as 1 -- and a replica inherits its parent's; later only this call changes them:
+ *   spans             1: fast mode records the timing events behind nghmm_kernel_ms around the
+ *                     kernel families of nghmm_mstep_indf / nghmm_estep_mstep / nghmm_iter_em (default 0:
+ *                     the events are packets the queue works through between two kernels, 0.05 ms per
+ *                     EM iteration -- 8 % of an iteration of 100 x 100 000 -- and an iteration then ends
+ *                     by a stream synchronisation instead of a polled word; nghmm_kernel_ms reads 0
+ *                     for those calls without it); exact mode always records
+ *   no_bg_stream      1: backward sweep and est_maf between the objective rounds on the handle's one
+ *                     stream instead of next to them on a second (bench.py --serial_kernels,
+ *                     profiles/collect.sh: every kernel's span is then its own)
+ *   no_dev_bfgs       1: fast mode's L-BFGS-B machines on the host, every round a round trip (what
+ *                     exact mode and groups of handles use; default 0: on the device,
+ *                     kernels_bfgs.hip -- the same steps, bit for bit)
+ *   estmaf_interp     0: every est_maf pass evaluated over all individuals (default 1: a checked
+ *                     interpolant carries most of them; tests hold the two together)
  *   estmaf_no_called  1: called genotypes (packed handles) through the general est_maf kernels
  *                     instead of their closed form (k_fast_estmaf_called_sums)
- *   no_xdeg2          1: the alpha probes' exp((alpha_0 - alpha_probe) d) always by the
- *                     degree-4 polynomial (default: degree 2 where |.| <= 1e-5, the same to
- *                     half an ulp)
- *   exact_serial      1: exact-mode recursions as one lane per chain (kernels_exact.hip)
- *                     instead of producer-consumer workgroups (kernels_exact_pc.hip): same bits
- *   estmaf_exact_lanes 1: exact-mode est_maf with a lane per site instead of a wave per site
- *                     (same bits; measured slower, kept for the comparison)
- *   estmaf_exact_sel  1: exact-mode est_maf on the select forms of det_exp / det_log (same
- *                     bits; measured slower since round 4's kernel, default 0)
- *   exact_bg_waves    exact mode, fused iteration: est_maf runs underneath the objective rounds
- *                     in 16 pieces capped at this many waves per SIMD (default 3; 0: uncapped;
- *                     -1: after the rounds); exact_bg_depth: pieces queued under a round (3)
- *   exact_estep_overlap 0: exact mode's fused iteration runs its E-step before the objective
- *                     rounds instead of next to the first of them (default 1)
- *   timing            1: host-side phase times of every M-step on stderr
- *   debug_modes       1: kernel versions of every objective round on stderr
- *   no_dev_bfgs       1: fast mode's L-BFGS-B machines on the host, every round a round trip
- *                     (rounds 1-4; default 0: on the device, kernels_bfgs.hip -- same results)
- *   no_bg_stream      1: with the machines on the device, backward sweep and est_maf between the
- *                     objective rounds on the handle's one stream instead of next to them on a
- *                     second (what bench.py --serial_kernels and profiles/collect.sh run: every
- *                     kernel's span is then its own)
- *   estmaf_w2         1: est_maf of 513 .. 1024 individuals on two waves of 8 per lane (measured
- *                     slower: 10.1 vs 8.5 ms at 1000 x 1M)
- *   spans             1: fast mode records the timing events behind nghmm_kernel_ms around the
- *                     kernel families of nghmm_mstep_indf / nghmm_estep_mstep / nghmm_iter_em
- *                     (default 0: the events are packets the queue works through between two
- *                     kernels, 0.05 ms per EM iteration -- 8 % of an iteration of 100 x 100 000;
- *                     nghmm_kernel_ms then reads 0 for those calls); exact mode always records
- * Fixed at creation (environment only): fast_c (waves per individual), spin_sync (replicas
- * wait spinning).  Unknown names return NGHMM_ERR_ARG.  Outside the handle: NGHMM_HOST_THREADS
- * (host threads of the L-BFGS-B state machines, read once per process). */
+ *   estmaf_no_rows    1: small cohorts take a wave per site instead of four sites per wave
+ *   bg_parts          host-planned rounds: est_maf goes behind the rounds in this many parts (default 2;
+ *                     0: backward sweep and est_maf after the rounds)
+ *   exact_serial      1: exact-mode recursions as one lane per chain (kernels_exact.hip) instead of
+ *                     producer-consumer workgroups (kernels_exact_pc.hip): the same bits
+ *   dbg_abort_round   test hook: a device-planned M-step returns an error after this round
+ * Fixed at creation (environment only): fast_c (waves per individual).  Unknown names return
+ * NGHMM_ERR_ARG.  Outside the handle: NGHMM_HOST_THREADS (host threads of the L-BFGS-B state
+ * machines, read once per process). */
 int nghmm_set_switch(nghmm_t* h, const char* name, long value);
 
 /* Fast-mode layout of the site axis: every individual's sites are cut into 64 * waves

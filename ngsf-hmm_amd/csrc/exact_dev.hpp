@@ -50,38 +50,6 @@ __device__ __forceinline__ void hwe_log(double maf, double F, double& h0, double
   if (F == 1) h1 = -kINF;
 }
 
-// The same two routines on the select forms of det_exp / det_log (detmath.h: for every argument
-// exactly the operations det_exp / det_log perform for it, the case analysis by selects on
-// values every lane computes -- the same bits, tests/test_detmath.py).  Lanes whose arguments
-// fall into different cases of the branching functions make a wave issue every case one after
-// the other; est_maf's lanes (individuals of one site, or sites) always do.
-__device__ __forceinline__ double logsum3_sel(double a0, double a1, double a2) {
-  double M = a0;
-  M = (a1 >= M) ? a1 : M;
-  M = (a2 >= M) ? a2 : M;
-  if (M == NEG_INFINITY) return NEG_INFINITY;
-  double sum = 0;
-  sum += det_exp_sel(a0 - M);
-  sum += det_exp_sel(a1 - M);
-  sum += det_exp_sel(a2 - M);
-  return det_log_pos(sum) + M;
-}
-
-__device__ __forceinline__ double log_or_minf_sel(double v) {
-  double r = det_log_pos(v);
-  return (r == NEG_INFINITY) ? -kINF : r;
-}
-
-__device__ __forceinline__ void hwe_log_sel(double maf, double F, double& h0, double& h1, double& h2) {
-  h0 = (1 - maf) * (1 - maf) + (1 - maf) * maf * F;
-  h1 = 2 * (1 - maf) * maf - 2 * (1 - maf) * maf * F;
-  h2 = maf * maf + (1 - maf) * maf * F;
-  h0 = log_or_minf_sel(h0);
-  h1 = log_or_minf_sel(h1);
-  h2 = log_or_minf_sel(h2);
-  if (F == 1) h1 = -kINF;
-}
-
 // calc_emission (shared/HMM.cpp:144-154)
 __device__ __forceinline__ double emission_log(double g0, double g1, double g2, double maf, int k) {
   double h0, h1, h2;

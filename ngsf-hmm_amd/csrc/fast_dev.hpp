@@ -45,12 +45,7 @@ constexpr int UG = 2;     // ... of this many sites each (NB * UG == RENORM)
 // are adjacent, so the 64 B sector around a posterior holds ONE site (est_maf fetches nothing
 // it does not use), and a group's 64 x 8 block of a tile row is 4 KB contiguous (the backward
 // sweep writes it with full wave-stores from eight waves through LDS).
-// NGHMM_POST8=0: the earlier [tile row][i][l] (a sector = 8 sites of one individual, which
-// est_maf shares between neighbouring workgroups through L2 as far as L2 keeps it).
-#ifndef NGHMM_POST8
-#define NGHMM_POST8 1
-#endif
-constexpr bool kPost8 = NGHMM_POST8 != 0;
+constexpr bool kPost8 = true;
 __host__ __device__ constexpr uint64_t post_tile_doubles(uint64_t I) {
   return kPost8 ? ((I + 7) / 8) * 512 : I * 64;
 }
@@ -255,18 +250,6 @@ __device__ __forceinline__ double exp_small(double x) {
   else return fma(x, fma(x, fma(x, fma(x, 1.0 / 24, 1.0 / 6), 0.5), 1.0), 1.0);
 }
 
-// exp(y) for -2^-6 <= y <= 0 without range reduction (y^8/8! < 1e-19)
-__device__ __forceinline__ double exp_tiny7(double y) {
-  double p = 1.0 / 5040.0;
-  p = fma(p, y, 1.0 / 720.0);
-  p = fma(p, y, 1.0 / 120.0);
-  p = fma(p, y, 1.0 / 24.0);
-  p = fma(p, y, 1.0 / 6.0);
-  p = fma(p, y, 0.5);
-  p = fma(p, y, 1.0);
-  return fma(p, y, 1.0);
-}
-
 // GroupDesc::mode: 0 = general points; else the finite-difference pattern of
 // shared/bfgs.cpp:22-43 -- point 0 = x, then NF probes that differ from it in F only,
 // then NA probes that differ in alpha only, by so little that exp(-(alpha +- eh) d) =
@@ -292,7 +275,7 @@ __host__ __device__ constexpr uint32_t fd_mode(int nf, int na, bool small, bool 
 // that small (alpha * mean finite distance < 1e-6) take the general-exp version, whose c = exp(-alpha
 // d), 1 - c round as the reference's do.
 __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, uint64_t T, bool forced_visits,
-                           bool allow_xdeg2, double alpha_small_min) {
+                           double alpha_small_min) {
   if (G.np < 2 || !(G.F[0] > 0 && G.F[0] < 1) || !(G.A[0] > 0)) return 0;
   int nf = 0, na = 0;
   bool ownex = false;
@@ -336,7 +319,7 @@ __host__ __device__ inline uint32_t fd_pattern(const GroupDesc& G, double dmax, 
   // caller of nghmm_lkl_batch chooses need not be, and then take the general-exp version.
   const bool kappa_ok = na == 0 || (dmax < KAPPA_DCLAMP && damax * KAPPA_DCLAMP <= 0.05);
   return fd_mode(nf, na, G.A[0] * dmax <= 0.015625 && G.A[0] >= alpha_small_min && kappa_ok,
-                 allow_xdeg2 && na > 0 && xmax <= 1e-5) |
+                 na > 0 && xmax <= 1e-5) |
          (ownex ? FD_OWNEX : 0u);
 }
 

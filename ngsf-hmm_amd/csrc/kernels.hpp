@@ -76,9 +76,13 @@ void launch_backward_exact_pc(hipStream_t st, const double* eprob, const double*
 
 // est_maf per site (shared/gen_func.cpp:974-1009): gl_sites [S_own][I_tot][3],
 // marg_sites [S_own][I_tot] -> freq_out[S_own]; passes_out (nullable) counts passes.
+// bg_waves = kExactBgWaves: the version capped at that many waves per SIMD, which runs on a second
+// stream underneath the objective rounds of exact mode's fused iteration (in kExactBgDepth pieces
+// queued at a time); 0: uncapped
+constexpr int kExactBgWaves = 3, kExactBgDepth = 3;
 void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
-                         uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out, int lanes = 0,
-                         int bg_waves = 0, bool sel = false);
+                         uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out,
+                         int bg_waves = 0);
 
 // --freq_est 2 / --e_prob 2 AS INTENDED (kernels_ld.hip; opt-in, parity unpinned: the reference
 // aborts).  The chain through the sites: gl = log GL (exact) or linear GL (fast), site-major;

@@ -84,7 +84,7 @@ struct DevPtrs {
   // fd_pattern's view of the data
   double dmax, alpha_small_min;
   uint64_t T;
-  int packed, allow_xdeg2;
+  int packed;
 };
 
 __host__ __device__ constexpr uint32_t slot_mode(uint32_t slot) {
@@ -114,7 +114,7 @@ __device__ inline void build_group(const BfgsProblem& p, uint32_t i, const DevPt
     ++np;
   }
   G.np = np;
-  G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.allow_xdeg2 != 0, D.alpha_small_min);
+  G.mode = fd_pattern(G, D.dmax, D.T, D.packed != 0, D.alpha_small_min);
 }
 
 // (the number of points the optimizer asked for: G.np before fd_pad fills the pattern up)
@@ -137,18 +137,6 @@ __device__ inline uint32_t build_group_padded(const BfgsProblem& p, uint32_t i, 
 // P_out - 1 into the machines of that plan's individuals, P_out planned.  Plans are numbered
 // through the handle's life (slot = P mod kRing, worklists by parity), so every kernel finds its
 // counters zeroed by the one two before it.
-#ifdef NGHMM_BFGS_TIMING   // phase times of the slowest wave (tools/bfgs_phase_timing.py)
-__device__ unsigned long long g_bfgs_phase[8];
-#define PHASE(k)                                                                      \
-  if (lane == 0) {                                                                    \
-    const unsigned long long now = wall_clock64();                                    \
-    atomicMax(&g_bfgs_phase[k], now - t_phase);                                       \
-    t_phase = now;                                                                    \
-  }
-#else
-#define PHASE(k)
-#endif
-
 constexpr uint32_t kRedone = 0xffffffffu;  // last_mode: the round was a site shard's repeat by the general kernel
 constexpr int kWg = 4;  // 4 x 10 KB of LDS: three workgroups per CU
 struct WaveLds {
@@ -161,9 +149,6 @@ static_assert(kWg * sizeof(WaveLds) <= 65536, "one workgroup's LDS");
 template <bool FIRST>
 __global__ void __launch_bounds__(64 * kWg)
 k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_fixed, int alpha_fixed) {
-#ifdef NGHMM_BFGS_TIMING
-  unsigned long long t_phase = wall_clock64();
-#endif
   __shared__ WaveLds wl[kWg];
   __shared__ uint32_t wg_slot[kWg];   // mode slot + 1 of the wave's individual in the next plan, 0: none
   __shared__ uint32_t wg_pos[kWg], wg_all;
@@ -210,7 +195,6 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       }
     }
   }
-  PHASE(0)  // problem + work arrays in LDS
   bool keep = false;        // the solver's arrays go back to memory
   bool walk = false;        // (lane 0) the round's values are good: the machine takes its step
   if (have && lane == 0) {
@@ -317,7 +301,6 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       {
         const bool again = state == 1;
         p.acc_ref_calls += (uint32_t)rc;
-        PHASE(1)  // solver scalars in, gradient, setulb calls
         if (again) {
           bfgs_plan<DetPow>(p);
           ++p.n_rounds;
@@ -333,7 +316,6 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
         }
         if (keep && mats_here) p.big_valid = 1;
         D.prob[i] = p;
-        PHASE(2)  // plan, descriptor, state out
       }
     }
     // vectors and index arrays back if the machine goes on; the matrices if this step wrote them
@@ -348,7 +330,6 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       }
     }
   }
-  PHASE(3)  // work arrays back
 
   // the workgroup's individuals into plan P_out: one atomic per mode present among them (its
   // worklist), one for the list of everybody, one ticket
@@ -450,7 +431,6 @@ k_bfgs_advance(DevPtrs D, uint32_t P_out, uint32_t n_in, uint32_t round, int F_f
       __hip_atomic_store(&t[0], P_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  PHASE(4)  // plan entries, ticket, publication
 }
 
 // the end of a fused iteration (FastState::DevBfgs::h_epi): see dbfgs_epilogue
@@ -496,7 +476,6 @@ DevPtrs dev_ptrs(const FastState& fs, double* d_F, double* d_A) {
   D.alpha_small_min = fs.alpha_small_min;
   D.T = fs.T;
   D.packed = fs.packed ? 1 : 0;
-  D.allow_xdeg2 = fs.sw.no_xdeg2 ? 0 : 1;
   return D;
 }
 
@@ -506,17 +485,6 @@ bool dmalloc(T** p, size_t n) {
 }
 
 }  // namespace
-
-#ifdef NGHMM_BFGS_TIMING
-extern "C" void nghmm_debug_bfgs_phases(unsigned long long* out, int reset) {
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfgs_phase), sizeof(unsigned long long) * 8);
-  if (reset) {
-    unsigned long long z[8] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bfgs_phase), z, sizeof z);
-  }
-}
-#endif
 
 bool dbfgs_available(const FastState& fs) {
   if (fs.I == 0 || fs.I > 0x0fffffffu) return false;

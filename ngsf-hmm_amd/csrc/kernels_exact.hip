@@ -229,7 +229,7 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 // 13.5 s alone, est_maf 4.2 s against 2.4 s alone).  Claiming 512 / BG_WAVES registers caps the
 // kernel at BG_WAVES waves per SIMD and leaves the other slots to the chains, whose waves
 // raise their issue priority.
-template <int BG_WAVES, bool SEL>
+template <int BG_WAVES>
 __global__ void __launch_bounds__(256)
 k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
                uint64_t I, double* __restrict__ freq_out, uint32_t* __restrict__ passes_out) {
@@ -258,16 +258,15 @@ k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
         double g0, g1, g2;
         gl_fetch(gl, site * I + i, g0, g1, g2);
         double h0, h1, h2;
-        if constexpr (SEL) hwe_log_sel(freq, F, h0, h1, h2);
-        else hwe_log(freq, F, h0, h1, h2);
+        hwe_log(freq, F, h0, h1, h2);
         double p0 = g0 + h0, p1 = g1 + h1, p2 = g2 + h2;  // post_prob, gen_func.cpp:920-932
-        const double norm = SEL ? logsum3_sel(p0, p1, p2) : logsum3(p0, p1, p2);
+        const double norm = logsum3(p0, p1, p2);
         p0 -= norm;
         p1 -= norm;
         p2 -= norm;
-        p0 = SEL ? det_exp_sel(p0) : det_exp(p0);
-        p1 = SEL ? det_exp_sel(p1) : det_exp(p1);
-        p2 = SEL ? det_exp_sel(p2) : det_exp(p2);
+        p0 = det_exp(p0);
+        p1 = det_exp(p1);
+        p2 = det_exp(p2);
         tn = p1 + p2 * (2 - F);
         td = 2 * p1 + (p0 + p2) * (2 - F);
       }
@@ -302,91 +301,6 @@ k_estmaf_exact(const GlView gl, const double* __restrict__ marg, uint64_t S_own,
     again = (adl > kEPS) && (iters++ < 100);
   } while (again);
   if (lane == 0) {
-    freq_out[site] = freq;
-    if (passes_out) passes_out[site] = passes;
-  }
-}
-
-// The same loop with a LANE per site (a wave = 64 consecutive sites).  A lane walks its site's
-// individuals in order and adds their terms to its own (num, den): the reference's serial sum
-// (gen_func.cpp:984-1003) is then the natural order of the loop -- the wave-per-site kernel
-// above spends as many instructions on adding 64 lanes' terms one by one through v_readlane
-// as on the ten transcendental calls that produce them.  The same device functions on the
-// same operands in the same order: every frequency is bit-identical.
-// The likelihoods are site-major (a lane's cells are I * 24 B from its neighbour's), so a
-// block of EL_B individuals of the wave's 64 rows is staged through LDS: whole 24 EL_B-byte row
-// segments in, one padded row per lane out (stride odd in doubles: conflict-free).
-constexpr int EL_B = 8;
-constexpr uint64_t kEstmafLanesMinSites = 65536;
-__global__ void __launch_bounds__(64)
-k_estmaf_exact_lanes(const GlView gl, const double* __restrict__ marg, uint64_t S_own, uint64_t I,
-                     double* __restrict__ freq_out, uint32_t* __restrict__ passes_out) {
-  __shared__ double sg[64][3 * EL_B + 1];
-  __shared__ double sm[64][EL_B + 1];
-  const int lane = threadIdx.x;
-  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
-  const uint64_t site = s0 + lane;
-  const int nrows = (S_own - s0) < 64 ? (int)(S_own - s0) : 64;
-  const bool dense = gl.dense != nullptr;
-  const double* gbase = dense ? gl.dense + (gl.cell0 + s0 * I) * 3 : nullptr;
-  const double* mbase = marg + s0 * I;
-
-  int iters = 0;
-  uint32_t passes = 0;
-  double num = 0, den = 0, freq = 0.01;
-  bool again = lane < nrows;
-  while (__ballot(again) != 0) {
-    const double prev_freq = freq;
-    for (uint64_t i0 = 0; i0 < I; i0 += EL_B) {
-      const int nb = (I - i0) < (uint64_t)EL_B ? (int)(I - i0) : EL_B;
-      if (dense) {
-        const int per_row = 3 * nb;
-        for (int k = lane; k < nrows * per_row; k += 64) {
-          const int r = k / per_row, c = k - r * per_row;
-          sg[r][c] = gbase[((uint64_t)r * I + i0) * 3 + c];
-        }
-      }
-      for (int k = lane; k < nrows * nb; k += 64) {
-        const int r = k / nb, c = k - r * nb;
-        sm[r][c] = mbase[(uint64_t)r * I + i0 + c];
-      }
-      __syncthreads();
-      if (again) {
-        for (int j = 0; j < nb; ++j) {
-          const double F = sm[lane][j];
-          double g0, g1, g2;
-          if (dense) {
-            g0 = sg[lane][3 * j];
-            g1 = sg[lane][3 * j + 1];
-            g2 = sg[lane][3 * j + 2];
-          } else {
-            gl_fetch(gl, site * I + i0 + j, g0, g1, g2);
-          }
-          double h0, h1, h2;
-          hwe_log(freq, F, h0, h1, h2);
-          double p0 = g0 + h0, p1 = g1 + h1, p2 = g2 + h2;  // post_prob, gen_func.cpp:920-932
-          const double norm = logsum3(p0, p1, p2);
-          p0 -= norm;
-          p1 -= norm;
-          p2 -= norm;
-          p0 = det_exp(p0);
-          p1 = det_exp(p1);
-          p2 = det_exp(p2);
-          num += p1 + p2 * (2 - F);
-          den += 2 * p1 + (p0 + p2) * (2 - F);
-        }
-      }
-      __syncthreads();
-    }
-    if (again) {
-      ++passes;
-      freq = num / den;
-      const double dlt = prev_freq - freq;
-      const double adl = (dlt >= 0) ? dlt : -dlt;
-      again = (adl > kEPS) && (iters++ < 100);
-    }
-  }
-  if (lane < nrows) {
     freq_out[site] = freq;
     if (passes_out) passes_out[site] = passes;
   }
@@ -1033,30 +947,15 @@ void launch_backward_exact(hipStream_t st, const double* eprob, const double* po
 
 void launch_estmaf_exact(hipStream_t st, const GlView& gl_sites, const double* marg_sites,
                          uint64_t S_own, uint64_t I_tot, double* freq_out, uint32_t* passes_out,
-                         int lanes, int bg_waves, bool sel) {
+                         int bg_waves) {
   if (S_own == 0) return;
-  // a lane per site needs enough sites to fill the chip's lanes (64 sites per wave); the few
-  // sites of a small shard or of a short data set take a wave each (lanes: -1 by size, 0 / 1)
-  if (lanes < 0 ? S_own >= kEstmafLanesMinSites : lanes != 0)
-    hipLaunchKernelGGL(k_estmaf_exact_lanes, dim3((unsigned)((S_own + 63) / 64)), dim3(64), 0, st,
-                       gl_sites, marg_sites, S_own, I_tot, freq_out, passes_out);
-  else {
-    const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
-#define ESTMAF_EXACT(BG)                                                                          \
-  do {                                                                                            \
-    if (sel)                                                                                      \
-      hipLaunchKernelGGL((k_estmaf_exact<BG, true>), grid, block, 0, st, gl_sites, marg_sites,    \
-                         S_own, I_tot, freq_out, passes_out);                                     \
-    else                                                                                          \
-      hipLaunchKernelGGL((k_estmaf_exact<BG, false>), grid, block, 0, st, gl_sites, marg_sites,   \
-                         S_own, I_tot, freq_out, passes_out);                                     \
-  } while (0)
-    if (bg_waves == 2) ESTMAF_EXACT(2);
-    else if (bg_waves == 3) ESTMAF_EXACT(3);
-    else if (bg_waves == 4) ESTMAF_EXACT(4);
-    else ESTMAF_EXACT(0);
-#undef ESTMAF_EXACT
-  }
+  const dim3 grid((unsigned)((S_own + 3) / 4)), block(256);
+  if (bg_waves == kExactBgWaves)
+    hipLaunchKernelGGL((k_estmaf_exact<kExactBgWaves>), grid, block, 0, st, gl_sites, marg_sites, S_own, I_tot,
+                       freq_out, passes_out);
+  else
+    hipLaunchKernelGGL((k_estmaf_exact<0>), grid, block, 0, st, gl_sites, marg_sites, S_own, I_tot, freq_out,
+                       passes_out);
 }
 
 void launch_viterbi_fwd_exact(hipStream_t st, const double* eprob, const double* pos, uint64_t S,

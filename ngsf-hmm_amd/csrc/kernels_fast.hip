@@ -265,21 +265,11 @@ struct SwitchName {
   int Switches::*field;
 };
 const SwitchName kSwitches[] = {
-    {"pipeline", &Switches::pipeline}, {"no_bg", &Switches::no_bg},
-    {"bg_parts", &Switches::bg_parts}, {"no_fuse", &Switches::no_fuse},
-    {"eager_emission", &Switches::eager_emission}, {"estmaf_interp", &Switches::estmaf_interp},
-    {"estmaf_sitemajor", &Switches::estmaf_sitemajor}, {"estmaf_no_rows", &Switches::estmaf_no_rows},
-    {"estmaf_no_called", &Switches::estmaf_no_called},
-    {"no_xdeg2", &Switches::no_xdeg2},
+    {"bg_parts", &Switches::bg_parts}, {"estmaf_interp", &Switches::estmaf_interp},
+    {"estmaf_no_rows", &Switches::estmaf_no_rows}, {"estmaf_no_called", &Switches::estmaf_no_called},
     {"fast_c", &Switches::fast_c}, {"exact_serial", &Switches::exact_serial},
-    {"estmaf_exact_lanes", &Switches::estmaf_exact_lanes}, {"exact_bg_waves", &Switches::exact_bg_waves},
-    {"exact_bg_depth", &Switches::exact_bg_depth}, {"estmaf_exact_sel", &Switches::estmaf_exact_sel},
-    {"exact_estep_overlap", &Switches::exact_estep_overlap},
-    {"spin_sync", &Switches::spin_sync}, {"timing", &Switches::timing},
-    {"debug_modes", &Switches::debug_modes}, {"no_dev_bfgs", &Switches::no_dev_bfgs}, {"estmaf_w2", &Switches::estmaf_w2},
-    {"dbg_abort_round", &Switches::dbg_abort_round},
-    {"no_bg_stream", &Switches::no_bg_stream}, {"spans", &Switches::spans},
-    {"no_epilogue", &Switches::no_epilogue}, {"no_preplan", &Switches::no_preplan}};
+    {"dbg_abort_round", &Switches::dbg_abort_round}, {"no_dev_bfgs", &Switches::no_dev_bfgs},
+    {"no_bg_stream", &Switches::no_bg_stream}, {"spans", &Switches::spans}};
 
 }  // namespace
 

@@ -16,32 +16,15 @@ namespace nghmm {
 // result beyond rounding.  Read from the environment ONCE, when the handle is created
 // (NGHMM_<NAME in capitals>); afterwards only nghmm_set_switch changes them.
 struct Switches {
-  int pipeline = -1;          // two-lane objective rounds: -1 by cohort size, 0 off, 1 on
-  int no_bg = 0;              // backward sweep and est_maf after the rounds, not behind them
-  int bg_parts = 2;           // est_maf behind the rounds in this many parts
-  int no_fuse = 0;            // E-step and M-step each with a forward walk of their own
-  int eager_emission = 0;     // refresh the stored emissions right after a frequency update
+  int bg_parts = 2;           // fused iteration, host-planned rounds: est_maf behind the rounds in this many parts (0: sweep and est_maf after the rounds)
   int estmaf_interp = 1;      // 0: every est_maf pass evaluated over all individuals
-  int estmaf_sitemajor = 0;   // est_maf on a site-major copy of the posteriors
   int estmaf_no_rows = 0;     // small cohorts: a wave per site instead of four sites per wave
   int estmaf_no_called = 0;   // called genotypes through the general est_maf kernels too
-  int no_xdeg2 = 0;           // alpha probes always by the degree-4 polynomial
   int fast_c = 0;             // waves per individual (0: by cohort size); at creation only
-  int exact_serial = 0;       // exact mode: one lane per chain instead of producer-consumer
-  int estmaf_exact_lanes = 0;   // exact est_maf with a lane per site (measured slower: 4.05 vs 2.38 s): 0 off, 1 on
-  int exact_bg_waves = 3;     // exact est_maf underneath the rounds: waves per SIMD (0: all; -1: after them)
-  int estmaf_exact_sel = 0;   // exact est_maf on the select forms of det_exp / det_log (same bits; measured 2.62 vs 2.38 s)
-  int exact_estep_overlap = 1;  // exact mode, fused iteration: the E-step next to the first objective rounds
-  int exact_bg_depth = 3;     // ... pieces of it queued underneath a round at most
-  int spin_sync = 0;          // replicas wait spinning instead of on a blocking event
-  int timing = 0;             // host-side phase times of every M-step on stderr
-  int debug_modes = 0;        // kernel versions of every objective round on stderr
-  int estmaf_w2 = 0;          // est_maf of 513..1024 individuals on two waves of 8 per lane (measured: see DESIGN.md)
+  int exact_serial = 0;       // exact mode: one lane per chain instead of producer-consumer workgroups (same bits)
   int dbg_abort_round = 0;    // test hook: a device-planned M-step returns an error after this round
   int no_dev_bfgs = 0;        // the M-step's L-BFGS-B machines on the host (rounds 1-4), not on the device
   int no_bg_stream = 0;       // device-planned rounds: backward sweep and est_maf between the rounds on the one stream, not next to them on a second
-  int no_epilogue = 0;        // device-planned iteration: its end by copies and a stream synchronisation instead of the epilogue kernel's pinned word
-  int no_preplan = 0;         // ... and the next M-step's first round planned when it starts, not when this one ends
   int spans = 0;              // fast mode: timing events around the kernel families of a fused iteration, for nghmm_kernel_ms (0.05 ms per iteration: 8 % of configs[1]'s)
   static Switches from_env();
   // false: no switch of that name

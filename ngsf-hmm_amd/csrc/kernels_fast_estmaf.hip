@@ -132,66 +132,23 @@ __device__ __forceinline__ double wave_sum_pair(double pn, double pd) {
 // same stopping rule, at ~1/60 of the cost per pass.  A pass whose stopping decision
 // would be closer than 1e-9 (relative) to the threshold, or whose r leaves the
 // interval, goes back to exact evaluation (one more build is allowed per site).
-#ifndef NGHMM_EST_EN
-#define NGHMM_EST_EN 12
-#endif
-constexpr int EN = NGHMM_EST_EN;        // Chebyshev nodes per interval
+constexpr int EN = 12;                  // Chebyshev nodes per interval
 constexpr int EST_SCALARS = 8;          // num, den, pnum, pden, iters, mid, half, tF
 constexpr int EST_FIELDS = EST_SCALARS + 2 * EN;
 enum : uint8_t { EST_DONE = 0, EST_INTERP = 1, EST_EXACT = 2 };
-#ifndef NGHMM_EST_K0
-#define NGHMM_EST_K0 2
-#endif
-constexpr int EST_K0 = NGHMM_EST_K0;    // exact passes before the first interval
+constexpr int EST_K0 = 2;               // exact passes before the first interval
 constexpr int EST_MIN_GAIN = 24;        // build only if about this many passes remain
-#ifndef NGHMM_EST_DMAX
-#define NGHMM_EST_DMAX 0.85
-#endif
-#ifndef NGHMM_EST_MULT
-#define NGHMM_EST_MULT 32.0
-#endif
-constexpr double EST_DMAX = NGHMM_EST_DMAX;  // interval length <= EST_DMAX * r ahead ...
+constexpr double EST_DMAX = 0.85;       // interval length <= EST_DMAX * r ahead ...
 constexpr double EST_BACK = 0.1;        // ... plus this fraction of it behind
-constexpr double EST_MULT = NGHMM_EST_MULT;  // ... and about this many current steps
-#ifndef NGHMM_EST_FIT
-#define NGHMM_EST_FIT 0.72
-#endif
-#ifndef NGHMM_EST_KMAX
-#define NGHMM_EST_KMAX 32
-#endif
-constexpr double EST_FIT = NGHMM_EST_FIT;    // build once k * step <= EST_FIT * EST_DMAX * r ...
-constexpr int EST_KMAX = NGHMM_EST_KMAX;     // ... or after this many passes at the latest
-#ifndef NGHMM_EST_TOL
-#define NGHMM_EST_TOL 1e-11
-#endif
-constexpr double EST_TOL = NGHMM_EST_TOL;  // interpolant vs exact pass, relative
+constexpr double EST_MULT = 32.0;       // ... and about this many current steps
+constexpr double EST_FIT = 0.72;        // build once k * step <= EST_FIT * EST_DMAX * r ...
+constexpr int EST_KMAX = 32;            // ... or after this many passes at the latest
+constexpr double EST_TOL = 1e-11;       // interpolant vs exact pass, relative
 constexpr double EST_GUARD = 1e-9;      // stopping decisions this close go back to exact
 // cos((2j+1) pi/(2 EN)) and (-1)^j sin((2j+1) pi/(2 EN)): first-kind Chebyshev nodes and
 // their barycentric weights
-#if NGHMM_EST_EN == 8
-__constant__ double kChebC[EN] = {0.9807852804032304, 0.8314696123025452, 0.5555702330196023, 0.19509032201612833, -0.1950903220161282, -0.555570233019602, -0.8314696123025453, -0.9807852804032304};
-__constant__ double kChebW[EN] = {0.19509032201612825, -0.5555702330196022, 0.8314696123025452, -0.9807852804032304, 0.9807852804032304, -0.8314696123025455, 0.5555702330196022, -0.1950903220161286};
-#elif NGHMM_EST_EN == 9
-__constant__ double kChebC[EN] = {0.984807753012208, 0.8660254037844387, 0.6427876096865394, 0.3420201433256688, 6.123233995736766e-17, -0.3420201433256685, -0.6427876096865394, -0.8660254037844385, -0.984807753012208};
-__constant__ double kChebW[EN] = {0.17364817766693033, -0.49999999999999994, 0.766044443118978, -0.9396926207859083, 1.0, -0.9396926207859084, 0.766044443118978, -0.5000000000000003, 0.17364817766693028};
-#elif NGHMM_EST_EN == 10
-__constant__ double kChebC[EN] = {0.9876883405951378, 0.8910065241883679, 0.7071067811865476, 0.4539904997395468, 0.15643446504023092, -0.1564344650402306, -0.4539904997395467, -0.7071067811865475, -0.8910065241883678, -0.9876883405951377};
-__constant__ double kChebW[EN] = {0.15643446504023087, -0.45399049973954675, 0.7071067811865475, -0.8910065241883678, 0.9876883405951378, -0.9876883405951378, 0.8910065241883679, -0.7071067811865476, 0.45399049973954686, -0.15643446504023098};
-#elif NGHMM_EST_EN == 11
-__constant__ double kChebC[EN] = {0.9898214418809327, 0.9096319953545184, 0.7557495743542583, 0.5406408174555977, 0.2817325568414298, 2.83276944882399e-16, -0.28173255684142967, -0.5406408174555972, -0.7557495743542582, -0.9096319953545182, -0.9898214418809327};
-__constant__ double kChebW[EN] = {0.14231483827328514, -0.4154150130018864, 0.6548607339452851, -0.8412535328311811, 0.9594929736144974, -1.0, 0.9594929736144974, -0.8412535328311814, 0.6548607339452852, -0.4154150130018867, 0.14231483827328517};
-#elif NGHMM_EST_EN == 12
 __constant__ double kChebC[EN] = {0.9914448613738104, 0.9238795325112867, 0.7933533402912352, 0.6087614290087207, 0.38268343236508984, 0.1305261922200517, -0.1305261922200516, -0.3826834323650895, -0.6087614290087207, -0.793353340291235, -0.9238795325112867, -0.9914448613738104};
 __constant__ double kChebW[EN] = {0.13052619222005157, -0.3826834323650898, 0.6087614290087207, -0.7933533402912352, 0.9238795325112867, -0.9914448613738104, 0.9914448613738104, -0.9238795325112868, 0.7933533402912352, -0.6087614290087209, 0.3826834323650899, -0.130526192220052};
-#elif NGHMM_EST_EN == 14
-__constant__ double kChebC[EN] = {0.9937122098932426, 0.9438833303083676, 0.8467241992282841, 0.7071067811865476, 0.5320320765153366, 0.3302790619551673, 0.11196447610330769, -0.11196447610330758, -0.3302790619551672, -0.5320320765153365, -0.7071067811865475, -0.8467241992282841, -0.9438833303083676, -0.9937122098932426};
-__constant__ double kChebW[EN] = {0.11196447610330786, -0.3302790619551671, 0.5320320765153366, -0.7071067811865475, 0.8467241992282841, -0.9438833303083675, 0.9937122098932426, -0.9937122098932426, 0.9438833303083675, -0.8467241992282842, 0.7071067811865476, -0.5320320765153367, 0.3302790619551672, -0.11196447610330798};
-#elif NGHMM_EST_EN == 16
-__constant__ double kChebC[EN] = {0.9951847266721969, 0.9569403357322088, 0.881921264348355, 0.773010453362737, 0.6343932841636455, 0.4713967368259978, 0.29028467725446233, 0.09801714032956077, -0.09801714032956065, -0.29028467725446216, -0.4713967368259977, -0.6343932841636454, -0.773010453362737, -0.8819212643483549, -0.9569403357322088, -0.9951847266721968};
-__constant__ double kChebW[EN] = {0.0980171403295606, -0.29028467725446233, 0.47139673682599764, -0.6343932841636455, 0.773010453362737, -0.8819212643483549, 0.9569403357322089, -0.9951847266721968, 0.9951847266721969, -0.9569403357322089, 0.881921264348355, -0.7730104533627371, 0.6343932841636455, -0.47139673682599786, 0.2902846772544624, -0.09801714032956083};
-#else
-#error "NGHMM_EST_EN must be 8 ... 12, 14 or 16"
-#endif
 
 // W = BLOCK/64 waves per site, NI individuals per lane held in registers.  With
 //   A = (1-f)^2, b = (1-f) f, C = f^2
@@ -268,11 +225,8 @@ __device__ __forceinline__ void estmaf_site(
   // has two memory round trips here, not NI of them.
   double sA[NI], sb[NI], sC[NI], u0[NI], nC[NI], fc[NI];
   {
-#ifndef NGHMM_EST_NB
-#define NGHMM_EST_NB 8
-#endif
-    // slots per batch of loads; NI = 12: two batches of six
-    constexpr int NB = NI < NGHMM_EST_NB ? NI : (NI % NGHMM_EST_NB ? NI / 2 : NGHMM_EST_NB);
+    // slots per batch of loads: eight; NI = 12: two batches of six
+    constexpr int NB = NI < 8 ? NI : (NI % 8 ? NI / 2 : 8);
     static_assert(NI % NB == 0, "whole batches");
     const bool one_block = (I_blk == I_tot);
     const uint32_t ib = (uint32_t)I_blk;
@@ -1264,7 +1218,6 @@ bool fast_estmaf_in_place(const FastState& fs, uint64_t I_tot) {
   // kernels up to 4096 individuals (measured at 10^9 site-individuals: in place 13.6 vs 14.4 ms
   // via the copy at 4000 individuals, 19.7 vs 16.5 ms at 8000: a site group's sectors outgrow
   // L2); the called-genotype sweep reads every cell once, whole sectors, at any size
-  if (fs.sw.estmaf_sitemajor) return false;
   return I_tot <= 4096 || (fs.packed && fs.called_table && !fs.sw.estmaf_no_called);
 }
 
@@ -1410,9 +1363,6 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       else if (I_tot <= 256) LAUNCH_TILE(4, 64);
       else if (I_tot <= 512) LAUNCH_TILE(8, 64);
       else if (I_tot <= 768) LAUNCH_TILE(12, 64);
-      // (experiment, switch estmaf_w2: a site of 513 .. 1024 individuals on TWO waves of 8
-      // individuals per lane -- half the per-individual constants per wave, more waves per SIMD)
-      else if (I_tot <= 1024 && fs.sw.estmaf_w2) LAUNCH_TILE(8, 128);
       else if (I_tot <= 1024) LAUNCH_TILE(16, 64);
       // several waves per site: a lane's slot k holds individual thread + BLOCK k, so a cohort
       // in the lower half of a size class leaves the upper slots of EVERY lane empty -- 12

@@ -14,14 +14,11 @@ namespace {
 // and per point the two rows' update; one exponent (point 0's) rescales all points, which are
 // perturbations of each other.
 //
-// SMALL versions run in the kappa form (fast_dev.hpp: op_step_k; NGHMM_KFORM=0 builds the earlier
-// form for A/B): the operators are kept divided by c_s = exp(-alpha d_s), whose product over the
+// SMALL versions run in the kappa form (fast_dev.hpp: op_step_k): the operators are kept divided
+// by c_s = exp(-alpha d_s), whose product over the
 // lane-chunk the end of the walk puts back -- 10 instructions for point 0 (the two rows 8), 10 per
 // F probe, 15 per alpha probe (kappa_probe = kappa m + (m - 1), m = exp((alpha_probe - alpha_0) d)
 // tiny-argument), 11 shared: 71 per site for the five points where the c form spends 87 (+ 3).
-#ifndef NGHMM_KFORM
-#define NGHMM_KFORM 1
-#endif
 template <int NF, int NA, bool SMALL, bool EMIT, int XDEG, bool OWNEX, typename Src>
 __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc& G,
                                            Op (&R)[MAXP], EmitPtrs emit, uint64_t wave,
@@ -29,7 +26,7 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
                                            uint32_t chunk) {
   static_assert(NB * UG == CK && RENORM == CK, "checkpoints are stored right after a rescale");
   constexpr int NPT = 1 + NF + NA;
-  constexpr bool KF = SMALL && NGHMM_KFORM != 0;
+  constexpr bool KF = SMALL;
   const uint64_t nblk = T / CK;
   const double al0 = G.A[0];
   const double q1 = G.F[0], q0 = 1 - q1;
@@ -80,15 +77,7 @@ __device__ __forceinline__ void lkl_run_fd(Src& src, uint64_t T, const GroupDesc
             op_step_k(R[1 + NF + a], rho, ka * q0, ka * eq1);
           }
         } else {
-          double c0;
-          if constexpr (SMALL) {
-            // chromosome starts are stored as d = kDStart: c = 0 there (the polynomial of the
-            // huge argument is finite; masking its bits keeps the loop body branch-free)
-            const uint64_t keep = (d < kDStart) ? ~0ull : 0ull;
-            c0 = ngh_from_bits(ngh_bits(exp_tiny7(-al0 * d)) & keep);
-          } else {
-            c0 = coanc(al0, d);
-          }
+          const double c0 = coanc(al0, d);
           const double a0 = 1 - c0;
           const double ce0 = c0, ce1 = c0 * rho;  // emissions (1, rho)
           const double eq0 = q0, eq1 = rho * q1;
@@ -309,14 +298,8 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
     renorm(r0);
     emit_lane_op(emit.lane_ops, i * C + c, lane, r0);
   }
-#ifdef NGHMM_TREE_SHFL  // (A/B builds: a shuffle tree per point)
-#pragma unroll
-  for (int p = 0; p < 1 + NF + NA; ++p)
-    lkl_store_wave_op(R[p], lane, part + (((uint64_t)g * C + c) * MAXP + p) * 5);
-#else
   __shared__ TreeLds tree;
   lkl_store_wave_ops<1 + NF + NA>(R, lane, part + ((uint64_t)g * C + c) * MAXP * 5, tree);
-#endif
 }
 
 template <int NP_MAX, int SRC>
@@ -550,7 +533,7 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
       ++k;
     }
     G.np = np;
-    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed, !fs.sw.no_xdeg2, fs.alpha_small_min);
+    G.mode = force_general ? 0u : fd_pattern(G, fs.dmax_finite, fs.T, fs.packed, fs.alpha_small_min);
     fd_pad(G);
     groups.push_back(G);
   }
@@ -566,18 +549,6 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
     k = e;
   }
   for (const auto& r : L.mode_ranges) fs.mode_ind_rounds[r.mode] += r.count;
-  if (fs.sw.debug_modes) {  // which loop-body versions this round uses
-    std::fprintf(stderr, "[nghmm modes] d_max %.6g:", fs.dmax_finite);
-    for (const auto& r : L.mode_ranges) {
-      if (r.mode)
-        std::fprintf(stderr, " %uF%uA%s%s%s x%u", (r.mode >> 2) & 3, r.mode & 3,
-                     (r.mode & FD_SMALL) ? "s" : "", (r.mode & FD_XDEG2) ? "2" : "",
-                     (r.mode & FD_OWNEX) ? "e" : "", r.count);
-      else
-        std::fprintf(stderr, " general x%u", r.count);
-    }
-    std::fprintf(stderr, "\n");
-  }
   const uint32_t ng = (uint32_t)groups.size();
   const size_t gbytes = (size_t)ng * sizeof(GroupDesc);
   if (gbytes > L.grp_cap) {
@@ -682,13 +653,11 @@ static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg
     hipLaunchKernelGGL(k_fast_shard_combine, dim3(((unsigned)ng * MAXP + 255) / 256), dim3(256), 0, st, dg,
                        ng, sh.recv, sh.world, (uint64_t)n_pts, d_lkl, d_flags, d_all);
     sh.edges_from_round = false;
-#ifndef NGHMM_NO_EDGE_MERGE  // (A/B builds: the E-step with an all-gather of its own)
-    if (emit_estep && !fs.sw.no_fuse) {  // every individual is in the batch: the E-step's edges too
+    if (emit_estep) {  // every individual is in the batch: the E-step's edges too
       hipLaunchKernelGGL(k_fast_shard_edges_from_round, dim3((ng + 255) / 256), dim3(256), 0, st, dg, ng,
                          sh.recv, sh.world, sh.rank, (uint64_t)n_pts, sh.edges, d_all);
       sh.edges_from_round = true;
     }
-#endif
     return hipGetLastError() == hipSuccess;
   }
   // (device-planned rounds: the planning kernel behind the round finishes its own individual's

@@ -180,12 +180,6 @@ int redo_nonfinite(nghmm_t* h, uint32_t n_pts, const uint32_t* ind, const double
     set_error("invalid Lkl found!");
     return NGHMM_ERR_INVALID_LKL;
   }
-  if (h->fast.sw.debug_modes) {
-    std::fprintf(stderr, "[nghmm modes] %zu of %u points came back non-finite:", bad.size(), n_pts);
-    for (size_t k = 0; k < bad.size() && k < 6; ++k)
-      std::fprintf(stderr, " (#%u ind %u F %.17g alpha %.17g -> %g)", bad[k], bind[k], bF[k], bA[k], lkl[bad[k]]);
-    std::fprintf(stderr, "\n");
-  }
   g_last_error.clear();
   int rc;
   if ((rc = ensure_points(h, bad.size()))) return rc;
@@ -358,9 +352,6 @@ int emission_impl(nghmm_t* h) {
   tic(h);
   if (h->mode == NGHMM_MODE_FAST) {
     if (!fast_refresh_freq_table(h->fast, h->stream, h->d_freq, h->d_flags)) return NGHMM_ERR_HIP;
-    if (h->fast.sw.eager_emission &&
-        !fast_refresh_emissions(h->fast, h->stream, h->d_freq, h->d_flags))
-      return NGHMM_ERR_HIP;
   } else {
     launch_emission_exact(h->stream, own_gl(h), h->d_freq, h->d_eprob, h->S, h->I, h->d_flags);
   }
@@ -644,7 +635,7 @@ int nghmm_create_replica(nghmm_t** out, nghmm_t* parent) {
   do {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = NGHMM_ERR_HIP; break; }
     // replicas are driven from one host thread each: wait without spinning
-    h->blocking_sync = !h->fast.sw.spin_sync;
+    h->blocking_sync = true;
     const unsigned evf = h->blocking_sync ? hipEventBlockingSync : hipEventDefault;
     if (hipEventCreateWithFlags(&h->ev0, evf) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev1, evf) != hipSuccess ||
@@ -841,19 +832,17 @@ struct MstepRun {
   }
 
   bool wants_background() const {
-    const Switches& sw = h->fast.sw;
+    // (bg_parts = 0: the backward sweep and est_maf after the objective rounds, not behind them)
     return fuse_freq && fuse_estep && !after_estep && h->mode == NGHMM_MODE_FAST &&
-           h->I_tot == h->I && !sw.eager_emission && !sw.no_bg;
+           h->I_tot == h->I && h->fast.sw.bg_parts != 0;
   }
 
   bool wants_two_lanes() const {
-    const int pl = h->fast.sw.pipeline;
     // a site shard: every handle of the chain must make the same sequence of exchanges, and the
     // rule below looks at the waves per individual, which depend on the handle's own number of
-    // sites -- only the switch (the same environment everywhere) may turn the two lanes on
-    if (h->fast.shard.world > 1) return h->mode == NGHMM_MODE_FAST && h->I >= 2 && pl > 0;
-    return h->mode == NGHMM_MODE_FAST && h->I >= 2 &&
-           (pl >= 0 ? pl != 0 : (uint64_t)h->I * h->fast.C < 16384);
+    // sites -- one lane there
+    if (h->fast.shard.world > 1) return false;
+    return h->mode == NGHMM_MODE_FAST && h->I >= 2 && (uint64_t)h->I * h->fast.C < 16384;
   }
 
   // the E-step's backward sweep onto the stream now, est_maf queued in parts
@@ -1050,7 +1039,7 @@ struct MstepRun {
     std::vector<FastState::ModeRange> ranges;
     const bool yield = h->blocking_sync;
     // the iteration ends by a word in pinned memory (dbfgs_epilogue) unless its kernels are timed
-    const bool zero_copy = !spans_on(h) && fs.dev.h_epi && !fs.sw.no_epilogue;
+    const bool zero_copy = !spans_on(h) && fs.dev.h_epi;
     // ... written by the SECOND stream behind est_maf and the frequency table, which nothing on the
     // handle's stream reads before the next iteration's walk: the M-step's end waits for nothing
     const bool aux_epilogue = zero_copy && fuse_freq && ind_lkl != nullptr;
@@ -1095,16 +1084,6 @@ struct MstepRun {
       }
       prev_active = n_active;
       for (const auto& r : ranges) fs.mode_ind_rounds[r.mode] += r.count;
-      if (fs.sw.debug_modes) {
-        std::fprintf(stderr, "[nghmm modes] round %u, %u active:", round, n_active);
-        for (const auto& r : ranges)
-          if (r.mode)
-            std::fprintf(stderr, " %uF%uA%s%s%s x%u", (r.mode >> 2) & 3, r.mode & 3, (r.mode & 0x200) ? "s" : "",
-                         (r.mode & 0x400) ? "2" : "", (r.mode & 0x800) ? "e" : "", r.count);
-          else
-            std::fprintf(stderr, " general x%u", r.count);
-        std::fprintf(stderr, "\n");
-      }
       bool emit = false;
       if (round == 1) {
         emit = estep_pending && n_active == h->I;
@@ -1151,8 +1130,6 @@ struct MstepRun {
       ++round;
     }
     t_lkl += since(t0);
-    if (fs.sw.timing)
-      std::fprintf(stderr, "[nghmm timing] mstep (device-planned): %.3f ms for %u rounds\n", t_lkl, round - 1);
     if (estep_pending && (rc = estep_then_hook(false))) return rc;
     if (bg_active && overlap && !aux_tail_queued && (rc = queue_aux_tail())) return rc;  // (an M-step of one round)
     if (bg_active && !(overlap && aux_epilogue)) {  // what is left of the background work, then the frequency table
@@ -1184,7 +1161,7 @@ struct MstepRun {
         return NGHMM_ERR_HIP;
       }
       h->flags_bg_clear = true;
-      if (!fs.sw.no_preplan) (void)dbfgs_preplan(fs, h->stream, indF_fixed != 0, alpha_fixed != 0);
+      (void)dbfgs_preplan(fs, h->stream, indF_fixed != 0, alpha_fixed != 0);
       int f[NFLAGS];
       if (!dbfgs_wait_epilogue(fs, overlap && aux_epilogue ? h->aux_stream : h->stream, f, (uint32_t)NFLAGS, yield)) {
         set_error("the iteration's epilogue kernel did not report: %s", hipGetErrorString(hipGetLastError()));
@@ -1254,12 +1231,6 @@ struct MstepRun {
       if (rc) return rc;
       first_round = false;
     }
-    if (h->fast.sw.timing)
-      std::fprintf(stderr,
-                   "[nghmm timing] mstep: gather %.3f ms, lkl calls %.3f ms (kernels %.3f), "
-                   "estep call %.3f ms (kernels %.3f), scatter %.3f ms, rounds %u\n",
-                   t_gather, t_lkl, h->ms[SLOT_LKL], t_estep, h->ms[SLOT_FORWARD], t_scatter,
-                   batch.rounds());
     if (estep_pending && (rc = estep_then_hook(false))) return rc;
     if (bg_active) {  // what is left of the background work, then the frequency table
       while (bg_next < bg_parts)
@@ -1450,8 +1421,7 @@ int capi::estmaf_and_refresh(nghmm_t* h, bool shard, const double* d_marg_blocks
     const GlView lg = !shard ? own_gl(h)
                       : h->packed ? gl_packed(h->d_codes_shard, h->d_cls_log)
                                   : gl_dense(h->d_gl_shard);
-    launch_estmaf_exact(h->stream, lg, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr,
-                        h->fast.sw.estmaf_exact_lanes, 0, h->fast.sw.estmaf_exact_sel != 0);
+    launch_estmaf_exact(h->stream, lg, d_marg_blocks, S_own, I_tot, d_freq_out, nullptr, 0);
   }
   if ((rc = toc(h, SLOT_ESTMAF, false))) return rc;
   HIP_TRY(hipGetLastError());
@@ -1491,8 +1461,7 @@ static int mstep_freq_ld_impl(nghmm_t* h, int freq_est, int e_prob) {
   const uint64_t n_est = freq_est == 1 ? h->S : 1;
   tic(h);
   if (exact) {
-    launch_estmaf_exact(h->stream, own_gl(h), h->d_marg, n_est, h->I, h->d_freq_new, nullptr,
-                        h->fast.sw.estmaf_exact_lanes, 0, h->fast.sw.estmaf_exact_sel != 0);
+    launch_estmaf_exact(h->stream, own_gl(h), h->d_marg, n_est, h->I, h->d_freq_new, nullptr, 0);
   } else if (!fast_estmaf(h->fast, h->stream, fast_gl_lin(h->fast), h->d_marg, n_est, h->I, h->I,
                           h->d_freq_new, false)) {
     return NGHMM_ERR_HIP;
@@ -1561,7 +1530,7 @@ int nghmm_estep_mstep(nghmm_t* h, int indF_fixed, int alpha_fixed, double* ind_l
   if (!h || !h->loaded) return NGHMM_ERR_ARG;
   int rc;
   if ((rc = use_device(h))) return rc;
-  if (h->mode == NGHMM_MODE_FAST && !h->fast.sw.no_fuse)
+  if (h->mode == NGHMM_MODE_FAST)
     return mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl, after_estep, user);
   if ((rc = nghmm_estep(h, ind_lkl))) return rc;
   if (after_estep) after_estep(user);
@@ -1576,14 +1545,14 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
   if ((rc = use_device(h))) return rc;
   // fast mode: E-step and indF/alpha M-step share their first forward walk, and the frequency
   // step runs in the shadow of the objective rounds (mstep_indf_impl)
-  if (h->mode == NGHMM_MODE_FAST && !h->fast.sw.no_fuse) {
+  if (h->mode == NGHMM_MODE_FAST) {
     bool freq_done = false;
     if ((rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, true, ind_lkl, nullptr, nullptr,
                               freq_est == 1, &freq_done)))
       return rc;
     return freq_done ? NGHMM_OK : nghmm_mstep_freq(h, freq_est);
   }
-  if (h->mode == NGHMM_MODE_EXACT && freq_est == 1 && h->I_tot == h->I && h->fast.sw.exact_bg_waves >= 0) {
+  if (h->mode == NGHMM_MODE_EXACT && freq_est == 1 && h->I_tot == h->I) {
     // Exact mode: est_maf (EM.cpp:209-257) reads the E-step's posteriors and the likelihoods
     // and writes the frequencies; the objective rounds (EM.cpp:198-201) read the emissions of
     // the OLD frequencies.  Neither touches what the other uses, and a round is a few hundred
@@ -1592,19 +1561,18 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     // holds every wave slot starves them: measured at 1000 x 1M, side by side at full occupancy
     // is no faster than one after the other (17.0 / 14.0 / 5.2 / 9.7 s either way).  So est_maf
     // goes onto a second stream in PIECES (ranges of sites): one piece per round, capped at
-    // exact_bg_waves waves per SIMD (k_estmaf_exact<BG_WAVES>) -- the chains, whose waves raise
+    // kExactBgWaves waves per SIMD (k_estmaf_exact<BG_WAVES>) -- the chains, whose waves raise
     // their issue priority, then lose ~8 % -- and whatever is left when the rounds are over
     // runs uncapped on the whole chip.  The emissions are refreshed when both are done.  Same
     // kernels, same data, same bits.
     // The E-step, too, is latency-bound chains (one per individual: 32 workgroups), and the
     // objective rounds need nothing from it -- both read the emissions of the old frequencies
     // and the current (indF, alpha).  It runs on the second stream NEXT TO the first rounds
-    // (switch exact_estep_overlap; its own copies of indF / alpha, since the M-step uploads the
+    // (its own copies of indF / alpha, since the M-step uploads the
     // new ones when it ends; its own error flags and events), est_maf's pieces queue up behind
     // it, and its fatal conditions are looked at first when everything is done -- the
     // reference's E-step comes before its M-step (EM.cpp:147-201).
-    const bool overlap_estep = h->fast.sw.exact_estep_overlap != 0;
-    if (!overlap_estep && (rc = nghmm_estep(h, ind_lkl))) return rc;
+    constexpr bool overlap_estep = true;
     if (!h->aux_stream) {
       HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreate(&h->aux_ev0));
@@ -1645,13 +1613,13 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     constexpr uint32_t kPieces = nghmm_t::kAuxPieces;
     const uint32_t n_pieces = h->S >= 64 * kPieces ? kPieces : 1;
     uint32_t next = 0, finished = 0;
-    const int cap = h->fast.sw.exact_bg_waves;
+    constexpr int cap = kExactBgWaves;
     auto push = [&](int bg_waves) -> int {
       const uint64_t s0 = h->S * next / n_pieces, s1 = h->S * (next + 1) / n_pieces;
       GlView gl = own_gl(h);
       gl.cell0 += s0 * h->I;
       launch_estmaf_exact(h->aux_stream, gl, h->d_marg + s0 * h->I, s1 - s0, h->I, h->d_freq + s0, nullptr,
-                          h->fast.sw.estmaf_exact_lanes, bg_waves, h->fast.sw.estmaf_exact_sel != 0);
+                          bg_waves);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(h->aux_piece_ev[next], h->aux_stream));
       ++next;
@@ -1660,7 +1628,7 @@ int nghmm_iter_em(nghmm_t* h, int freq_est, int indF_fixed, int alpha_fixed, dou
     auto before_round = [&]() -> int {  // at most two pieces queued underneath a round
       while (finished < next && hipEventQuery(h->aux_piece_ev[finished]) == hipSuccess) ++finished;
       (void)hipGetLastError();          // (hipErrorNotReady is not an error)
-      if (next < n_pieces && (int)(next - finished) < h->fast.sw.exact_bg_depth) return push(cap);
+      if (next < n_pieces && (int)(next - finished) < kExactBgDepth) return push(cap);
       return NGHMM_OK;
     };
     rc = mstep_indf_impl(h, indF_fixed, alpha_fixed, stats, false, nullptr, nullptr, nullptr, false,
@@ -1742,9 +1710,8 @@ void nghmm_free_host(void* p) {
 int nghmm_set_switch(nghmm_t* h, const char* name, long value) {
   g_last_error.clear();
   if (!h || !name) return NGHMM_ERR_ARG;
-  if (std::strcmp(name, "fast_c") == 0 || std::strcmp(name, "spin_sync") == 0) {
-    set_error("nghmm_set_switch: %s is fixed when the handle is created (NGHMM_%s in the environment)",
-              name, std::strcmp(name, "fast_c") == 0 ? "FAST_C" : "SPIN_SYNC");
+  if (std::strcmp(name, "fast_c") == 0) {
+    set_error("nghmm_set_switch: fast_c is fixed when the handle is created (NGHMM_FAST_C in the environment)");
     return NGHMM_ERR_ARG;
   }
   if (!h->fast.sw.set(name, value)) {

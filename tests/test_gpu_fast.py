@@ -452,9 +452,11 @@ def test_fast_more_than_64_waves_per_individual(pkg, orc_libm):
 def test_fast_background_pieces_change_nothing(pkg, monkeypatch, shape):
     """nghmm_iter_em puts the backward sweep and est_maf (in parts) onto the stream behind the
     objective rounds' kernels (nghmm_capi.hip: bg_*).  Same kernels on the same data in a
-    different order: with the pieces after the rounds (NGHMM_NO_BG) or est_maf cut differently
-    (NGHMM_BG_PARTS) every array of three iterations must come out bit for bit the same --
-    600 individuals: whole rounds, est_maf in tile-row parts; 90: the two-lane rounds."""
+    different order: with the pieces after the rounds (NGHMM_BG_PARTS=0), est_maf cut differently
+    (NGHMM_BG_PARTS), the rounds planned by the host (NGHMM_NO_DEV_BFGS: where the pieces go
+    BETWEEN the rounds) or everything on one stream (NGHMM_NO_BG_STREAM), every array of three
+    iterations must come out bit for bit the same -- 600 individuals: whole rounds, est_maf in
+    tile-row parts; 90: the two-lane rounds."""
     I, S = shape
     d = pkg.simulate.simulate(I, S, seed=4242, n_chrom=3, missing_rate=0.05, indF="r", freq="r")
     gl = pkg.simulate.normalise_log_gl(d.gl)
@@ -472,7 +474,9 @@ def test_fast_background_pieces_change_nothing(pkg, monkeypatch, shape):
             return out
 
     ref = run()
-    for env in ({"NGHMM_NO_BG": "1"}, {"NGHMM_BG_PARTS": "1"}, {"NGHMM_BG_PARTS": "5"}):
+    for env in ({"NGHMM_BG_PARTS": "0"}, {"NGHMM_BG_PARTS": "1"}, {"NGHMM_BG_PARTS": "5"},
+                {"NGHMM_NO_DEV_BFGS": "1"}, {"NGHMM_NO_DEV_BFGS": "1", "NGHMM_BG_PARTS": "0"},
+                {"NGHMM_NO_DEV_BFGS": "1", "NGHMM_BG_PARTS": "5"}, {"NGHMM_NO_BG_STREAM": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()

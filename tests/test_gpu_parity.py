@@ -82,13 +82,12 @@ def test_mstep_freq_bitwise(pkg, orc_det, small_sim):
 
 @pytest.mark.parametrize("shape,packed", [((1, 1), False), ((37, 70), False), ((100, 130), False),
                                           ((9, 1000), False), ((70, 515), True), ((130, 64), True)])
-def test_mstep_freq_lane_per_site_kernel_bitwise(pkg, orc_det, shape, packed):
-    """est_maf in exact mode with a LANE per site (k_estmaf_exact_lanes: a wave holds 64 sites,
-    a lane walks its site's individuals in order -- the reference's serial sum,
-    gen_func.cpp:984-1003, is the loop itself; what large site counts take by default) against
-    the wave-per-site kernel and the oracle: the same frequencies bit for bit, dense and packed
-    handles, ragged site and individual counts (blocks of 8 individuals staged through LDS,
-    partly filled waves)."""
+def test_mstep_freq_exact_kernel_bitwise_on_ragged_shapes(pkg, orc_det, shape, packed):
+    """est_maf in exact mode (k_estmaf_exact: a wave per site, the reference's serial sum of
+    gen_func.cpp:984-1003 kept in individual order) against the oracle: the same frequencies bit
+    for bit, dense and packed handles, ragged site and individual counts (partly filled waves),
+    alone and inside a whole fused iteration (est_maf on the second stream underneath the
+    rounds)."""
     import orclib
     I, S = shape
     d = pkg.simulate.simulate(I, S, seed=I * 1000 + S, n_chrom=2, missing_rate=0.07, indF="r", freq="r")
@@ -99,14 +98,12 @@ def test_mstep_freq_lane_per_site_kernel_bitwise(pkg, orc_det, shape, packed):
     got = {}
     with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT | (pkg.GENO_PACKED if packed else 0)) as hmm:
         hmm.load_raw(d.gl, d.pos_dist_mb, space=0, call_geno=packed)
-        for lanes in (0, 1):
-            hmm.set_switch("estmaf_exact_lanes", lanes)
-            hmm.set_params(0.3, 0.1, 0.15)
-            hmm.init_emission()
-            hmm.estep()
-            hmm.mstep_freq(1)
-            got[lanes] = hmm.freq
-            assert np.array_equal(got[lanes], em.freq), lanes
+        hmm.set_params(0.3, 0.1, 0.15)
+        hmm.init_emission()
+        hmm.estep()
+        hmm.mstep_freq(1)
+        got[0] = hmm.freq
+        assert np.array_equal(got[0], em.freq)
         # a whole fused iteration (est_maf on the second stream underneath the rounds)
         hmm.set_params(0.3, 0.1, 0.15)
         hmm.init_emission()
@@ -117,12 +114,13 @@ def test_mstep_freq_lane_per_site_kernel_bitwise(pkg, orc_det, shape, packed):
         assert np.array_equal(hmm.freq, em.freq) and np.array_equal(hmm.indF, em.indF)
 
 
-def test_fused_exact_iteration_schedules_give_the_same_bits(pkg, orc_det):
+def test_fused_exact_iteration_gives_the_oracles_bits(pkg, orc_det):
     """Exact mode's fused iteration (nghmm_iter_em) runs its E-step on a second stream next to the
-    first objective rounds and est_maf underneath the rest in capped pieces; every schedule --
-    E-step first (exact_estep_overlap 0), est_maf after the rounds (exact_bg_waves -1), uncapped
-    (0), other caps and depths -- is the same kernels on the same data: three iterations of each
-    are bit-identical to the oracle's.  Sites enough for the 16 pieces to exist (>= 1024)."""
+    first objective rounds and est_maf underneath the rest in capped pieces (three waves per SIMD,
+    three pieces queued at a time: kernels.hpp) -- the same kernels on the same data in another
+    order: three iterations are bit-identical to the oracle's, with the serial recursion kernels
+    (exact_serial) as with the producer-consumer ones.  Sites enough for the 16 pieces to exist
+    (>= 1024)."""
     import orclib
     I, S = 45, 1500
     d = pkg.simulate.simulate(I, S, seed=61, n_chrom=3, missing_rate=0.05, indF="r")
@@ -134,8 +132,7 @@ def test_fused_exact_iteration_schedules_give_the_same_bits(pkg, orc_det):
     for _ in range(3):
         assert em.iterate() == 0
         want.append((em.ind_lkl.copy(), em.indF.copy(), em.alpha.copy(), em.freq.copy(), em.marg.copy()))
-    for sw in ({}, {"exact_estep_overlap": 0}, {"exact_bg_waves": -1}, {"exact_bg_waves": 0},
-               {"exact_bg_waves": 2, "exact_bg_depth": 1}, {"exact_bg_waves": 4, "exact_bg_depth": 16}):
+    for sw in ({}, {"exact_serial": 1}):
         with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT) as hmm:
             for k, v in sw.items():
                 hmm.set_switch(k, v)

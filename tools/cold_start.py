@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The first iterations of a run (the cold start BASELINE's "EM iters/sec" includes): wall time,
 objective rounds and kernel-family milliseconds of every iteration from the starting values, and
-with NGHMM_DEBUG_MODES=1 the kernel version of every round on stderr.
+the kernel versions of its rounds from nghmm_debug_mode_counts.
    python tools/cold_start.py [workload [iterations]]     (needs an MI355X)"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
