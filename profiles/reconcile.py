@@ -44,7 +44,9 @@ def main():
         calls[k] = calls.get(k, 0) + int(r["Calls"])
     b = json.load(open(bench))
     iters = calls.get("k_fast_bwd_recompute8", 0) or calls.get("k_fast_bwd_recompute", 0)
-    rounds = calls.get("k_fast_lkl_finish", 0)
+    # (round 6: the planning kernel finishes its own individual's points -- no k_fast_lkl_finish in
+    # device-planned rounds; one k_bfgs_advance per round + one per M-step that plans round 1)
+    rounds = calls.get("k_fast_lkl_finish", 0) or max(calls.get("k_bfgs_advance", 0) - iters, 0)
     out = {"em_iterations_in_trace": iters, "objective_rounds_in_trace": rounds,
            "bench_steps": b["steps"], "families": {}}
     for fam, kernels in FAMILIES.items():

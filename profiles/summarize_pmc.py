@@ -88,7 +88,9 @@ def main():
     # the backward sweep runs exactly once per EM iteration of the pass
     iters = (res.get("k_fast_bwd_recompute8") or res.get("k_fast_bwd_recompute", {})).get(
         "launches_fetch_pass", 0)
-    rounds = res.get("k_fast_lkl_finish", {}).get("launches_fetch_pass", 0)
+    # (round 6: no k_fast_lkl_finish in device-planned rounds: one k_bfgs_advance<false> per round)
+    rounds = (res.get("k_fast_lkl_finish", {}).get("launches_fetch_pass", 0) or
+              res.get("k_bfgs_advance<false>", {}).get("launches_fetch_pass", 0))
     fam = {}
     for name, prefixes in FAMILIES.items():
         tot = 0.0
