@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Identity of the build a committed profile belongs to: sha256 over the sources of the library
-(ngsf-hmm_amd/csrc/**: .hip .hpp .h .cpp Makefile, and include/nghmm.h), path and content, in
+(ngsf-hmm_amd/csrc/**: .hip .hpp .h .cpp Makefile, and include/nghmm.h, include/nghmm_debug.h), path and content, in
 sorted order -- 16 hex digits.  profiles/collect.sh stores it in rNN_pmc_summary.json,
 tools/isa_report.py in rNN_isa_summary.txt, bench.py --write_check in check_n1.json; bench.py
 compares it with the sources it runs from and drops replayed counters (HBM traffic, instruction
@@ -15,7 +15,7 @@ EXT = (".hip", ".hpp", ".h", ".cpp")
 
 
 def build_id(root=ROOT):
-    files = [os.path.join(root, "include", "nghmm.h")]
+    files = [os.path.join(root, "include", "nghmm.h"), os.path.join(root, "include", "nghmm_debug.h")]
     csrc = os.path.join(root, "ngsf-hmm_amd", "csrc")
     for d, _, names in os.walk(csrc):
         for n in names:

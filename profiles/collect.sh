@@ -8,7 +8,7 @@
 #                                      section HBM prescribes
 #   <tag>_pmc_summary.json           profiles/summarize_pmc.py over the three passes
 set -e -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT/pmc
 export TMPDIR=/tmp

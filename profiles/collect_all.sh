@@ -8,7 +8,7 @@
 # lines, `collect_all.sh r04 2` = the other workloads; the committed profiles/<tag>_pmc_summary.json of
 # part 1 must be in place for part 2's lines to carry `traffic`)
 set -e -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -39,6 +39,16 @@ done
 python3 bench.py --workload c2 --no_cpu_baseline --steps 200 --warmup 20 > $OUT/${TAG}_bench_c2_n1.json
 python3 bench.py --workload c2 --no_cpu_baseline --steps 100 --warmup 10 --replicas 10 > $OUT/${TAG}_bench_c2_replicas10_n1.json
 python3 bench.py --workload c5share --no_cpu_baseline > $OUT/${TAG}_bench_c5share_n1.json
+# off examples/test.sh's operating point (round-5 review, item 1): the simulator's `r` options at depth 5
+# and 2, a transition rate beyond the small-alpha kernels, likelihood cohorts above 1024 individuals; the
+# driver's flags; the CPU restatement beside the first of them
+python3 bench.py --workload c3r --steps 20 --warmup 5 --no_exact_line > $OUT/${TAG}_bench_c3r_n1.json
+for w in c3r2 c3hi c2k c5k; do
+  python3 bench.py --workload $w --steps 20 --warmup 5 --no_cpu_baseline --no_exact_line > $OUT/${TAG}_bench_${w}_n1.json
+done
+python3 bench.py --workload c2r --no_cpu_baseline --no_exact_line --steps 200 --warmup 20 > $OUT/${TAG}_bench_c2r_n1.json
+# one steady-state iteration of configs[1] as the device ran it (tools/c2_timeline.py)
+bash tools/c2_timeline.sh c2 > /dev/null && cp gpurun_out/timeline_c2/timeline.txt $OUT/${TAG}_c2_timeline.txt
 # config 5's share as a site shard: all 5000 individuals x 625 000 sites (one of eight ranks)
 python3 bench.py --workload c5 --emulate_ranks 8 --no_cpu_baseline > $OUT/${TAG}_bench_c5_rank_of_8_sites.json
 # the called genotypes' est_maf (k_fast_estmaf_called_sums: one sweep over codes and posteriors) on
