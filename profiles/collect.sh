@@ -17,7 +17,7 @@ export TMPDIR=/tmp
 # --serial_kernels: the backward sweep and est_maf between the objective rounds on the one
 # stream (round 5 runs them NEXT TO the rounds on a second stream, where a kernel's span holds its
 # neighbours' work too): every duration and every counter below is then the kernel's own.
-BENCH="bench.py --steps 7 --warmup 0 --no_cpu_baseline --no_exact_line --no_check --serial_kernels"
+BENCH="bench.py --steps 7 --warmup 0 --no_cpu_baseline --no_exact_line --no_check --no_cold --serial_kernels"
 
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $BENCH \
   > $OUT/bench_under_trace.json 2> $OUT/trace.err
@@ -27,7 +27,7 @@ python3 profiles/reconcile.py $OUT/${TAG}_c3_fast_kernel_stats.csv $OUT/${TAG}_b
   > $OUT/${TAG}_trace_vs_bench.json
 echo "trace done"
 
-PMCBENCH="bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_exact_line --no_check --serial_kernels"
+PMCBENCH="bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_exact_line --no_check --no_cold --serial_kernels"
 filter() {  # keep the header and this library's kernels
   python3 - "$1" "$2" <<'EOF'
 import csv, sys

@@ -53,7 +53,7 @@ bash tools/c2_timeline.sh c2 > /dev/null && cp gpurun_out/timeline_c2/timeline.t
 python3 bench.py --workload c5 --emulate_ranks 8 --no_cpu_baseline > $OUT/${TAG}_bench_c5_rank_of_8_sites.json
 # the called genotypes' est_maf (k_fast_estmaf_called_sums: one sweep over codes and posteriors) on
 # config 5's rank: kernel trace + FETCH_SIZE / WRITE_SIZE passes of a two-iteration run
-C5="bench.py --workload c5 --emulate_ranks 8 --steps 2 --warmup 1 --no_cpu_baseline"
+C5="bench.py --workload c5 --emulate_ranks 8 --steps 2 --warmup 1 --no_cpu_baseline --no_cold"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5trace -o trace -- python3 $C5 > /dev/null 2> $OUT/c5trace.err
 cp "$(find $OUT/c5trace -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_c5_rank_kernel_stats.csv
 timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c5fetch -o fetch -- python3 $C5 > /dev/null 2> $OUT/c5fetch.err

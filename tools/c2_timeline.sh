@@ -8,7 +8,7 @@ OUT=gpurun_out/timeline_$WL
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 bench.py \
-  --workload $WL --steps 10 --warmup 6 --no_cpu_baseline --no_exact_line --no_check "$@" \
+  --workload $WL --steps 10 --warmup 6 --no_cpu_baseline --no_exact_line --no_check --no_cold "$@" \
   > $OUT/bench.json 2> $OUT/trace.err
 cp "$(find $OUT/trace -name '*kernel_trace.csv' | head -1)" $OUT/kernel_trace.csv
 rm -rf $OUT/trace
