@@ -320,7 +320,7 @@ __device__ __forceinline__ void estmaf_site(
       // reciprocals four at a time (Montgomery's trick): one v_rcp_f64 + Newton step and
       // 9 multiplies instead of four reciprocals; v_rcp_f64 is the slow instruction
 #pragma unroll
-      for (int k0 = 0; k0 < NI; k0 += 4) {
+      for (int k0 = 0; k0 + 4 <= NI; k0 += 4) {
         double sm[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) sm[j] = fma(r, fma(r, sC[k0 + j], sb[k0 + j]), sA[k0 + j]);
@@ -339,6 +339,17 @@ __device__ __forceinline__ void estmaf_site(
         pd = fma(fc[k0 + 2], inv2, pd);
         pn = fma(fma(nC[k0 + 3], r, u0[k0 + 3]), inv3, pn);
         pd = fma(fc[k0 + 3], inv3, pd);
+      }
+      if constexpr (NI % 4 == 2) {  // (10 or 14 individuals per lane: the last two share a reciprocal)
+        constexpr int k0 = NI - 2;
+        const double s0 = fma(r, fma(r, sC[k0], sb[k0]), sA[k0]);
+        const double s1 = fma(r, fma(r, sC[k0 + 1], sb[k0 + 1]), sA[k0 + 1]);
+        const double R = rcp_nr(s0 * s1);
+        const double inv0 = R * s1, inv1 = R * s0;
+        pn = fma(fma(nC[k0], r, u0[k0]), inv0, pn);
+        pd = fma(fc[k0], inv0, pd);
+        pn = fma(fma(nC[k0 + 1], r, u0[k0 + 1]), inv1, pn);
+        pd = fma(fc[k0 + 1], inv1, pd);
       }
     } else {
 #pragma unroll
@@ -1214,11 +1225,12 @@ bool fast_estmaf_called(const FastState& fs, const GlView& gl) {
 }
 
 bool fast_estmaf_in_place(const FastState& fs, uint64_t I_tot) {
-  // est_maf on the E-step's tile-major posteriors, without the site-major copy: the register
-  // kernels up to 4096 individuals (measured at 10^9 site-individuals: in place 13.6 vs 14.4 ms
-  // via the copy at 4000 individuals, 19.7 vs 16.5 ms at 8000: a site group's sectors outgrow
-  // L2); the called-genotype sweep reads every cell once, whole sectors, at any size
-  return I_tot <= 4096 || (fs.packed && fs.called_table && !fs.sw.estmaf_no_called);
+  // est_maf on the E-step's tile-major posteriors, without the site-major copy: every cohort the
+  // register kernels hold (round 6, with the posteriors' groups of eight individuals adjacent:
+  // est_maf 8.4 -> 7.4 ms at 5000 x 100k, 6.7 -> 6.0 at 8000 x 60k, no difference at 3000; rounds
+  // 3-4 measured the copy faster above 4096 on the earlier layout); the called-genotype sweep
+  // reads every cell once, whole sectors, at any size
+  return I_tot <= 8192 || (fs.packed && fs.called_table && !fs.sw.estmaf_no_called);
 }
 
 bool fast_estmaf_splittable(const FastState& fs, uint64_t I_tot, bool tile_major) {
@@ -1371,7 +1383,11 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
       else if (I_tot <= 2048) LAUNCH_TILE(16, 128);
       else if (I_tot <= 3072) LAUNCH_TILE(12, 256);
       else if (I_tot <= 4096) LAUNCH_TILE(16, 256);
+      // (above 4096 a workgroup is a CU's eight waves and a site's time goes with the slots per
+      // lane: 10 and 14 where they hold the cohort)
+      else if (I_tot <= 5120) LAUNCH_TILE(10, 512);
       else if (I_tot <= 6144) LAUNCH_TILE(12, 512);
+      else if (I_tot <= 7168) LAUNCH_TILE(14, 512);
       else LAUNCH_TILE(16, 512);
     } else if (I_tot <= 64) LAUNCH_NI(1, 64);
     else if (I_tot <= 128) LAUNCH_NI(2, 64);
@@ -1383,7 +1399,9 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
     else if (I_tot <= 2048) LAUNCH_NI(16, 128);
     else if (I_tot <= 3072) LAUNCH_NI(12, 256);
     else if (I_tot <= 4096) LAUNCH_NI(16, 256);
+    else if (I_tot <= 5120) LAUNCH_NI(10, 512);
     else if (I_tot <= 6144) LAUNCH_NI(12, 512);
+    else if (I_tot <= 7168) LAUNCH_NI(14, 512);
     else LAUNCH_NI(16, 512);
     return true;
   };
