@@ -71,7 +71,6 @@ CASES = {
     "config3_slice_1000x10k": (1000, 1_000_000, (0, 1000), (0, 10_000), {}, "test.sh"),
     "c2r_100x100k_in_full_true_values": (100, 100_000, (0, 100), (0, 100_000), REGIME_R, "true"),
     "c3r_slice_1000x10k_true_values": (1000, 1_000_000, (0, 1000), (0, 10_000), REGIME_R, "true"),
-    "c3r_slice_1000x10k_start_values": (1000, 1_000_000, (0, 1000), (0, 10_000), REGIME_R, "test.sh"),
     "c3hi_slice_1000x10k_true_values": (1000, 1_000_000, (0, 1000), (0, 10_000), REGIME_HI, "true"),
     "c3hi_100x100k_true_values": (100, 100_000, (0, 100), (0, 100_000), REGIME_HI, "true"),
 }
