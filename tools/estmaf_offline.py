@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 which = sys.argv[1] if len(sys.argv) > 1 else "post6"
-d = np.load("gpurun_out/estmaf_sample.npz")
+d = np.load(sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/estmaf_sample.npz")
 p = np.exp(d["gl"].astype(np.float64))
 F = d[which]
 p0, p1, p2 = p[..., 0], p[..., 1], p[..., 2]
@@ -174,3 +174,38 @@ for kb in (2, 3):
         for mh in (0.05, 0.15, 0.3):
             ba, lo_p, hi_p = predicted_rule(kb, mh, 0.02, nodes, max_ratio)
             report(f"secant after pass {kb}, margin {mh}, {nodes} nodes, ratio <= {max_ratio}", ba, lo_p, hi_p, nodes)
+
+
+# ---- what a perfect knowledge of the travel would buy (round 6: the simulator's r regimes) -------
+def oracle_policy(max_ratio=2.0, nodes=12, wide_ratio=None, wide_nodes=24, back=1.02):
+    """Every site builds at the first pass from which the odds' hull to the end fits an interval of
+    ratio max_ratio (or, when a wide interval is allowed and cheaper than waiting, wide_ratio)."""
+    cost = np.zeros(n)
+    built = np.zeros(n, int)
+    for s in range(n):
+        best = price(passes[s], 0)             # never build: every pass exact
+        for k in range(2, min(passes[s] - 1, 40)):
+            seg = R[k:passes[s], s]
+            ratio = seg.max() / seg.min() * back
+            left = passes[s] - k
+            if left < 24:
+                break
+            c = None
+            if ratio <= max_ratio:
+                c = price(k + 1, nodes)
+            elif wide_ratio and ratio <= wide_ratio:
+                c = price(k + 1, wide_nodes)
+            if c is not None and c < best:
+                best, built[s] = c, k
+                if ratio <= max_ratio:
+                    break
+        cost[s] = best
+    return cost.mean(), np.mean(built > 0), np.mean(built[built > 0])
+
+
+c_now = report("current rule again", *current_rule(), 12)
+for label, kw in (("perfect knowledge, narrow only", {}),
+                  ("perfect knowledge, narrow or wide (7.6, 24 nodes)", dict(wide_ratio=7.6)),
+                  ("perfect knowledge, narrow or medium (3.2, 16 nodes)", dict(wide_ratio=3.2, wide_nodes=16))):
+    c, b, kb = oracle_policy(**kw)
+    print(f"{label}: VALU per site {c:.0f} ({c / c_now:.3f} of the current rule's), builds {b:.3f} at pass {kb:.2f} on average")
