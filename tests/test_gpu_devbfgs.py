@@ -147,3 +147,82 @@ def test_an_mstep_that_ends_early_leaves_the_handle_usable(pkg):
             assert _stats(sa) == _stats(sb)
             assert np.array_equal(h.indF, fresh.indF) and np.array_equal(h.alpha, fresh.alpha)
             assert np.array_equal(h.ind_lkl, fresh.ind_lkl) and np.array_equal(h.freq, fresh.freq)
+
+
+def test_a_round_planned_in_advance_never_outlives_its_parameters(pkg):
+    """When an M-step ends the device plans the NEXT M-step's first round at once (dbfgs_preplan:
+    the parameters are final), and an iteration ends by a word the second stream's epilogue kernel
+    writes.  Whatever happens between two iterations -- new indF / alpha (nghmm_set_params), only
+    new frequencies, a change of the fixed parameters, the machines moved to the host and back, a
+    standalone M-step, a reload of the data -- the next iteration must be the one a handle without
+    that history computes: every array bit for bit against a fresh handle given the same state."""
+    I, S = 120, 9_000
+    d = pkg.simulate.simulate(I, S, seed=77, n_chrom=2, missing_rate=0.04, indF="r", freq="r", alpha=0.3)
+    gl = pkg.simulate.normalise_log_gl(d.gl)
+    rng = np.random.default_rng(5)
+
+    def state(h):
+        return (h.ind_lkl.copy(), h.indF.copy(), h.alpha.copy(), h.freq.copy(), h.marg_prob.copy())
+
+    def fresh(F, A, f, fixed=(False, False), n=1):
+        with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as g:
+            g.load(gl, d.pos_dist_mb)
+            g.set_params(F, A, f)
+            g.init_emission()
+            for _ in range(n):
+                g.iter_EM(1, *fixed)
+            return state(g)
+
+    def same(a, b, what):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), what
+
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST) as h:
+        h.load(gl, d.pos_dist_mb)
+        h.set_params(0.1, 0.2, 0.1)
+        h.init_emission()
+        h.iter_EM()
+        h.iter_EM()
+        same(state(h), fresh(0.1, 0.2, 0.1, n=2), "two plain iterations")
+        # new indF / alpha under the plan made in advance
+        F1, A1 = rng.uniform(0.05, 0.8, I), rng.uniform(0.05, 2.0, I)
+        f_now = h.freq
+        h.set_params(F1, A1, None)
+        h.init_emission()
+        h.iter_EM()
+        same(state(h), fresh(F1, A1, f_now), "after new indF / alpha")
+        # only new frequencies: the plan stays valid, the emissions do not
+        F2, A2 = h.indF, h.alpha
+        f2 = rng.uniform(0.05, 0.5, S)
+        h.set_params(None, None, f2)
+        h.init_emission()
+        h.iter_EM()
+        same(state(h), fresh(F2, A2, f2), "after new frequencies")
+        # another choice of fixed parameters than the plan was made for
+        F3, A3, f3 = h.indF, h.alpha, h.freq
+        h.iter_EM(1, True, False)
+        same(state(h), fresh(F3, A3, f3, fixed=(True, False)), "indF fixed")
+        # the machines on the host for an iteration, then back on the device
+        F4, A4, f4 = h.indF, h.alpha, h.freq
+        h.set_switch("no_dev_bfgs", 1)
+        h.iter_EM()
+        h.set_switch("no_dev_bfgs", 0)
+        h.iter_EM()
+        same(state(h), fresh(F4, A4, f4, n=2), "host machines in between")
+        # a standalone M-step (no E-step, no frequency step), then an iteration
+        F5, A5, f5 = h.indF, h.alpha, h.freq
+        h.mstep_indf()
+        F6, A6 = h.indF, h.alpha
+        h.iter_EM()
+        same(state(h), fresh(F6, A6, f5), "after a standalone M-step")
+        # the same data loaded again
+        F7, A7, f7 = h.indF, h.alpha, h.freq
+        h.load(gl, d.pos_dist_mb)
+        h.set_params(F7, A7, f7)
+        h.init_emission()
+        h.iter_EM()
+        same(state(h), fresh(F7, A7, f7), "after a reload")
+        # and the counters of the rare code paths answer (include/nghmm_debug.h)
+        mc, ec = h.mode_counts(), h.estmaf_counts()
+        assert sum(mc.values()) > 0 and all(k == "general" or k.startswith("2F2A") for k in mc), mc
+        assert set(ec) == {"check_failed", "second_interval", "third_interval", "log_space", "exact_tail"}
