@@ -226,3 +226,17 @@ def test_a_round_planned_in_advance_never_outlives_its_parameters(pkg):
         mc, ec = h.mode_counts(), h.estmaf_counts()
         assert sum(mc.values()) > 0 and all(k == "general" or k.startswith("2F2A") for k in mc), mc
         assert set(ec) == {"check_failed", "second_interval", "third_interval", "log_space", "exact_tail"}
+
+
+def test_asynchronous_iteration_soak():
+    """tools/stress_async.py, short: 90 fused iterations with everything asynchronous on (second
+    stream, epilogue word, pre-planned rounds) against the same iterations on one stream with timing
+    events and a stream synchronisation at the end, and four replicas driven concurrently against the
+    same runs one after the other -- every iteration's arrays bit for bit, on three cohort shapes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_async.py"), "90", "4"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
