@@ -507,3 +507,57 @@ def test_random_shapes_against_the_oracle_with_every_difference_explained(pkg, o
     print(f"60 shapes: worst lkl {worst['lkl']:.1e}, posteriors {worst['post']:.1e} (apart from snap flips on "
           f"{n_flip_sites} sites), frequencies {worst['freq']:.1e}; {n_explained} frequencies beyond 1e-9 (up to "
           f"{worst['freq_explained']:.1e}) reproduced to 1e-12 by the oracle's est_maf fed the GPU's posteriors")
+
+
+def test_called_genotypes_in_the_random_regime_against_the_oracle(pkg, orc_det, orc_libm):
+    """BASELINE configs[4] calls genotypes (--call_geno: 2-bit packed handles, est_maf's closed form);
+    its tests ran on test.sh's constants.  Here a 1000 x 10 000 slice of the simulator's `r` regime
+    (indF, alpha ~ U(0,1) per individual, freq ~ U(0,1) per site, depth 5, 2 % missing cells), called
+    on the device, from the simulation's true parameters: exact mode BITWISE against the oracle over a
+    whole iter_EM + Viterbi; fast mode per call -- log-likelihoods 1e-12, frequencies 1e-12 when the
+    oracle's est_maf is fed the GPU's posteriors (gen_func.cpp:886-914, 974-1009; HMM.cpp:6-60)."""
+    import torch
+    I, S = 1000, 10_000
+    nt = _threads()
+    dev = torch.device("cuda", 0)
+    sim = pkg.simulate.IndexedSim(I, 1_000_000, dev, seed=12345, **REGIME_R)
+    gl_d, pos_d = sim.gl((0, I), (0, S)), sim.pos_dist(0, S)
+    torch.cuda.synchronize()
+    raw, pos = gl_d.cpu().numpy(), pos_d.cpu().numpy()
+    tF, tA = sim.true_params((0, I))
+    F0 = np.clip(tF.cpu().numpy(), 1e-6, 1 - 1e-6)
+    A0 = np.clip(tA.cpu().numpy(), 1e-6, 1 - 1e-6)
+    f0 = np.clip(sim.site_freq(0, S).cpu().numpy(), 1e-3, 1 - 1e-3)
+    glc = orc_det.prepare_gl(raw, 0, call_geno=True)
+    em = orclib.OracleEM(orc_det, glc, pos)
+    em.set_params(F0, A0, f0)
+    assert em.init_emission() == 0
+    assert em.iterate(1, False, False, nt, True) == 0
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_EXACT | pkg.GENO_PACKED) as ex:
+        ex.load_raw(raw, pos, space=0, call_geno=True)
+        ex.set_params(F0, A0, f0)
+        ex.init_emission()
+        ex.iter_EM()
+        assert np.array_equal(ex.ind_lkl, em.ind_lkl) and np.array_equal(ex.marg_prob, em.marg)
+        assert np.array_equal(ex.indF, em.indF) and np.array_equal(ex.alpha, em.alpha)
+        assert np.array_equal(ex.freq, em.freq)
+        assert np.array_equal(ex.viterbi(), em.viterbi(nt))
+    em.close()
+    glm = orc_libm.prepare_gl(raw, 0, call_geno=True)
+    em = orclib.OracleEM(orc_libm, glm, pos)
+    em.set_params(F0, A0, f0)
+    assert em.init_emission() == 0 and em.estep(nt) == 0
+    with pkg.NgsFHMM(I, S, mode=pkg.MODE_FAST | pkg.GENO_PACKED) as fa:
+        fa.load_raw(raw, pos, space=0, call_geno=True)
+        fa.set_params(F0, A0, f0)
+        fa.init_emission()
+        lk = fa.estep().copy()
+        np.testing.assert_allclose(lk, em.ind_lkl, rtol=1e-12)
+        pf = fa.marg_prob
+        fa.mstep_freq(1)
+        f_gpu = fa.freq
+        sites = np.arange(0, S, 7)
+        with ThreadPoolExecutor(nt) as pool:
+            fed = np.array(list(pool.map(lambda s: orc_libm.est_maf(glm[s], pf[:, s])[0], sites)))
+        np.testing.assert_allclose(f_gpu[sites], fed, rtol=1e-12, atol=1e-300)
+    em.close()
