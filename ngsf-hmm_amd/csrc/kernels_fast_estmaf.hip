@@ -5,6 +5,8 @@
 // measurements.)
 #include "fast_dev.hpp"
 
+#include <mutex>
+
 namespace nghmm {
 
 namespace {
@@ -210,7 +212,8 @@ __device__ __forceinline__ void estmaf_site(
     int n_exact, int allow_build, uint64_t site, const double* __restrict__ tile_col,
     uint32_t* __restrict__ cnt, double (&xch)[2][ESTMAF_MAXW][2],
     double2 (&nodebuf)[(BLOCK == 64 && NI >= 8) ? EN : 1][(BLOCK == 64 && NI >= 8) ? 65 : 1],
-    double2 (&xnode)[(BLOCK == 64 && NI >= 8) ? 1 : EN][(BLOCK == 64 && NI >= 8) ? 1 : BLOCK / 64]) {
+    double2 (&xnode)[(BLOCK == 64 && NI >= 8) ? 1 : EN][(BLOCK == 64 && NI >= 8) ? 1 : BLOCK / 64],
+    double2* park = nullptr) {
   constexpr int W = BLOCK / 64;
   constexpr bool PARK = (W == 1 && NI >= 8);
   const int lane = threadIdx.x & 63;
@@ -493,27 +496,53 @@ __device__ __forceinline__ void estmaf_site(
             my_gd = ad;
             check = true;
           } else {
-            // several waves per site: every wave reduces its own part of each node and the
-            // waves' parts meet in LDS once for the whole interval (one barrier instead of
-            // one per node), added in wave order
             const double tnl = half * kChebC[lane < EN ? lane : 0];
             const double r_nodes = mid * (1 + tnl) * rcp_nr2(1 - tnl);
-#pragma unroll 1
-            for (int nd = 0; nd < EN; ++nd) {
-              double pn, pd;
-              lane_sums(lane_value(r_nodes, nd), pn, pd);
-              const double v = wave_sum_pair(pn, pd);
-              const double sn = lane_value(v, 31), sd = lane_value(v, 63);
-              if (lane == 0) xnode[nd][wv] = double2{sn, sd};
-            }
-            __syncthreads();
             double an = 0, ad = 0;
-            if (lane < EN) {
+            if constexpr (W > 1) {
+              // several waves per site: as in the one-wave kernel no node is reduced on its own --
+              // every thread parks its partial sums of the EN nodes in LDS (park[node][thread], the
+              // kernel's dynamic shared memory), and wave w then adds up the nodes w, w + W, ...:
+              // a lane the W waves' partials of its lane index in wave order, one reduction tree per
+              // node instead of one per node AND wave (round 6: 360 -> 50-160 instructions per wave
+              // and site)
+#pragma unroll 1
+              for (int nd = 0; nd < EN; ++nd) {
+                double pn, pd;
+                lane_sums(lane_value(r_nodes, nd), pn, pd);
+                park[nd * BLOCK + (int)tix] = double2{pn, pd};
+              }
+              __syncthreads();
+              for (int nd = wv; nd < EN; nd += W) {
+                double sn = 0, sd = 0;
 #pragma unroll
-              for (int w = 0; w < W; ++w) {
-                const double2 t2 = xnode[lane][w];
-                an += t2.x;
-                ad += t2.y;
+                for (int w = 0; w < W; ++w) {
+                  const double2 t2 = park[nd * BLOCK + w * 64 + lane];
+                  sn += t2.x;
+                  sd += t2.y;
+                }
+                const double v = wave_sum_pair(sn, sd);
+                const double tn = lane_value(v, 31), td = lane_value(v, 63);
+                if (lane == 0) xnode[nd][0] = double2{tn, td};
+              }
+              __syncthreads();
+              if (lane < EN) {
+                an = xnode[lane][0].x;
+                ad = xnode[lane][0].y;
+              }
+              __syncthreads();  // (the shared buffers serve the passes that follow)
+            } else {
+              // one wave, few individuals per lane (NI < 8): every node reduced in registers
+#pragma unroll 1
+              for (int nd = 0; nd < EN; ++nd) {
+                double pn, pd;
+                lane_sums(lane_value(r_nodes, nd), pn, pd);
+                const double v = wave_sum_pair(pn, pd);
+                const double sn = lane_value(v, 31), sd = lane_value(v, 63);
+                if (lane == nd) {
+                  an = sn;
+                  ad = sd;
+                }
               }
             }
             my_gn = an;
@@ -575,9 +604,10 @@ k_fast_estmaf(const GlView gl, const double* __restrict__ marg_blocks,
   } else {
     site = blockIdx.x;
   }
+  extern __shared__ double2 park_mem[];  // BLOCK > 64: [EN][BLOCK] partial node sums (estmaf_site)
   estmaf_site<NI, BLOCK, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status, state,
                                state_stride, 1, n_exact, allow_build, site, tile_col, cnt, xch, nodebuf,
-                               xnode);
+                               xnode, park_mem);
 }
 
 // The sites k_fast_estmaf_interp handed back (status EST_EXACT) resume from `state`.  They are
@@ -592,6 +622,7 @@ k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
                      uint64_t state_stride, int n_exact, int allow_build, uint64_t row0,
                      uint64_t row1, uint32_t* __restrict__ cnt, int cnt_slot) {
   ESTMAF_SHARED(NI, BLOCK);
+  extern __shared__ double2 park_mem[];
   const int lane = threadIdx.x & 63;
   for (uint64_t base = (uint64_t)blockIdx.x * 64; base < S_own; base += (uint64_t)gridDim.x * 64) {
     const uint64_t s = base + lane;
@@ -606,7 +637,7 @@ k_fast_estmaf_resume(const GlView gl, const double* __restrict__ marg_blocks,
       const double* tile_col = TILE ? estmaf_tile_col(marg_blocks, site, tile_T, I_tot) : nullptr;
       estmaf_site<NI, BLOCK, TILE>(gl, marg_blocks, S_own, I_tot, I_blk, freq_out, redo, status,
                                    state, state_stride, 0, n_exact, allow_build, site, tile_col, cnt,
-                                   xch, nodebuf, xnode);
+                                   xch, nodebuf, xnode, park_mem);
       if constexpr (BLOCK > 64) __syncthreads();  // the shared buffers serve the next site
     }
   }
@@ -1261,6 +1292,26 @@ bool fast_estmaf_reserve(FastState& fs, uint64_t S_own) {
   return true;
 }
 
+// dynamic LDS of an est_maf kernel; beyond 64 KB the kernel has to be told once
+static size_t estmaf_dyn_lds(const void* kernel, size_t bytes) {
+  if (bytes > 65536) {
+    // (per device: the handles of a chain sit on several; under a lock: replicas launch from
+    // several host threads)
+    static std::vector<std::pair<const void*, int>> told;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<const void*, int> key{kernel, dev};
+    if (std::find(told.begin(), told.end(), key) == told.end()) {
+      if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        (void)hipGetLastError();
+      told.push_back(key);
+    }
+  }
+  return bytes;
+}
+
 bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
                  const double* d_marg_blocks, uint64_t S_own, uint64_t I_tot, uint64_t I_blk,
                  double* d_freq_out, bool tile_major, uint32_t part, uint32_t n_parts) {
@@ -1312,15 +1363,21 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   // resuming launches: 64 statuses per workgroup and turn
   const uint64_t scan_wgs_all = (S_own + 63) / 64;
   const unsigned scan_wgs = (unsigned)(scan_wgs_all < 16384 ? scan_wgs_all : 16384);
+  // (kernels of several waves per site park the interval's partial node sums in dynamic LDS,
+  // EN * B double2: 24 / 48 / 96 KB at 2 / 4 / 8 waves -- four, two, one workgroup per CU either way)
+#define ESTMAF_DYN(K, B)                                                                        \
+  ((B) > 64 ? estmaf_dyn_lds(reinterpret_cast<const void*>(K), (size_t)EN * (B) * sizeof(double2)) : (size_t)0)
 #define LAUNCH_NI(N, B)                                                                         \
   do {                                                                                          \
     if (fresh)                                                                                  \
-      hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B), 0, st,    \
+      hipLaunchKernelGGL((k_fast_estmaf<N, B, false>), dim3((unsigned)S_own), dim3(B),           \
+                         ESTMAF_DYN((k_fast_estmaf<N, B, false>), B), st,                        \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
                          d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
                          n_exact, allow_build, (uint64_t)0, fs.est_counts);                     \
     else                                                                                        \
-      hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, false>), dim3(scan_wgs), dim3(B), 0, st,   \
+      hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, false>), dim3(scan_wgs), dim3(B),          \
+                         ESTMAF_DYN((k_fast_estmaf_resume<N, B, false>), B), st,                 \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, (uint64_t)0,           \
                          d_freq_out, fs.redo, fs.est_status, fs.est_state, fs.redo_cap,         \
                          n_exact, allow_build, row0, row1, fs.est_counts, cnt_slot);            \
@@ -1328,12 +1385,14 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
 #define LAUNCH_TILE(N, B)                                                                       \
   do {                                                                                          \
     if (fresh)                                                                                  \
-      hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)nblk), dim3(B), 0, st,     \
+      hipLaunchKernelGGL((k_fast_estmaf<N, B, true>), dim3((unsigned)nblk), dim3(B),            \
+                         ESTMAF_DYN((k_fast_estmaf<N, B, true>), B), st,                         \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
                          allow_build, blk0, fs.est_counts);                                     \
     else                                                                                        \
-      hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, true>), dim3(scan_wgs), dim3(B), 0, st,    \
+      hipLaunchKernelGGL((k_fast_estmaf_resume<N, B, true>), dim3(scan_wgs), dim3(B),           \
+                         ESTMAF_DYN((k_fast_estmaf_resume<N, B, true>), B), st,                  \
                          d_gl_sites, d_marg_blocks, S_own, I_tot, I_blk, tile_T, d_freq_out,    \
                          fs.redo, fs.est_status, fs.est_state, fs.redo_cap, n_exact,            \
                          allow_build, row0, row1, fs.est_counts, cnt_slot);                     \
@@ -1427,6 +1486,7 @@ bool fast_estmaf(FastState& fs, hipStream_t st, const GlView& d_gl_sites,
   hipLaunchKernelGGL(k_fast_estmaf_stream, grid, block, 0, st, d_gl_sites, d_marg_blocks, S_own,
                      I_tot, I_blk, tile_T, d_freq_out, redo, row0, row1, fs.est_counts);
 #undef LAUNCH_NI
+#undef ESTMAF_DYN
 #undef LAUNCH_TILE
 #undef LAUNCH_ROWS
   return hipGetLastError() == hipSuccess;

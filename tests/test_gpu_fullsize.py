@@ -126,6 +126,11 @@ def test_est_maf_properties_at_full_size(pkg, big):
     (1000, 100_000, dict(freq="r", depth=10.0)),
     (2000, 50_000, dict(freq="r")),
     (100, 200_000, dict(freq="r")),
+    # several waves per site: 4 (3000), 8 with 10 / 14 / 16 individuals per lane (5000, 6500, 8000)
+    (3000, 20_000, dict(freq="r")),
+    (5000, 20_000, dict(freq="r")),
+    (6500, 9_000, dict(freq="r")),
+    (8000, 8_000, dict(freq="r")),
 ])
 def test_est_maf_interpolated_passes_equal_exact_passes(pkg, n_ind, n_sites, kw):
     """est_maf runs most of its <= 101 passes per site on a checked Chebyshev interpolant of
