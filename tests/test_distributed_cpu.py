@@ -448,8 +448,8 @@ def test_bench_eight_rank_dry_launch():
     """`bench.py --gpus 8 --dry_launch`: the child launcher, the rendezvous of eight ranks, the
     known-answer preflight of the collectives and every rank's shard of the default workload in
     both layouts -- what an 8-GPU run does before its first GPU call, on the CPU (the build's
-    one-GPU boxes admit at most six processes on a card, so the eight-rank launch itself is
-    rehearsed here).  The shards tile the 1000 x 1M job."""
+    one-GPU boxes admit at most six processes on a card -- four ranks and their launcher in practice
+    -- so the eight-rank launch itself is rehearsed here).  The shards tile the 1000 x 1M job."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry_launch"],
                        capture_output=True, text=True, timeout=300)
