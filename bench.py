@@ -1510,13 +1510,15 @@ def regime_object(tl, K, n_ind, n_sites, site_shards):
     per site instead of an exponential; `general` = an exponential per point and site) and the share
     of the frequency step's sites that left its common route (exact passes, one checked
     interpolant, the rest on it).  This rank's handle(s)."""
-    mc, ec = tl.get("mode_counts") or {}, tl.get("estmaf_counts") or {}
+    mc, ec = dict(tl.get("mode_counts") or {}), tl.get("estmaf_counts") or {}
     if not mc and not ec:
         return None
+    mixed = mc.pop("rounds_of_mixed_versions", 0)   # (rounds, not individual-rounds: include/nghmm_debug.h)
     tot = float(sum(mc.values())) or 1.0
     sites = float(n_sites) / site_shards * K
     return {"objective_kernel_versions": {k: {"ind_rounds_per_iter": v / K, "share": v / tot}
                                           for k, v in sorted(mc.items(), key=lambda kv: -kv[1])},
+            "rounds_of_mixed_versions_in_one_launch_per_iter": mixed / K,
             "small_alpha_share": sum(v for k, v in mc.items() if k != "general" and "s" in k) / tot,
             "general_kernel_share": mc.get("general", 0) / tot,
             "est_maf_sites_off_the_common_route": {k: {"sites_per_iter": v / K, "share": v / sites}

@@ -73,7 +73,10 @@ int nghmm_kernel_ms(nghmm_t* h, int slot, double* ms, uint32_t* launches);
  * individual-rounds evaluated by that version), n = how many versions were used (at most cap are
  * written).  mode 0 = the general kernel (an exp per point and site); else bits 0-1 alpha probes,
  * bits 2-3 F probes, 0x200 small-alpha (kappa form, polynomial instead of exp), 0x400 degree-2
- * alpha probes, 0x800 an exponent per point.
+ * alpha probes, 0x800 an exponent per point.  One more entry may follow them, mode 0xffffffff: the
+ * number of ROUNDS (not individual-rounds) whose versions shared one launch -- a device-planned round
+ * of at most 16384 waves with individuals of several versions (kernels_fast_walks.hip,
+ * k_fast_lkl_fd_mix).
  *
  * nghmm_debug_estmaf_counts: sites of the allele-frequency step (est_maf, gen_func.cpp:974-1009)
  * that left its common route -- out[0] the interpolant's check failed (the site ran every

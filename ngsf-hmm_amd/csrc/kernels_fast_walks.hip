@@ -261,22 +261,13 @@ __device__ __forceinline__ void lkl_store_wave_ops(Op (&R)[MAXP], int lane, doub
   }
 }
 
-// One kernel per loop-body version (each gets its own register allocation); the host
-// sorts the groups of a round by mode and launches every version on its range
-// [g_begin, g_begin + gridDim.x / C).
-template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG, bool OWNEX = false>
-__global__ void __launch_bounds__(64)
-k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
-              uint32_t g_begin, double* __restrict__ part, EmitPtrs emit,
-              const uint32_t* __restrict__ worklist = nullptr) {
+// One wave's part of a group's objective: the lanes' operators over the T sites of lane-chunk c, the
+// by-products of an emitting round, the wave's ordered product to part[g][c].
+template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG, bool OWNEX>
+__device__ __forceinline__ void lkl_fd_wave(const LklArrays& arr, uint64_t T, uint32_t C,
+                                            const GroupDesc* __restrict__ groups, uint32_t g, uint32_t c,
+                                            double* __restrict__ part, const EmitPtrs& emit, TreeLds& tree) {
   static_assert(EMIT || SRC == SRC_PLAIN, "the fresh walk is the first round of an M-step");
-  // chunk-major: the waves resident at a time walk the same few slices of the shared
-  // distance / frequency tables, which then stay in L2
-  const uint32_t n_g = gridDim.x / C;
-  // (rounds planned on the device, kernels_bfgs.hip: the mode's worklist names the groups,
-  // which lie -- descriptors and partial operators -- by individual)
-  const uint32_t g = worklist ? worklist[blockIdx.x % n_g] : g_begin + blockIdx.x % n_g;
-  const uint32_t c = blockIdx.x / n_g;
   const int lane = threadIdx.x;
   const GroupDesc& G = groups[g];
   const uint64_t i = G.ind;
@@ -298,8 +289,73 @@ k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict
     renorm(r0);
     emit_lane_op(emit.lane_ops, i * C + c, lane, r0);
   }
-  __shared__ TreeLds tree;
   lkl_store_wave_ops<1 + NF + NA>(R, lane, part + ((uint64_t)g * C + c) * MAXP * 5, tree);
+}
+
+// One kernel per loop-body version (each gets its own register allocation); the host
+// sorts the groups of a round by mode and launches every version on its range
+// [g_begin, g_begin + gridDim.x / C).
+template <int NF, int NA, bool SMALL, bool EMIT, int SRC, int XDEG, bool OWNEX = false>
+__global__ void __launch_bounds__(64)
+k_fast_lkl_fd(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
+              uint32_t g_begin, double* __restrict__ part, EmitPtrs emit,
+              const uint32_t* __restrict__ worklist = nullptr) {
+  // chunk-major: the waves resident at a time walk the same few slices of the shared
+  // distance / frequency tables, which then stay in L2
+  const uint32_t n_g = gridDim.x / C;
+  // (rounds planned on the device, kernels_bfgs.hip: the mode's worklist names the groups,
+  // which lie -- descriptors and partial operators -- by individual)
+  const uint32_t g = worklist ? worklist[blockIdx.x % n_g] : g_begin + blockIdx.x % n_g;
+  const uint32_t c = blockIdx.x / n_g;
+  __shared__ TreeLds tree;
+  lkl_fd_wave<NF, NA, SMALL, EMIT, SRC, XDEG, OWNEX>(arr, T, C, groups, g, c, part, emit, tree);
+}
+
+// A SMALL round planned on the device whose individuals are of several versions (small and general
+// alpha, degree 4 and 2): launched one version after the other, each launch is as long as one wave's
+// walk -- a few thousand waves do not fill the chip -- and the round as long as their sum.  Here
+// the versions share ONE launch: the block picks its version's worklist and loop body (the same
+// code as k_fast_lkl_fd's, the same bits; the registers of the largest).
+struct MixVersions {
+  const uint32_t* worklist[8];
+  uint32_t end[8];      // running count of groups up to and including version k
+  uint32_t version[8];  // bit 0: small alpha, bit 1: degree 2, bit 2: an exponent per point
+  uint32_t n;
+};
+__global__ void __launch_bounds__(64)
+k_fast_lkl_fd_mix(LklArrays arr, uint64_t T, uint32_t C, const GroupDesc* __restrict__ groups,
+                  double* __restrict__ part, MixVersions mix) {
+  const uint32_t n_g = gridDim.x / C;
+  const uint32_t idx = blockIdx.x % n_g, c = blockIdx.x / n_g;
+  // (the block's version by compares on the arguments' scalars: no indexed copy of them)
+  uint32_t first = 0, version = mix.version[0];
+  const uint32_t* wl = mix.worklist[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) {
+    if ((uint32_t)j < mix.n && idx >= mix.end[j - 1]) {
+      first = mix.end[j - 1];
+      version = mix.version[j];
+      wl = mix.worklist[j];
+    }
+  }
+  const uint32_t g = wl[idx - first];
+  const EmitPtrs emit{nullptr, nullptr};
+  __shared__ TreeLds tree;
+  switch (version) {
+#define MIX_CASE(V, SM, XD, OX)                                                                       \
+  case V:                                                                                             \
+    lkl_fd_wave<2, 2, SM, false, SRC_PLAIN, XD, OX>(arr, T, C, groups, g, c, part, emit, tree);      \
+    break;
+    MIX_CASE(0, false, 4, false)
+    MIX_CASE(1, true, 4, false)
+    MIX_CASE(2, false, 2, false)
+    MIX_CASE(3, true, 2, false)
+    MIX_CASE(4, false, 4, true)
+    MIX_CASE(5, true, 4, true)
+    MIX_CASE(6, false, 2, true)
+    MIX_CASE(7, true, 2, true)
+#undef MIX_CASE
+  }
 }
 
 template <int NP_MAX, int SRC>
@@ -582,6 +638,9 @@ bool fast_lkl_prepare(FastState& fs, hipStream_t st, uint32_t n_pts, const uint3
 // Device-planned rounds (d_worklists != null, kernels_bfgs.hip): the descriptors lie by
 // individual, range r = the first r.count entries of mode r.mode's worklist
 // (d_worklists + mode_slot(mode) * wl_stride), d_all = the ng groups of the round in one list.
+// (waves of a round up to which its versions share a launch: four times what the chip holds at once)
+constexpr uint64_t kMixMaxWaves = 16384;
+constexpr uint32_t kModeMixedRounds = 0xffffffffu;  // nghmm_debug_mode_counts: the rounds that did
 static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg,
                               const std::vector<FastState::ModeRange>& mode_ranges, uint32_t ng,
                               uint32_t n_pts, double* part, double* d_lkl, int* d_flags,
@@ -600,7 +659,30 @@ static bool lkl_launch_groups(FastState& fs, hipStream_t st, const GroupDesc* dg
   // (the kernel versions of one round side by side on helper streams, so that they share one
   // partly filled last wave batch: measured, no gain -- 26.6-26.9 vs 27.0-27.1 ms per iteration
   // at 1000 x 1M)
+  // a small device-planned round of several versions of the padded pattern: one launch (k_fast_lkl_fd_mix)
+  bool mixed = false;
+  if (d_worklists && !emit_estep && mode_ranges.size() > 1 && mode_ranges.size() <= 8 &&
+      (uint64_t)ng * fs.C <= kMixMaxWaves) {
+    MixVersions mix{};
+    uint32_t end = 0;
+    bool all_padded = true;
+    for (const auto& r : mode_ranges) {
+      const uint32_t full = fd_mode(2, 2, (r.mode & FD_SMALL) != 0, (r.mode & FD_XDEG2) != 0);
+      all_padded = all_padded && (r.mode & ~FD_OWNEX) == full;
+      end += r.count;
+      mix.worklist[mix.n] = d_worklists + (uint64_t)mode_slot(r.mode) * wl_stride;
+      mix.end[mix.n] = end;
+      mix.version[mix.n] = ((r.mode & FD_SMALL) ? 1u : 0u) | ((r.mode & FD_XDEG2) ? 2u : 0u) | ((r.mode & FD_OWNEX) ? 4u : 0u);
+      ++mix.n;
+    }
+    if (all_padded && end == ng) {
+      hipLaunchKernelGGL(k_fast_lkl_fd_mix, dim3(ng * fs.C), dim3(64), 0, st, arr, fs.T, fs.C, dg, part, mix);
+      mixed = true;
+      ++fs.mode_ind_rounds[kModeMixedRounds];
+    }
+  }
   for (const auto& r : mode_ranges) {
+    if (mixed) break;
     const dim3 grid(r.count * fs.C), block(64);
     const uint32_t* wl = d_worklists ? d_worklists + (uint64_t)mode_slot(r.mode) * wl_stride : nullptr;
     // a group that needs an exponent per point (FD_OWNEX) in a round that also emits the

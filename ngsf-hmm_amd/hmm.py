@@ -585,6 +585,8 @@ class NgsFHMM:
     def mode_name(mode):
         """A loop-body version of the objective kernels as debug_modes prints it: 2F2As2 = two F
         probes, two alpha probes, small-alpha (kappa) form, degree-2 alpha probes."""
+        if mode == 0xffffffff:
+            return "rounds_of_mixed_versions"
         if mode == 0:
             return "general"
         return (f"{(mode >> 2) & 3}F{mode & 3}A" + ("s" if mode & 0x200 else "") +
